@@ -1,0 +1,177 @@
+/* wavenet_hip.h -- C ABI of libwavenet_hip.so (gfx950 / MI355X).
+ *
+ * The drop-in boundary of the reference (jyegerlehner/tensorflow-wavenet) is
+ * its Python class API (wavenet/__init__.py:1-4); it has no FFI of its own.
+ * This C ABI is the new, internal boundary under the Python host
+ * (tensorflow-wavenet_amd/wavenet): each entry point names the reference
+ * code it replaces.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Contract (all entry points)
+ *   - plain C: raw device pointers + explicit sizes, no torch / C++ types;
+ *   - every buffer is allocated and owned by the caller; the library never
+ *     allocates, frees or retains a pointer past return;
+ *   - asynchronous on the caller's `stream` (a hipStream_t passed as void*),
+ *     no internal synchronisation, no mutable globals: re-entrant, safe for
+ *     one process per GPU and for several streams;
+ *   - returns WN_OK (0) or a negative WN_ERR_* code; no C++ exception
+ *     crosses the boundary;
+ *   - activation "planes" are [rows][32] fp32 with rows = B*T (reference
+ *     layout [B,T,C], channels innermost, residual/dilation channels zero-
+ *     padded to 32); weights keep the reference's [K][Cin][Cout] order.
+ *   - device pointers and leading dimensions must be 16-byte aligned.
+ */
+#ifndef WAVENET_HIP_H_
+#define WAVENET_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WN_OK 0
+#define WN_ERR_BAD_SHAPE (-1)
+#define WN_ERR_UNSUPPORTED (-2)
+#define WN_ERR_MISALIGNED (-3)
+#define WN_ERR_LAUNCH (-4)
+#define WN_ERR_NULL (-5)
+
+int wn_version(void);
+const char* wn_error_string(int code);
+
+/* ---- mu-law companding: wavenet/ops.py:65-73 (encode), :76-85 (decode) ---
+ * Host: build the Q-1 float32 decision thresholds / the Q-entry decode table
+ * of the float32 chain (host memory).  Device: bit-exact encode by threshold
+ * search, decode by table lookup. */
+int wn_mu_law_thresholds_host(int Q, float* thr_out);
+int wn_mu_law_decode_table_host(int Q, float* lut_out);
+int wn_mu_law_encode(const float* audio, int32_t* codes, long n,
+                     const float* thr_dev, int Q, void* stream);
+int wn_mu_law_decode(const int32_t* codes, float* audio, long n,
+                     const float* lut_dev, int Q, void* stream);
+
+/* ---- causal layer on one-hot input as a gather: wavenet/model.py:227-234
+ * (_create_causal_layer) + :518-531 (_one_hot).  Wc is [2][Q][32]. */
+int wn_causal_gather(const int32_t* q, const float* Wc, float* x0, int B,
+                     int T, int Q, void* stream);
+
+/* ---- fused residual block: wavenet/model.py:236-330
+ * (_create_dilation_layer) incl. both causal_conv calls, ops.py:46-62.
+ * wblock = Wf[2][32][32] Wg[2][32][32] Wd[32][32] bf[32] bg[32] bd[32].
+ * bias_fg: [B or 1][64] per-clip (bias + global-conditioning) or NULL. */
+int wn_layer_fwd(const float* x, float* x_out, float* z, float* th, float* sg,
+                 const float* wblock, const float* bias_fg,
+                 int bias_clip_stride, int B, int T, int dilation,
+                 int has_dense, int save_ts, void* stream);
+/* backward-data of the same block (TF autodiff of model.py:236-330):
+ * phase B of layer l (dx from da[t], da[t+d]) and/or phase A of layer l-1
+ * (da from dZ, dx, tanh, sigmoid). */
+int wn_layer_bwd(const float* daf_cur, const float* dag_cur, const float* dxin,
+                 float* dx_out, const float* wblock_b, const float* dZ,
+                 const float* th, const float* sg, const float* wblock_a,
+                 float* daf_next, float* dag_next, int B, int T, int dilation,
+                 int do_b, int do_a, void* stream);
+/* backward-weights of the block into per-workgroup slabs (layout = wblock) */
+int wn_layer_wgrad_slab_floats(void);
+int wn_layer_wgrad(const float* x, const float* daf, const float* dag,
+                   const float* z, const float* dxin, float* slabs,
+                   int num_slabs, int B, int T, int dilation, void* stream);
+
+/* ---- fp32 MFMA GEMMs: the skip sum + post-processing of
+ * wavenet/model.py:303-305, 430-440 (_create_network) and their gradients */
+int wn_gemm_nn(const float* A, long lda, int a_planes, long a_plane_stride,
+               const float* W, int ldw, const float* bias, const float* mask,
+               long ld_mask, const float* addend, long ld_add, float* C,
+               long ldc, int c_planes, long c_plane_stride, float* Cpre,
+               long M, int N, int K, int relu, void* stream);
+long wn_gemm_tn_slab_floats(int Mw, int Nw);
+int wn_gemm_tn(const float* A, long lda, int a_planes, long a_plane_stride,
+               const int32_t* codes, int shift, int T, const float* G,
+               long ldg, float* slabs, int splits, long rows, int Mw, int Nw,
+               int want_colsum, void* stream);
+int wn_reduce_slabs(const float* slabs, int num_slabs, long slab_stride,
+                    int batch, long in_batch_stride, long offset, long n,
+                    float* dst, long out_batch_stride, int replicate,
+                    long rep_stride, void* stream);
+int wn_transpose(const float* in, int rows, int cols, long in_ld, float* out,
+                 long out_ld, void* stream);
+
+/* ---- loss: wavenet/model.py:654-666 (shifted one-hot softmax xent, mean),
+ * forward + TF-compatible backward; predict softmax in float64
+ * (model.py:584-585, 620-621) */
+int wn_xent_partials(long rows);
+int wn_xent(const float* logits, long ld, const int32_t* q, float* dlogits,
+            float* loss_partials, int B, int T, int Q, int tf_quirk,
+            void* stream);
+int wn_softmax64_row(const float* logits_row, int Q, float* proba,
+                     void* stream);
+
+/* ---- optimizers with TensorFlow-0.10 update rules: wavenet/ops.py:6-24 */
+int wn_adam(float* p, const float* g, float* m, float* v, long n, float lr_t,
+            float beta1, float beta2, float eps, float grad_scale, float l2,
+            const float* l2_mask, void* stream);
+int wn_momentum(float* p, const float* g, float* acc, long n, float lr,
+                float momentum, float grad_scale, float l2,
+                const float* l2_mask, void* stream);
+int wn_rmsprop(float* p, const float* g, float* ms, float* mom, long n,
+               float lr, float decay, float momentum, float eps,
+               float grad_scale, float l2, const float* l2_mask,
+               void* stream);
+int wn_l2_partials_count(void);
+int wn_l2_partials(const float* p, long n, const float* mask, float* partials,
+                   void* stream);
+
+/* ---- global conditioning: wavenet/model.py:272-284, 533-562 */
+int wn_gc_bias(const float* layer0, long layer_stride, long off_bias,
+               long off_gc, int G, const float* emb, int card,
+               const int32_t* ids, float* out, int L, int B, void* stream);
+int wn_colsum_clip(const float* plane, int B, int T, float* out,
+                   int out_stride, void* stream);
+int wn_gc_grad(const float* layer0, long layer_stride, long off_gc, int G,
+               const float* emb, int card, const int32_t* ids,
+               const float* dsum, int L, int B, float* glayer0, float* gemb,
+               void* stream);
+
+/* ---- thin exported ops of wavenet/__init__.py:1-4 (arbitrary shapes):
+ * causal_conv ops.py:46-62, time_to_batch :27-34, batch_to_time :37-43 */
+int wn_causal_conv(const float* x, const float* w, float* y, int B, int T,
+                   int Cin, int Cout, int K, int dilation, void* stream);
+int wn_time_to_batch(const float* in, float* out, int B, int T, int C,
+                     int dilation, void* stream);
+int wn_batch_to_time(const float* in, float* out, int B_out, int U, int C,
+                     int dilation, void* stream);
+
+/* ---- utilities */
+int wn_axpy(float* y, const float* x, float a, const float* mask, long n,
+            void* stream);
+int wn_fill(float* p, long n, float value, void* stream);
+int wn_sum_rows(const float* in, int rows, int n, float* out, void* stream);
+
+/* ---- fast generation: wavenet/model.py:332-387, 444-516, 592-626
+ * (_create_generator / predict_proba_incremental) and the host loop of
+ * generate.py:213-241, as ONE persistent kernel with the FIFO state on the
+ * device and on-device sampling. */
+long wn_fastgen_state_floats(const int32_t* dilations_host, int L);
+int wn_fastgen_init(float* state, long state_floats, int32_t* cursors, int L,
+                    void* stream);
+/* samples_io holds n_steps + 1 codes; the first n_given are inputs (seed /
+ * priming, generate.py:195-210), the rest are drawn on the device.  Step i
+ * consumes samples_io[i]; proba_out (optional) receives the next-sample
+ * distribution of every proba_every-th step.  push = 0 (n_steps must be 1)
+ * evaluates a step without advancing the queues (the reference's proba op run
+ * without net.push_ops, test/test_generation.py:66-68). */
+int wn_fastgen_run(const float* params_causal, const float* layer0,
+                   long layer_stride, const float* skip_w,
+                   const float* skip_bsum, const float* post1_w,
+                   const float* post1_b, const float* post2_w,
+                   const float* post2_b, const float* gc_bias_fg,
+                   const int32_t* dilations_dev, int L, int S, int Q,
+                   float* state, int32_t* cursors, int32_t* samples_io,
+                   int n_given, int n_steps, float temperature, uint64_t seed,
+                   float* proba_out, int proba_every, int use_biases,
+                   int push, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WAVENET_HIP_H_ */

@@ -1,0 +1,132 @@
+// Shared device helpers for the gfx950 (CDNA4 / MI355X) WaveNet kernels.
+//
+// Conventions used by every MFMA kernel in this directory
+// -------------------------------------------------------
+// * Activations live in HBM as "planes": [rows][32] fp32, rows = B*T, one
+//   128-byte line per audio sample (reference layout [B,T,C] with C padded to
+//   32; wavenet/model.py keeps residual/dilation channels innermost too).
+// * A "fragment" is a 32(time) x 32(channel) tile held by one 64-lane wave in
+//   16 VGPRs per lane.  Lane l = (j = l & 31, h = l >> 5) owns time row j and
+//   the 16 channels  c(r,h) = 8*(r>>2) + 4*h + (r&3),  r = 0..15.
+//   This is exactly the C/D layout of v_mfma_f32_32x32x2_f32 when the product
+//   is computed transposed (channels on the M axis, time on the N axis):
+//       OUT^T[ch, time] += W^T[ch, k] * X^T[k, time]
+//   so an accumulator IS a fragment: it feeds the next MFMA as the B operand
+//   with no lane movement and no LDS round trip, and it is loaded/stored with
+//   four 16-byte accesses per lane (channels 8q+4h .. 8q+4h+3, q = 0..3).
+// * Weights are the A operand, read from LDS in the reference's own
+//   [k][n] (Cin-major, Cout contiguous) order: lane (i, h) reads
+//   W[c(r,h)][n0 + i] -> 32 consecutive floats per half-wave, conflict-free.
+// * fp32 in / fp32 accumulate MFMA is bit-for-bit an fmaf chain, so parity
+//   with the fp32 CPU oracle is limited only by summation order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define WN_OK 0
+#define WN_ERR_BAD_SHAPE (-1)
+#define WN_ERR_UNSUPPORTED (-2)
+#define WN_ERR_MISALIGNED (-3)
+#define WN_ERR_LAUNCH (-4)
+#define WN_ERR_NULL (-5)
+
+#define WN_CH 32  // padded residual/dilation channel count of every plane
+
+// Layer parameter block (floats), contiguous per layer in the flat buffer:
+//   Wf[2][32][32] Wg[2][32][32] Wd[32][32] bf[32] bg[32] bd[32]
+//   (+ Wgc_filter[G][32] Wgc_gate[G][32] when globally conditioned)
+#define LAYER_W_FLOATS (5 * 1024)
+#define LAYER_OFF_BF 5120
+#define LAYER_OFF_BG 5152
+#define LAYER_OFF_BD 5184
+#define LAYER_BLOCK_FLOATS (LAYER_W_FLOATS + 96)
+#define LAYER_OFF_GC LAYER_BLOCK_FLOATS
+
+static inline int wn_check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? WN_OK : WN_ERR_LAUNCH;
+}
+
+static inline bool wn_aligned16(const void* p) {
+  return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
+}
+
+#ifdef __HIPCC__
+
+__device__ __forceinline__ f32x16 frag_zero() {
+  f32x16 f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) f[r] = 0.f;
+  return f;
+}
+
+// Load the fragment of plane rows [row0, row0+32) ; `rowp` already points at
+// this lane's row (row0 + j), `h` = lane >> 5.  valid=false gives zeros (rows
+// before the clip start / past its end: the causal zero padding of
+// wavenet/ops.py:50-51).
+__device__ __forceinline__ f32x16 frag_load(const float* __restrict__ rowp,
+                                            int h, bool valid) {
+  f32x16 f;
+  const f32x4* p = reinterpret_cast<const f32x4*>(rowp + 4 * h);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (valid) v = p[2 * q];
+    f[4 * q + 0] = v[0];
+    f[4 * q + 1] = v[1];
+    f[4 * q + 2] = v[2];
+    f[4 * q + 3] = v[3];
+  }
+  return f;
+}
+
+__device__ __forceinline__ void frag_store(float* __restrict__ rowp, int h,
+                                           bool valid, const f32x16& f) {
+  if (!valid) return;
+  f32x4* p = reinterpret_cast<f32x4*>(rowp + 4 * h);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x4 v = {f[4 * q + 0], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]};
+    p[2 * q] = v;
+  }
+}
+
+// Per-channel vector (bias) from LDS/global as a fragment (same value for
+// every time row).
+__device__ __forceinline__ f32x16 frag_bcast(const float* __restrict__ vec,
+                                             int h) {
+  f32x16 f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f[4 * q + e] = vec[8 * q + 4 * h + e];
+  }
+  return f;
+}
+
+// acc^T[n0+i, time] += sum_k W[k][n0+i] * frag[time, k]   (k over 32 channels)
+// wl: LDS, row-major [32][ldw] with the contraction index k as the row.
+// `wl_lane` must already be  wl + n0 + i + 4*h*ldw  (per-lane base), so the
+// 16 reads are base + compile-time offsets.
+template <int LDW>
+__device__ __forceinline__ void mma32(f32x16& acc, const f32x16& frag,
+                                      const float* wl_lane) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float a = wl_lane[(8 * (r >> 2) + (r & 3)) * LDW];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, frag[r], acc, 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ float wn_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.f + __expf(-x));
+}
+__device__ __forceinline__ float wn_tanh(float x) {
+  // 1 - 2/(e^{2x}+1); saturates correctly at +-inf of the exp.
+  return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x));
+}
+
+#endif  // __HIPCC__

@@ -1,0 +1,457 @@
+// fp32 MFMA GEMMs of the WaveNet stack (v_mfma_f32_32x32x2_f32, exact fp32).
+//
+//  wn_gemm_nn : C[M,N] = epi(A[M,K] * W[K,N])      rows M = B*T audio samples
+//     - the 50 skip 1x1 convs as ONE contraction over the z planes
+//       (sum(outputs), wavenet/model.py:303-305 + 430:  K = L*32, N = S)
+//     - postprocess1 / postprocess2 (model.py:432-440), ReLU/bias fused
+//     - backward-data of the same (dY * W^T with the ReLU mask fused)
+//  wn_gemm_tn : dW[Mw,Nw] = sum_rows A[row,:]^T G[row,:]   (weight grads),
+//     split over rows into slabs that wn_reduce_slabs sums in a fixed order
+//     (deterministic; no float atomics).  A may be dense, the z planes, or a
+//     one-hot generated on the fly from the mu-law codes (causal-layer grad,
+//     model.py:227-234 / 518-531: the one-hot tensor is never materialised).
+//
+// Orientation: "time on the MFMA N axis" (see wn_common.h): activations are
+// the B operand as 32x32 fragments, weights the A operand from LDS.
+#include "wn_common.h"
+
+// ---------------------------------------------------------------------------
+// NN
+// ---------------------------------------------------------------------------
+struct GemmNN {
+  const float* A;
+  long lda;             // dense mode row stride (floats)
+  long a_plane_stride;  // plane mode: floats between planes
+  int a_planes;         // 0 = dense [M][lda]; >0 = planes [a_planes][M][32]
+  const float* W;       // [K][ldw]
+  int ldw;
+  const float* bias;    // [N] or null
+  const float* mask;    // [M][ld_mask] multiply by (mask > 0) or null
+  long ld_mask;
+  const float* addend;  // [M][ld_add] added after relu/mask, or null
+  long ld_add;
+  float* C;
+  long ldc;
+  long c_plane_stride;
+  int c_planes;         // 0 = dense; >0 = planes [c_planes][M][32]
+  float* Cpre;          // optional pre-activation copy (dense, ldc) or null
+  long M;
+  int N, K;
+  int relu;
+  int tiles_n;
+  int nwg;
+};
+
+#define NN_TM 128
+#define NN_TN 128
+#define NN_KC 32
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  // bijective "contiguous chunk per XCD" remap (8 XCDs, round-robin dispatch)
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+__global__ __launch_bounds__(256) void gemm_nn_kernel(GemmNN g) {
+  __shared__ __attribute__((aligned(16))) float As[2][NN_TM * NN_KC];
+  __shared__ __attribute__((aligned(16))) float Bs[2][NN_KC * NN_TN];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int logical = xcd_remap(blockIdx.x, g.nwg);
+  const int tile_n = logical % g.tiles_n;
+  const long m0 = (long)(logical / g.tiles_n) * NN_TM;
+  const int n0 = tile_n * NN_TN;
+  const int nk = (g.K + NN_KC - 1) / NN_KC;
+
+  f32x4 ra[4], rb[4];
+  auto gload = [&](int kc) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (tid >> 3) + 32 * i, ch = tid & 7;
+      const long m = m0 + row;
+      const int k = kc * NN_KC + ch * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < g.M && k < g.K) {
+        const float* p = g.a_planes
+                             ? g.A + (long)kc * g.a_plane_stride + m * 32 + ch * 4
+                             : g.A + m * g.lda + k;
+        v = *reinterpret_cast<const f32x4*>(p);
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int kk = (tid >> 5) + 8 * i, c4 = tid & 31;
+      const int k = kc * NN_KC + kk, n = n0 + c4 * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (k < g.K && n < g.N)
+        v = *reinterpret_cast<const f32x4*>(g.W + (long)k * g.ldw + n);
+      rb[i] = v;
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (tid >> 3) + 32 * i, ch = tid & 7;
+      const int sw = ch ^ ((row >> 1) & 7);  // 16-byte chunk swizzle
+      *reinterpret_cast<f32x4*>(&As[buf][row * NN_KC + sw * 4]) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int kk = (tid >> 5) + 8 * i, c4 = tid & 31;
+      *reinterpret_cast<f32x4*>(&Bs[buf][kk * NN_TN + c4 * 4]) = rb[i];
+    }
+  };
+
+  f32x16 acc[2][2];  // [fn][fm]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = frag_zero();
+
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  for (int kc = 0; kc < nk; ++kc) {
+    const int buf = kc & 1;
+    if (kc + 1 < nk) gload(kc + 1);
+    // fragments of the activation tile (B operand)
+    f32x16 fa[2];
+#pragma unroll
+    for (int fm = 0; fm < 2; ++fm) {
+      const int row = wm * 64 + fm * 32 + j;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int sw = (2 * q + h) ^ ((j >> 1) & 7);
+        const f32x4 v =
+            *reinterpret_cast<const f32x4*>(&As[buf][row * NN_KC + sw * 4]);
+        fa[fm][4 * q + 0] = v[0];
+        fa[fm][4 * q + 1] = v[1];
+        fa[fm][4 * q + 2] = v[2];
+        fa[fm][4 * q + 3] = v[3];
+      }
+    }
+    const float* bl = &Bs[buf][4 * h * NN_TN + wn * 64 + j];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ko = (8 * (r >> 2) + (r & 3)) * NN_TN;
+      const float w0 = bl[ko], w1 = bl[ko + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, fa[0][r], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, fa[1][r], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, fa[0][r], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, fa[1][r], acc[1][1], 0, 0, 0);
+    }
+    if (kc + 1 < nk) sstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue
+#pragma unroll
+  for (int fn = 0; fn < 2; ++fn) {
+#pragma unroll
+    for (int fm = 0; fm < 2; ++fm) {
+      const long m = m0 + wm * 64 + fm * 32 + j;
+      if (m >= g.M) continue;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + wn * 64 + fn * 32 + 8 * q + 4 * h;
+        if (n >= g.N) continue;
+        f32x4 v = {acc[fn][fm][4 * q], acc[fn][fm][4 * q + 1],
+                   acc[fn][fm][4 * q + 2], acc[fn][fm][4 * q + 3]};
+        if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + n);
+        if (g.Cpre) *reinterpret_cast<f32x4*>(g.Cpre + m * g.ldc + n) = v;
+        if (g.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (g.mask) {
+          const f32x4 mk =
+              *reinterpret_cast<const f32x4*>(g.mask + m * g.ld_mask + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
+        }
+        if (g.addend)
+          v += *reinterpret_cast<const f32x4*>(g.addend + m * g.ld_add + n);
+        float* dst = g.c_planes
+                         ? g.C + (long)(n >> 5) * g.c_plane_stride + m * 32 + (n & 31)
+                         : g.C + m * g.ldc + n;
+        *reinterpret_cast<f32x4*>(dst) = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// TN (weight gradients), LDS-free: operands are 4-byte loads of full lines.
+// ---------------------------------------------------------------------------
+struct GemmTN {
+  const float* A;       // dense [rows][lda] / planes [a_planes][rows][32]
+  long lda;
+  long a_plane_stride;
+  int a_planes;
+  const int32_t* codes; // one-hot mode: A[row][m] = (codes[row-shift] == m)
+  int shift;            // rows (within a clip of length T) the codes lag
+  int T;
+  const float* G;       // [rows][ldg]
+  long ldg;
+  float* slabs;         // [splits][Mw*Nw + Nw]
+  long slab_stride;
+  long rows;
+  long rows_per_split;  // even
+  int Mw, Nw;
+  int tiles_m, tiles_n; // wave tiles
+  int want_colsum;
+};
+
+template <int MF, int NF>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int wt = blockIdx.x * 4 + wave;
+  if (wt >= g.tiles_m * g.tiles_n) return;
+  // consecutive waves share the m tile (same A columns -> L1/L2 reuse)
+  const int tn = wt % g.tiles_n, tm = wt / g.tiles_n;
+  const int m0 = tm * MF * 32, n0 = tn * NF * 32;
+  const long r_begin = (long)blockIdx.y * g.rows_per_split;
+  long r_end = r_begin + g.rows_per_split;
+  if (r_end > g.rows) r_end = g.rows;
+
+  f32x16 acc[MF][NF];
+#pragma unroll
+  for (int a = 0; a < MF; ++a)
+#pragma unroll
+    for (int b = 0; b < NF; ++b) acc[a][b] = frag_zero();
+  float cs[NF];
+#pragma unroll
+  for (int b = 0; b < NF; ++b) cs[b] = 0.f;
+
+  bool mv[MF], nv[NF];
+#pragma unroll
+  for (int a = 0; a < MF; ++a) mv[a] = (m0 + a * 32 + i) < g.Mw;
+#pragma unroll
+  for (int b = 0; b < NF; ++b) nv[b] = (n0 + b * 32 + i) < g.Nw;
+
+  const int nsteps = (int)((r_end - r_begin + 1) >> 1);
+  int tcl = g.codes ? (int)((r_begin + h) % g.T) : 0;  // time inside the clip
+  for (int st = 0; st < nsteps; ++st) {
+    const long row = r_begin + 2 * (long)st + h;
+    const bool rv = row < r_end;
+    float av[MF], bv[NF];
+    if (g.codes) {
+      int code = -1;
+      if (rv && tcl >= g.shift) code = g.codes[row - g.shift];
+      tcl += 2;
+      while (tcl >= g.T) tcl -= g.T;
+#pragma unroll
+      for (int a = 0; a < MF; ++a)
+        av[a] = (code == m0 + a * 32 + i) ? 1.f : 0.f;
+    } else {
+#pragma unroll
+      for (int a = 0; a < MF; ++a) {
+        const int m = m0 + a * 32 + i;
+        float v = 0.f;
+        if (rv && mv[a])
+          v = g.a_planes ? g.A[(long)(m >> 5) * g.a_plane_stride + row * 32 + (m & 31)]
+                         : g.A[row * g.lda + m];
+        av[a] = v;
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NF; ++b) {
+      float v = 0.f;
+      if (rv && nv[b]) v = g.G[row * g.ldg + n0 + b * 32 + i];
+      bv[b] = v;
+      cs[b] += v;
+    }
+#pragma unroll
+    for (int a = 0; a < MF; ++a)
+#pragma unroll
+      for (int b = 0; b < NF; ++b)
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+  }
+
+  float* slab = g.slabs + (long)blockIdx.y * g.slab_stride;
+#pragma unroll
+  for (int a = 0; a < MF; ++a)
+#pragma unroll
+    for (int b = 0; b < NF; ++b) {
+      const int n = n0 + b * 32 + i;
+      if (n >= g.Nw) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + a * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+        if (m < g.Mw) slab[(long)m * g.Nw + n] = acc[a][b][r];
+      }
+    }
+  if (g.want_colsum && tm == 0) {
+#pragma unroll
+    for (int b = 0; b < NF; ++b) {
+      float v = cs[b] + __shfl_xor(cs[b], 32);
+      const int n = n0 + b * 32 + i;
+      if (h == 0 && n < g.Nw) slab[(long)g.Mw * g.Nw + n] = v;
+    }
+  }
+}
+
+// out[b][rep][e] = sum_s slabs[b][s][offset + e]   (fixed order over s)
+__global__ void reduce_slabs_kernel(const float* __restrict__ slabs,
+                                    int num_slabs, long slab_stride,
+                                    long in_batch_stride, long offset, long n,
+                                    float* __restrict__ dst,
+                                    long out_batch_stride, int replicate,
+                                    long rep_stride) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const int b = blockIdx.y;
+  const float* p = slabs + (long)b * in_batch_stride + offset + e;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int s = 0;
+  for (; s + 3 < num_slabs; s += 4) {
+    s0 += p[(long)s * slab_stride];
+    s1 += p[(long)(s + 1) * slab_stride];
+    s2 += p[(long)(s + 2) * slab_stride];
+    s3 += p[(long)(s + 3) * slab_stride];
+  }
+  for (; s < num_slabs; ++s) s0 += p[(long)s * slab_stride];
+  const float v = (s0 + s1) + (s2 + s3);
+  for (int r = 0; r < replicate; ++r)
+    dst[(long)b * out_batch_stride + (long)r * rep_stride + e] = v;
+}
+
+__global__ void transpose_pad_kernel(const float* __restrict__ in, int rows,
+                                     int cols, long in_ld,
+                                     float* __restrict__ out, long out_ld) {
+  // out[c][r] = in[r][c]; 32x32 LDS tiles
+  __shared__ float tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 thr: ty 0..7
+  for (int k = ty; k < 32; k += 8) {
+    const int r = by + k, c = bx + tx;
+    tile[k][tx] = (r < rows && c < cols) ? in[(long)r * in_ld + c] : 0.f;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int c = bx + k, r = by + tx;
+    if (c < cols && r < rows) out[(long)c * out_ld + r] = tile[tx][k];
+  }
+}
+
+extern "C" {
+
+int wn_gemm_nn(const float* A, long lda, int a_planes, long a_plane_stride,
+               const float* W, int ldw, const float* bias, const float* mask,
+               long ld_mask, const float* addend, long ld_add, float* C,
+               long ldc, int c_planes, long c_plane_stride, float* Cpre,
+               long M, int N, int K, int relu, void* stream) {
+  if (!A || !W || !C) return WN_ERR_NULL;
+  if (M <= 0 || N <= 0 || K <= 0) return WN_ERR_BAD_SHAPE;
+  if ((N & 3) || (K & 3) || (ldw & 3)) return WN_ERR_UNSUPPORTED;
+  if (a_planes) {
+    if (K != a_planes * 32) return WN_ERR_BAD_SHAPE;
+  } else if (lda & 3) {
+    return WN_ERR_UNSUPPORTED;
+  }
+  if (c_planes) {
+    if (N != c_planes * 32) return WN_ERR_BAD_SHAPE;
+  } else if (ldc & 3) {
+    return WN_ERR_UNSUPPORTED;
+  }
+  if ((mask && (ld_mask & 3)) || (addend && (ld_add & 3)))
+    return WN_ERR_UNSUPPORTED;
+  const void* ptrs[] = {A, W, bias, mask, addend, C, Cpre};
+  for (const void* p : ptrs)
+    if (p && !wn_aligned16(p)) return WN_ERR_MISALIGNED;
+  GemmNN g;
+  g.A = A; g.lda = lda; g.a_plane_stride = a_plane_stride; g.a_planes = a_planes;
+  g.W = W; g.ldw = ldw; g.bias = bias; g.mask = mask; g.ld_mask = ld_mask;
+  g.addend = addend; g.ld_add = ld_add; g.C = C; g.ldc = ldc;
+  g.c_plane_stride = c_plane_stride; g.c_planes = c_planes; g.Cpre = Cpre;
+  g.M = M; g.N = N; g.K = K; g.relu = relu;
+  const long tiles_m = (M + NN_TM - 1) / NN_TM;
+  g.tiles_n = (N + NN_TN - 1) / NN_TN;
+  const long nwg = tiles_m * g.tiles_n;
+  if (nwg > 0x7fffffffL) return WN_ERR_BAD_SHAPE;
+  g.nwg = (int)nwg;
+  hipLaunchKernelGGL(gemm_nn_kernel, dim3((unsigned)nwg), dim3(256), 0,
+                     (hipStream_t)stream, g);
+  return wn_check_launch();
+}
+
+// Number of floats one slab needs for wn_gemm_tn.
+long wn_gemm_tn_slab_floats(int Mw, int Nw) { return (long)Mw * Nw + Nw; }
+
+int wn_gemm_tn(const float* A, long lda, int a_planes, long a_plane_stride,
+               const int32_t* codes, int shift, int T, const float* G,
+               long ldg, float* slabs, int splits, long rows, int Mw, int Nw,
+               int want_colsum, void* stream) {
+  if (!G || !slabs) return WN_ERR_NULL;
+  if (!A && !codes) return WN_ERR_NULL;
+  if (rows <= 0 || Mw <= 0 || Nw <= 0 || splits <= 0) return WN_ERR_BAD_SHAPE;
+  if (a_planes && Mw != a_planes * 32) return WN_ERR_BAD_SHAPE;
+  if (codes && T <= 0) return WN_ERR_BAD_SHAPE;
+  GemmTN g;
+  g.A = A; g.lda = lda; g.a_plane_stride = a_plane_stride; g.a_planes = a_planes;
+  g.codes = codes; g.shift = shift; g.T = T > 0 ? T : 1; g.G = G; g.ldg = ldg;
+  g.slabs = slabs; g.slab_stride = wn_gemm_tn_slab_floats(Mw, Nw);
+  g.rows = rows;
+  long rps = (rows + splits - 1) / splits;
+  rps += rps & 1;
+  g.rows_per_split = rps;
+  g.Mw = Mw; g.Nw = Nw; g.want_colsum = want_colsum;
+  hipStream_t s = (hipStream_t)stream;
+  // wave-tile shape: least padding waste, then largest tile
+  const int m32 = (Mw + 31) / 32, n32 = (Nw + 31) / 32;
+  int NF = (n32 % 2 == 0) ? 2 : 1;
+  int MF;
+  if (m32 % 5 == 0) MF = 5;
+  else if (m32 % 4 == 0) MF = 4;
+  else if (m32 % 2 == 0) MF = 2;
+  else MF = 1;
+  g.tiles_m = (m32 + MF - 1) / MF;
+  g.tiles_n = (n32 + NF - 1) / NF;
+  const int wtiles = g.tiles_m * g.tiles_n;
+  dim3 grid((wtiles + 3) / 4, splits), block(256);
+#define LAUNCH(mf, nf) \
+  hipLaunchKernelGGL((gemm_tn_kernel<mf, nf>), grid, block, 0, s, g)
+  if (NF == 2) {
+    if (MF == 5) LAUNCH(5, 2);
+    else if (MF == 4) LAUNCH(4, 2);
+    else if (MF == 2) LAUNCH(2, 2);
+    else LAUNCH(1, 2);
+  } else {
+    if (MF == 5) LAUNCH(5, 1);
+    else if (MF == 4) LAUNCH(4, 1);
+    else if (MF == 2) LAUNCH(2, 1);
+    else LAUNCH(1, 1);
+  }
+#undef LAUNCH
+  return wn_check_launch();
+}
+
+int wn_reduce_slabs(const float* slabs, int num_slabs, long slab_stride,
+                    int batch, long in_batch_stride, long offset, long n,
+                    float* dst, long out_batch_stride, int replicate,
+                    long rep_stride, void* stream) {
+  if (!slabs || !dst) return WN_ERR_NULL;
+  if (num_slabs <= 0 || n <= 0 || batch <= 0 || replicate <= 0)
+    return WN_ERR_BAD_SHAPE;
+  dim3 grid((unsigned)((n + 255) / 256), batch), block(256);
+  hipLaunchKernelGGL(reduce_slabs_kernel, grid, block, 0, (hipStream_t)stream,
+                     slabs, num_slabs, slab_stride, in_batch_stride, offset, n,
+                     dst, out_batch_stride, replicate, rep_stride);
+  return wn_check_launch();
+}
+
+int wn_transpose(const float* in, int rows, int cols, long in_ld, float* out,
+                 long out_ld, void* stream) {
+  if (!in || !out) return WN_ERR_NULL;
+  if (rows <= 0 || cols <= 0) return WN_ERR_BAD_SHAPE;
+  dim3 grid((cols + 31) / 32, (rows + 31) / 32), block(256);
+  hipLaunchKernelGGL(transpose_pad_kernel, grid, block, 0, (hipStream_t)stream,
+                     in, rows, cols, in_ld, out, out_ld);
+  return wn_check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,345 @@
+// Fused residual-block kernels (forward, backward-data, backward-weights).
+//
+// Replaces, per dilation layer, the ~40 TensorFlow ops of
+// WaveNetModel._create_dilation_layer (wavenet/model.py:236-330) and the two
+// causal_conv calls inside it (wavenet/ops.py:46-62: pad, time_to_batch,
+// conv1d, batch_to_time, slice -- for filter and for gate):
+//
+//   a_f = x[t-d]*Wf[0] + x[t]*Wf[1] + b_f (+gc_f)     model.py:269-290
+//   a_g = x[t-d]*Wg[0] + x[t]*Wg[1] + b_g (+gc_g)
+//   z   = tanh(a_f) * sigmoid(a_g)                     model.py:292
+//   x'  = x + z*Wd + b_d                               model.py:294-300,330
+// The skip 1x1 (model.py:303-305) is NOT done here: z is written once as a
+// plane and all L skip convs become one [B*T, L*32] x [L*32, S] MFMA GEMM
+// (wn_gemm.hip) -- see DESIGN.md.
+//
+// Layer parameter block (all channel dims padded to 32, reference [K,Cin,Cout]
+// order inside each matrix), contiguous in the flat parameter buffer:
+//   Wf[2][32][32]  Wg[2][32][32]  Wd[32][32]  bf[32] bg[32] bd[32]
+#include "wn_common.h"
+
+
+// One workgroup = 4 waves = 4 consecutive 32-row tiles of ONE clip.
+// grid.x = tiles_per_clip_groups, grid.y = B.
+template <bool HAS_DENSE, bool SAVE_TS>
+__global__ __launch_bounds__(256) void layer_fwd_kernel(
+    const float* __restrict__ x, float* __restrict__ xo, float* __restrict__ z,
+    float* __restrict__ th, float* __restrict__ sg,
+    const float* __restrict__ wblock,      // LAYER_BLOCK_FLOATS
+    const float* __restrict__ bias_fg,     // [B or 1][64] (bias + gc), or null
+    int bias_clip_stride, int T, int d) {
+  __shared__ __attribute__((aligned(16))) float wl[LAYER_W_FLOATS + 96];
+  const int tid = threadIdx.x;
+  // stage weights (5120 floats) + biases
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(wblock);
+    f32x4* dst = reinterpret_cast<f32x4*>(wl);
+    for (int i = tid; i < LAYER_W_FLOATS / 4; i += 256) dst[i] = src[i];
+    if (tid < 64) {
+      const int b = blockIdx.y;
+      wl[LAYER_W_FLOATS + tid] =
+          bias_fg ? bias_fg[(size_t)b * bias_clip_stride + tid] : 0.f;
+    } else if (tid < 96) {
+      wl[LAYER_W_FLOATS + tid] = wblock[LAYER_W_FLOATS + tid];  // bd
+    }
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int t0 = (blockIdx.x * 4 + wave) * 32;
+  if (t0 >= T) return;
+  const int t = t0 + j;
+  const size_t clip = (size_t)blockIdx.y * T;
+  const bool vc = t < T;
+  const bool vp = vc && (t - d >= 0);
+  const float* xrow = x + (clip + t) * WN_CH;
+  f32x16 xc = frag_load(xrow, h, vc);
+  f32x16 xp = frag_load(xrow - (size_t)d * WN_CH, h, vp);
+
+  const float* wlane = wl + j + 4 * h * 32;  // n0 = 0, i = j
+  f32x16 af = frag_bcast(wl + LAYER_W_FLOATS, h);
+  f32x16 ag = frag_bcast(wl + LAYER_W_FLOATS + 32, h);
+  mma32<32>(af, xp, wlane + 0 * 1024);  // Wf[0]: past tap
+  mma32<32>(af, xc, wlane + 1 * 1024);  // Wf[1]: current tap
+  mma32<32>(ag, xp, wlane + 2 * 1024);  // Wg[0]
+  mma32<32>(ag, xc, wlane + 3 * 1024);  // Wg[1]
+  f32x16 zz;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    af[r] = wn_tanh(af[r]);
+    ag[r] = wn_sigmoid(ag[r]);
+    zz[r] = af[r] * ag[r];
+  }
+  const size_t off = (clip + t) * WN_CH;
+  frag_store(z + off, h, vc, zz);
+  if (SAVE_TS) {
+    frag_store(th + off, h, vc, af);
+    frag_store(sg + off, h, vc, ag);
+  }
+  if (HAS_DENSE) {
+    f32x16 bd = frag_bcast(wl + LAYER_W_FLOATS + 64, h);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = xc[r] + bd[r];
+    mma32<32>(acc, zz, wlane + 4 * 1024);  // Wd
+    frag_store(xo + off, h, vc, acc);
+  }
+}
+
+// Backward-data.  Phase B of layer l then phase A of layer l-1 on the same
+// rows (a kernel boundary is only needed before phase B because of the
+// anti-causal tap t+d):
+//   B(l):   dx_l[t]  = dxin[t] + da_l[t]*W1^T + da_l[t+d]*W0^T
+//   A(l-1): dz       = dZ_{l-1}[t] + dx_l[t]*Wd_{l-1}^T
+//           da_f     = dz * sig * (1 - tanh^2);  da_g = dz * tanh * sig*(1-sig)
+// da is stored as two planes: daf[rows][32], dag[rows][32].
+template <bool DO_B, bool DO_A, bool HAS_DXIN>
+__global__ __launch_bounds__(256) void layer_bwd_kernel(
+    const float* __restrict__ daf_cur, const float* __restrict__ dag_cur,
+    const float* __restrict__ dxin, float* __restrict__ dx_out,
+    const float* __restrict__ wblock_b,   // layer l block (phase B)
+    const float* __restrict__ dZ, const float* __restrict__ th,
+    const float* __restrict__ sg, const float* __restrict__ wblock_a,  // l-1
+    float* __restrict__ daf_next, float* __restrict__ dag_next, int T, int d) {
+  // LDS: transposed weights, rows padded to 33 floats so that both the
+  // transposing stores and the MFMA A-operand reads are bank-conflict free.
+  // [0..4) conv: Wf0^T, Wf1^T, Wg0^T, Wg1^T with row = dilation channel
+  // (contraction), col = residual channel; [4] Wd^T with row = residual
+  // channel (contraction), col = dilation channel.
+  constexpr int LDT = 33, MT = 32 * LDT;
+  __shared__ float wl[5 * MT];
+  const int tid = threadIdx.x;
+  if (DO_B) {
+    for (int i = tid; i < 4096; i += 256) {
+      const int m = i >> 10, rr = (i >> 5) & 31, cc = i & 31;  // W[m][rr][cc]
+      wl[m * MT + cc * LDT + rr] = wblock_b[i];
+    }
+  }
+  if (DO_A) {
+    for (int i = tid; i < 1024; i += 256) {
+      const int rr = i >> 5, cc = i & 31;  // Wd[dch rr][res cc]
+      wl[4 * MT + cc * LDT + rr] = wblock_a[4096 + i];
+    }
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int t0 = (blockIdx.x * 4 + wave) * 32;
+  if (t0 >= T) return;
+  const int t = t0 + j;
+  const size_t clip = (size_t)blockIdx.y * T;
+  const bool vc = t < T;
+  const size_t off = (clip + t) * WN_CH;
+  const float* wlane = wl + j + 4 * h * LDT;
+
+  f32x16 dx;
+  if (HAS_DXIN)
+    dx = frag_load(dxin + off, h, vc);
+  else
+    dx = frag_zero();
+  if (DO_B) {
+    const bool vf = vc && (t + d < T);
+    f32x16 f0 = frag_load(daf_cur + off, h, vc);
+    f32x16 g0 = frag_load(dag_cur + off, h, vc);
+    f32x16 f1 = frag_load(daf_cur + off + (size_t)d * WN_CH, h, vf);
+    f32x16 g1 = frag_load(dag_cur + off + (size_t)d * WN_CH, h, vf);
+    mma32<LDT>(dx, f0, wlane + 1 * MT);  // da_f[t]   * Wf[1]^T
+    mma32<LDT>(dx, g0, wlane + 3 * MT);  // da_g[t]   * Wg[1]^T
+    mma32<LDT>(dx, f1, wlane + 0 * MT);  // da_f[t+d] * Wf[0]^T
+    mma32<LDT>(dx, g1, wlane + 2 * MT);  // da_g[t+d] * Wg[0]^T
+    frag_store(dx_out + off, h, vc, dx);
+  }
+  if (DO_A) {
+    f32x16 dz = frag_load(dZ + off, h, vc);
+    if (DO_B || HAS_DXIN) mma32<LDT>(dz, dx, wlane + 4 * MT);
+    f32x16 tt = frag_load(th + off, h, vc);
+    f32x16 ss = frag_load(sg + off, h, vc);
+    f32x16 df, dg;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float zs = dz[r] * ss[r];
+      df[r] = zs * (1.f - tt[r] * tt[r]);
+      dg[r] = zs * tt[r] * (1.f - ss[r]);
+    }
+    frag_store(daf_next + off, h, vc, df);
+    frag_store(dag_next + off, h, vc, dg);
+  }
+}
+
+// Backward-weights of one layer: every wave walks a strided set of 32-row
+// tiles and keeps 5 accumulator tiles (channels on BOTH MFMA axes, the row
+// pair of each step is the contraction):
+//   dWf[0] += x[t-d]^T da_f   dWf[1] += x[t]^T da_f   (same for gate)
+//   dWd    += z^T dxin        db_f,g += colsum(da)    dbd += colsum(dxin)
+// Operands are plain 4-byte loads: lane (i,h) reads M[row 2s+h][i] -> two
+// full 128-byte lines per wave instruction, no LDS staging needed at the
+// fp32 MFMA rate.  The 4 waves of a workgroup reduce through LDS and the
+// workgroup writes ONE slab; wn_reduce_slabs sums slabs in a fixed order
+// (deterministic, no float atomics).
+// Slab layout == layer gradient block layout (LAYER_BLOCK_FLOATS).
+template <bool HAS_DENSE>
+__global__ __launch_bounds__(256) void layer_wgrad_kernel(
+    const float* __restrict__ x, const float* __restrict__ daf,
+    const float* __restrict__ dag, const float* __restrict__ z,
+    const float* __restrict__ dxin, float* __restrict__ slabs, int B, int T,
+    int d) {
+  __shared__ float red[LAYER_BLOCK_FLOATS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int tiles_per_clip = (T + 31) / 32;
+  const int ntiles = tiles_per_clip * B;
+  const int nwaves = gridDim.x * 4;
+  f32x16 cf0 = frag_zero(), cf1 = frag_zero(), cg0 = frag_zero(),
+         cg1 = frag_zero(), cd = frag_zero();
+  float sf = 0.f, sgs = 0.f, sd = 0.f;
+  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += nwaves) {
+    const int b = tile / tiles_per_clip;
+    const int t0 = (tile - b * tiles_per_clip) * 32;
+    const size_t base = ((size_t)b * T + t0) * WN_CH;
+#pragma unroll 4
+    for (int s = 0; s < 16; ++s) {
+      const int t = t0 + 2 * s + h;
+      const bool v = t < T;
+      const size_t o = base + (size_t)(2 * s + h) * WN_CH + i;
+      const float xc = v ? x[o] : 0.f;
+      const float xp = (v && t >= d) ? x[o - (size_t)d * WN_CH] : 0.f;
+      const float f = v ? daf[o] : 0.f;
+      const float g = v ? dag[o] : 0.f;
+      cf0 = __builtin_amdgcn_mfma_f32_32x32x2f32(xp, f, cf0, 0, 0, 0);
+      cf1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xc, f, cf1, 0, 0, 0);
+      cg0 = __builtin_amdgcn_mfma_f32_32x32x2f32(xp, g, cg0, 0, 0, 0);
+      cg1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xc, g, cg1, 0, 0, 0);
+      sf += f;
+      sgs += g;
+      if (HAS_DENSE) {
+        const float zz = v ? z[o] : 0.f;
+        const float dd = v ? dxin[o] : 0.f;
+        cd = __builtin_amdgcn_mfma_f32_32x32x2f32(zz, dd, cd, 0, 0, 0);
+        sd += dd;
+      }
+    }
+  }
+  // column sums: add the two row-parity halves
+  sf += __shfl_xor(sf, 32);
+  sgs += __shfl_xor(sgs, 32);
+  sd += __shfl_xor(sd, 32);
+  // cross-wave reduction through LDS, fixed order wave 0..3
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+      // C tile: row m = 8*(r>>2)+4*h+(r&3) (A-operand channel), col = i.
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = 8 * (r >> 2) + 4 * h + (r & 3);
+        const int e = m * 32 + i;
+        if (w == 0) {
+          red[0 * 1024 + e] = cf0[r];
+          red[1 * 1024 + e] = cf1[r];
+          red[2 * 1024 + e] = cg0[r];
+          red[3 * 1024 + e] = cg1[r];
+          red[4 * 1024 + e] = cd[r];
+        } else {
+          red[0 * 1024 + e] += cf0[r];
+          red[1 * 1024 + e] += cf1[r];
+          red[2 * 1024 + e] += cg0[r];
+          red[3 * 1024 + e] += cg1[r];
+          red[4 * 1024 + e] += cd[r];
+        }
+      }
+      if (h == 0) {
+        if (w == 0) {
+          red[LAYER_W_FLOATS + i] = sf;
+          red[LAYER_W_FLOATS + 32 + i] = sgs;
+          red[LAYER_W_FLOATS + 64 + i] = sd;
+        } else {
+          red[LAYER_W_FLOATS + i] += sf;
+          red[LAYER_W_FLOATS + 32 + i] += sgs;
+          red[LAYER_W_FLOATS + 64 + i] += sd;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* out = slabs + (size_t)blockIdx.x * LAYER_BLOCK_FLOATS;
+  for (int e = tid; e < LAYER_BLOCK_FLOATS; e += 256) out[e] = red[e];
+}
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int wn_layer_fwd(const float* x, float* x_out, float* z, float* th, float* sg,
+                 const float* wblock, const float* bias_fg,
+                 int bias_clip_stride, int B, int T, int dilation,
+                 int has_dense, int save_ts, void* stream) {
+  if (!x || !z || !wblock) return WN_ERR_NULL;
+  if (B <= 0 || T <= 0 || dilation <= 0) return WN_ERR_BAD_SHAPE;
+  if (has_dense && !x_out) return WN_ERR_NULL;
+  if (save_ts && (!th || !sg)) return WN_ERR_NULL;
+  if (!wn_aligned16(x) || !wn_aligned16(z) || !wn_aligned16(wblock) ||
+      (x_out && !wn_aligned16(x_out)) || (th && !wn_aligned16(th)) ||
+      (sg && !wn_aligned16(sg)))
+    return WN_ERR_MISALIGNED;
+  dim3 grid((T + 127) / 128, B), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(HD, TS)                                                      \
+  hipLaunchKernelGGL((layer_fwd_kernel<HD, TS>), grid, block, 0, s, x,      \
+                     x_out, z, th, sg, wblock, bias_fg, bias_clip_stride, T, \
+                     dilation)
+  if (has_dense && save_ts) LAUNCH(true, true);
+  else if (has_dense) LAUNCH(true, false);
+  else if (save_ts) LAUNCH(false, true);
+  else LAUNCH(false, false);
+#undef LAUNCH
+  return wn_check_launch();
+}
+
+int wn_layer_bwd(const float* daf_cur, const float* dag_cur, const float* dxin,
+                 float* dx_out, const float* wblock_b, const float* dZ,
+                 const float* th, const float* sg, const float* wblock_a,
+                 float* daf_next, float* dag_next, int B, int T, int dilation,
+                 int do_b, int do_a, void* stream) {
+  if (B <= 0 || T <= 0 || dilation <= 0) return WN_ERR_BAD_SHAPE;
+  if (!do_a && !do_b) return WN_ERR_BAD_SHAPE;
+  if (do_b && (!daf_cur || !dag_cur || !dx_out || !wblock_b)) return WN_ERR_NULL;
+  if (do_a && (!dZ || !th || !sg || !wblock_a || !daf_next || !dag_next))
+    return WN_ERR_NULL;
+  const void* ptrs[] = {daf_cur, dag_cur, dxin, dx_out, dZ, th,
+                        sg,      daf_next, dag_next};
+  for (const void* p : ptrs)
+    if (p && !wn_aligned16(p)) return WN_ERR_MISALIGNED;
+  dim3 grid((T + 127) / 128, B), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  const bool hx = dxin != nullptr;
+#define LAUNCH(DB, DA, HX)                                                   \
+  hipLaunchKernelGGL((layer_bwd_kernel<DB, DA, HX>), grid, block, 0, s,      \
+                     daf_cur, dag_cur, dxin, dx_out, wblock_b, dZ, th, sg,   \
+                     wblock_a, daf_next, dag_next, T, dilation)
+  if (do_b && do_a) { if (hx) LAUNCH(true, true, true); else LAUNCH(true, true, false); }
+  else if (do_b) { if (hx) LAUNCH(true, false, true); else LAUNCH(true, false, false); }
+  else { if (hx) LAUNCH(false, true, true); else LAUNCH(false, true, false); }
+#undef LAUNCH
+  return wn_check_launch();
+}
+
+int wn_layer_wgrad_slab_floats(void) { return LAYER_BLOCK_FLOATS; }
+
+int wn_layer_wgrad(const float* x, const float* daf, const float* dag,
+                   const float* z, const float* dxin, float* slabs,
+                   int num_slabs, int B, int T, int dilation, void* stream) {
+  if (!x || !daf || !dag || !slabs) return WN_ERR_NULL;
+  if (B <= 0 || T <= 0 || dilation <= 0 || num_slabs <= 0)
+    return WN_ERR_BAD_SHAPE;
+  if ((dxin != nullptr) != (z != nullptr)) return WN_ERR_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(num_slabs), block(256);
+  if (dxin)
+    hipLaunchKernelGGL((layer_wgrad_kernel<true>), grid, block, 0, s, x, daf,
+                       dag, z, dxin, slabs, B, T, dilation);
+  else
+    hipLaunchKernelGGL((layer_wgrad_kernel<false>), grid, block, 0, s, x, daf,
+                       dag, z, dxin, slabs, B, T, dilation);
+  return wn_check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,725 @@
+// Streaming (HBM-bound) kernels around the MFMA core: mu-law companding, the
+// one-hot "conv" of the causal layer as a 2-row gather, fused softmax
+// cross-entropy, optimizers with TensorFlow update rules, global-conditioning
+// helpers, and the thin exported ops (causal_conv, time_to_batch, ...).
+#include "wn_common.h"
+#include <cmath>
+
+// ---------------------------------------------------------------------------
+// mu-law  (wavenet/ops.py:65-85)
+//
+// Bit-exactness: ops.py:65-73 is a float32 chain whose only non-IEEE-exact
+// step is log().  The chain is DEFINED here with the correctly rounded
+// float32 log (double log rounded once).  encode() is a monotone step
+// function of x on [-1,1], so the device encodes by binary search over the
+// Q-1 float32 decision thresholds of that chain (built once on the host by
+// wn_mu_law_thresholds_host) -- exact by construction, independent of the
+// device's logf.  |x| > 1 (outside the table) evaluates the chain itself.
+// ---------------------------------------------------------------------------
+#pragma clang fp contract(off)
+static inline int mu_chain_host(float x, int Q) {
+  const float mu = (float)(Q - 1);
+  const float ax = std::fabs(x);
+  const float arg = 1.0f + mu * ax;
+  const float num = (float)std::log((double)arg);
+  const float den = (float)std::log((double)(1.0f + mu));
+  const float mag = num / den;
+  const float sgn = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
+  float v = sgn * mag;
+  v = v + 1.0f;
+  v = v / 2.0f;
+  v = v * mu;
+  v = v + 0.5f;
+  return (int)v;
+}
+
+static inline uint32_t f2key(float f) {
+  uint32_t u;
+  __builtin_memcpy(&u, &f, 4);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+static inline float key2f(uint32_t k) {
+  uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+  float f;
+  __builtin_memcpy(&f, &u, 4);
+  return f;
+}
+
+__device__ __forceinline__ int mu_chain_dev(float x, int Q) {
+  // same chain on the device for |x| > 1; double log keeps it within the
+  // definition above (OCML double log, rounded once to float).
+  const float mu = (float)(Q - 1);
+  const float arg = __fadd_rn(1.0f, __fmul_rn(mu, fabsf(x)));
+  const float num = (float)log((double)arg);
+  const float den = (float)log((double)__fadd_rn(1.0f, mu));
+  const float mag = __fdiv_rn(num, den);
+  const float sgn = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
+  float v = __fmul_rn(sgn, mag);
+  v = __fadd_rn(v, 1.0f);
+  v = __fdiv_rn(v, 2.0f);
+  v = __fmul_rn(v, mu);
+  v = __fadd_rn(v, 0.5f);
+  return (int)v;
+}
+
+__global__ void mu_law_encode_kernel(const float* __restrict__ audio,
+                                     int32_t* __restrict__ codes, long n,
+                                     const float* __restrict__ thr, int Q) {
+  extern __shared__ float sthr[];
+  for (int i = threadIdx.x; i < Q - 1; i += blockDim.x) sthr[i] = thr[i];
+  __syncthreads();
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
+       idx += (long)gridDim.x * blockDim.x) {
+    const float x = audio[idx];
+    int code;
+    if (x >= -1.f && x <= 1.f) {
+      int lo = 0, hi = Q - 1;  // count of thresholds <= x  (upper bound)
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (sthr[mid] <= x) lo = mid + 1; else hi = mid;
+      }
+      code = lo;
+    } else {
+      code = mu_chain_dev(x, Q);
+    }
+    codes[idx] = code;
+  }
+}
+
+__device__ __forceinline__ float mu_decode_dev(int code, int Q) {
+  const float mu = (float)(Q - 1);
+  const float s = __fsub_rn(__fmul_rn(2.0f, __fdiv_rn((float)code, mu)), 1.0f);
+  const float p = (float)pow((double)__fadd_rn(1.0f, mu), (double)fabsf(s));
+  const float mag = __fmul_rn(__fdiv_rn(1.0f, mu), __fsub_rn(p, 1.0f));
+  const float sgn = (s > 0.f) ? 1.f : ((s < 0.f) ? -1.f : 0.f);
+  return __fmul_rn(sgn, mag);
+}
+
+__global__ void mu_law_decode_kernel(const int32_t* __restrict__ codes,
+                                     float* __restrict__ audio, long n,
+                                     const float* __restrict__ lut, int Q) {
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
+       idx += (long)gridDim.x * blockDim.x) {
+    const int c = codes[idx];
+    audio[idx] = (c >= 0 && c < Q) ? lut[c] : mu_decode_dev(c, Q);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// causal layer on one-hot input == gather   (model.py:227-234, 518-531)
+//   x0[t] = Wc[0][q[t-1]] + Wc[1][q[t]]   (first term 0 at t = 0; an
+//   out-of-range code is an all-zero one-hot row)
+// Wc: [2][Q][32] (R padded to 32).  8 threads x 16 B per row.
+// ---------------------------------------------------------------------------
+__global__ void causal_gather_kernel(const int32_t* __restrict__ q,
+                                     const float* __restrict__ Wc,
+                                     float* __restrict__ x0, long rows, int T,
+                                     int Q) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long row = idx >> 3;
+  const int c4 = (idx & 7) * 4;
+  if (row >= rows) return;
+  const int t = (int)(row % T);
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (t >= 1) {
+    const int qp = q[row - 1];
+    if (qp >= 0 && qp < Q)
+      v = *reinterpret_cast<const f32x4*>(Wc + (long)qp * 32 + c4);
+  }
+  const int qc = q[row];
+  if (qc >= 0 && qc < Q)
+    v += *reinterpret_cast<const f32x4*>(Wc + ((long)Q + qc) * 32 + c4);
+  *reinterpret_cast<f32x4*>(x0 + row * 32 + c4) = v;
+}
+
+// ---------------------------------------------------------------------------
+// fused softmax cross-entropy, forward + backward   (model.py:654-666)
+// One wave per row.  target of row (b,t) = q[b][t+1]; the last row of every
+// clip has the all-zero label row the reference pads in (model.py:659): its
+// loss term is 0 but it stays in the mean's denominator, and with
+// tf_quirk != 0 it back-propagates softmax/(B*T) like TF's fused kernel
+// (backprop = softmax - labels).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void xent_kernel(
+    const float* __restrict__ logits, long ld, const int32_t* __restrict__ q,
+    float* __restrict__ dlogits, float* __restrict__ loss_partials, long rows,
+    int T, int Q, float inv_n, int tf_quirk) {
+  __shared__ float wsum[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float lsum = 0.f;
+  const long nwaves = (long)gridDim.x * 4;
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += nwaves) {
+    const float* lp = logits + row * ld;
+    const int t = (int)(row % T);
+    const int label = (t + 1 < T) ? q[row + 1] : -1;
+    const bool has_label = label >= 0 && label < Q;
+    float m = -INFINITY;
+    for (int c = lane * 4; c < Q; c += 256) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(lp + c);
+      m = fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float se = 0.f;
+    for (int c = lane * 4; c < Q; c += 256) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(lp + c);
+      se += expf(v[0] - m) + expf(v[1] - m) + expf(v[2] - m) + expf(v[3] - m);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) se += __shfl_xor(se, o);
+    const float lse = m + logf(se);
+    if (has_label && lane == 0) lsum += lse - lp[label];
+    const float inv_se = 1.f / se;
+    const bool back = has_label || tf_quirk;
+    if (dlogits) {
+      float* dp = dlogits + row * ld;
+      for (int c = lane * 4; c < Q; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(lp + c);
+        f32x4 g;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float p = back ? expf(v[e] - m) * inv_se : 0.f;
+          if (has_label && c + e == label) p -= 1.f;
+          g[e] = p * inv_n;
+        }
+        *reinterpret_cast<f32x4*>(dp + c) = g;
+      }
+    }
+  }
+  if (lane == 0) wsum[wave] = lsum;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    loss_partials[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+// softmax of ONE row in float64, cast to float32 (model.py:584-585, 620-621)
+__global__ void softmax64_row_kernel(const float* __restrict__ logits, int Q,
+                                     float* __restrict__ proba) {
+  __shared__ double red[256];
+  const int tid = threadIdx.x;
+  double m = -INFINITY;
+  for (int c = tid; c < Q; c += 256) m = fmax(m, (double)logits[c]);
+  red[tid] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] = fmax(red[tid], red[tid + s]);
+    __syncthreads();
+  }
+  m = red[0];
+  __syncthreads();
+  double se = 0.0;
+  for (int c = tid; c < Q; c += 256) se += exp((double)logits[c] - m);
+  red[tid] = se;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  se = red[0];
+  for (int c = tid; c < Q; c += 256)
+    proba[c] = (float)(exp((double)logits[c] - m) / se);
+}
+
+// ---------------------------------------------------------------------------
+// optimizers, TensorFlow-0.10 update rules (wavenet/ops.py:6-24)
+//   g' = g * grad_scale + l2 * p * (l2_mask ? l2_mask[i] : 1)
+// ---------------------------------------------------------------------------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                            float* __restrict__ m, float* __restrict__ v,
+                            long n, float lr_t, float b1, float b2, float eps,
+                            float grad_scale, float l2,
+                            const float* __restrict__ l2_mask) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long)gridDim.x * blockDim.x) {
+    const float w = p[i];
+    float gg = g[i] * grad_scale;
+    if (l2 != 0.f) gg += l2 * w * (l2_mask ? l2_mask[i] : 1.f);
+    const float mm = b1 * m[i] + (1.f - b1) * gg;
+    const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
+    m[i] = mm;
+    v[i] = vv;
+    p[i] = w - lr_t * mm / (sqrtf(vv) + eps);
+  }
+}
+
+__global__ void momentum_kernel(float* __restrict__ p,
+                                const float* __restrict__ g,
+                                float* __restrict__ acc, long n, float lr,
+                                float mom, float grad_scale, float l2,
+                                const float* __restrict__ l2_mask) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long)gridDim.x * blockDim.x) {
+    const float w = p[i];
+    float gg = g[i] * grad_scale;
+    if (l2 != 0.f) gg += l2 * w * (l2_mask ? l2_mask[i] : 1.f);
+    const float a = mom * acc[i] + gg;
+    acc[i] = a;
+    p[i] = w - lr * a;
+  }
+}
+
+__global__ void rmsprop_kernel(float* __restrict__ p,
+                               const float* __restrict__ g,
+                               float* __restrict__ ms, float* __restrict__ mo,
+                               long n, float lr, float decay, float mom,
+                               float eps, float grad_scale, float l2,
+                               const float* __restrict__ l2_mask) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long)gridDim.x * blockDim.x) {
+    const float w = p[i];
+    float gg = g[i] * grad_scale;
+    if (l2 != 0.f) gg += l2 * w * (l2_mask ? l2_mask[i] : 1.f);
+    const float s = decay * ms[i] + (1.f - decay) * gg * gg;
+    const float mm = mom * mo[i] + lr * gg / sqrtf(s + eps);
+    ms[i] = s;
+    mo[i] = mm;
+    p[i] = w - mm;
+  }
+}
+
+// sum of squares / 2 (tf.nn.l2_loss) partials, with optional mask
+__global__ void l2_partials_kernel(const float* __restrict__ p, long n,
+                                   const float* __restrict__ mask,
+                                   float* __restrict__ partials) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long)gridDim.x * blockDim.x) {
+    const float w = p[i];
+    s += w * w * (mask ? mask[i] : 1.f);
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partials[blockIdx.x] = 0.5f * red[0];
+}
+
+// ---------------------------------------------------------------------------
+// global conditioning   (model.py:272-284, 533-562)
+// The GC 1x1 conv of a [B,1,G] embedding broadcast over T is a per-(clip,
+// layer) bias:  bias_fg[l][b][0:32] = bf_l + emb[id_b] * Wgcf_l, [32:64] gate.
+// ---------------------------------------------------------------------------
+__global__ void gc_bias_kernel(const float* __restrict__ layer0, long layer_stride,
+                               long off_bias, long off_gc, int G,
+                               const float* __restrict__ emb, int card,
+                               const int32_t* __restrict__ ids,
+                               float* __restrict__ out, int B) {
+  const int l = blockIdx.x, b = blockIdx.y, c = threadIdx.x;  // c < 64
+  const float* blk = layer0 + (long)l * layer_stride;
+  float v = blk[off_bias + c];  // bf (0..31) then bg (32..63)
+  if (emb) {
+    const int id = ids[b];
+    if (id >= 0 && id < card) {
+      // Wgcf [G][32] at off_gc, Wgcg [G][32] at off_gc + G*32
+      const float* w = blk + off_gc + (c >= 32 ? (long)G * 32 : 0) + (c & 31);
+      const float* e = emb + (long)id * G;
+      for (int g = 0; g < G; ++g) v += e[g] * w[(long)g * 32];
+    }
+  }
+  out[((long)l * B + b) * 64 + c] = v;
+}
+
+// per-clip column sums of a plane: out[b][c] = sum_t P[b][t][c]
+__global__ void colsum_clip_kernel(const float* __restrict__ P, int T,
+                                   float* __restrict__ out, int out_stride) {
+  __shared__ float red[8][32];
+  const int b = blockIdx.x, c = threadIdx.x & 31, w = threadIdx.x >> 5;
+  const float* p = P + (long)b * T * 32;
+  float s = 0.f;
+  for (int t = w; t < T; t += 8) s += p[(long)t * 32 + c];
+  red[w][c] = s;
+  __syncthreads();
+  if (w == 0) {
+    float v = 0.f;
+    for (int k = 0; k < 8; ++k) v += red[k][c];
+    out[(long)b * out_stride + c] = v;
+  }
+}
+
+// dWgc_l = emb[ids]^T dsum_l ; demb[id_b] += sum_l dsum_l[b] Wgc_l^T
+// dsum: [L][B][64] (f | g).  grid.x = L (+1 block for the embedding rows).
+__global__ void gc_grad_kernel(const float* __restrict__ layer0, long layer_stride,
+                               long off_gc, int G, const float* __restrict__ emb,
+                               int card, const int32_t* __restrict__ ids,
+                               const float* __restrict__ dsum, int L, int B,
+                               float* __restrict__ glayer0,
+                               float* __restrict__ gemb) {
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x < L) {
+    const int l = blockIdx.x;
+    float* gw = glayer0 + (long)l * layer_stride + off_gc;
+    for (int e = tid; e < 2 * G * 32; e += blockDim.x) {
+      const int which = e / (G * 32), g = (e / 32) % G, c = e & 31;
+      float s = 0.f;
+      for (int b = 0; b < B; ++b) {
+        const int id = ids[b];
+        if (id < 0 || id >= card) continue;
+        s += emb[(long)id * G + g] * dsum[((long)l * B + b) * 64 + which * 32 + c];
+      }
+      gw[e] = s;
+    }
+  } else {
+    // embedding rows: serial over clips (deterministic when ids repeat)
+    for (int e = tid; e < card * G; e += blockDim.x) gemb[e] = 0.f;
+    __syncthreads();
+    for (int b = 0; b < B; ++b) {
+      const int id = ids[b];
+      if (id < 0 || id >= card) continue;
+      for (int g = tid; g < G; g += blockDim.x) {
+        float s = 0.f;
+        for (int l = 0; l < L; ++l) {
+          const float* w = layer0 + (long)l * layer_stride + off_gc;
+          const float* ds = dsum + ((long)l * B + b) * 64;
+          for (int c = 0; c < 32; ++c)
+            s += ds[c] * w[(long)g * 32 + c] +
+                 ds[32 + c] * w[(long)(G + g) * 32 + c];
+        }
+        gemb[(long)id * G + g] += s;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// thin exported ops (wavenet/__init__.py:1-4), arbitrary shapes, not hot
+// ---------------------------------------------------------------------------
+__global__ void causal_conv_kernel(const float* __restrict__ x,
+                                   const float* __restrict__ w,
+                                   float* __restrict__ y, int B, int T, int Cin,
+                                   int Cout, int K, int d) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * T * Cout;
+  if (idx >= total) return;
+  const int co = (int)(idx % Cout);
+  const long bt = idx / Cout;
+  const int t = (int)(bt % T);
+  const long b = bt / T;
+  float acc = 0.f;
+  for (int k = 0; k < K; ++k) {
+    // ops.py:46-62 closed form incl. TF 'SAME' centring for K > 2
+    const long shift = (long)(K - 1 - k + (K - 1) / 2) * d;
+    if (t - shift < 0) continue;
+    const float* xr = x + ((b * T) + (t - shift)) * Cin;
+    const float* wk = w + (long)k * Cin * Cout + co;
+    for (int ci = 0; ci < Cin; ++ci) acc += xr[ci] * wk[(long)ci * Cout];
+  }
+  y[idx] = acc;
+}
+
+// time_to_batch (ops.py:27-34): out[(p*B + b), u, c] = in[b, u*d + p, c] (0 pad)
+__global__ void time_to_batch_kernel(const float* __restrict__ in,
+                                     float* __restrict__ out, int B, int T,
+                                     int C, int d, int U) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * d * U * C;
+  if (idx >= total) return;
+  const int c = (int)(idx % C);
+  long r = idx / C;
+  const int u = (int)(r % U);
+  r /= U;  // r = p*B + b
+  const int b = (int)(r % B), p = (int)(r / B);
+  const long t = (long)u * d + p;
+  out[idx] = t < T ? in[((long)b * T + t) * C + c] : 0.f;
+}
+
+// batch_to_time (ops.py:37-43): out[b, u*d + p, c] = in[(p*B + b), u, c]
+__global__ void batch_to_time_kernel(const float* __restrict__ in,
+                                     float* __restrict__ out, int B, int U,
+                                     int C, int d) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * d * U * C;
+  if (idx >= total) return;
+  const int c = (int)(idx % C);
+  long r = idx / C;
+  const int tt = (int)(r % ((long)U * d));
+  const int b = (int)(r / ((long)U * d));
+  const int u = tt / d, p = tt % d;
+  out[idx] = in[(((long)p * B + b) * U + u) * C + c];
+}
+
+// y += a * x * (mask ? mask : 1)   (gradient of the L2 term, model.py:674-680)
+__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x,
+                            float a, const float* __restrict__ mask, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long)gridDim.x * blockDim.x)
+    y[i] += a * x[i] * (mask ? mask[i] : 1.f);
+}
+
+__global__ void fill_kernel(float* __restrict__ p, long n, float v) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long)gridDim.x * blockDim.x)
+    p[i] = v;
+}
+
+// sum over layers of the skip biases (epilogue bias of the skip GEMM)
+__global__ void sum_rows_kernel(const float* __restrict__ in, int rows, int n,
+                                float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  float s = 0.f;
+  for (int r = 0; r < rows; ++r) s += in[(long)r * n + c];
+  out[c] = s;
+}
+
+static inline int grid1d(long n, int block, int cap = 2048) {
+  long g = (n + block - 1) / block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+extern "C" {
+
+int wn_version(void) { return 100; }
+
+const char* wn_error_string(int code) {
+  switch (code) {
+    case WN_OK: return "ok";
+    case WN_ERR_BAD_SHAPE: return "bad shape";
+    case WN_ERR_UNSUPPORTED: return "unsupported configuration";
+    case WN_ERR_MISALIGNED: return "pointer or leading dimension not 16-byte aligned";
+    case WN_ERR_LAUNCH: return "kernel launch failed";
+    case WN_ERR_NULL: return "null pointer";
+    default: return "unknown error";
+  }
+}
+
+int wn_mu_law_thresholds_host(int Q, float* thr_out) {
+  if (!thr_out) return WN_ERR_NULL;
+  if (Q < 2) return WN_ERR_BAD_SHAPE;
+  const uint32_t lo0 = f2key(-1.0f), hi0 = f2key(1.0f);
+  for (int k = 1; k < Q; ++k) {
+    uint32_t lo = lo0, hi = hi0;
+    if (mu_chain_host(key2f(lo), Q) >= k) { thr_out[k - 1] = key2f(lo); continue; }
+    while (hi - lo > 1) {
+      const uint32_t mid = lo + (hi - lo) / 2;
+      if (mu_chain_host(key2f(mid), Q) >= k) hi = mid; else lo = mid;
+    }
+    thr_out[k - 1] = key2f(hi);
+  }
+  return WN_OK;
+}
+
+int wn_mu_law_decode_table_host(int Q, float* lut_out) {
+  if (!lut_out) return WN_ERR_NULL;
+  if (Q < 2) return WN_ERR_BAD_SHAPE;
+  const float mu = (float)(Q - 1);
+  for (int c = 0; c < Q; ++c) {
+    float s = (float)c / mu;
+    s = 2.0f * s;
+    s = s - 1.0f;
+    const float p = (float)std::pow((double)(1.0f + mu), (double)std::fabs(s));
+    float mag = 1.0f / mu;
+    const float pm1 = p - 1.0f;
+    mag = mag * pm1;
+    const float sgn = (s > 0.f) ? 1.f : ((s < 0.f) ? -1.f : 0.f);
+    lut_out[c] = sgn * mag;
+  }
+  return WN_OK;
+}
+
+int wn_mu_law_encode(const float* audio, int32_t* codes, long n,
+                     const float* thr_dev, int Q, void* stream) {
+  if (!audio || !codes || !thr_dev) return WN_ERR_NULL;
+  if (n <= 0 || Q < 2 || Q > 8192) return WN_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(mu_law_encode_kernel, dim3(grid1d(n, 256)), dim3(256),
+                     (Q - 1) * sizeof(float), (hipStream_t)stream, audio, codes,
+                     n, thr_dev, Q);
+  return wn_check_launch();
+}
+
+int wn_mu_law_decode(const int32_t* codes, float* audio, long n,
+                     const float* lut_dev, int Q, void* stream) {
+  if (!audio || !codes || !lut_dev) return WN_ERR_NULL;
+  if (n <= 0 || Q < 2) return WN_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(mu_law_decode_kernel, dim3(grid1d(n, 256)), dim3(256), 0,
+                     (hipStream_t)stream, codes, audio, n, lut_dev, Q);
+  return wn_check_launch();
+}
+
+int wn_causal_gather(const int32_t* q, const float* Wc, float* x0, int B,
+                     int T, int Q, void* stream) {
+  if (!q || !Wc || !x0) return WN_ERR_NULL;
+  if (B <= 0 || T <= 0 || Q <= 0) return WN_ERR_BAD_SHAPE;
+  if (!wn_aligned16(Wc) || !wn_aligned16(x0)) return WN_ERR_MISALIGNED;
+  const long rows = (long)B * T;
+  const long threads = rows * 8;
+  hipLaunchKernelGGL(causal_gather_kernel, dim3((unsigned)((threads + 255) / 256)),
+                     dim3(256), 0, (hipStream_t)stream, q, Wc, x0, rows, T, Q);
+  return wn_check_launch();
+}
+
+int wn_xent_partials(long rows) {
+  long g = (rows + 3) / 4;
+  if (g > 1024) g = 1024;
+  return (int)g;
+}
+
+int wn_xent(const float* logits, long ld, const int32_t* q, float* dlogits,
+            float* loss_partials, int B, int T, int Q, int tf_quirk,
+            void* stream) {
+  if (!logits || !q || !loss_partials) return WN_ERR_NULL;
+  if (B <= 0 || T <= 0 || Q <= 0) return WN_ERR_BAD_SHAPE;
+  if ((Q & 3) || (ld & 3)) return WN_ERR_UNSUPPORTED;
+  if (!wn_aligned16(logits) || (dlogits && !wn_aligned16(dlogits)))
+    return WN_ERR_MISALIGNED;
+  const long rows = (long)B * T;
+  const float inv_n = 1.0f / (float)rows;
+  hipLaunchKernelGGL(xent_kernel, dim3(wn_xent_partials(rows)), dim3(256), 0,
+                     (hipStream_t)stream, logits, ld, q, dlogits,
+                     loss_partials, rows, T, Q, inv_n, tf_quirk);
+  return wn_check_launch();
+}
+
+int wn_softmax64_row(const float* logits_row, int Q, float* proba,
+                     void* stream) {
+  if (!logits_row || !proba) return WN_ERR_NULL;
+  if (Q <= 0) return WN_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(softmax64_row_kernel, dim3(1), dim3(256), 0,
+                     (hipStream_t)stream, logits_row, Q, proba);
+  return wn_check_launch();
+}
+
+int wn_adam(float* p, const float* g, float* m, float* v, long n, float lr_t,
+            float beta1, float beta2, float eps, float grad_scale, float l2,
+            const float* l2_mask, void* stream) {
+  if (!p || !g || !m || !v) return WN_ERR_NULL;
+  if (n <= 0) return WN_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(adam_kernel, dim3(grid1d(n, 256)), dim3(256), 0,
+                     (hipStream_t)stream, p, g, m, v, n, lr_t, beta1, beta2,
+                     eps, grad_scale, l2, l2_mask);
+  return wn_check_launch();
+}
+
+int wn_momentum(float* p, const float* g, float* acc, long n, float lr,
+                float momentum, float grad_scale, float l2,
+                const float* l2_mask, void* stream) {
+  if (!p || !g || !acc) return WN_ERR_NULL;
+  if (n <= 0) return WN_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(momentum_kernel, dim3(grid1d(n, 256)), dim3(256), 0,
+                     (hipStream_t)stream, p, g, acc, n, lr, momentum,
+                     grad_scale, l2, l2_mask);
+  return wn_check_launch();
+}
+
+int wn_rmsprop(float* p, const float* g, float* ms, float* mom, long n,
+               float lr, float decay, float momentum, float eps,
+               float grad_scale, float l2, const float* l2_mask,
+               void* stream) {
+  if (!p || !g || !ms || !mom) return WN_ERR_NULL;
+  if (n <= 0) return WN_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(rmsprop_kernel, dim3(grid1d(n, 256)), dim3(256), 0,
+                     (hipStream_t)stream, p, g, ms, mom, n, lr, decay,
+                     momentum, eps, grad_scale, l2, l2_mask);
+  return wn_check_launch();
+}
+
+int wn_l2_partials_count(void) { return 256; }
+
+int wn_l2_partials(const float* p, long n, const float* mask, float* partials,
+                   void* stream) {
+  if (!p || !partials) return WN_ERR_NULL;
+  if (n <= 0) return WN_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(l2_partials_kernel, dim3(256), dim3(256), 0,
+                     (hipStream_t)stream, p, n, mask, partials);
+  return wn_check_launch();
+}
+
+int wn_gc_bias(const float* layer0, long layer_stride, long off_bias,
+               long off_gc, int G, const float* emb, int card,
+               const int32_t* ids, float* out, int L, int B, void* stream) {
+  if (!layer0 || !out) return WN_ERR_NULL;
+  if (emb && !ids) return WN_ERR_NULL;
+  if (L <= 0 || B <= 0) return WN_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(gc_bias_kernel, dim3(L, B), dim3(64), 0,
+                     (hipStream_t)stream, layer0, layer_stride, off_bias,
+                     off_gc, G, emb, card, ids, out, B);
+  return wn_check_launch();
+}
+
+int wn_colsum_clip(const float* plane, int B, int T, float* out,
+                   int out_stride, void* stream) {
+  if (!plane || !out) return WN_ERR_NULL;
+  if (B <= 0 || T <= 0) return WN_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(colsum_clip_kernel, dim3(B), dim3(256), 0,
+                     (hipStream_t)stream, plane, T, out, out_stride);
+  return wn_check_launch();
+}
+
+int wn_gc_grad(const float* layer0, long layer_stride, long off_gc, int G,
+               const float* emb, int card, const int32_t* ids,
+               const float* dsum, int L, int B, float* glayer0, float* gemb,
+               void* stream) {
+  if (!layer0 || !emb || !ids || !dsum || !glayer0 || !gemb) return WN_ERR_NULL;
+  if (L <= 0 || B <= 0 || G <= 0 || card <= 0) return WN_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(gc_grad_kernel, dim3(L + 1), dim3(256), 0,
+                     (hipStream_t)stream, layer0, layer_stride, off_gc, G, emb,
+                     card, ids, dsum, L, B, glayer0, gemb);
+  return wn_check_launch();
+}
+
+int wn_causal_conv(const float* x, const float* w, float* y, int B, int T,
+                   int Cin, int Cout, int K, int dilation, void* stream) {
+  if (!x || !w || !y) return WN_ERR_NULL;
+  if (B <= 0 || T <= 0 || Cin <= 0 || Cout <= 0 || K <= 0 || dilation <= 0)
+    return WN_ERR_BAD_SHAPE;
+  const long total = (long)B * T * Cout;
+  hipLaunchKernelGGL(causal_conv_kernel, dim3((unsigned)((total + 255) / 256)),
+                     dim3(256), 0, (hipStream_t)stream, x, w, y, B, T, Cin,
+                     Cout, K, dilation);
+  return wn_check_launch();
+}
+
+int wn_time_to_batch(const float* in, float* out, int B, int T, int C,
+                     int dilation, void* stream) {
+  if (!in || !out) return WN_ERR_NULL;
+  if (B <= 0 || T <= 0 || C <= 0 || dilation <= 0) return WN_ERR_BAD_SHAPE;
+  const int U = (T + dilation - 1) / dilation;
+  const long total = (long)B * dilation * U * C;
+  hipLaunchKernelGGL(time_to_batch_kernel, dim3((unsigned)((total + 255) / 256)),
+                     dim3(256), 0, (hipStream_t)stream, in, out, B, T, C,
+                     dilation, U);
+  return wn_check_launch();
+}
+
+int wn_batch_to_time(const float* in, float* out, int B_out, int U, int C,
+                     int dilation, void* stream) {
+  if (!in || !out) return WN_ERR_NULL;
+  if (B_out <= 0 || U <= 0 || C <= 0 || dilation <= 0) return WN_ERR_BAD_SHAPE;
+  const long total = (long)B_out * dilation * U * C;
+  hipLaunchKernelGGL(batch_to_time_kernel, dim3((unsigned)((total + 255) / 256)),
+                     dim3(256), 0, (hipStream_t)stream, in, out, B_out, U, C,
+                     dilation);
+  return wn_check_launch();
+}
+
+int wn_axpy(float* y, const float* x, float a, const float* mask, long n,
+            void* stream) {
+  if (!y || !x) return WN_ERR_NULL;
+  if (n <= 0) return WN_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(axpy_kernel, dim3(grid1d(n, 256)), dim3(256), 0,
+                     (hipStream_t)stream, y, x, a, mask, n);
+  return wn_check_launch();
+}
+
+int wn_fill(float* p, long n, float value, void* stream) {
+  if (!p) return WN_ERR_NULL;
+  if (n <= 0) return WN_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(fill_kernel, dim3(grid1d(n, 256)), dim3(256), 0,
+                     (hipStream_t)stream, p, n, value);
+  return wn_check_launch();
+}
+
+int wn_sum_rows(const float* in, int rows, int n, float* out, void* stream) {
+  if (!in || !out) return WN_ERR_NULL;
+  if (rows <= 0 || n <= 0) return WN_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(sum_rows_kernel, dim3((n + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, in, rows, n, out);
+  return wn_check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,128 @@
+"""ctypes binding of libwavenet_hip.so (include/wavenet_hip.h).
+
+The HIP library is THE compute path: there is no CPU or PyTorch fallback.
+If the shared object is missing or a call fails, this module raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'libwavenet_hip.so')
+
+c_int, c_long, c_float = ctypes.c_int, ctypes.c_long, ctypes.c_float
+c_void_p, c_u64 = ctypes.c_void_p, ctypes.c_uint64
+P = c_void_p  # every device / host pointer crosses as a raw address
+
+# name -> (restype, argtypes); mirrors include/wavenet_hip.h one to one
+SIGNATURES = {
+    'wn_version': (c_int, []),
+    'wn_error_string': (ctypes.c_char_p, [c_int]),
+    'wn_mu_law_thresholds_host': (c_int, [c_int, P]),
+    'wn_mu_law_decode_table_host': (c_int, [c_int, P]),
+    'wn_mu_law_encode': (c_int, [P, P, c_long, P, c_int, P]),
+    'wn_mu_law_decode': (c_int, [P, P, c_long, P, c_int, P]),
+    'wn_causal_gather': (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    'wn_layer_fwd': (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int,
+                             c_int, c_int, P]),
+    'wn_layer_bwd': (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int,
+                             c_int, c_int, c_int, P]),
+    'wn_layer_wgrad_slab_floats': (c_int, []),
+    'wn_layer_wgrad': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int,
+                               P]),
+    'wn_gemm_nn': (c_int, [P, c_long, c_int, c_long, P, c_int, P, P, c_long,
+                           P, c_long, P, c_long, c_int, c_long, P, c_long,
+                           c_int, c_int, c_int, P]),
+    'wn_gemm_tn_slab_floats': (c_long, [c_int, c_int]),
+    'wn_gemm_tn': (c_int, [P, c_long, c_int, c_long, P, c_int, c_int, P,
+                           c_long, P, c_int, c_long, c_int, c_int, c_int, P]),
+    'wn_reduce_slabs': (c_int, [P, c_int, c_long, c_int, c_long, c_long,
+                                c_long, P, c_long, c_int, c_long, P]),
+    'wn_transpose': (c_int, [P, c_int, c_int, c_long, P, c_long, P]),
+    'wn_xent_partials': (c_int, [c_long]),
+    'wn_xent': (c_int, [P, c_long, P, P, P, c_int, c_int, c_int, c_int, P]),
+    'wn_softmax64_row': (c_int, [P, c_int, P, P]),
+    'wn_adam': (c_int, [P, P, P, P, c_long, c_float, c_float, c_float,
+                        c_float, c_float, c_float, P, P]),
+    'wn_momentum': (c_int, [P, P, P, c_long, c_float, c_float, c_float,
+                            c_float, P, P]),
+    'wn_rmsprop': (c_int, [P, P, P, P, c_long, c_float, c_float, c_float,
+                           c_float, c_float, c_float, P, P]),
+    'wn_l2_partials_count': (c_int, []),
+    'wn_l2_partials': (c_int, [P, c_long, P, P, P]),
+    'wn_gc_bias': (c_int, [P, c_long, c_long, c_long, c_int, P, c_int, P, P,
+                           c_int, c_int, P]),
+    'wn_colsum_clip': (c_int, [P, c_int, c_int, P, c_int, P]),
+    'wn_gc_grad': (c_int, [P, c_long, c_long, c_int, P, c_int, P, P, c_int,
+                           c_int, P, P, P]),
+    'wn_causal_conv': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int,
+                               c_int, P]),
+    'wn_time_to_batch': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    'wn_batch_to_time': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    'wn_axpy': (c_int, [P, P, c_float, P, c_long, P]),
+    'wn_fill': (c_int, [P, c_long, c_float, P]),
+    'wn_sum_rows': (c_int, [P, c_int, c_int, P, P]),
+    'wn_fastgen_state_floats': (c_long, [P, c_int]),
+    'wn_fastgen_init': (c_int, [P, c_long, P, c_int, P]),
+    'wn_fastgen_run': (c_int, [P, P, c_long, P, P, P, P, P, P, P, P, c_int,
+                               c_int, c_int, P, P, P, c_int, c_int, c_float,
+                               c_u64, P, c_int, c_int, c_int, P]),
+}
+
+_lib = None
+
+
+class WaveNetHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library (once).  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise WaveNetHipError(
+            'libwavenet_hip.so not found at %s: build it with '
+            '`python __graft_entry__.py build` (hipcc --offload-arch=gfx950). '
+            'There is no CPU fallback.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code, what=''):
+    if code != 0:
+        lib = load()
+        msg = lib.wn_error_string(int(code)).decode()
+        raise WaveNetHipError('%s failed: %s (code %d)' % (what, msg, code))
+
+
+def call(name, *args):
+    """Call an int-returning entry point and raise on a non-zero code."""
+    lib = load()
+    code = getattr(lib, name)(*args)
+    check(code, name)
+
+
+def ptr(t):
+    """Raw address of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise WaveNetHipError(
+            'no MI355X/ROCm device visible: the wavenet HIP path needs a GPU '
+            '(there is no CPU fallback)')

@@ -1,0 +1,774 @@
+"""WaveNetModel on MI355X: host-side mirror of the reference's
+wavenet/model.py::WaveNetModel (same constructor signature :46-60, same
+`variables` nesting/names/shapes :118-225, same public methods `loss` :628,
+`predict_proba` :564, `predict_proba_incremental` :592) driving hand-written
+HIP kernels through the C ABI of include/wavenet_hip.h.
+
+MI355X-first design:
+  * all parameters live in ONE flat fp32 device buffer (`params`), all
+    gradients in ONE flat bucket (`grads`) -> one RCCL all-reduce, one fused
+    optimizer launch; `variables[...]` are reference-shaped views into it;
+  * activations are [B*T][32] planes; each residual block is one fused MFMA
+    kernel; the 50 skip 1x1 convs are a single [B*T, L*32] x [L*32, S] GEMM;
+  * the one-hot input tensor is never materialised (causal layer = gather,
+    its weight gradient = one-hot-on-the-fly MFMA contraction);
+  * backward is hand-written (the reference relies on TF autodiff).
+There is no CPU / PyTorch compute fallback: without the HIP library or a GPU
+every entry point raises.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from .ops import mu_law_encode, mu_law_decode, mu_law_tables
+
+CH = 32                      # padded residual / dilation channels per plane
+LAYER_W = 5 * 1024           # Wf[2][32][32] Wg[2][32][32] Wd[32][32]
+OFF_BF, OFF_BG, OFF_BD = 5120, 5152, 5184
+LAYER_BLOCK = LAYER_W + 96
+OFF_GC = LAYER_BLOCK
+
+
+def _align(n, a=32):
+    return (n + a - 1) // a * a
+
+
+def _xavier_(t, gen):
+    """tf.contrib.layers.xavier_initializer_conv2d (uniform), model.py:10:
+    limit sqrt(6 / (fan_in + fan_out)) with the receptive field folded in."""
+    shape = tuple(t.shape)
+    rf = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
+    lim = math.sqrt(6.0 / (rf * shape[-2] + rf * shape[-1]))
+    vals = (torch.rand(shape, generator=gen, dtype=torch.float32) * 2 - 1) * lim
+    t.copy_(vals.to(t.device))
+
+
+def _tn_tiles(mw, nw):
+    m32, n32 = (mw + 31) // 32, (nw + 31) // 32
+    nf = 2 if n32 % 2 == 0 else 1
+    mf = 5 if m32 % 5 == 0 else 4 if m32 % 4 == 0 else 2 if m32 % 2 == 0 else 1
+    return ((m32 + mf - 1) // mf) * ((n32 + nf - 1) // nf)
+
+
+def _tn_splits(rows, mw, nw, target_wgs=1024):
+    wgs = (_tn_tiles(mw, nw) + 3) // 4
+    s = max(1, target_wgs // wgs)
+    s = min(s, max(1, rows // 64))
+    return int(s)
+
+
+class _Workspace(object):
+    """Caller-owned device buffers for one (B, T) shape (the library never
+    allocates).  Sized for 288 GB HBM: everything stays resident."""
+
+    def __init__(self, net, B, T, training):
+        dev = net.device
+        L, S, Q = net.L, net.S, net.Q
+        N = B * T
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.B, self.T, self.N, self.training = B, T, N, training
+        self.q = torch.empty(N, dtype=torch.int32, device=dev)
+        self.X = torch.empty((L, N, CH), **f32)
+        self.Z = torch.empty((L, N, CH), **f32)
+        self.h1 = torch.empty((N, S), **f32)
+        self.h2 = torch.empty((N, S), **f32)
+        self.logits = torch.empty((N, Q), **f32)
+        self.bias_fg = torch.empty((L, B, 64), **f32)
+        self.bsum = torch.empty(S, **f32)
+        self.total = torch.empty((N, S), **f32) if net.residual_postproc else None
+        self.nparts = _lib.load().wn_xent_partials(N)
+        self.loss_parts = torch.empty(self.nparts, **f32)
+        self.loss = torch.zeros(1, **f32)
+        self.proba = torch.empty(Q, **f32)
+        if not training:
+            return
+        self.TH = torch.empty((L, N, CH), **f32)
+        self.SG = torch.empty((L, N, CH), **f32)
+        self.dZ = torch.empty((L, N, CH), **f32)
+        self.dc1 = torch.empty((N, S), **f32)
+        self.dtotal = torch.empty((N, S), **f32)
+        self.dh2 = torch.empty((N, S), **f32) if net.residual_postproc else None
+        self.c1 = torch.empty((N, S), **f32) if net.residual_postproc else None
+        self.da = torch.empty((2, 2, N, CH), **f32)   # [pingpong][f|g]
+        self.dx = torch.empty((2, N, CH), **f32)
+        self.w2t = torch.empty((Q, S), **f32)
+        self.w1t = torch.empty((S, S), **f32)
+        self.wst = torch.empty((S, L * CH), **f32)
+        ntiles = B * ((T + 31) // 32)
+        self.nslab = max(1, min(256, ntiles // 4))
+        self.lslabs = torch.empty((L, self.nslab, LAYER_BLOCK), **f32)
+        lib = _lib.load()
+        need = 0
+        self.splits = {}
+        for key, (mw, nw) in dict(post2=(S, Q), post1=(S, S), skip=(L * CH, S),
+                                  causal=(Q, CH)).items():
+            sp = _tn_splits(N, mw, nw)
+            self.splits[key] = sp
+            need = max(need, sp * lib.wn_gemm_tn_slab_floats(mw, nw))
+        self.slabs = torch.empty(need, **f32)
+        self.dsum = torch.empty((L, B, 64), **f32) if net.G else None
+        self.l2_parts = torch.empty(lib.wn_l2_partials_count(), **f32)
+        self.l2 = torch.zeros(1, **f32)
+
+
+class WaveNetModel(object):
+    '''Implements the WaveNet network for generative audio (MI355X / HIP).
+
+    Usage mirrors the reference (model.py:31-44):
+        net = WaveNetModel(batch_size, dilations, filter_width,
+                           residual_channels, dilation_channels, skip_channels)
+        loss = net.loss(input_batch)          # forward + backward on the GPU
+        optimizer.minimize(loss)              # fused TF-rule update
+    '''
+
+    def __init__(self,
+                 batch_size,
+                 dilations,
+                 filter_width,
+                 residual_channels,
+                 dilation_channels,
+                 skip_channels,
+                 quantization_channels=2**8,
+                 use_biases=False,
+                 scalar_input=False,
+                 initial_filter_width=32,
+                 histograms=False,
+                 global_condition_channels=None,
+                 global_condition_cardinality=None,
+                 residual_postproc=False,
+                 device=None,
+                 seed=0):
+        self.batch_size = batch_size
+        self.dilations = list(dilations)
+        self.filter_width = filter_width
+        self.residual_channels = residual_channels
+        self.dilation_channels = dilation_channels
+        self.quantization_channels = quantization_channels
+        self.use_biases = use_biases
+        self.skip_channels = skip_channels
+        self.scalar_input = scalar_input
+        self.initial_filter_width = initial_filter_width
+        self.histograms = histograms
+        self.global_condition_channels = global_condition_channels
+        self.global_condition_cardinality = global_condition_cardinality
+        self.residual_postproc = residual_postproc
+        # TF's fused softmax-xent back-propagates softmax/(B*T) through the
+        # all-zero-label last row of every clip [inferred].
+        self.tf_xent_zero_label_quirk = True
+        # model.py:28 passes the bias *name* as `trainable`, so the reference's
+        # L2 filter "'bias' in v.name" (model.py:676) does not exclude biases.
+        self.tf_bias_name_quirk = True
+
+        _lib.load()
+        _lib.require_gpu()
+        self.device = torch.device(
+            'cuda', torch.cuda.current_device()) if device is None \
+            else torch.device(device)
+        self.L, self.S, self.Q = len(self.dilations), skip_channels, \
+            quantization_channels
+        self.R, self.D = residual_channels, dilation_channels
+        self.G = global_condition_channels
+        self.card = global_condition_cardinality
+        self._unsupported = None
+        if filter_width != 2:
+            self._unsupported = ('filter_width != 2 is not on the HIP path yet '
+                                 '(SURVEY 8f-4)')
+        elif scalar_input:
+            self._unsupported = ('scalar_input is not on the HIP path yet '
+                                 '(SURVEY 8f-4)')
+        elif self.R > CH or self.D > CH:
+            self._unsupported = 'residual/dilation channels > 32 not supported yet'
+        elif self.S % 4 or self.Q % 4:
+            self._unsupported = 'skip/quantization channels must be multiples of 4'
+        elif self.G is not None and self.card is None:
+            self._unsupported = ('dense-vector global conditioning cannot run in '
+                                 'the reference either (model.py:547,553)')
+        self._ws = {}
+        self._gen = None
+        self.init_ops = []
+        self.push_ops = []
+        self.variables = self._create_variables(seed)
+
+    # ------------------------------------------------------------------ params
+    def _create_variables(self, seed):
+        '''Creates all variables (model.py:118-225) as views into one flat
+        buffer; same nesting, keys and [K, Cin, Cout] shapes as the reference.'''
+        L, S, Q, R, D, G, card = (self.L, self.S, self.Q, self.R, self.D,
+                                  self.G, self.card)
+        if self._unsupported:
+            self.params = torch.zeros(4, device=self.device)
+            self.grads = torch.zeros(4, device=self.device)
+            return {}
+        self.layer_stride = LAYER_BLOCK + (2 * G * CH if G else 0)
+        seg, off = {}, 0
+        def add(name, n):
+            nonlocal off
+            seg[name] = (off, n)
+            off = _align(off + n)
+        if card is not None:
+            add('emb', card * G)
+        add('causal', 2 * Q * CH)
+        add('layers', L * self.layer_stride)
+        add('skip_w', L * CH * S)
+        add('skip_b', L * S)
+        add('post1_w', S * S)
+        add('post2_w', S * Q)
+        add('post1_b', S)
+        add('post2_b', Q)
+        self.segments = seg
+        self.params = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.grads = torch.zeros_like(self.params)
+        self.variables = self._views(self.params)
+        self.gradients = self._views(self.grads)
+        self._init_variables(seed)
+        return self.variables
+
+    def _seg(self, flat, name):
+        o, n = self.segments[name]
+        return flat[o:o + n]
+
+    def _views(self, flat):
+        L, S, Q, R, D, G, card = (self.L, self.S, self.Q, self.R, self.D,
+                                  self.G, self.card)
+        var = dict()
+        if card is not None:
+            var['embeddings'] = {
+                'gc_embedding': self._seg(flat, 'emb').view(card, G)}
+        var['causal_layer'] = {
+            'filter': self._seg(flat, 'causal').view(2, Q, CH)[:, :, :R]}
+        layers = self._seg(flat, 'layers').view(L, self.layer_stride)
+        skw = self._seg(flat, 'skip_w').view(L, 1, CH, S)
+        skb = self._seg(flat, 'skip_b').view(L, S)
+        var['dilated_stack'] = []
+        for i in range(L):
+            blk = layers[i]
+            cur = dict()
+            cur['filter'] = blk[0:2048].view(2, CH, CH)[:, :R, :D]
+            cur['gate'] = blk[2048:4096].view(2, CH, CH)[:, :R, :D]
+            cur['dense'] = blk[4096:5120].view(1, CH, CH)[:, :D, :R]
+            cur['skip'] = skw[i][:, :D, :]
+            if G is not None:
+                gcf = blk[OFF_GC:OFF_GC + G * CH].view(1, G, CH)
+                gcg = blk[OFF_GC + G * CH:OFF_GC + 2 * G * CH].view(1, G, CH)
+                cur['gc_gateweights'] = gcg[:, :, :D]
+                cur['gc_filtweights'] = gcf[:, :, :D]
+            if self.use_biases:
+                cur['filter_bias'] = blk[OFF_BF:OFF_BF + D]
+                cur['gate_bias'] = blk[OFF_BG:OFF_BG + D]
+                cur['dense_bias'] = blk[OFF_BD:OFF_BD + R]
+                cur['skip_bias'] = skb[i]
+            var['dilated_stack'].append(cur)
+        post = dict()
+        post['postprocess1'] = self._seg(flat, 'post1_w').view(1, S, S)
+        post['postprocess2'] = self._seg(flat, 'post2_w').view(1, S, Q)
+        if self.use_biases:
+            post['postprocess1_bias'] = self._seg(flat, 'post1_b')
+            post['postprocess2_bias'] = self._seg(flat, 'post2_b')
+        var['postprocessing'] = post
+        return var
+
+    def _init_variables(self, seed):
+        gen = torch.Generator().manual_seed(int(seed))
+        v = self.variables
+        with torch.no_grad():
+            if self.card is not None:
+                e = v['embeddings']['gc_embedding']
+                if self.card == self.G:                      # model.py:16-19
+                    e.copy_(torch.eye(self.card, device=self.device))
+                else:
+                    _xavier_(e, gen)
+            _xavier_(v['causal_layer']['filter'], gen)
+            for cur in v['dilated_stack']:
+                for k in ['filter', 'gate', 'dense', 'skip', 'gc_gateweights',
+                          'gc_filtweights']:
+                    if k in cur:
+                        _xavier_(cur[k], gen)
+            _xavier_(v['postprocessing']['postprocess1'], gen)
+            _xavier_(v['postprocessing']['postprocess2'], gen)
+            # biases: zeros (model.py:27)
+
+    def named_variables(self, tree=None, prefix='wavenet'):
+        """(reference variable name, view) pairs, creation order."""
+        tree = self.variables if tree is None else tree
+        out = []
+        if 'embeddings' in tree:
+            out.append((prefix + '/embeddings/gc_embedding',
+                        tree['embeddings']['gc_embedding']))
+        out.append((prefix + '/causal_layer/filter',
+                    tree['causal_layer']['filter']))
+        order = ['filter', 'gate', 'dense', 'skip', 'gc_gateweights',
+                 'gc_filtweights', 'filter_bias', 'gate_bias', 'dense_bias',
+                 'skip_bias']
+        tfname = {'gc_gateweights': 'gc_gate', 'gc_filtweights': 'gc_filter',
+                  'skip_bias': 'slip_bias'}       # sic, model.py:183-204
+        for i, cur in enumerate(tree['dilated_stack']):
+            for k in order:
+                if k in cur:
+                    out.append(('%s/dilated_stack/layer%d/%s'
+                                % (prefix, i, tfname.get(k, k)), cur[k]))
+        for k in ['postprocess1', 'postprocess2', 'postprocess1_bias',
+                  'postprocess2_bias']:
+            if k in tree['postprocessing']:
+                out.append((prefix + '/postprocessing/' + k,
+                            tree['postprocessing'][k]))
+        return out
+
+    def state_dict(self):
+        return {n: v.detach().cpu().clone() for n, v in self.named_variables()}
+
+    def load_state_dict(self, sd):
+        with torch.no_grad():
+            for n, v in self.named_variables():
+                v.copy_(torch.as_tensor(sd[n]).to(self.device))
+        self._gen = None
+
+    def load_nested(self, tree):
+        """Load a nested dict shaped like `variables` (numpy / tensors)."""
+        def rec(dst, src):
+            if isinstance(dst, dict):
+                for k in dst:
+                    rec(dst[k], src[k])
+            elif isinstance(dst, list):
+                for a, b in zip(dst, src):
+                    rec(a, b)
+            else:
+                dst.copy_(torch.as_tensor(np.asarray(src),
+                                          dtype=torch.float32).to(self.device))
+        with torch.no_grad():
+            rec(self.variables, tree)
+        self._gen = None
+
+    # ------------------------------------------------------------------ helpers
+    def _check_supported(self):
+        if self._unsupported:
+            raise NotImplementedError(self._unsupported)
+
+    def _workspace(self, B, T, training):
+        key = (B, T)
+        ws = self._ws.get(key)
+        if ws is None or (training and not ws.training):
+            ws = _Workspace(self, B, T, training)
+            self._ws = {key: ws}      # keep one shape resident
+        return ws
+
+    def _gc_ids(self, global_condition, B):
+        if self.card is None or global_condition is None:
+            if self.G is not None and self.card is not None:
+                raise ValueError('model was built with global conditioning; '
+                                 'a global_condition id batch is required')
+            return None
+        ids = global_condition
+        if not isinstance(ids, torch.Tensor):
+            ids = torch.as_tensor(np.asarray(ids))
+        ids = ids.reshape(-1).to(device=self.device, dtype=torch.int32)
+        if ids.numel() != B:
+            raise ValueError('global_condition has %d ids, batch_size is %d'
+                             % (ids.numel(), B))
+        return ids.contiguous()
+
+    def _layer_block(self, flat, l):
+        o, _ = self.segments['layers']
+        return flat[o + l * self.layer_stride: o + (l + 1) * self.layer_stride]
+
+    def _bias_fg(self, ws_bias, ids, B):
+        """Per-(layer, clip) filter|gate bias (+ GC 1x1 conv of the broadcast
+        embedding, model.py:272-290).  Returns (tensor or None, clip stride)."""
+        if not self.use_biases and ids is None:
+            return None, 0
+        nb = B if ids is not None else 1
+        out = ws_bias.view(-1)[:self.L * nb * 64].view(self.L, nb, 64)
+        emb = self._seg(self.params, 'emb') if ids is not None else None
+        _lib.call('wn_gc_bias', _lib.ptr(self._layer_block(self.params, 0)),
+                  self.layer_stride, OFF_BF, OFF_GC, self.G or 0,
+                  _lib.ptr(emb), self.card or 0, _lib.ptr(ids), _lib.ptr(out),
+                  self.L, nb, _lib.stream())
+        return out, (64 if ids is not None else 0)
+
+    # ------------------------------------------------------------------ forward
+    def _forward(self, ws, ids, save_ts):
+        """_create_network (model.py:389-442) on codes ws.q -> ws.logits."""
+        st = _lib.stream()
+        B, T, N, L, S, Q = ws.B, ws.T, ws.N, self.L, self.S, self.Q
+        P = self.params
+        _lib.call('wn_causal_gather', _lib.ptr(ws.q),
+                  _lib.ptr(self._seg(P, 'causal')), _lib.ptr(ws.X[0]), B, T, Q,
+                  st)
+        bias, bstride = self._bias_fg(ws.bias_fg, ids, B)
+        for l, d in enumerate(self.dilations):
+            last = l == L - 1
+            _lib.call('wn_layer_fwd', _lib.ptr(ws.X[l]),
+                      None if last else _lib.ptr(ws.X[l + 1]),
+                      _lib.ptr(ws.Z[l]),
+                      _lib.ptr(ws.TH[l]) if save_ts else None,
+                      _lib.ptr(ws.SG[l]) if save_ts else None,
+                      _lib.ptr(self._layer_block(P, l)),
+                      None if bias is None else _lib.ptr(bias[l]), bstride,
+                      B, T, int(d), 0 if last else 1, 1 if save_ts else 0, st)
+        bsum = None
+        if self.use_biases:
+            _lib.call('wn_sum_rows', _lib.ptr(self._seg(P, 'skip_b')), L, S,
+                      _lib.ptr(ws.bsum), st)
+            bsum = ws.bsum
+        # total = sum_l z_l * Ws_l (+ sum_l bs_l); h1 = relu(total)
+        _lib.call('wn_gemm_nn', _lib.ptr(ws.Z), 0, L, N * CH,
+                  _lib.ptr(self._seg(P, 'skip_w')), S, _lib.ptr(bsum), None, 0,
+                  None, 0, _lib.ptr(ws.h1), S, 0, 0,
+                  _lib.ptr(ws.total) if self.residual_postproc else None,
+                  N, S, L * CH, 1, st)
+        b1 = self._seg(P, 'post1_b') if self.use_biases else None
+        b2 = self._seg(P, 'post2_b') if self.use_biases else None
+        rp = self.residual_postproc
+        _lib.call('wn_gemm_nn', _lib.ptr(ws.h1), S, 0, 0,
+                  _lib.ptr(self._seg(P, 'post1_w')), S, _lib.ptr(b1), None, 0,
+                  _lib.ptr(ws.total) if rp else None, S, _lib.ptr(ws.h2), S, 0,
+                  0, _lib.ptr(ws.c1) if (rp and ws.training) else None,
+                  N, S, S, 1, st)
+        _lib.call('wn_gemm_nn', _lib.ptr(ws.h2), S, 0, 0,
+                  _lib.ptr(self._seg(P, 'post2_w')), Q, _lib.ptr(b2), None, 0,
+                  None, 0, _lib.ptr(ws.logits), Q, 0, 0, None, N, Q, S, 0, st)
+
+    # ------------------------------------------------------------------ backward
+    def _backward(self, ws, ids):
+        """Hand-written gradient of loss() (the reference uses TF autodiff of
+        model.py:628-685).  Consumes ws.logits == dlogits (in place)."""
+        st = _lib.stream()
+        B, T, N, L, S, Q = ws.B, ws.T, ws.N, self.L, self.S, self.Q
+        P, Gr = self.params, self.grads
+        ub = 1 if self.use_biases else 0
+        rp = self.residual_postproc
+        dlog = ws.logits
+        lib = _lib.load()
+
+        def tn(A, lda, a_planes, a_pstride, codes, shift, Gm, ldg, key, mw, nw,
+               dst, dst_bias, replicate=1, rep_stride=0):
+            sp = ws.splits[key]
+            sl = lib.wn_gemm_tn_slab_floats(mw, nw)
+            _lib.call('wn_gemm_tn', A, lda, a_planes, a_pstride, codes, shift,
+                      T, Gm, ldg, _lib.ptr(ws.slabs), sp, N, mw, nw, ub, st)
+            _lib.call('wn_reduce_slabs', _lib.ptr(ws.slabs), sp, sl, 1, 0, 0,
+                      mw * nw, dst, 0, 1, 0, st)
+            if ub and dst_bias is not None:
+                _lib.call('wn_reduce_slabs', _lib.ptr(ws.slabs), sp, sl, 1, 0,
+                          mw * nw, nw, dst_bias, 0, replicate, rep_stride, st)
+
+        # postprocess2:  dW2 = h2^T dlogits ; dh2 = dlogits W2^T
+        tn(_lib.ptr(ws.h2), S, 0, 0, None, 0, _lib.ptr(dlog), Q, 'post2', S, Q,
+           _lib.ptr(self._seg(Gr, 'post2_w')),
+           _lib.ptr(self._seg(Gr, 'post2_b')))
+        _lib.call('wn_transpose', _lib.ptr(self._seg(P, 'post2_w')), S, Q, Q,
+                  _lib.ptr(ws.w2t), S, st)
+        # dc1 = dh2 * [c1 > 0]   (h2 = relu(c1) (+ total))
+        _lib.call('wn_gemm_nn', _lib.ptr(dlog), Q, 0, 0, _lib.ptr(ws.w2t), S,
+                  None, _lib.ptr(ws.c1 if rp else ws.h2), S, None, 0,
+                  _lib.ptr(ws.dc1), S, 0, 0, _lib.ptr(ws.dh2) if rp else None,
+                  N, S, Q, 0, st)
+        # postprocess1
+        tn(_lib.ptr(ws.h1), S, 0, 0, None, 0, _lib.ptr(ws.dc1), S, 'post1', S,
+           S, _lib.ptr(self._seg(Gr, 'post1_w')),
+           _lib.ptr(self._seg(Gr, 'post1_b')))
+        _lib.call('wn_transpose', _lib.ptr(self._seg(P, 'post1_w')), S, S, S,
+                  _lib.ptr(ws.w1t), S, st)
+        # dtotal = (dc1 W1^T) * [total > 0] (+ dh2 when residual_postproc)
+        _lib.call('wn_gemm_nn', _lib.ptr(ws.dc1), S, 0, 0, _lib.ptr(ws.w1t), S,
+                  None, _lib.ptr(ws.h1), S, _lib.ptr(ws.dh2) if rp else None,
+                  S, _lib.ptr(ws.dtotal), S, 0, 0, None, N, S, S, 0, st)
+        # skip convs: dWs_all = Z^T dtotal ; dbs_l = colsum(dtotal) for every l
+        tn(_lib.ptr(ws.Z), 0, L, N * CH, None, 0, _lib.ptr(ws.dtotal), S,
+           'skip', L * CH, S, _lib.ptr(self._seg(Gr, 'skip_w')),
+           _lib.ptr(self._seg(Gr, 'skip_b')), replicate=L, rep_stride=S)
+        # dZ planes = dtotal Ws_all^T
+        _lib.call('wn_transpose', _lib.ptr(self._seg(P, 'skip_w')), L * CH, S,
+                  S, _lib.ptr(ws.wst), L * CH, st)
+        _lib.call('wn_gemm_nn', _lib.ptr(ws.dtotal), S, 0, 0, _lib.ptr(ws.wst),
+                  L * CH, None, None, 0, None, 0, _lib.ptr(ws.dZ), 0, L,
+                  N * CH, None, N, L * CH, S, 0, st)
+
+        # residual stack, last layer first
+        def da(p):
+            return ws.da[p][0], ws.da[p][1]
+        cur = 0
+        f, g = da(cur)
+        # phase A of the last layer (no gradient flows into its x' output)
+        _lib.call('wn_layer_bwd', None, None, None, None, None,
+                  _lib.ptr(ws.dZ[L - 1]), _lib.ptr(ws.TH[L - 1]),
+                  _lib.ptr(ws.SG[L - 1]),
+                  _lib.ptr(self._layer_block(P, L - 1)), _lib.ptr(f),
+                  _lib.ptr(g), B, T, 1, 0, 1, st)
+        dxin = None           # dL/dx' of layer l (None for the last layer)
+        xp = 0
+        for l in range(L - 1, -1, -1):
+            d = int(self.dilations[l])
+            f, g = da(cur)
+            _lib.call('wn_layer_wgrad', _lib.ptr(ws.X[l]), _lib.ptr(f),
+                      _lib.ptr(g),
+                      None if dxin is None else _lib.ptr(ws.Z[l]),
+                      None if dxin is None else _lib.ptr(dxin),
+                      _lib.ptr(ws.lslabs[l]), ws.nslab, B, T, d, st)
+            if ws.dsum is not None:
+                _lib.call('wn_colsum_clip', _lib.ptr(f), B, T,
+                          _lib.ptr(ws.dsum[l]), 64, st)
+                _lib.call('wn_colsum_clip', _lib.ptr(g), B, T,
+                          _lib.ptr(ws.dsum[l].view(-1)[32:]), 64, st)
+            dxo = ws.dx[xp]
+            if l > 0:
+                fn, gn = da(1 - cur)
+                _lib.call('wn_layer_bwd', _lib.ptr(f), _lib.ptr(g),
+                          None if dxin is None else _lib.ptr(dxin),
+                          _lib.ptr(dxo), _lib.ptr(self._layer_block(P, l)),
+                          _lib.ptr(ws.dZ[l - 1]), _lib.ptr(ws.TH[l - 1]),
+                          _lib.ptr(ws.SG[l - 1]),
+                          _lib.ptr(self._layer_block(P, l - 1)), _lib.ptr(fn),
+                          _lib.ptr(gn), B, T, d, 1, 1, st)
+                cur = 1 - cur
+            else:
+                _lib.call('wn_layer_bwd', _lib.ptr(f), _lib.ptr(g),
+                          None if dxin is None else _lib.ptr(dxin),
+                          _lib.ptr(dxo), _lib.ptr(self._layer_block(P, l)),
+                          None, None, None, None, None, None, B, T, d, 1, 0,
+                          st)
+            dxin = dxo
+            xp = 1 - xp
+        # layer-block gradients: fixed-order sum of the per-workgroup slabs
+        lo, _ = self.segments['layers']
+        _lib.call('wn_reduce_slabs', _lib.ptr(ws.lslabs), ws.nslab,
+                  LAYER_BLOCK, L, ws.nslab * LAYER_BLOCK, 0,
+                  LAYER_BLOCK if ub else LAYER_W, _lib.ptr(Gr[lo:]),
+                  self.layer_stride, 1, 0, st)
+        # causal layer: dWc[1][v] = sum_t [q[t]==v] dx0[t]; dWc[0][v] likewise
+        # with q[t-1]  (one-hot operand generated on the fly)
+        gc_ = self._seg(Gr, 'causal')
+        for tap, shift in ((1, 0), (0, 1)):
+            sp = ws.splits['causal']
+            sl = lib.wn_gemm_tn_slab_floats(Q, CH)
+            _lib.call('wn_gemm_tn', None, 0, 0, 0, _lib.ptr(ws.q), shift, T,
+                      _lib.ptr(dxin), CH, _lib.ptr(ws.slabs), sp, N, Q, CH, 0,
+                      st)
+            _lib.call('wn_reduce_slabs', _lib.ptr(ws.slabs), sp, sl, 1, 0, 0,
+                      Q * CH, _lib.ptr(gc_[tap * Q * CH:]), 0, 1, 0, st)
+        if ws.dsum is not None:
+            _lib.call('wn_gc_grad', _lib.ptr(self._layer_block(P, 0)),
+                      self.layer_stride, OFF_GC, self.G,
+                      _lib.ptr(self._seg(P, 'emb')), self.card, _lib.ptr(ids),
+                      _lib.ptr(ws.dsum), L, B,
+                      _lib.ptr(self._layer_block(Gr, 0)),
+                      _lib.ptr(self._seg(Gr, 'emb')), st)
+
+    # ------------------------------------------------------------------ API
+    def encode(self, input_batch, B=None):
+        """mu-law codes [B, T] of float audio (model.py:639-640)."""
+        B = self.batch_size if B is None else B
+        a = input_batch
+        if not isinstance(a, torch.Tensor):
+            a = torch.as_tensor(np.asarray(a), dtype=torch.float32)
+        a = a.to(device=self.device, dtype=torch.float32).reshape(B, -1)
+        return mu_law_encode(a, self.Q)
+
+    def loss(self,
+             input_batch,
+             global_condition_batch=None,
+             l2_regularization_strength=None,
+             name='wavenet',
+             backward=True):
+        '''Creates a WaveNet network and returns the autoencoding loss
+        (model.py:628-685).  input_batch: float audio in [-1, 1], anything
+        reshapeable to [batch_size, -1].  With backward=True (default) the
+        gradient of the returned loss w.r.t. every variable is left in
+        `self.grads` (the flat bucket `optimizer.minimize` consumes).'''
+        self._check_supported()
+        B = self.batch_size
+        q = self.encode(input_batch, B)
+        return self.loss_from_codes(q, global_condition_batch,
+                                    l2_regularization_strength, backward)
+
+    def loss_from_codes(self, q, global_condition_batch=None,
+                        l2_regularization_strength=None, backward=True):
+        self._check_supported()
+        B = self.batch_size
+        q = q.reshape(B, -1)
+        T = q.shape[1]
+        N = B * T
+        ws = self._workspace(B, T, backward)
+        ws.q.copy_(q.reshape(-1))
+        ids = self._gc_ids(global_condition_batch, B)
+        st = _lib.stream()
+        self._forward(ws, ids, save_ts=backward)
+        _lib.call('wn_xent', _lib.ptr(ws.logits), self.Q, _lib.ptr(ws.q),
+                  _lib.ptr(ws.logits) if backward else None,
+                  _lib.ptr(ws.loss_parts), B, T, self.Q,
+                  1 if self.tf_xent_zero_label_quirk else 0, st)
+        _lib.call('wn_reduce_slabs', _lib.ptr(ws.loss_parts), ws.nparts, 1, 1,
+                  0, 0, 1, _lib.ptr(ws.loss), 0, 1, 0, st)
+        loss = ws.loss[0] / float(N)                    # reduce_mean, :666
+        if backward:
+            self._backward(ws, ids)
+        if l2_regularization_strength is not None:
+            lam = float(l2_regularization_strength)
+            mask = None if self.tf_bias_name_quirk else self._l2_mask()
+            _lib.call('wn_l2_partials', _lib.ptr(self.params),
+                      self.params.numel(), _lib.ptr(mask),
+                      _lib.ptr(ws.l2_parts) if backward else
+                      _lib.ptr(self._l2_tmp()), st)
+            parts = ws.l2_parts if backward else self._l2_tmp()
+            loss = loss + lam * parts.sum()             # model.py:674-680
+            if backward:
+                _lib.call('wn_axpy', _lib.ptr(self.grads),
+                          _lib.ptr(self.params), lam, _lib.ptr(mask),
+                          self.params.numel(), st)
+        loss._wn_model = self
+        loss._wn_has_grads = bool(backward)
+        return loss
+
+    def _l2_tmp(self):
+        if not hasattr(self, '_l2_parts'):
+            self._l2_parts = torch.empty(_lib.load().wn_l2_partials_count(),
+                                         dtype=torch.float32,
+                                         device=self.device)
+        return self._l2_parts
+
+    def _l2_mask(self):
+        """1 for weights, 0 for biases (only used when the TF bias-name quirk
+        is switched off)."""
+        if not hasattr(self, '_l2m'):
+            m = torch.ones_like(self.params)
+            tree = self._views(m)
+            for n, v in self.named_variables(tree):
+                if 'bias' in n.split('/')[-1]:
+                    v.zero_()
+            self._l2m = m
+        return self._l2m
+
+    def predict_proba(self, waveform, global_condition=None, name='wavenet'):
+        '''Computes the probability distribution of the next sample based on
+        all samples in the input waveform (model.py:564-590).  waveform:
+        already-quantised int samples.'''
+        self._check_supported()
+        B = self.batch_size
+        w = waveform
+        if not isinstance(w, torch.Tensor):
+            w = torch.as_tensor(np.asarray(w))
+        w = w.to(device=self.device, dtype=torch.int32).reshape(B, -1)
+        T = w.shape[1]
+        ws = self._workspace(B, T, False)
+        ws.q.copy_(w.reshape(-1))
+        ids = self._gc_ids(global_condition, B)
+        self._forward(ws, ids, save_ts=False)
+        out = torch.empty(self.Q, dtype=torch.float32, device=self.device)
+        _lib.call('wn_softmax64_row', _lib.ptr(ws.logits[B * T - 1]), self.Q,
+                  _lib.ptr(out), _lib.stream())
+        return out
+
+    # ---------------------------------------------------------- fast generation
+    def _generator(self, global_condition):
+        """Device-resident incremental-generation state (_create_generator,
+        model.py:444-516): ring buffers standing in for the FIFO queues."""
+        if self._gen is None:
+            lib = _lib.load()
+            dil = np.asarray(self.dilations, dtype=np.int32)
+            nfl = lib.wn_fastgen_state_floats(dil.ctypes.data, self.L)
+            g = dict(
+                state=torch.zeros(nfl, dtype=torch.float32, device=self.device),
+                cursors=torch.zeros(2, dtype=torch.int32, device=self.device),
+                dil=torch.from_numpy(dil).to(self.device),
+                bias=torch.zeros((self.L, 1, 64), dtype=torch.float32,
+                                 device=self.device),
+                bsum=torch.zeros(self.S, dtype=torch.float32,
+                                 device=self.device),
+                proba=torch.empty(self.Q, dtype=torch.float32,
+                                  device=self.device),
+                io=torch.zeros(2, dtype=torch.int32, device=self.device))
+            self._gen = g
+            self._gen_reset()
+        return self._gen
+
+    def _gen_reset(self):
+        g = self._gen
+        _lib.call('wn_fastgen_init', _lib.ptr(g['state']), g['state'].numel(),
+                  _lib.ptr(g['cursors']), self.L, _lib.stream())
+
+    def _gen_run(self, samples_io, n_given, n_steps, temperature, seed,
+                 proba_out, proba_every, global_condition, push=True):
+        g = self._generator(global_condition)
+        ids = self._gc_ids(global_condition, 1) if self.card is not None \
+            else None
+        bias, _ = self._bias_fg(g['bias'], ids, 1)
+        P = self.params
+        bsum = None
+        if self.use_biases:
+            _lib.call('wn_sum_rows', _lib.ptr(self._seg(P, 'skip_b')), self.L,
+                      self.S, _lib.ptr(g['bsum']), _lib.stream())
+            bsum = g['bsum']
+        ub = self.use_biases
+        _lib.call('wn_fastgen_run', _lib.ptr(self._seg(P, 'causal')),
+                  _lib.ptr(self._layer_block(P, 0)), self.layer_stride,
+                  _lib.ptr(self._seg(P, 'skip_w')), _lib.ptr(bsum),
+                  _lib.ptr(self._seg(P, 'post1_w')),
+                  _lib.ptr(self._seg(P, 'post1_b')) if ub else None,
+                  _lib.ptr(self._seg(P, 'post2_w')),
+                  _lib.ptr(self._seg(P, 'post2_b')) if ub else None,
+                  None if bias is None else _lib.ptr(bias), _lib.ptr(g['dil']),
+                  self.L, self.S, self.Q, _lib.ptr(g['state']),
+                  _lib.ptr(g['cursors']), _lib.ptr(samples_io), int(n_given),
+                  int(n_steps), float(temperature), int(seed) & (2**64 - 1),
+                  _lib.ptr(proba_out), int(proba_every), 1 if ub else 0,
+                  1 if push else 0, _lib.stream())
+
+    def predict_proba_incremental(self, waveform, global_condition=None,
+                                  name='wavenet', push=True):
+        '''Computes the probability distribution of the next sample
+        incrementally, based on a single sample and all previously passed
+        samples (model.py:592-626).  Eager counterpart of running the
+        reference's proba op together with `net.push_ops` (push=True) or
+        alone (push=False); `net.reset_generator()` is `net.init_ops`.'''
+        if self.filter_width > 2:
+            raise NotImplementedError("Incremental generation does not "
+                                      "support filter_width > 2.")
+        if self.scalar_input:
+            raise NotImplementedError("Scalar input is not supported by "
+                                      "fast generation.")
+        self._check_supported()
+        g = self._generator(global_condition)
+        w = waveform
+        if isinstance(w, torch.Tensor):
+            g['io'][0:1].copy_(w.reshape(-1)[-1:].to(torch.int32))
+        else:
+            g['io'][0] = int(np.asarray(w).reshape(-1)[-1])
+        self._gen_run(g['io'], 1, 1, 1.0, 0, g['proba'], 1, global_condition,
+                      push=push)
+        return g['proba'].clone()
+
+    def reset_generator(self):
+        """net.init_ops: refill every queue with zeros (model.py:457-479)."""
+        self._generator(None)
+        self._gen_reset()
+
+    def generate(self, num_samples, seed_samples=None, temperature=1.0,
+                 global_condition=None, seed=0, return_proba_every=0):
+        """The whole generate.py:195-241 loop on the device: prime with
+        `seed_samples` (int codes; default one random-free seed 128 as in
+        test_model.py:63), then draw `num_samples` samples with temperature.
+        Returns int32 codes [len(seed) + num_samples] (and the probabilities
+        of every `return_proba_every`-th step when requested)."""
+        self._check_supported()
+        if self.filter_width > 2 or self.scalar_input:
+            raise NotImplementedError('fast generation needs filter_width 2 '
+                                      'and one-hot input')
+        if seed_samples is None:
+            seed_samples = [self.Q // 2]
+        s = torch.as_tensor(np.asarray(seed_samples), dtype=torch.int32).reshape(-1)
+        n_given = int(s.numel())
+        n_steps = n_given - 1 + int(num_samples)
+        io = torch.zeros(n_steps + 1, dtype=torch.int32, device=self.device)
+        io[:n_given] = s.to(self.device)
+        self.reset_generator()
+        pe = int(return_proba_every)
+        proba = None
+        if pe > 0:
+            proba = torch.empty(((n_steps + pe - 1) // pe, self.Q),
+                                dtype=torch.float32, device=self.device)
+        if n_steps > 0:
+            self._gen_run(io, n_given, n_steps, temperature, seed, proba,
+                          pe if pe > 0 else 1, global_condition)
+        out = io[:n_given + int(num_samples)]
+        return (out, proba) if pe > 0 else out

@@ -1,0 +1,85 @@
+"""Data-parallel training over the GPUs of one node (new capability; the
+reference is single-process: train.py:261, no collective anywhere).
+
+One process per GPU (torchrun), `torch.distributed` with backend "nccl"
+(= RCCL over xGMI on ROCm).  Clips are independent and the loss is a mean over
+B*T rows (wavenet/model.py:666), so with equal per-rank B*T
+
+    g_global = (1/N) * sum_r g_r          (exact, incl. the zero-label row)
+
+The whole gradient lives in ONE flat fp32 bucket (6.06 MB for the default
+stack), so a step needs exactly one all-reduce(sum); the 1/N is folded into
+the optimizer kernel (`grad_scale`).  At 6 MB the ring moves 2(N-1)/N * 6 MB
+per GPU (~70 us at N=8 over per-link-bound xGMI) against a >= 7 ms step, so the
+collective is issued on the compute stream right before the update instead of
+being bucketed/overlapped.
+
+The helpers are device-agnostic on purpose: they only touch flat tensors, so
+the sharding / averaging logic is covered on CPU by world_size-2 `gloo` tests.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def is_distributed():
+    return dist.is_available() and dist.is_initialized() and \
+        dist.get_world_size() > 1
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (the
+    launcher's env).  Returns (rank, world, local_rank).  No-op when
+    WORLD_SIZE is absent or 1."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(global_batch, rank, world):
+    """Clips [lo, hi) of the global minibatch owned by `rank` (equal shards;
+    the exact-mean identity above needs equal per-rank B*T)."""
+    if global_batch % world:
+        raise ValueError('global batch %d is not divisible by world size %d'
+                         % (global_batch, world))
+    per = global_batch // world
+    return rank * per, (rank + 1) * per
+
+
+def allreduce_flat_(flat):
+    """In-place all-reduce(sum) of one flat bucket; returns the scale (1/N)
+    the caller must apply (folded into the optimizer kernel)."""
+    if not is_distributed():
+        return 1.0
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    return 1.0 / dist.get_world_size()
+
+
+def allreduce_gradients(model):
+    """All-reduce the model's flat gradient bucket; returns grad_scale."""
+    return allreduce_flat_(model.grads)
+
+
+def broadcast_parameters(model, src=0):
+    """Make every rank start from rank `src`'s weights (one flat broadcast)."""
+    if is_distributed():
+        dist.broadcast(model.params, src=src)
+
+
+def allreduce_mean_scalar(value_tensor):
+    """Mean of a scalar (e.g. the loss) over ranks, for logging."""
+    if not is_distributed():
+        return value_tensor
+    t = value_tensor.detach().clone()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t / dist.get_world_size()

@@ -1,0 +1,75 @@
+"""Shared test helpers: build the HIP model and the CPU oracle on identical
+weights.  (tests/ may import oracle/; the product never does.)"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, 'tensorflow-wavenet_amd')
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from oracle import wavenet_oracle as O  # noqa: E402
+
+TINY = dict(dilations=[1, 2, 4, 8, 1, 2, 4, 8], filter_width=2,
+            residual_channels=8, dilation_channels=8, skip_channels=16,
+            quantization_channels=16, use_biases=True)
+MID = dict(dilations=[1, 2, 4, 8, 16, 32, 64, 1, 2, 4, 8, 16, 32, 64],
+           filter_width=2, residual_channels=32, dilation_channels=32,
+           skip_channels=64, quantization_channels=256, use_biases=True)
+DEFAULT = dict(dilations=[2 ** i for i in range(10)] * 5, filter_width=2,
+               residual_channels=32, dilation_channels=32, skip_channels=512,
+               quantization_channels=256, use_biases=True)
+
+
+def cfg_with(base, **kw):
+    c = dict(base)
+    c.update(kw)
+    return c
+
+
+def synth_audio(B, T, seed=1234, sample_rate=16000):
+    """BASELINE.md synthetic clips: sine + noise, clipped to [-1, 1]."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(T)
+    out = np.empty((B, T), np.float32)
+    for b in range(B):
+        f = 110.0 * 2 ** (b / 12.0)
+        x = 0.5 * np.sin(2 * np.pi * f * t / sample_rate) + \
+            0.05 * rng.standard_normal(T)
+        out[b] = np.clip(x, -1, 1)
+    return out
+
+
+def model_kwargs(cfg):
+    keys = ['batch_size', 'dilations', 'filter_width', 'residual_channels',
+            'dilation_channels', 'skip_channels', 'quantization_channels',
+            'use_biases', 'scalar_input', 'initial_filter_width',
+            'global_condition_channels', 'global_condition_cardinality',
+            'residual_postproc']
+    return {k: cfg[k] for k in keys if k in cfg}
+
+
+def build_pair(cfg, seed=0, bias_scale=0.1):
+    """(HIP model, oracle variables float64) with identical weights."""
+    from wavenet import WaveNetModel
+    var = O.create_variables(cfg, seed=seed, dtype=np.float64,
+                             bias_scale=bias_scale if cfg.get('use_biases')
+                             else 0.0)
+    net = WaveNetModel(**model_kwargs(cfg))
+    net.load_nested(var)
+    return net, var
+
+
+def flat_named(tree):
+    return O.flatten_variables(tree)
+
+
+def tree_to_numpy(tree):
+    if isinstance(tree, dict):
+        return {k: tree_to_numpy(v) for k, v in tree.items()}
+    if isinstance(tree, list):
+        return [tree_to_numpy(v) for v in tree]
+    return tree.detach().cpu().numpy().astype(np.float64)

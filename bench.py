@@ -1,0 +1,214 @@
+#!/usr/bin/env python
+"""Headline benchmark: audio samples/sec of a full WaveNet training step
+(mu-law encode + forward + loss + backward + gradient all-reduce + Adam) on
+the default wavenet_params.json stack, fp32, synthetic 16 kHz clips resident
+in HBM (BASELINE.json metric; config[1]: B=8 clips x 16000 samples per GPU).
+
+    python bench.py --gpus N --steps K --warmup W
+N > 1 is launched by torch.distributed.run, one rank per GPU over RCCL; the
+per-GPU work is fixed (weak scaling), `value` is the whole-job aggregate.
+
+Extra objects on the JSON line:
+  roofline     - the dominant kernel (gemm_nn_kernel: the skip-sum /
+                 post-processing fp32 MFMA GEMMs and their data gradients),
+                 timed live with HIP events on the launch stream inside the
+                 timed region; achieved = algorithmic FLOPs / kernel time.
+  cpu_baseline - the reference graph restated op for op in PyTorch-CPU
+                 (oracle/torch_graph.py, kind "port": TF 0.10 cannot be
+                 installed here) timed on this host's cores on a bounded
+                 sample (config[0]: B=1, T=16000), rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'tensorflow-wavenet_amd'),
+          os.path.join(ROOT, 'tests')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+
+
+def synth_audio(B, T, first_clip=0, seed=1234, sample_rate=16000):
+    """clip b = 0.5 sin(2 pi 110 2^(b/12) t / 16000) + 0.05 N(0,1),
+    clipped to [-1, 1]; b is the GLOBAL clip index."""
+    rng = np.random.default_rng(seed + first_clip)
+    t = np.arange(T)
+    out = np.empty((B, T), np.float32)
+    for i in range(B):
+        f = 110.0 * 2 ** ((first_clip + i) / 12.0)
+        x = 0.5 * np.sin(2 * np.pi * f * t / sample_rate) + \
+            0.05 * rng.standard_normal(T)
+        out[i] = np.clip(x, -1, 1)
+    return out
+
+
+def host_cores(cap=16):
+    """CPU threads this process may really use: affinity mask, cgroup quota,
+    and the GPU box's per-GPU CPU share (16), whichever is smallest."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') \
+        else (os.cpu_count() or 1)
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            quota, period = f.read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(float(quota) / float(period) + 0.999)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get('WN_CPU_THREADS', cap))))
+
+
+def log(msg):
+    sys.stderr.write('[bench] %s\n' % msg)
+    sys.stderr.flush()
+
+
+def cpu_baseline(params, T, max_seconds=30.0):
+    """Time the op-for-op CPU restatement of the reference graph (checker /
+    baseline only; never part of the measured GPU path)."""
+    from oracle import wavenet_oracle as O, torch_graph as TG
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    log('cpu baseline on %d threads' % cores)
+    cfg = dict(params)
+    cfg['batch_size'] = 1
+    var = O.create_variables(cfg, seed=0, dtype=np.float32)
+    step = TG.train_step_fn(cfg, var)
+    q = torch.tensor(O.mu_law_encode(synth_audio(1, T), 256).astype(np.int64))
+    t0 = time.time()
+    step(q)                                   # warm-up (allocator, threads)
+    log('cpu warm-up step %.1f s' % (time.time() - t0))
+    n, t0 = 0, time.time()
+    while n < 3 and (time.time() - t0) < max_seconds:
+        step(q)
+        n += 1
+        log('cpu step %d done (%.1f s elapsed)' % (n, time.time() - t0))
+    dt = (time.time() - t0) / max(n, 1)
+    return {'value': T / dt, 'unit': 'audio samples/s', 'cores': cores,
+            'kind': 'port',
+            'sample': '%d full training steps (fwd+bwd+TF-Adam) of the '
+                      'op-for-op PyTorch-CPU restatement of the reference '
+                      'graph, default wavenet_params.json, B=1, T=%d '
+                      '(%.2f s/step)' % (n, T, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=8, help='clips per GPU')
+    ap.add_argument('--samples', type=int, default=16000, help='T per clip')
+    ap.add_argument('--gc', action='store_true',
+                    help='config[3]: global conditioning 32 x 377')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    from wavenet import WaveNetModel, optimizer_factory, parallel
+    rank, world, local = parallel.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit('WORLD_SIZE %d != --gpus %d' % (world, args.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+
+    with open(os.path.join(ROOT, 'wavenet_params.json')) as f:
+        params = json.load(f)
+    B, T = args.batch, args.samples
+    kw = dict(batch_size=B, dilations=params['dilations'],
+              filter_width=params['filter_width'],
+              residual_channels=params['residual_channels'],
+              dilation_channels=params['dilation_channels'],
+              skip_channels=params['skip_channels'],
+              quantization_channels=params['quantization_channels'],
+              use_biases=params['use_biases'],
+              scalar_input=params['scalar_input'],
+              initial_filter_width=params['initial_filter_width'],
+              residual_postproc=params.get('residual_postproc', False))
+    gc_ids = None
+    if args.gc:
+        kw.update(global_condition_channels=32,
+                  global_condition_cardinality=377)
+        gc_ids = torch.tensor([(37 * (rank * B + b)) % 377 for b in range(B)],
+                              dtype=torch.int32, device=dev)
+    net = WaveNetModel(seed=0, **kw)
+    parallel.broadcast_parameters(net)
+    opt = optimizer_factory['adam'](learning_rate=1e-3, momentum=0.9)
+    audio = torch.from_numpy(synth_audio(B, T, first_clip=rank * B)).to(dev)
+
+    def step():
+        loss = net.loss(audio, gc_ids)
+        opt.minimize(loss)
+        return loss
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    log('rank %d/%d: model built, warming up' % (rank, world))
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    log('warm-up done, timing %d steps' % args.steps)
+    net._gemm_events = []                    # live HIP-event timing of the GEMMs
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    events = net._gemm_events
+    net._gemm_events = None
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt[0])
+    if rank != 0:
+        return
+
+    value = world * B * T * args.steps / dt
+    log('gpu: %.0f samples/s, %.2f ms/step' % (value, dt / args.steps * 1e3))
+    flops = sum(e[2] for e in events)
+    ktime = sum(e[0].elapsed_time(e[1]) for e in events) * 1e-3
+    achieved = flops / ktime / 1e12 if ktime > 0 else 0.0
+    nlaunch = len(events)
+    out = {
+        'metric': 'audio samples/sec (train, default wavenet_params.json)',
+        'value': value, 'unit': 'audio samples/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+        'data': 'synthetic',
+        'config': {'workload': 'default wavenet_params.json stack (50 dilation '
+                               'layers, R=D=32, S=512, Q=256), full training '
+                               'step, %d clips x %d samples per GPU, fp32%s'
+                               % (B, T, ', global conditioning 32x377'
+                                  if args.gc else ''),
+                   'clips_per_gpu': B, 'samples_per_clip': T,
+                   'global_batch': world * B,
+                   'parallelism': 'dp%d' % world,
+                   'final_loss': float(loss)},
+        'roofline': {'bound': 'mfma', 'kernel': 'gemm_nn_kernel',
+                     'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS,
+                     'unit': 'TFLOP/s', 'frac': achieved / FP32_MFMA_PEAK_TFLOPS,
+                     'traffic': None,
+                     'launches_per_step': nlaunch // max(args.steps, 1),
+                     'avg_launch_us': ktime / max(nlaunch, 1) * 1e6,
+                     'flops_per_step': flops / max(args.steps, 1)},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(params, T)
+        out['gpu_over_cpu'] = value / out['cpu_baseline']['value']
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

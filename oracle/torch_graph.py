@@ -194,6 +194,6 @@ def train_step_fn(cfg, var_np, lr=1e-3):
         l = loss(cfg, var, q)
         l.backward()
         opt.step()
-        return float(l)
+        return float(l.detach())
 
     return step

@@ -386,6 +386,20 @@ class WaveNetModel(object):
                   self.L, nb, _lib.stream())
         return out, (64 if ids is not None else 0)
 
+    def _nn(self, *args):
+        """wn_gemm_nn, optionally bracketed by HIP events on the launch stream
+        (bench.py's live roofline measurement)."""
+        ev = getattr(self, '_gemm_events', None)
+        if ev is None:
+            _lib.call('wn_gemm_nn', *args)
+            return
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        _lib.call('wn_gemm_nn', *args)
+        e.record()
+        ev.append((s, e, 2.0 * args[-5] * args[-4] * args[-3]))
+
     # ------------------------------------------------------------------ forward
     def _forward(self, ws, ids, save_ts):
         """_create_network (model.py:389-442) on codes ws.q -> ws.logits."""
@@ -412,7 +426,7 @@ class WaveNetModel(object):
                       _lib.ptr(ws.bsum), st)
             bsum = ws.bsum
         # total = sum_l z_l * Ws_l (+ sum_l bs_l); h1 = relu(total)
-        _lib.call('wn_gemm_nn', _lib.ptr(ws.Z), 0, L, N * CH,
+        self._nn(_lib.ptr(ws.Z), 0, L, N * CH,
                   _lib.ptr(self._seg(P, 'skip_w')), S, _lib.ptr(bsum), None, 0,
                   None, 0, _lib.ptr(ws.h1), S, 0, 0,
                   _lib.ptr(ws.total) if self.residual_postproc else None,
@@ -420,12 +434,12 @@ class WaveNetModel(object):
         b1 = self._seg(P, 'post1_b') if self.use_biases else None
         b2 = self._seg(P, 'post2_b') if self.use_biases else None
         rp = self.residual_postproc
-        _lib.call('wn_gemm_nn', _lib.ptr(ws.h1), S, 0, 0,
+        self._nn(_lib.ptr(ws.h1), S, 0, 0,
                   _lib.ptr(self._seg(P, 'post1_w')), S, _lib.ptr(b1), None, 0,
                   _lib.ptr(ws.total) if rp else None, S, _lib.ptr(ws.h2), S, 0,
                   0, _lib.ptr(ws.c1) if (rp and ws.training) else None,
                   N, S, S, 1, st)
-        _lib.call('wn_gemm_nn', _lib.ptr(ws.h2), S, 0, 0,
+        self._nn(_lib.ptr(ws.h2), S, 0, 0,
                   _lib.ptr(self._seg(P, 'post2_w')), Q, _lib.ptr(b2), None, 0,
                   None, 0, _lib.ptr(ws.logits), Q, 0, 0, None, N, Q, S, 0, st)
 
@@ -460,7 +474,7 @@ class WaveNetModel(object):
         _lib.call('wn_transpose', _lib.ptr(self._seg(P, 'post2_w')), S, Q, Q,
                   _lib.ptr(ws.w2t), S, st)
         # dc1 = dh2 * [c1 > 0]   (h2 = relu(c1) (+ total))
-        _lib.call('wn_gemm_nn', _lib.ptr(dlog), Q, 0, 0, _lib.ptr(ws.w2t), S,
+        self._nn(_lib.ptr(dlog), Q, 0, 0, _lib.ptr(ws.w2t), S,
                   None, _lib.ptr(ws.c1 if rp else ws.h2), S, None, 0,
                   _lib.ptr(ws.dc1), S, 0, 0, _lib.ptr(ws.dh2) if rp else None,
                   N, S, Q, 0, st)
@@ -471,7 +485,7 @@ class WaveNetModel(object):
         _lib.call('wn_transpose', _lib.ptr(self._seg(P, 'post1_w')), S, S, S,
                   _lib.ptr(ws.w1t), S, st)
         # dtotal = (dc1 W1^T) * [total > 0] (+ dh2 when residual_postproc)
-        _lib.call('wn_gemm_nn', _lib.ptr(ws.dc1), S, 0, 0, _lib.ptr(ws.w1t), S,
+        self._nn(_lib.ptr(ws.dc1), S, 0, 0, _lib.ptr(ws.w1t), S,
                   None, _lib.ptr(ws.h1), S, _lib.ptr(ws.dh2) if rp else None,
                   S, _lib.ptr(ws.dtotal), S, 0, 0, None, N, S, S, 0, st)
         # skip convs: dWs_all = Z^T dtotal ; dbs_l = colsum(dtotal) for every l
@@ -481,7 +495,7 @@ class WaveNetModel(object):
         # dZ planes = dtotal Ws_all^T
         _lib.call('wn_transpose', _lib.ptr(self._seg(P, 'skip_w')), L * CH, S,
                   S, _lib.ptr(ws.wst), L * CH, st)
-        _lib.call('wn_gemm_nn', _lib.ptr(ws.dtotal), S, 0, 0, _lib.ptr(ws.wst),
+        self._nn(_lib.ptr(ws.dtotal), S, 0, 0, _lib.ptr(ws.wst),
                   L * CH, None, None, 0, None, 0, _lib.ptr(ws.dZ), 0, L,
                   N * CH, None, N, L * CH, S, 0, st)
 

@@ -31,6 +31,11 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
   return x ^ (x >> 31);
 }
 
+// v_readlane_b32 on a float (the builtin is typed int: bit-cast, never convert)
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
 struct FastGen {
   const float* causal;   // [2][Q][32]
   const float* layer0;   // layer blocks
@@ -103,8 +108,8 @@ __global__ __launch_bounds__(FG_THREADS) void fastgen_kernel(FastGen g) {
           float a = g.bias_fg ? g.bias_fg[l * 64 + lane] : 0.f;
 #pragma unroll
           for (int k = 0; k < 32; ++k) {
-            const float sk = __builtin_amdgcn_readlane(stv, k);
-            const float xk = __builtin_amdgcn_readlane(x, k);
+            const float sk = readlane_f(stv, k);
+            const float xk = readlane_f(x, k);
             a = fmaf(sk, wcol[k * 32], a);           // W[0]: past tap
             a = fmaf(xk, wcol[1024 + k * 32], a);    // W[1]: current tap
           }
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(FG_THREADS) void fastgen_kernel(FastGen g) {
             const float* wd = blk + 4096 + (lane & 31);
 #pragma unroll
             for (int k = 0; k < 32; ++k) {
-              const float zk = __builtin_amdgcn_readlane(z, k);
+              const float zk = readlane_f(z, k);
               dsum = fmaf(zk, wd[k * 32], dsum);
             }
             if (lane < 32) x += dsum;

@@ -162,10 +162,13 @@ class WaveNetModel(object):
         self.tf_bias_name_quirk = True
 
         _lib.load()
-        _lib.require_gpu()
-        self.device = torch.device(
-            'cuda', torch.cuda.current_device()) if device is None \
-            else torch.device(device)
+        if device is None:
+            _lib.require_gpu()
+            self.device = torch.device('cuda', torch.cuda.current_device())
+        else:
+            # device='cpu' is allowed for parameter bookkeeping only (variable
+            # names / shapes / checkpoints); every compute entry point raises.
+            self.device = torch.device(device)
         self.L, self.S, self.Q = len(self.dilations), skip_channels, \
             quantization_channels
         self.R, self.D = residual_channels, dilation_channels
@@ -344,6 +347,10 @@ class WaveNetModel(object):
     def _check_supported(self):
         if self._unsupported:
             raise NotImplementedError(self._unsupported)
+        if self.device.type != 'cuda':
+            raise _lib.WaveNetHipError(
+                'WaveNetModel compute needs an MI355X (device=%s); there is '
+                'no CPU fallback' % self.device)
 
     def _workspace(self, B, T, training):
         key = (B, T)

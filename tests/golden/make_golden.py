@@ -1,0 +1,135 @@
+"""Generates the committed golden fixtures (tests/golden/*.npz).
+
+The reference (TensorFlow 0.10 graph code) cannot be imported in this image
+(`import wavenet` -> ModuleNotFoundError: tensorflow, an ordinary Python
+error), so the vectors are (a) literal known-answer data restated from the
+reference's own tests and (b) outputs of this repo's CPU oracle
+(oracle/wavenet_oracle.py, float64) on small seeded inputs.  Run from the
+repo root:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from oracle import wavenet_oracle as O  # noqa: E402
+from util import TINY, cfg_with  # noqa: E402
+
+
+def literal():
+    """Known answers held by the reference's tests (data only)."""
+    out = {}
+    # test/test_mu_law.py:113-124 (testEncodePrecomputed)
+    out['mulaw_x'] = np.array([-1.0, 1.0, 0.6, -0.25, 0.01, 0.33, -0.9999,
+                               0.42, 0.1, -0.45], np.float32)
+    out['mulaw_codes'] = np.array([0, 255, 243, 32, 157, 230, 0, 235, 203,
+                                   18], np.int32)
+    # test/test_causal_conv.py:11-27 (testCausalConv): x = 1..20 twice,
+    # filter ones[2,1,1], dilation 4  -> convolve(x,[1,0,0,0,1])[:-4]
+    x1 = np.arange(1, 21, dtype=np.float32)
+    out['cc_x'] = np.append(x1, x1).reshape(2, 20, 1)
+    out['cc_f'] = np.ones((2, 1, 1), np.float32)
+    ref = np.convolve(x1, [1, 0, 0, 0, 1])[:-4]
+    out['cc_y'] = np.append(ref, ref).reshape(2, 20, 1).astype(np.float32)
+    # test/test_causal_conv.py:29-58 (testNoTimeShift): filter [0,1], d=2
+    out['nts_x'] = np.arange(1, 11, dtype=np.float32).reshape(1, 10, 1)
+    out['nts_f'] = np.array([0.0, 1.0], np.float32).reshape(2, 1, 1)
+    return out
+
+
+def mulaw_families():
+    """Inputs of test/test_mu_law.py:126-178, 205-261 (seeds 42/1944/40) and
+    the oracle's float32-chain codes / decodes."""
+    out = {}
+    np.random.seed(42)
+    out['enc_uniform_x'] = np.random.uniform(-1, 1, 2048).astype(np.float32)
+    np.random.seed(1944)
+    c = np.zeros(1024, np.float32)
+    c.fill(np.random.uniform(-1, 1))
+    out['enc_const_x'] = c
+    out['enc_ramp_x'] = np.arange(-1.0, 1.0, 2.0 / 1024).astype(np.float32)
+    out['enc_zeros_x'] = np.zeros(1024, np.float32)
+    for k in ['uniform', 'const', 'ramp', 'zeros']:
+        out['enc_%s_codes' % k] = O.mu_law_encode(out['enc_%s_x' % k], 256)
+    np.random.seed(40)
+    x = np.random.uniform(-1, 1, 512)
+    y = O.mu_law_encode(x.astype(np.float32), 128)
+    out['dec128_codes'] = y
+    out['dec128_audio'] = O.mu_law_decode(y, 128)
+    out['dec256_all'] = O.mu_law_decode(np.arange(256), 256)
+    for q in (16, 123, 128, 256):
+        out['thr_%d' % q] = O.mu_law_thresholds(q)
+    return out
+
+
+def stack_case(name, cfg, T, gc=False, l2=None, seed=0, quirk=True):
+    B = cfg['batch_size']
+    var = O.create_variables(cfg, seed=seed, dtype=np.float64, bias_scale=0.1)
+    rng = np.random.default_rng(100 + seed)
+    audio = rng.uniform(-1, 1, (B, T)).astype(np.float32)
+    ids = rng.integers(0, cfg['global_condition_cardinality'], B) if gc \
+        else None
+    loss, g = O.loss_and_grads(cfg, var, audio, ids, l2=l2, dtype=np.float64,
+                               tf_xent_zero_label_quirk=quirk)
+    _, c = O.loss(cfg, var, audio, ids, l2, np.float64, keep=True)
+    out = {'audio': audio, 'loss': np.float64(loss),
+           'logits': c['logits'].astype(np.float32),
+           'quirk': np.int32(quirk)}
+    if ids is not None:
+        out['ids'] = ids.astype(np.int32)
+    if l2 is not None:
+        out['l2'] = np.float64(l2)
+    for i, (n, a) in enumerate(O.flatten_variables(var)):
+        out['w%03d' % i] = a.astype(np.float32)
+    for i, (n, a) in enumerate(O.flatten_variables(g)):
+        out['g%03d' % i] = a.astype(np.float32)
+    out['names'] = np.array([n for n, _ in O.flatten_variables(var)])
+    return {name + '/' + k: v for k, v in out.items()}
+
+
+def incremental_case(cfg, n, seed=0):
+    var = O.create_variables(cfg, seed=seed, dtype=np.float64, bias_scale=0.1)
+    rng = np.random.default_rng(7)
+    Q = cfg['quantization_channels']
+    wave = rng.integers(0, Q, n)
+    gen = O.IncrementalGenerator(cfg, var, dtype=np.float64)
+    probs = np.stack([gen.step(int(s)) for s in wave])
+    naive_last = O.predict_proba(cfg, var, wave, dtype=np.float64)
+    out = {'inc/wave': wave.astype(np.int32), 'inc/probs': probs,
+           'inc/naive_last': naive_last}
+    for i, (nm, a) in enumerate(O.flatten_variables(var)):
+        out['inc/w%03d' % i] = a.astype(np.float32)
+    return out
+
+
+def main():
+    np.savez_compressed(os.path.join(HERE, 'reference_literals.npz'),
+                        **literal())
+    np.savez_compressed(os.path.join(HERE, 'mulaw_families.npz'),
+                        **mulaw_families())
+    cases = {}
+    cases.update(stack_case('tiny', cfg_with(TINY, batch_size=2), 37))
+    cases.update(stack_case('tiny_nobias',
+                            cfg_with(TINY, batch_size=1, use_biases=False), 5))
+    cases.update(stack_case('tiny_gc', cfg_with(
+        TINY, batch_size=3, global_condition_channels=4,
+        global_condition_cardinality=5), 50, gc=True))
+    cases.update(stack_case('tiny_rp_l2', cfg_with(
+        TINY, batch_size=2, residual_postproc=True), 40, l2=0.01))
+    cases.update(stack_case('tiny_noquirk', cfg_with(TINY, batch_size=2), 33,
+                            quirk=False, seed=3))
+    np.savez_compressed(os.path.join(HERE, 'stack_cases.npz'), **cases)
+    # receptive field of TINY = 2*(1+2+4+8)+2 = 32 -> 80 steps > RF
+    np.savez_compressed(os.path.join(HERE, 'incremental.npz'),
+                        **incremental_case(cfg_with(TINY, batch_size=1), 80))
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith('.npz'):
+            print(f, os.path.getsize(os.path.join(HERE, f)))
+
+
+if __name__ == '__main__':
+    main()

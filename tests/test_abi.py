@@ -1,0 +1,86 @@
+"""The C-ABI library: loads without a GPU, exports every symbol the public
+header declares, argument validation returns error codes (no compute calls
+here), and its host-side mu-law tables equal the oracle's."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from util import O, ROOT
+
+HEADER = os.path.join(ROOT, 'include', 'wavenet_hip.h')
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(wn_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_header_symbols_exported(hip_lib):
+    syms = declared_symbols()
+    assert len(syms) >= 35
+    for s in syms:
+        assert hasattr(hip_lib, s), 'missing export %s' % s
+
+
+def test_binding_table_matches_header(hip_lib):
+    from wavenet import _lib
+    assert sorted(_lib.SIGNATURES) == declared_symbols()
+
+
+def test_version_and_error_strings(hip_lib):
+    assert hip_lib.wn_version() >= 100
+    for code in (0, -1, -2, -3, -4, -5):
+        assert len(hip_lib.wn_error_string(code)) > 0
+
+
+def test_argument_validation_without_gpu(hip_lib):
+    # all of these return before any launch
+    assert hip_lib.wn_layer_fwd(None, None, None, None, None, None, None, 0,
+                                1, 8, 1, 1, 1, None) == -5       # NULL
+    assert hip_lib.wn_causal_gather(None, None, None, 1, 1, 1, None) == -5
+    buf = (ctypes.c_float * 64)()
+    a = ctypes.addressof(buf)
+    assert hip_lib.wn_gemm_nn(a, 8, 0, 0, a, 8, None, None, 0, None, 0, a, 8,
+                              0, 0, None, 0, 8, 8, 0, None) == -1  # M <= 0
+    assert hip_lib.wn_gemm_nn(a, 8, 0, 0, a, 8, None, None, 0, None, 0, a, 8,
+                              0, 0, None, 4, 6, 8, 0, None) == -2  # N % 4
+    assert hip_lib.wn_gemm_nn(a + 4, 8, 0, 0, a, 8, None, None, 0, None, 0, a,
+                              8, 0, 0, None, 4, 8, 8, 0, None) == -3  # align
+    assert hip_lib.wn_xent(a, 6, a, a, a, 1, 1, 6, 1, None) == -2
+    assert hip_lib.wn_layer_bwd(None, None, None, None, None, None, None, None,
+                                None, None, None, 1, 8, 1, 0, 0, None) == -1
+    assert hip_lib.wn_mu_law_thresholds_host(1, a) == -1
+    assert hip_lib.wn_fastgen_run(a, a, 0, a, None, a, None, a, None, None, a,
+                                  2, 1024, 16, a, a, a, 1, 1, 1.0, 0, None, 1,
+                                  0, 1, None) == -2              # S > 512
+
+
+@pytest.mark.parametrize('q', [2, 16, 123, 128, 256])
+def test_host_tables_equal_oracle(hip_lib, q):
+    thr = np.empty(q - 1, np.float32)
+    lut = np.empty(q, np.float32)
+    assert hip_lib.wn_mu_law_thresholds_host(q, thr.ctypes.data) == 0
+    assert hip_lib.wn_mu_law_decode_table_host(q, lut.ctypes.data) == 0
+    assert np.array_equal(thr, O.mu_law_thresholds(q))
+    assert np.array_equal(lut, O.mu_law_decode(np.arange(q), q))
+
+
+def test_product_does_not_import_oracle():
+    """The shipped package must never route through the oracle."""
+    pkg = os.path.join(ROOT, 'tensorflow-wavenet_amd', 'wavenet')
+    for f in os.listdir(pkg):
+        if f.endswith('.py'):
+            src = open(os.path.join(pkg, f)).read()
+            assert 'oracle' not in src, f
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from wavenet import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libwavenet_hip.so')
+    with pytest.raises(_lib.WaveNetHipError):
+        _lib.load()

@@ -1,0 +1,146 @@
+"""BASELINE.json-sized runs (default stack, B=8, T=16000) checked through
+size-independent properties of the domain: clip independence (DP identity),
+causality, loss-mean decomposition, determinism -- plus the behavioural
+training thresholds of the reference's test/test_model.py."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from util import O, ROOT, DEFAULT, cfg_with, model_kwargs, synth_audio
+
+pytestmark = pytest.mark.gpu
+
+
+def default_cfg(B):
+    p = json.load(open(os.path.join(ROOT, 'wavenet_params.json')))
+    c = {k: p[k] for k in p if k != 'sample_rate'}
+    c['batch_size'] = B
+    return c
+
+
+def test_full_size_dp_identity_and_determinism(hip_lib):
+    """grad(B=8) == mean over two B=4 shards, loss likewise; two
+    runs are bitwise identical (slab reductions, no float atomics)."""
+    from wavenet import WaveNetModel
+    T = 16000
+    audio = synth_audio(8, T)
+    net8 = WaveNetModel(seed=0, **model_kwargs(default_cfg(8)))
+    l8 = float(net8.loss(audio))
+    g8 = net8.grads.clone()
+    l8b = float(net8.loss(audio))
+    assert l8 == l8b and torch.equal(g8, net8.grads)
+    net4 = WaveNetModel(seed=0, **model_kwargs(default_cfg(4)))
+    assert torch.equal(net4.params, net8.params)
+    la = float(net4.loss(audio[:4]))
+    ga = net4.grads.clone()
+    lb = float(net4.loss(audio[4:]))
+    gb = net4.grads.clone()
+    assert abs(0.5 * (la + lb) - l8) < 1e-5
+    gm = 0.5 * (ga + gb)
+    scale = float(g8.abs().max())
+    assert float((gm - g8).abs().max()) < 1e-4 * max(1.0, scale)
+    assert float((gm - g8).abs().max()) < 2e-3 * scale
+
+
+def test_full_size_causality(hip_lib):
+    """Changing samples at t >= t0 must not change logits before t0."""
+    from wavenet import WaveNetModel
+    T, t0 = 16000, 9000
+    audio = synth_audio(1, T)
+    net = WaveNetModel(seed=0, **model_kwargs(default_cfg(1)))
+    net.loss(audio, backward=False)
+    ws = list(net._ws.values())[0]
+    a = ws.logits.clone()
+    audio2 = audio.copy()
+    audio2[0, t0:] = -audio2[0, t0:]
+    net.loss(audio2, backward=False)
+    b = ws.logits
+    assert torch.equal(a[:t0], b[:t0])
+    assert not torch.equal(a[t0:], b[t0:])
+
+
+def test_default_stack_prefix_vs_oracle(hip_lib):
+    """The first 6000 logits of a 16000-sample clip equal the oracle run on
+    the 6000-sample prefix (causality lets the oracle finish in seconds)."""
+    from wavenet import WaveNetModel
+    T, Tp = 16000, 6000
+    cfg = default_cfg(1)
+    audio = synth_audio(1, T)
+    net = WaveNetModel(seed=0, **model_kwargs(cfg))
+    var = {k: v for k, v in _to_numpy(net.variables).items()}
+    net.loss(audio, backward=False)
+    ws = list(net._ws.values())[0]
+    got = ws.logits[:Tp].cpu().numpy()
+    q = O.mu_law_encode(audio[:, :Tp], 256)
+    ref = O.network_forward(cfg, O.cast_variables(var, np.float64),
+                            O.one_hot(q, 256, np.float64))
+    assert np.abs(got - ref[0]).max() < 1e-4
+
+
+def _to_numpy(tree):
+    if isinstance(tree, dict):
+        return {k: _to_numpy(v) for k, v in tree.items()}
+    if isinstance(tree, list):
+        return [_to_numpy(v) for v in tree]
+    return tree.detach().cpu().numpy()
+
+
+def make_sine_chord(n=1000, rate=2000.0):
+    # test/test_model.py:29-58 (no global conditioning): E-flat chord
+    t = np.arange(0.0, n / rate, 1.0 / rate)[:n]
+    f1, f2, f3 = 155.56, 196.00, 233.08
+    return (np.sin(t * 2 * np.pi * f1) / 3 + np.sin(t * 2 * np.pi * f2) / 3 +
+            np.sin(t * 2 * np.pi * f3) / 3).astype(np.float32)
+
+
+@pytest.mark.parametrize('use_biases', [False, True])
+def test_end_to_end_training_thresholds(hip_lib, use_biases):
+    """test/test_model.py:179-334 (TestNet / TestNetWithBiases): 14 layers,
+    SGD momentum 0.95 lr 0.02, 400 iterations on a 1000-sample chord:
+    initial loss > 0.1, final < 0.1, final/initial < 0.02."""
+    from wavenet import WaveNetModel, optimizer_factory
+    net = WaveNetModel(batch_size=1,
+                       dilations=[1, 2, 4, 8, 16, 32, 64] * 2,
+                       filter_width=2, residual_channels=32,
+                       dilation_channels=32, quantization_channels=256,
+                       use_biases=use_biases, skip_channels=32, seed=1)
+    audio = make_sine_chord()
+    opt = optimizer_factory['sgd'](learning_rate=0.02, momentum=0.95)
+    initial = float(net.loss(audio, backward=False))
+    for i in range(400):
+        loss = net.loss(audio)
+        opt.minimize(loss)
+    final = float(loss)
+    assert initial > 0.1
+    assert final < 0.1
+    assert final / initial < 0.02
+
+
+def test_rmsprop_training_then_fast_generation_spectrum(hip_lib):
+    """test/test_model.py:337-356 + 137-158: rmsprop lr 1e-3, skip 256; the
+    fast-generated waveform carries > 70% of its power at the chord's three
+    frequencies."""
+    from wavenet import WaveNetModel, optimizer_factory, mu_law_decode
+    net = WaveNetModel(batch_size=1, dilations=[1, 2, 4, 8, 16, 32, 64] * 2,
+                       filter_width=2, residual_channels=32,
+                       dilation_channels=32, quantization_channels=256,
+                       skip_channels=256, seed=1)
+    audio = make_sine_chord()
+    opt = optimizer_factory['rmsprop'](learning_rate=1e-3, momentum=0.95)
+    initial = float(net.loss(audio, backward=False))
+    for i in range(400):
+        loss = net.loss(audio)
+        opt.minimize(loss)
+    assert float(loss) < 0.1 and float(loss) / initial < 0.02
+    codes = net.generate(1000, seed_samples=[128], seed=3)
+    wav = mu_law_decode(codes[256:], 256).cpu().numpy()   # skip RF, :91-93
+    power = np.abs(np.fft.fft(wav)) ** 2
+    freqs = np.fft.fftfreq(wav.size, 1.0 / 2000.0)
+    sel = (freqs >= 0) & (freqs <= 500.0)
+    power, freqs = power[sel], freqs[sel]
+    near = lambda f: power[np.abs(freqs - f).argmin()]
+    expected = near(155.56) + near(196.00) + near(233.08)
+    assert expected > 0.7 * power.sum()

@@ -1,0 +1,246 @@
+"""GPU parity of the WaveNet hot path (forward, loss, hand-written backward,
+optimizers, naive and incremental prediction) against the CPU oracle and the
+committed golden fixtures.  fp32 tolerance: 1e-4 (BASELINE.json north_star),
+gradients relative to the largest entry of each variable."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from util import (O, TINY, MID, DEFAULT, cfg_with, build_pair, flat_named,
+                  tree_to_numpy, model_kwargs, synth_audio)
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+TOL = 1e-4
+
+
+def check_grads(net, ref_g, tol=TOL):
+    got = tree_to_numpy(net.gradients)
+    for (n, a), (_, b) in zip(flat_named(got), flat_named(ref_g)):
+        err = np.abs(a - b).max()
+        assert err <= tol * max(1.0, np.abs(b).max()) and \
+            err <= 2e-3 * np.abs(b).max() + 1e-7, (n, err, np.abs(b).max())
+
+
+CASES = [
+    ('tiny', cfg_with(TINY, batch_size=2), 37, False, None),
+    ('tiny_T_lt_32', cfg_with(TINY, batch_size=3), 5, False, None),
+    ('tiny_T1', cfg_with(TINY, batch_size=2), 1, False, None),
+    ('tiny_ragged', cfg_with(TINY, batch_size=2), 131, False, None),
+    ('nobias', cfg_with(TINY, batch_size=1, use_biases=False), 70, False, None),
+    ('mid', cfg_with(MID, batch_size=2), 300, False, None),
+    ('mid_T_lt_d', cfg_with(MID, batch_size=1), 50, False, None),
+    ('gc', cfg_with(TINY, batch_size=3, global_condition_channels=4,
+                    global_condition_cardinality=5), 50, True, None),
+    ('gc_square', cfg_with(MID, batch_size=3, global_condition_channels=3,
+                           global_condition_cardinality=3), 90, True, None),
+    ('rp_l2', cfg_with(TINY, batch_size=2, residual_postproc=True), 40, False,
+     0.01),
+    ('r16', cfg_with(MID, batch_size=1, residual_channels=16,
+                     dilation_channels=16, skip_channels=32,
+                     quantization_channels=128), 200, False, None),
+    ('default', cfg_with(DEFAULT, batch_size=1), 1500, False, None),
+    ('default_gc', cfg_with(DEFAULT, batch_size=2,
+                            global_condition_channels=32,
+                            global_condition_cardinality=377), 700, True, None),
+]
+
+
+@pytest.mark.parametrize('name,cfg,T,gc,l2', CASES, ids=[c[0] for c in CASES])
+def test_loss_and_gradients_vs_oracle(hip_lib, name, cfg, T, gc, l2):
+    B = cfg['batch_size']
+    net, var = build_pair(cfg)
+    rng = np.random.default_rng(7)
+    audio = rng.uniform(-1, 1, (B, T)).astype(np.float32)
+    ids = rng.integers(0, cfg['global_condition_cardinality'], B) if gc \
+        else None
+    ref_loss, ref_g = O.loss_and_grads(cfg, var, audio, ids, l2=l2,
+                                       dtype=np.float64)
+    _, c = O.loss(cfg, var, audio, ids, l2, np.float64, keep=True)
+    loss = net.loss(audio, ids, l2)
+    torch.cuda.synchronize()
+    ws = list(net._ws.values())[0]
+    # codes: bit exact
+    assert np.array_equal(ws.q.cpu().numpy().reshape(B, T),
+                          O.mu_law_encode(audio, cfg['quantization_channels']))
+    assert abs(float(loss) - ref_loss) < TOL
+    check_grads(net, ref_g)
+    # forward-only path gives the same loss and identical logits to the oracle
+    loss2 = net.loss(audio, ids, l2, backward=False)
+    assert abs(float(loss2) - ref_loss) < TOL
+    logits = ws.logits.cpu().numpy().reshape(B, T, -1)
+    assert np.abs(logits - c['logits']).max() < TOL
+
+
+def test_xent_quirk_switch(hip_lib):
+    cfg = cfg_with(TINY, batch_size=2)
+    net, var = build_pair(cfg)
+    audio = np.random.default_rng(1).uniform(-1, 1, (2, 33)).astype(np.float32)
+    for quirk in (True, False):
+        net.tf_xent_zero_label_quirk = quirk
+        ref_loss, ref_g = O.loss_and_grads(
+            cfg, var, audio, dtype=np.float64, tf_xent_zero_label_quirk=quirk)
+        loss = net.loss(audio)
+        assert abs(float(loss) - ref_loss) < TOL
+        check_grads(net, ref_g)
+
+
+def test_l2_bias_name_quirk_switch(hip_lib):
+    cfg = cfg_with(TINY, batch_size=2)
+    net, var = build_pair(cfg)
+    audio = np.random.default_rng(1).uniform(-1, 1, (2, 33)).astype(np.float32)
+    for quirk in (True, False):
+        net.tf_bias_name_quirk = quirk
+        ref_loss, ref_g = O.loss_and_grads(cfg, var, audio, l2=0.05,
+                                           dtype=np.float64,
+                                           tf_bias_name_quirk=quirk)
+        loss = net.loss(audio, None, 0.05)
+        assert abs(float(loss) - ref_loss) < TOL
+        check_grads(net, ref_g)
+
+
+GOLD_CFG = {
+    'tiny': cfg_with(TINY, batch_size=2),
+    'tiny_nobias': cfg_with(TINY, batch_size=1, use_biases=False),
+    'tiny_gc': cfg_with(TINY, batch_size=3, global_condition_channels=4,
+                        global_condition_cardinality=5),
+    'tiny_rp_l2': cfg_with(TINY, batch_size=2, residual_postproc=True),
+    'tiny_noquirk': cfg_with(TINY, batch_size=2),
+}
+
+
+@pytest.mark.parametrize('name', sorted(GOLD_CFG))
+def test_golden_fixtures(hip_lib, name):
+    from wavenet import WaveNetModel
+    z = np.load(os.path.join(GOLD, 'stack_cases.npz'))
+    c = {k.split('/', 1)[1]: z[k] for k in z.files if k.startswith(name + '/')}
+    cfg = GOLD_CFG[name]
+    net = WaveNetModel(**model_kwargs(cfg))
+    with torch.no_grad():
+        for i, (n, v) in enumerate(net.named_variables()):
+            v.copy_(torch.from_numpy(c['w%03d' % i]).to(v.device))
+    net.tf_xent_zero_label_quirk = bool(c['quirk'])
+    l2 = float(c['l2']) if 'l2' in c else None
+    loss = net.loss(c['audio'], c.get('ids'), l2)
+    assert abs(float(loss) - float(c['loss'])) < TOL
+    ws = list(net._ws.values())[0]
+    B = cfg['batch_size']
+    for i, (n, g) in enumerate(net.named_variables(net.gradients)):
+        ref = c['g%03d' % i]
+        assert np.abs(g.cpu().numpy() - ref).max() <= \
+            TOL * max(1.0, np.abs(ref).max()), n
+
+
+@pytest.mark.parametrize('kind,lr,mom', [('adam', 1e-3, 0.9),
+                                         ('sgd', 0.02, 0.95),
+                                         ('rmsprop', 1e-3, 0.9)])
+def test_optimizer_trajectory_vs_oracle(hip_lib, kind, lr, mom):
+    """Three full training steps: HIP (loss + fused update) vs oracle
+    (float64 loss/grads + TF-rule optimizer)."""
+    from wavenet import optimizer_factory
+    cfg = cfg_with(TINY, batch_size=2)
+    net, var = build_pair(cfg)
+    audio = np.random.default_rng(2).uniform(-1, 1, (2, 40)).astype(np.float32)
+    opt = optimizer_factory[kind](learning_rate=lr, momentum=mom)
+    ref_opt = O.TFOptimizer(kind, lr, mom)
+    for step in range(3):
+        ref_loss, ref_g = O.loss_and_grads(cfg, var, audio, dtype=np.float64)
+        O.unpack_into(var, ref_opt.apply(O.pack(var), O.pack(ref_g)))
+        loss = net.loss(audio)
+        opt.minimize(loss)
+        assert abs(float(loss) - ref_loss) < TOL, step
+    got = tree_to_numpy(net.variables)
+    for (n, a), (_, b) in zip(flat_named(got), flat_named(var)):
+        assert np.abs(a - b).max() < 2e-5, n
+
+
+def test_predict_proba_vs_oracle(hip_lib):
+    # test/test_generation.py:19-32 shapes (9 layers, R=D=16, Q=128, S=32)
+    cfg = dict(batch_size=1, dilations=[1, 2, 4, 8, 16, 32, 64, 128, 256],
+               filter_width=2, residual_channels=16, dilation_channels=16,
+               quantization_channels=128, skip_channels=32, use_biases=True)
+    net, var = build_pair(cfg)
+    np.random.seed(0)
+    data = np.random.randint(128, size=1000)
+    p = net.predict_proba(data).cpu().numpy()
+    assert p.shape == (128,)
+    assert np.all((p >= 0) & (p <= 1)) and abs(p.sum() - 1) < 1e-5
+    ref = O.predict_proba(cfg, var, data, dtype=np.float64)
+    assert np.abs(p - ref).max() < 1e-5
+
+
+def test_incremental_vs_oracle_and_naive(hip_lib):
+    """test/test_generation.py:50-72 strengthened: compare over more than the
+    receptive field (RF 32 -> 80 steps), against the golden trace, the oracle
+    and the naive forward."""
+    from wavenet import WaveNetModel
+    z = np.load(os.path.join(GOLD, 'incremental.npz'))
+    cfg = cfg_with(TINY, batch_size=1)
+    net = WaveNetModel(**model_kwargs(cfg))
+    with torch.no_grad():
+        for i, (n, v) in enumerate(net.named_variables()):
+            v.copy_(torch.from_numpy(z['inc/w%03d' % i]).to(v.device))
+    wave, probs = z['inc/wave'], z['inc/probs']
+    net.reset_generator()
+    for i, s in enumerate(wave):
+        if i == len(wave) - 1:
+            # the reference's final proba op runs WITHOUT push_ops
+            p = net.predict_proba_incremental(int(s), push=False).cpu().numpy()
+            p_again = net.predict_proba_incremental(int(s)).cpu().numpy()
+            assert np.array_equal(p, p_again)
+        else:
+            p = net.predict_proba_incremental(int(s)).cpu().numpy()
+        assert np.abs(p - probs[i]).max() < 1e-5, i
+    naive = net.predict_proba(wave).cpu().numpy()
+    assert np.abs(naive - z['inc/naive_last']).max() < 1e-5
+    assert np.abs(naive - p).max() < 1e-5
+    # the persistent kernel in one launch (teacher forced) gives the same trace
+    out, pr = net.generate(0, seed_samples=wave, return_proba_every=1)
+    assert np.array_equal(out.cpu().numpy(), wave)
+    assert np.abs(pr.cpu().numpy() - probs[:len(wave) - 1]).max() < 1e-5
+
+
+def test_generate_sampling(hip_lib):
+    cfg = cfg_with(MID, batch_size=1)
+    net, var = build_pair(cfg)
+    a = net.generate(300, seed_samples=[128], seed=11).cpu().numpy()
+    b = net.generate(300, seed_samples=[128], seed=11).cpu().numpy()
+    c = net.generate(300, seed_samples=[128], seed=12).cpu().numpy()
+    assert a.shape == (301,) and a[0] == 128
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    assert a.min() >= 0 and a.max() < 256
+    # drawn samples follow the predicted distribution: teacher-force the drawn
+    # sequence through the oracle and compare empirical log-likelihood ranks
+    gen = O.IncrementalGenerator(cfg, var, dtype=np.float64)
+    ll = 0.0
+    for i in range(120):
+        p = gen.step(int(a[i]))
+        ll += np.log(p[a[i + 1]] + 1e-30)
+    assert ll / 120 > np.log(1.0 / 256) - 1.0   # far better than uniform-1nat
+    # low temperature -> (nearly) argmax decoding
+    g = net.generate(40, seed_samples=[128], temperature=1e-3, seed=5)
+    g = g.cpu().numpy()
+    gen = O.IncrementalGenerator(cfg, var, dtype=np.float64)
+    for i in range(40):
+        p = gen.step(int(g[i]))
+        assert g[i + 1] == int(np.argmax(p)) or \
+            p[g[i + 1]] > 0.999 * p.max()
+
+
+def test_unsupported_configs_raise(hip_lib):
+    from wavenet import WaveNetModel
+    for kw in (dict(filter_width=3), dict(scalar_input=True),
+               dict(residual_channels=64)):
+        cfg = cfg_with(TINY, batch_size=1, **kw)
+        net = WaveNetModel(**model_kwargs(cfg))
+        with pytest.raises(NotImplementedError):
+            net.loss(np.zeros(16, np.float32))
+    net = WaveNetModel(**model_kwargs(cfg_with(
+        TINY, batch_size=2, global_condition_channels=4,
+        global_condition_cardinality=5)))
+    with pytest.raises(ValueError):
+        net.loss(np.zeros((2, 16), np.float32), np.array([1, 2, 3]))
+    with pytest.raises(ValueError):
+        net.loss(np.zeros((2, 16), np.float32))

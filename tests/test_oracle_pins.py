@@ -1,0 +1,127 @@
+"""The oracle against every known answer the reference's own tests hold for
+the hot path: these PIN causal_conv and mu-law."""
+import os
+
+import numpy as np
+
+from util import O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def test_causal_conv_known_answer():
+    # test/test_causal_conv.py:11-27
+    lit = np.load(os.path.join(GOLD, 'reference_literals.npz'))
+    out = O.causal_conv(lit['cc_x'], lit['cc_f'], 4)
+    assert np.array_equal(out, lit['cc_y'])
+    assert np.array_equal(O.causal_conv_literal(lit['cc_x'], lit['cc_f'], 4),
+                          lit['cc_y'])
+
+
+def test_causal_conv_no_time_shift():
+    # test/test_causal_conv.py:29-58
+    lit = np.load(os.path.join(GOLD, 'reference_literals.npz'))
+    out = O.causal_conv(lit['nts_x'], lit['nts_f'], 2)
+    assert out.shape == lit['nts_x'].shape
+    assert np.array_equal(out, lit['nts_x'])
+
+
+def test_closed_form_equals_literal_graph():
+    rng = np.random.default_rng(1)
+    for K in (2, 3, 4, 32):
+        for d in (1, 2, 3, 7, 64):
+            for T in (5, 20, 37):
+                x = rng.standard_normal((3, T, 4))
+                w = rng.standard_normal((K, 4, 5))
+                assert np.allclose(O.causal_conv(x, w, d),
+                                   O.causal_conv_literal(x, w, d), atol=1e-12)
+
+
+def test_time_to_batch_roundtrip():
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((2, 24, 3))
+    for d in (1, 2, 3, 4, 8):
+        y = O.time_to_batch(x, d)
+        assert y.shape == (2 * d, 24 // d, 3)
+        assert np.array_equal(O.batch_to_time(y, d), x)
+
+
+def test_mu_law_encode_precomputed():
+    # test/test_mu_law.py:113-124
+    lit = np.load(os.path.join(GOLD, 'reference_literals.npz'))
+    assert np.array_equal(O.mu_law_encode(lit['mulaw_x'], 256),
+                          lit['mulaw_codes'])
+
+
+def test_mu_law_decode_encode_all_levels():
+    # test/test_mu_law.py:37-51
+    x = np.arange(256)
+    assert np.array_equal(O.mu_law_encode(O.mu_law_decode(x, 256), 256), x)
+
+
+def test_mu_law_min_max_range():
+    # test/test_mu_law.py:53-68
+    d = O.mu_law_decode(np.arange(256), 256)
+    assert abs(d.max() - 1.0) < 1e-10 and abs(d.min() + 1.0) < 1e-10
+
+
+def test_mu_law_shift_and_invariance():
+    # test/test_mu_law.py:70-104
+    x = np.linspace(-1, 1, 1000).astype(np.float32)
+    x1 = O.mu_law_decode(O.mu_law_encode(x, 256), 256)
+    slope, icpt = np.polyfit(x, x1, 1)
+    assert abs(slope - 1.0) < 1e-4 and abs(icpt) < 1e-4
+    assert np.allclose(x, x1, rtol=1e-1, atol=0.05)
+    x2 = O.mu_law_decode(O.mu_law_encode(x1, 256), 256)
+    assert np.allclose(x1, x2)
+
+
+def test_mu_law_surjective_123():
+    # test/test_mu_law.py:106-111
+    x = np.linspace(-1, 1, 10000).astype(np.float32)
+    assert len(np.unique(O.mu_law_encode(x, 123))) == 123
+
+
+def _manual_encode_f32(signal, channels):
+    """test/test_mu_law.py:11-22 restated with the float32 arithmetic it had
+    under the NumPy of its day (weak python scalars)."""
+    mu = np.float32(channels - 1)
+    s = signal.astype(np.float32)
+    mag = np.log(np.float32(1) + mu * np.abs(s)) / np.log(np.float32(1) + mu)
+    s = np.sign(s) * mag
+    s = (s + np.float32(1)) / np.float32(2) * mu + np.float32(0.5)
+    return s.astype(np.int32)
+
+
+def test_mu_law_seeded_families():
+    # inputs of test/test_mu_law.py:126-178; the oracle's correctly-rounded-log
+    # chain must agree with the plain float32 numpy chain and the fixtures
+    fam = np.load(os.path.join(GOLD, 'mulaw_families.npz'))
+    for k in ['uniform', 'const', 'ramp', 'zeros']:
+        x = fam['enc_%s_x' % k]
+        got = O.mu_law_encode(x, 256)
+        assert np.array_equal(got, fam['enc_%s_codes' % k])
+        assert np.array_equal(got, _manual_encode_f32(x, 256))
+
+
+def test_mu_law_decode_family():
+    # test/test_mu_law.py:205-261 (128 channels)
+    fam = np.load(os.path.join(GOLD, 'mulaw_families.npz'))
+    assert np.array_equal(O.mu_law_decode(fam['dec128_codes'], 128),
+                          fam['dec128_audio'])
+    assert np.array_equal(O.mu_law_decode(np.arange(256), 256),
+                          fam['dec256_all'])
+
+
+def test_thresholds_reproduce_encode():
+    fam = np.load(os.path.join(GOLD, 'mulaw_families.npz'))
+    rng = np.random.default_rng(0)
+    for q in (16, 123, 128, 256):
+        thr = O.mu_law_thresholds(q)
+        assert np.array_equal(thr, fam['thr_%d' % q])
+        assert np.all(np.diff(thr) > 0)
+        x = np.concatenate([rng.uniform(-1, 1, 50000).astype(np.float32), thr,
+                            np.nextafter(thr, np.float32(-2)),
+                            np.float32([-1, 1, 0, -0.0])])
+        assert np.array_equal(O.mu_law_encode(x, q),
+                              np.searchsorted(thr, x, side='right'))

@@ -1,0 +1,87 @@
+"""Data-parallel path on CPU: two `gloo` ranks.  The flat-bucket all-reduce +
+1/N scaling of wavenet.parallel must reproduce the single-process gradient of
+the full batch ("N ranks x B/N == 1 rank x B").  Per-rank gradients
+come from the CPU oracle here (tests may use it as a stand-in producer; on the
+GPU the same helpers run on the HIP bucket over RCCL)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from util import O, TINY, cfg_with, ROOT, PKG
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _Bucket(object):
+    def __init__(self, flat):
+        self.grads = flat
+        self.params = flat.clone()
+
+
+def _worker(rank, world, port, out_dir):
+    for p in (ROOT, PKG, os.path.join(ROOT, 'tests')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from wavenet import parallel
+    r, w, _ = parallel.init_from_env(backend='gloo')
+    assert (r, w) == (rank, world) and parallel.is_distributed()
+    B, T = 4, 21
+    cfg = cfg_with(TINY, batch_size=B // world)
+    var = O.create_variables(cfg, seed=0, dtype=np.float64, bias_scale=0.1)
+    audio = np.random.default_rng(5).uniform(-1, 1, (B, T)).astype(np.float32)
+    lo, hi = parallel.shard_range(B, rank, world)
+    loss, g = O.loss_and_grads(cfg, var, audio[lo:hi], dtype=np.float64)
+    bucket = _Bucket(torch.from_numpy(O.pack(g)))
+    # rank 1 starts from garbage weights: broadcast must fix that
+    ref_params = torch.from_numpy(O.pack(var))
+    bucket.params = ref_params.clone() + (1.0 if rank == 1 else 0.0)
+    parallel.broadcast_parameters(bucket, src=0)
+    assert torch.equal(bucket.params, ref_params)
+    scale = parallel.allreduce_gradients(bucket)
+    avg = bucket.grads * scale
+    mloss = parallel.allreduce_mean_scalar(torch.tensor(loss))
+    np.save(os.path.join(out_dir, 'g%d.npy' % rank), avg.numpy())
+    np.save(os.path.join(out_dir, 'l%d.npy' % rank), mloss.numpy())
+    dist.destroy_process_group()
+
+
+def test_dp_two_ranks_equal_full_batch(tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world,
+             join=True)
+    B, T = 4, 21
+    cfg = cfg_with(TINY, batch_size=B)
+    var = O.create_variables(cfg, seed=0, dtype=np.float64, bias_scale=0.1)
+    audio = np.random.default_rng(5).uniform(-1, 1, (B, T)).astype(np.float32)
+    loss, g = O.loss_and_grads(cfg, var, audio, dtype=np.float64)
+    full = O.pack(g)
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), 'g%d.npy' % r))
+        assert np.abs(got - full).max() < 1e-12
+        assert abs(float(np.load(os.path.join(str(tmp_path),
+                                              'l%d.npy' % r))) - loss) < 1e-12
+
+
+def test_world_size_one_is_identity():
+    from wavenet import parallel
+    t = torch.arange(5, dtype=torch.float32)
+    assert parallel.allreduce_flat_(t) == 1.0
+    assert torch.equal(t, torch.arange(5, dtype=torch.float32))
+    assert not parallel.is_distributed()

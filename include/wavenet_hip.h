@@ -141,6 +141,9 @@ int wn_time_to_batch(const float* in, float* out, int B, int T, int C,
 int wn_batch_to_time(const float* in, float* out, int B_out, int U, int C,
                      int dilation, void* stream);
 
+/* ---- diagnostics: register-only fp32 MFMA loop (clock-limited ceiling) */
+int wn_diag_mfma_peak(float* out, int blocks, int iters, void* stream);
+
 /* ---- utilities */
 int wn_axpy(float* y, const float* x, float a, const float* mask, long n,
             void* stream);

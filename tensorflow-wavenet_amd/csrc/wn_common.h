@@ -94,6 +94,107 @@ __device__ __forceinline__ void frag_store(float* __restrict__ rowp, int h,
   }
 }
 
+// ---------------------------------------------------------------------------
+// Coalesced plane I/O through a wave-private LDS tile.
+// A fragment access touches 32 rows x 32 B per instruction; HBM/L2 like whole
+// 128-byte lines better (measured: 3.6 -> see DESIGN.md).  So global memory is
+// always accessed "row-contiguous" (lane l <-> row 8c + (l>>3), 16-byte chunk
+// l&7: one instruction = 8 full rows = 1 KiB contiguous) and the 32x32 tile is
+// turned into fragment layout through LDS.  Tile layout: [row][32 floats],
+// chunk c of row r stored at chunk c ^ (r & 7): conflict-free for the
+// row-contiguous side, 2-way for the fragment side.  A wave's DS operations
+// execute in order, so no barrier is needed between the two sides.
+// ---------------------------------------------------------------------------
+struct RowRegs {
+  f32x4 v[4];
+};
+
+// rows [lo, hi) of the 32-row tile are real, the others read as zero
+__device__ __forceinline__ RowRegs rows_load(const float* __restrict__ tile0,
+                                             int lane, int lo, int hi) {
+  RowRegs R;
+  const float* p = tile0 + (long)(lane >> 3) * 32 + (lane & 7) * 4;
+  if (lo <= 0 && hi >= 32) {  // wave-uniform: whole tile real -> no predicates
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      R.v[c] = *reinterpret_cast<const f32x4*>(p + c * 256);
+  } else {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int r = 8 * c + (lane >> 3);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r >= lo && r < hi) v = *reinterpret_cast<const f32x4*>(p + c * 256);
+      R.v[c] = v;
+    }
+  }
+  return R;
+}
+
+__device__ __forceinline__ void rows_store(float* __restrict__ tile0, int lane,
+                                           int hi, const RowRegs& R) {
+  float* p = tile0 + (long)(lane >> 3) * 32 + (lane & 7) * 4;
+  if (hi >= 32) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) *reinterpret_cast<f32x4*>(p + c * 256) = R.v[c];
+  } else {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int r = 8 * c + (lane >> 3);
+      if (r < hi) *reinterpret_cast<f32x4*>(p + c * 256) = R.v[c];
+    }
+  }
+}
+
+__device__ __forceinline__ void rows_to_lds(float* tile, int lane,
+                                            const RowRegs& R) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int r = 8 * c + (lane >> 3);
+    *reinterpret_cast<f32x4*>(tile + r * 32 + (((lane & 7) ^ (r & 7)) << 2)) =
+        R.v[c];
+  }
+}
+
+__device__ __forceinline__ RowRegs rows_from_lds(const float* tile, int lane) {
+  RowRegs R;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int r = 8 * c + (lane >> 3);
+    R.v[c] = *reinterpret_cast<const f32x4*>(
+        tile + r * 32 + (((lane & 7) ^ (r & 7)) << 2));
+  }
+  return R;
+}
+
+__device__ __forceinline__ f32x16 frag_from_lds(const float* tile, int j,
+                                                int h) {
+  f32x16 f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(
+        tile + j * 32 + (((2 * q + h) ^ (j & 7)) << 2));
+    f[4 * q + 0] = v[0];
+    f[4 * q + 1] = v[1];
+    f[4 * q + 2] = v[2];
+    f[4 * q + 3] = v[3];
+  }
+  return f;
+}
+
+__device__ __forceinline__ void frag_to_lds(float* tile, int j, int h,
+                                            const f32x16& f) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x4 v = {f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]};
+    *reinterpret_cast<f32x4*>(tile + j * 32 + (((2 * q + h) ^ (j & 7)) << 2)) = v;
+  }
+}
+
+// element [row][ch] of a swizzled tile (transposed, channel-on-lane reads)
+__device__ __forceinline__ float tile_elem(const float* tile, int row, int ch) {
+  return tile[row * 32 + (((ch >> 2) ^ (row & 7)) << 2) + (ch & 3)];
+}
+
 // Per-channel vector (bias) from LDS/global as a fragment (same value for
 // every time row).
 __device__ __forceinline__ f32x16 frag_bcast(const float* __restrict__ vec,

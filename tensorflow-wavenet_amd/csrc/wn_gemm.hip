@@ -66,29 +66,50 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmNN g) {
   const int nk = (g.K + NN_KC - 1) / NN_KC;
 
   f32x4 ra[4], rb[4];
+  const bool full_m = m0 + NN_TM <= g.M, full_n = n0 + NN_TN <= g.N;
   auto gload = [&](int kc) {
+    const bool full_k = (kc + 1) * NN_KC <= g.K;
+    if (full_m && full_k) {  // interior tile: no predicates, no branches
+      const float* pa = g.a_planes
+                            ? g.A + (long)kc * g.a_plane_stride + m0 * 32
+                            : g.A + m0 * g.lda + kc * NN_KC;
+      const long ld = g.a_planes ? 32 : g.lda;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = (tid >> 3) + 32 * i, ch = tid & 7;
-      const long m = m0 + row;
-      const int k = kc * NN_KC + ch * 4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m < g.M && k < g.K) {
-        const float* p = g.a_planes
-                             ? g.A + (long)kc * g.a_plane_stride + m * 32 + ch * 4
-                             : g.A + m * g.lda + k;
-        v = *reinterpret_cast<const f32x4*>(p);
+      for (int i = 0; i < 4; ++i)
+        ra[i] = *reinterpret_cast<const f32x4*>(
+            pa + (long)((tid >> 3) + 32 * i) * ld + (tid & 7) * 4);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = (tid >> 3) + 32 * i, ch = tid & 7;
+        const long m = m0 + row;
+        const int k = kc * NN_KC + ch * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m < g.M && k < g.K) {
+          const float* p = g.a_planes
+                               ? g.A + (long)kc * g.a_plane_stride + m * 32 + ch * 4
+                               : g.A + m * g.lda + k;
+          v = *reinterpret_cast<const f32x4*>(p);
+        }
+        ra[i] = v;
       }
-      ra[i] = v;
     }
+    if (full_n && full_k) {
+      const float* pb = g.W + (long)kc * NN_KC * g.ldw + n0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int kk = (tid >> 5) + 8 * i, c4 = tid & 31;
-      const int k = kc * NN_KC + kk, n = n0 + c4 * 4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (k < g.K && n < g.N)
-        v = *reinterpret_cast<const f32x4*>(g.W + (long)k * g.ldw + n);
-      rb[i] = v;
+      for (int i = 0; i < 4; ++i)
+        rb[i] = *reinterpret_cast<const f32x4*>(
+            pb + (long)((tid >> 5) + 8 * i) * g.ldw + (tid & 31) * 4);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int kk = (tid >> 5) + 8 * i, c4 = tid & 31;
+        const int k = kc * NN_KC + kk, n = n0 + c4 * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k < g.K && n < g.N)
+          v = *reinterpret_cast<const f32x4*>(g.W + (long)k * g.ldw + n);
+        rb[i] = v;
+      }
     }
   };
   auto sstore = [&](int buf) {
@@ -205,8 +226,94 @@ struct GemmTN {
   int want_colsum;
 };
 
+// Software-pipelined: a group = TN_U steps (2*TN_U rows).  The operands of
+// group g+1 are loaded into a second named register set while the MFMAs of
+// group g issue, so the b32 loads' HBM/L2 latency hides under ~TN_U*MF*NF
+// MFMAs (64 cycles each) instead of serialising with them.
+// steps per pipeline group: 4, or 3 for the 160-accumulator <5,2> tile
+#define TN_UF(MF, NF) (((MF) * (NF) >= 10) ? 3 : 4)
+
 template <int MF, int NF>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g) {
+struct TnRegs {
+  float a[TN_UF(MF, NF)][MF];
+  float b[TN_UF(MF, NF)][NF];
+};
+
+// Guarded (edge) loader: any shape, 64-bit addressing, per-element predicates.
+template <int MF, int NF>
+__device__ __forceinline__ void tn_load(const GemmTN& g, TnRegs<MF, NF>& R,
+                                        long r0, long r_end, int h, int i,
+                                        int m0, int n0, const bool* mv,
+                                        const bool* nv, int& tcl) {
+#pragma unroll
+  for (int u = 0; u < TN_UF(MF, NF); ++u) {
+    const long row = r0 + 2 * u + h;
+    const bool rv = row < r_end;
+    if (g.codes) {
+      int code = -1;
+      if (rv && tcl >= g.shift) code = g.codes[row - g.shift];
+      tcl += 2;
+      while (tcl >= g.T) tcl -= g.T;
+#pragma unroll
+      for (int a = 0; a < MF; ++a)
+        R.a[u][a] = (code == m0 + a * 32 + i) ? 1.f : 0.f;
+    } else {
+#pragma unroll
+      for (int a = 0; a < MF; ++a) {
+        const int m = m0 + a * 32 + i;
+        float v = 0.f;
+        if (rv && mv[a])
+          v = g.a_planes ? g.A[(long)(m >> 5) * g.a_plane_stride + row * 32 + (m & 31)]
+                         : g.A[row * g.lda + m];
+        R.a[u][a] = v;
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NF; ++b) {
+      float v = 0.f;
+      if (rv && nv[b]) v = g.G[row * g.ldg + n0 + b * 32 + i];
+      R.b[u][b] = v;
+    }
+  }
+}
+
+// Fast loader for interior groups of full tiles: no predicates, no branches,
+// wave-uniform base pointers + 32-bit per-lane offsets (the common case: every
+// group but the last of a split, channel counts multiples of 32).
+template <int MF, int NF>
+__device__ __forceinline__ void tn_load_fast(const GemmTN& g,
+                                             TnRegs<MF, NF>& R,
+                                             const float* const* abase,
+                                             const float* const* gbase,
+                                             unsigned aoff, unsigned goff,
+                                             unsigned astep, unsigned gstep) {
+#pragma unroll
+  for (int u = 0; u < TN_UF(MF, NF); ++u) {
+#pragma unroll
+    for (int a = 0; a < MF; ++a) R.a[u][a] = abase[a][aoff + u * astep];
+#pragma unroll
+    for (int b = 0; b < NF; ++b) R.b[u][b] = gbase[b][goff + u * gstep];
+  }
+}
+
+template <int MF, int NF>
+__device__ __forceinline__ void tn_mma(const TnRegs<MF, NF>& R,
+                                       f32x16 (&acc)[MF][NF], float (&cs)[NF]) {
+#pragma unroll
+  for (int u = 0; u < TN_UF(MF, NF); ++u) {
+#pragma unroll
+    for (int b = 0; b < NF; ++b) cs[b] += R.b[u][b];
+#pragma unroll
+    for (int a = 0; a < MF; ++a)
+#pragma unroll
+      for (int b = 0; b < NF; ++b)
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(R.a[u][a], R.b[u][b],
+                                                          acc[a][b], 0, 0, 0);
+  }
+}
+
+template <int MF, int NF>
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
   const int wt = blockIdx.x * 4 + wave;
@@ -233,44 +340,43 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g) {
 #pragma unroll
   for (int b = 0; b < NF; ++b) nv[b] = (n0 + b * 32 + i) < g.Nw;
 
-  const int nsteps = (int)((r_end - r_begin + 1) >> 1);
   int tcl = g.codes ? (int)((r_begin + h) % g.T) : 0;  // time inside the clip
-  for (int st = 0; st < nsteps; ++st) {
-    const long row = r_begin + 2 * (long)st + h;
-    const bool rv = row < r_end;
-    float av[MF], bv[NF];
-    if (g.codes) {
-      int code = -1;
-      if (rv && tcl >= g.shift) code = g.codes[row - g.shift];
-      tcl += 2;
-      while (tcl >= g.T) tcl -= g.T;
+  constexpr int GR = 2 * TN_UF(MF, NF);                // rows per group
+  TnRegs<MF, NF> RA, RB;
+  // fast path: dense/plane A (not one-hot), full channel tiles, offsets < 2^32
+  const long a_ld = g.a_planes ? 32 : g.lda;
+  const bool fast = !g.codes && (m0 + MF * 32 <= g.Mw) && (n0 + NF * 32 <= g.Nw) &&
+                    (g.rows * (a_ld > g.ldg ? a_ld : g.ldg) < (1L << 30));
+  const float* abase[MF];
+  const float* gbase[NF];
 #pragma unroll
-      for (int a = 0; a < MF; ++a)
-        av[a] = (code == m0 + a * 32 + i) ? 1.f : 0.f;
-    } else {
+  for (int a = 0; a < MF; ++a)
+    abase[a] = g.a_planes ? g.A + (long)((m0 >> 5) + a) * g.a_plane_stride
+                          : g.A + m0 + a * 32;
 #pragma unroll
-      for (int a = 0; a < MF; ++a) {
-        const int m = m0 + a * 32 + i;
-        float v = 0.f;
-        if (rv && mv[a])
-          v = g.a_planes ? g.A[(long)(m >> 5) * g.a_plane_stride + row * 32 + (m & 31)]
-                         : g.A[row * g.lda + m];
-        av[a] = v;
-      }
-    }
-#pragma unroll
-    for (int b = 0; b < NF; ++b) {
-      float v = 0.f;
-      if (rv && nv[b]) v = g.G[row * g.ldg + n0 + b * 32 + i];
-      bv[b] = v;
-      cs[b] += v;
-    }
-#pragma unroll
-    for (int a = 0; a < MF; ++a)
-#pragma unroll
-      for (int b = 0; b < NF; ++b)
-        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+  for (int b = 0; b < NF; ++b) gbase[b] = g.G + n0 + b * 32;
+  const unsigned astep = 2u * (unsigned)a_ld, gstep = 2u * (unsigned)g.ldg;
+  long r = r_begin;
+#define TN_LOAD(REG, R0)                                                       \
+  do {                                                                         \
+    if (fast && (R0) + GR <= r_end)                                            \
+      tn_load_fast<MF, NF>(g, REG, abase, gbase,                               \
+                           (unsigned)(((R0) + h) * a_ld) + i,                  \
+                           (unsigned)(((R0) + h) * g.ldg) + i, astep, gstep);  \
+    else                                                                       \
+      tn_load<MF, NF>(g, REG, (R0), r_end, h, i, m0, n0, mv, nv, tcl);         \
+  } while (0)
+  if (r < r_end) TN_LOAD(RA, r);
+  while (r < r_end) {
+    if (r + GR < r_end) TN_LOAD(RB, r + GR);
+    tn_mma<MF, NF>(RA, acc, cs);
+    r += GR;
+    if (r >= r_end) break;
+    if (r + GR < r_end) TN_LOAD(RA, r + GR);
+    tn_mma<MF, NF>(RB, acc, cs);
+    r += GR;
   }
+#undef TN_LOAD
 
   float* slab = g.slabs + (long)blockIdx.y * g.slab_stride;
 #pragma unroll
@@ -280,9 +386,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g) {
       const int n = n0 + b * 32 + i;
       if (n >= g.Nw) continue;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + a * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-        if (m < g.Mw) slab[(long)m * g.Nw + n] = acc[a][b][r];
+      for (int rr = 0; rr < 16; ++rr) {
+        const int m = m0 + a * 32 + 8 * (rr >> 2) + 4 * h + (rr & 3);
+        if (m < g.Mw) slab[(long)m * g.Nw + n] = acc[a][b][rr];
       }
     }
   if (g.want_colsum && tm == 0) {
@@ -338,7 +444,36 @@ __global__ void transpose_pad_kernel(const float* __restrict__ in, int rows,
   }
 }
 
+// Diagnostic: register-only fp32 MFMA loop (no memory traffic) -- calibrates
+// the clock-limited MFMA ceiling of the device the benchmark runs on.
+__global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters) {
+  f32x16 a0 = frag_zero(), a1 = frag_zero(), a2 = frag_zero(), a3 = frag_zero();
+  float x = 1.0f + threadIdx.x * 1e-3f, y = 0.5f - threadIdx.x * 1e-3f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, a1, 0, 0, 0);
+      a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, x, a2, 0, 0, 0);
+      a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, y, a3, 0, 0, 0);
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s += a0[r] + a1[r] + a2[r] + a3[r];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 extern "C" {
+
+// Launches `blocks` x 4 waves, each issuing iters*32 MFMAs (4096 FLOP each).
+int wn_diag_mfma_peak(float* out, int blocks, int iters, void* stream) {
+  if (!out) return WN_ERR_NULL;
+  if (blocks <= 0 || iters <= 0) return WN_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0,
+                     (hipStream_t)stream, out, iters);
+  return wn_check_launch();
+}
 
 int wn_gemm_nn(const float* A, long lda, int a_planes, long a_plane_stride,
                const float* W, int ldw, const float* bias, const float* mask,
@@ -397,7 +532,7 @@ int wn_gemm_tn(const float* A, long lda, int a_planes, long a_plane_stride,
   g.slabs = slabs; g.slab_stride = wn_gemm_tn_slab_floats(Mw, Nw);
   g.rows = rows;
   long rps = (rows + splits - 1) / splits;
-  rps += rps & 1;
+  rps = (rps + 23) / 24 * 24;  // whole pipeline groups (6- or 8-row)
   g.rows_per_split = rps;
   g.Mw = Mw; g.Nw = Nw; g.want_colsum = want_colsum;
   hipStream_t s = (hipStream_t)stream;

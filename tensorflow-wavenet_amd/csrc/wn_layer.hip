@@ -19,70 +19,100 @@
 #include "wn_common.h"
 
 
-// One workgroup = 4 waves = 4 consecutive 32-row tiles of ONE clip.
-// grid.x = tiles_per_clip_groups, grid.y = B.
+// Persistent workgroups: one 1024-thread workgroup (16 waves, 4 per SIMD) per
+// CU stages the layer's weights into LDS ONCE, then every wave walks 32-row
+// tiles (tile = clip b, rows t0..t0+31) with a grid stride.
+#define LAYER_WG 1024
+#define LAYER_WAVES (LAYER_WG / 64)
+
 template <bool HAS_DENSE, bool SAVE_TS>
-__global__ __launch_bounds__(256) void layer_fwd_kernel(
+__global__ __launch_bounds__(LAYER_WG) void layer_fwd_kernel(
     const float* __restrict__ x, float* __restrict__ xo, float* __restrict__ z,
     float* __restrict__ th, float* __restrict__ sg,
     const float* __restrict__ wblock,      // LAYER_BLOCK_FLOATS
     const float* __restrict__ bias_fg,     // [B or 1][64] (bias + gc), or null
-    int bias_clip_stride, int T, int d) {
-  __shared__ __attribute__((aligned(16))) float wl[LAYER_W_FLOATS + 96];
+    int bias_clip_stride, int B, int T, int d) {
+  __shared__ __attribute__((aligned(16))) float wl[LAYER_W_FLOATS + 32];
+  __shared__ __attribute__((aligned(16))) float tiles[LAYER_WAVES * 2 * 1024];
   const int tid = threadIdx.x;
-  // stage weights (5120 floats) + biases
   {
     const f32x4* src = reinterpret_cast<const f32x4*>(wblock);
     f32x4* dst = reinterpret_cast<f32x4*>(wl);
-    for (int i = tid; i < LAYER_W_FLOATS / 4; i += 256) dst[i] = src[i];
-    if (tid < 64) {
-      const int b = blockIdx.y;
-      wl[LAYER_W_FLOATS + tid] =
-          bias_fg ? bias_fg[(size_t)b * bias_clip_stride + tid] : 0.f;
-    } else if (tid < 96) {
-      wl[LAYER_W_FLOATS + tid] = wblock[LAYER_W_FLOATS + tid];  // bd
-    }
+    for (int i = tid; i < LAYER_W_FLOATS / 4; i += LAYER_WG) dst[i] = src[i];
+    if (tid < 32) wl[LAYER_W_FLOATS + tid] = wblock[LAYER_OFF_BD + tid];
   }
   __syncthreads();
   const int lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, h = lane >> 5;
-  const int t0 = (blockIdx.x * 4 + wave) * 32;
-  if (t0 >= T) return;
-  const int t = t0 + j;
-  const size_t clip = (size_t)blockIdx.y * T;
-  const bool vc = t < T;
-  const bool vp = vc && (t - d >= 0);
-  const float* xrow = x + (clip + t) * WN_CH;
-  f32x16 xc = frag_load(xrow, h, vc);
-  f32x16 xp = frag_load(xrow - (size_t)d * WN_CH, h, vp);
-
-  const float* wlane = wl + j + 4 * h * 32;  // n0 = 0, i = j
-  f32x16 af = frag_bcast(wl + LAYER_W_FLOATS, h);
-  f32x16 ag = frag_bcast(wl + LAYER_W_FLOATS + 32, h);
-  mma32<32>(af, xp, wlane + 0 * 1024);  // Wf[0]: past tap
-  mma32<32>(af, xc, wlane + 1 * 1024);  // Wf[1]: current tap
-  mma32<32>(ag, xp, wlane + 2 * 1024);  // Wg[0]
-  mma32<32>(ag, xc, wlane + 3 * 1024);  // Wg[1]
-  f32x16 zz;
+  float* ta = tiles + wave * 2048;
+  float* tb = ta + 1024;
+  const int tiles_per_clip = (T + 31) >> 5;
+  const int ntiles = tiles_per_clip * B;
+  for (int tile = blockIdx.x * LAYER_WAVES + wave; tile < ntiles;
+       tile += gridDim.x * LAYER_WAVES) {
+    // opaque per-iteration LDS offset: keeps the 80 weight reads next to their
+    // MFMAs instead of being hoisted into (and spilling from) registers
+    int woff = j + 4 * h * 32;  // n0 = 0, i = j
+    asm volatile("" : "+v"(woff));
+    const float* wlane = wl + woff;
+    const int b = tile / tiles_per_clip;
+    const int t0 = (tile - b * tiles_per_clip) * 32;
+    const int hi = min(32, T - t0);          // real rows of this tile
+    const int lo_p = max(0, d - t0);         // rows whose past tap exists
+    const size_t off0 = ((size_t)b * T + t0) * WN_CH;
+    // coalesced loads (8 full rows per instruction), then LDS -> fragments
+    const RowRegs rc = rows_load(x + off0, lane, 0, hi);
+    const RowRegs rp = rows_load(x + off0 - (size_t)d * WN_CH, lane, lo_p, hi);
+    rows_to_lds(ta, lane, rc);
+    rows_to_lds(tb, lane, rp);
+    __builtin_amdgcn_wave_barrier();
+    f32x16 xc = frag_from_lds(ta, j, h);
+    f32x16 xp = frag_from_lds(tb, j, h);
+    f32x16 af, ag;
+    if (bias_fg) {
+      const float* bp = bias_fg + (size_t)b * bias_clip_stride;
+      af = frag_bcast(bp, h);
+      ag = frag_bcast(bp + 32, h);
+    } else {
+      af = frag_zero();
+      ag = frag_zero();
+    }
+    mma32<32>(af, xp, wlane + 0 * 1024);  // Wf[0]: past tap
+    mma32<32>(af, xc, wlane + 1 * 1024);  // Wf[1]: current tap
+    mma32<32>(ag, xp, wlane + 2 * 1024);  // Wg[0]
+    mma32<32>(ag, xc, wlane + 3 * 1024);  // Wg[1]
+    f32x16 zz;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    af[r] = wn_tanh(af[r]);
-    ag[r] = wn_sigmoid(ag[r]);
-    zz[r] = af[r] * ag[r];
-  }
-  const size_t off = (clip + t) * WN_CH;
-  frag_store(z + off, h, vc, zz);
-  if (SAVE_TS) {
-    frag_store(th + off, h, vc, af);
-    frag_store(sg + off, h, vc, ag);
-  }
-  if (HAS_DENSE) {
-    f32x16 bd = frag_bcast(wl + LAYER_W_FLOATS + 64, h);
-    f32x16 acc;
+    for (int r = 0; r < 16; ++r) {
+      af[r] = wn_tanh(af[r]);
+      ag[r] = wn_sigmoid(ag[r]);
+      zz[r] = af[r] * ag[r];
+    }
+    // fragments -> LDS -> coalesced stores
+    __builtin_amdgcn_wave_barrier();
+    frag_to_lds(ta, j, h, zz);
+    if (SAVE_TS) frag_to_lds(tb, j, h, af);
+    __builtin_amdgcn_wave_barrier();
+    rows_store(z + off0, lane, hi, rows_from_lds(ta, lane));
+    if (SAVE_TS) {
+      rows_store(th + off0, lane, hi, rows_from_lds(tb, lane));
+      __builtin_amdgcn_wave_barrier();
+      frag_to_lds(tb, j, h, ag);
+      __builtin_amdgcn_wave_barrier();
+      rows_store(sg + off0, lane, hi, rows_from_lds(tb, lane));
+    }
+    if (HAS_DENSE) {
+      const f32x16 bd = frag_bcast(wl + LAYER_W_FLOATS + (woff - j - 128 * h), h);
+      f32x16 acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = xc[r] + bd[r];
-    mma32<32>(acc, zz, wlane + 4 * 1024);  // Wd
-    frag_store(xo + off, h, vc, acc);
+      for (int r = 0; r < 16; ++r) acc[r] = xc[r] + bd[r];
+      mma32<32>(acc, zz, wlane + 4 * 1024);  // Wd
+      __builtin_amdgcn_wave_barrier();
+      frag_to_lds(ta, j, h, acc);
+      __builtin_amdgcn_wave_barrier();
+      rows_store(xo + off0, lane, hi, rows_from_lds(ta, lane));
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -94,13 +124,14 @@ __global__ __launch_bounds__(256) void layer_fwd_kernel(
 //           da_f     = dz * sig * (1 - tanh^2);  da_g = dz * tanh * sig*(1-sig)
 // da is stored as two planes: daf[rows][32], dag[rows][32].
 template <bool DO_B, bool DO_A, bool HAS_DXIN>
-__global__ __launch_bounds__(256) void layer_bwd_kernel(
+__global__ __launch_bounds__(LAYER_WG) void layer_bwd_kernel(
     const float* __restrict__ daf_cur, const float* __restrict__ dag_cur,
     const float* __restrict__ dxin, float* __restrict__ dx_out,
     const float* __restrict__ wblock_b,   // layer l block (phase B)
     const float* __restrict__ dZ, const float* __restrict__ th,
     const float* __restrict__ sg, const float* __restrict__ wblock_a,  // l-1
-    float* __restrict__ daf_next, float* __restrict__ dag_next, int T, int d) {
+    float* __restrict__ daf_next, float* __restrict__ dag_next, int B, int T,
+    int d) {
   // LDS: transposed weights, rows padded to 33 floats so that both the
   // transposing stores and the MFMA A-operand reads are bank-conflict free.
   // [0..4) conv: Wf0^T, Wf1^T, Wg0^T, Wg1^T with row = dilation channel
@@ -108,15 +139,16 @@ __global__ __launch_bounds__(256) void layer_bwd_kernel(
   // channel (contraction), col = dilation channel.
   constexpr int LDT = 33, MT = 32 * LDT;
   __shared__ float wl[5 * MT];
+  __shared__ __attribute__((aligned(16))) float tiles[LAYER_WAVES * 2 * 1024];
   const int tid = threadIdx.x;
   if (DO_B) {
-    for (int i = tid; i < 4096; i += 256) {
+    for (int i = tid; i < 4096; i += LAYER_WG) {
       const int m = i >> 10, rr = (i >> 5) & 31, cc = i & 31;  // W[m][rr][cc]
       wl[m * MT + cc * LDT + rr] = wblock_b[i];
     }
   }
   if (DO_A) {
-    for (int i = tid; i < 1024; i += 256) {
+    for (int i = tid; i < 1024; i += LAYER_WG) {
       const int rr = i >> 5, cc = i & 31;  // Wd[dch rr][res cc]
       wl[4 * MT + cc * LDT + rr] = wblock_a[4096 + i];
     }
@@ -124,69 +156,116 @@ __global__ __launch_bounds__(256) void layer_bwd_kernel(
   __syncthreads();
   const int lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, h = lane >> 5;
-  const int t0 = (blockIdx.x * 4 + wave) * 32;
-  if (t0 >= T) return;
-  const int t = t0 + j;
-  const size_t clip = (size_t)blockIdx.y * T;
-  const bool vc = t < T;
-  const size_t off = (clip + t) * WN_CH;
-  const float* wlane = wl + j + 4 * h * LDT;
-
-  f32x16 dx;
-  if (HAS_DXIN)
-    dx = frag_load(dxin + off, h, vc);
-  else
-    dx = frag_zero();
-  if (DO_B) {
-    const bool vf = vc && (t + d < T);
-    f32x16 f0 = frag_load(daf_cur + off, h, vc);
-    f32x16 g0 = frag_load(dag_cur + off, h, vc);
-    f32x16 f1 = frag_load(daf_cur + off + (size_t)d * WN_CH, h, vf);
-    f32x16 g1 = frag_load(dag_cur + off + (size_t)d * WN_CH, h, vf);
-    mma32<LDT>(dx, f0, wlane + 1 * MT);  // da_f[t]   * Wf[1]^T
-    mma32<LDT>(dx, g0, wlane + 3 * MT);  // da_g[t]   * Wg[1]^T
-    mma32<LDT>(dx, f1, wlane + 0 * MT);  // da_f[t+d] * Wf[0]^T
-    mma32<LDT>(dx, g1, wlane + 2 * MT);  // da_g[t+d] * Wg[0]^T
-    frag_store(dx_out + off, h, vc, dx);
-  }
-  if (DO_A) {
-    f32x16 dz = frag_load(dZ + off, h, vc);
-    if (DO_B || HAS_DXIN) mma32<LDT>(dz, dx, wlane + 4 * MT);
-    f32x16 tt = frag_load(th + off, h, vc);
-    f32x16 ss = frag_load(sg + off, h, vc);
-    f32x16 df, dg;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float zs = dz[r] * ss[r];
-      df[r] = zs * (1.f - tt[r] * tt[r]);
-      dg[r] = zs * tt[r] * (1.f - ss[r]);
+  float* ta = tiles + wave * 2048;
+  float* tb = ta + 1024;
+  const int tiles_per_clip = (T + 31) >> 5;
+  const int ntiles = tiles_per_clip * B;
+  for (int tile = blockIdx.x * LAYER_WAVES + wave; tile < ntiles;
+       tile += gridDim.x * LAYER_WAVES) {
+    int woff = j + 4 * h * LDT;  // opaque: no hoisting of the weight reads
+    asm volatile("" : "+v"(woff));
+    const float* wlane = wl + woff;
+    const int b = tile / tiles_per_clip;
+    const int t0 = (tile - b * tiles_per_clip) * 32;
+    const int hi = min(32, T - t0);
+    const int hi_f = min(hi, T - d - t0);   // rows whose t+d tap exists (may be <= 0)
+    const size_t off0 = ((size_t)b * T + t0) * WN_CH;
+    f32x16 dx;
+    if (HAS_DXIN) {
+      rows_to_lds(ta, lane, rows_load(dxin + off0, lane, 0, hi));
+      __builtin_amdgcn_wave_barrier();
+      dx = frag_from_lds(ta, j, h);
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      dx = frag_zero();
     }
-    frag_store(daf_next + off, h, vc, df);
-    frag_store(dag_next + off, h, vc, dg);
+    if (DO_B) {
+      const RowRegs rf0 = rows_load(daf_cur + off0, lane, 0, hi);
+      const RowRegs rg0 = rows_load(dag_cur + off0, lane, 0, hi);
+      const RowRegs rf1 = rows_load(daf_cur + off0 + (size_t)d * WN_CH, lane, 0, hi_f);
+      const RowRegs rg1 = rows_load(dag_cur + off0 + (size_t)d * WN_CH, lane, 0, hi_f);
+      rows_to_lds(ta, lane, rf0);
+      rows_to_lds(tb, lane, rg0);
+      __builtin_amdgcn_wave_barrier();
+      f32x16 f0 = frag_from_lds(ta, j, h);
+      f32x16 g0 = frag_from_lds(tb, j, h);
+      mma32<LDT>(dx, f0, wlane + 1 * MT);  // da_f[t]   * Wf[1]^T
+      mma32<LDT>(dx, g0, wlane + 3 * MT);  // da_g[t]   * Wg[1]^T
+      __builtin_amdgcn_wave_barrier();
+      rows_to_lds(ta, lane, rf1);
+      rows_to_lds(tb, lane, rg1);
+      __builtin_amdgcn_wave_barrier();
+      f32x16 f1 = frag_from_lds(ta, j, h);
+      f32x16 g1 = frag_from_lds(tb, j, h);
+      mma32<LDT>(dx, f1, wlane + 0 * MT);  // da_f[t+d] * Wf[0]^T
+      mma32<LDT>(dx, g1, wlane + 2 * MT);  // da_g[t+d] * Wg[0]^T
+      __builtin_amdgcn_wave_barrier();
+      frag_to_lds(ta, j, h, dx);
+      __builtin_amdgcn_wave_barrier();
+      rows_store(dx_out + off0, lane, hi, rows_from_lds(ta, lane));
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (DO_A) {
+      const RowRegs rz = rows_load(dZ + off0, lane, 0, hi);
+      const RowRegs rt = rows_load(th + off0, lane, 0, hi);
+      const RowRegs rs = rows_load(sg + off0, lane, 0, hi);
+      rows_to_lds(ta, lane, rz);
+      rows_to_lds(tb, lane, rt);
+      __builtin_amdgcn_wave_barrier();
+      f32x16 dz = frag_from_lds(ta, j, h);
+      f32x16 tt = frag_from_lds(tb, j, h);
+      __builtin_amdgcn_wave_barrier();
+      rows_to_lds(ta, lane, rs);
+      __builtin_amdgcn_wave_barrier();
+      f32x16 ss = frag_from_lds(ta, j, h);
+      if (DO_B || HAS_DXIN) mma32<LDT>(dz, dx, wlane + 4 * MT);
+      f32x16 df, dg;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float zs = dz[r] * ss[r];
+        df[r] = zs * (1.f - tt[r] * tt[r]);
+        dg[r] = zs * tt[r] * (1.f - ss[r]);
+      }
+      __builtin_amdgcn_wave_barrier();
+      frag_to_lds(ta, j, h, df);
+      frag_to_lds(tb, j, h, dg);
+      __builtin_amdgcn_wave_barrier();
+      rows_store(daf_next + off0, lane, hi, rows_from_lds(ta, lane));
+      rows_store(dag_next + off0, lane, hi, rows_from_lds(tb, lane));
+      __builtin_amdgcn_wave_barrier();
+    }
   }
 }
 
-// Backward-weights of one layer: every wave walks a strided set of 32-row
-// tiles and keeps 5 accumulator tiles (channels on BOTH MFMA axes, the row
-// pair of each step is the contraction):
+// Backward-weights of one layer.  Every wave walks 32-row tiles and keeps 5
+// accumulator tiles with channels on BOTH MFMA axes (the row pair of a step
+// is the contraction):
 //   dWf[0] += x[t-d]^T da_f   dWf[1] += x[t]^T da_f   (same for gate)
 //   dWd    += z^T dxin        db_f,g += colsum(da)    dbd += colsum(dxin)
-// Operands are plain 4-byte loads: lane (i,h) reads M[row 2s+h][i] -> two
-// full 128-byte lines per wave instruction, no LDS staging needed at the
-// fp32 MFMA rate.  The 4 waves of a workgroup reduce through LDS and the
-// workgroup writes ONE slab; wn_reduce_slabs sums slabs in a fixed order
-// (deterministic, no float atomics).
+// Tiles are loaded as coalesced 16-byte fragments (time on lanes), pushed
+// through a wave-private XOR-swizzled LDS tile and read back transposed
+// (channel on lanes) as MFMA operands -- conflict-free both ways; a wave's DS
+// operations execute in order, so no barrier is needed.  The 4 waves of a
+// workgroup reduce through LDS and the workgroup writes ONE slab;
+// wn_reduce_slabs sums slabs in a fixed order (deterministic, no atomics).
 // Slab layout == layer gradient block layout (LAYER_BLOCK_FLOATS).
+#define WG_TILE 1024  // floats per 32x32 LDS tile
+
+
 template <bool HAS_DENSE>
 __global__ __launch_bounds__(256) void layer_wgrad_kernel(
     const float* __restrict__ x, const float* __restrict__ daf,
     const float* __restrict__ dag, const float* __restrict__ z,
     const float* __restrict__ dxin, float* __restrict__ slabs, int B, int T,
     int d) {
-  __shared__ float red[LAYER_BLOCK_FLOATS];
+  __shared__ __attribute__((aligned(16))) float lds[4 * 4 * WG_TILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
-  const int tiles_per_clip = (T + 31) / 32;
+  float* t_xp = lds + wave * 4 * WG_TILE;
+  float* t_xc = t_xp + WG_TILE;
+  float* t_f = t_xc + WG_TILE;
+  float* t_g = t_f + WG_TILE;
+  const int tiles_per_clip = (T + 31) >> 5;
   const int ntiles = tiles_per_clip * B;
   const int nwaves = gridDim.x * 4;
   f32x16 cf0 = frag_zero(), cf1 = frag_zero(), cg0 = frag_zero(),
@@ -195,34 +274,59 @@ __global__ __launch_bounds__(256) void layer_wgrad_kernel(
   for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += nwaves) {
     const int b = tile / tiles_per_clip;
     const int t0 = (tile - b * tiles_per_clip) * 32;
-    const size_t base = ((size_t)b * T + t0) * WN_CH;
-#pragma unroll 4
+    const int hi = min(32, T - t0);
+    const size_t off0 = ((size_t)b * T + t0) * WN_CH;
+    {
+      const RowRegs rxc = rows_load(x + off0, lane, 0, hi);
+      const RowRegs rxp = rows_load(x + off0 - (size_t)d * WN_CH, lane,
+                                    max(0, d - t0), hi);
+      const RowRegs rf = rows_load(daf + off0, lane, 0, hi);
+      const RowRegs rg = rows_load(dag + off0, lane, 0, hi);
+      __builtin_amdgcn_wave_barrier();
+      rows_to_lds(t_xp, lane, rxp);
+      rows_to_lds(t_xc, lane, rxc);
+      rows_to_lds(t_f, lane, rf);
+      rows_to_lds(t_g, lane, rg);
+      __builtin_amdgcn_wave_barrier();
+    }
+    RowRegs rz, rd;
+    if (HAS_DENSE) {
+      rz = rows_load(z + off0, lane, 0, hi);
+      rd = rows_load(dxin + off0, lane, 0, hi);
+    }
+#pragma unroll
     for (int s = 0; s < 16; ++s) {
-      const int t = t0 + 2 * s + h;
-      const bool v = t < T;
-      const size_t o = base + (size_t)(2 * s + h) * WN_CH + i;
-      const float xc = v ? x[o] : 0.f;
-      const float xp = (v && t >= d) ? x[o - (size_t)d * WN_CH] : 0.f;
-      const float f = v ? daf[o] : 0.f;
-      const float g = v ? dag[o] : 0.f;
-      cf0 = __builtin_amdgcn_mfma_f32_32x32x2f32(xp, f, cf0, 0, 0, 0);
-      cf1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xc, f, cf1, 0, 0, 0);
-      cg0 = __builtin_amdgcn_mfma_f32_32x32x2f32(xp, g, cg0, 0, 0, 0);
-      cg1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xc, g, cg1, 0, 0, 0);
-      sf += f;
-      sgs += g;
-      if (HAS_DENSE) {
-        const float zz = v ? z[o] : 0.f;
-        const float dd = v ? dxin[o] : 0.f;
-        cd = __builtin_amdgcn_mfma_f32_32x32x2f32(zz, dd, cd, 0, 0, 0);
-        sd += dd;
+      const int row = 2 * s + h;
+      const float axp = tile_elem(t_xp, row, i), axc = tile_elem(t_xc, row, i);
+      const float bf = tile_elem(t_f, row, i), bg = tile_elem(t_g, row, i);
+      cf0 = __builtin_amdgcn_mfma_f32_32x32x2f32(axp, bf, cf0, 0, 0, 0);
+      cf1 = __builtin_amdgcn_mfma_f32_32x32x2f32(axc, bf, cf1, 0, 0, 0);
+      cg0 = __builtin_amdgcn_mfma_f32_32x32x2f32(axp, bg, cg0, 0, 0, 0);
+      cg1 = __builtin_amdgcn_mfma_f32_32x32x2f32(axc, bg, cg1, 0, 0, 0);
+      sf += bf;
+      sgs += bg;
+    }
+    if (HAS_DENSE) {
+      __builtin_amdgcn_wave_barrier();
+      rows_to_lds(t_xp, lane, rz);   // reuse: the reads above are already issued
+      rows_to_lds(t_xc, lane, rd);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int row = 2 * s + h;
+        const float az = tile_elem(t_xp, row, i), bd = tile_elem(t_xc, row, i);
+        cd = __builtin_amdgcn_mfma_f32_32x32x2f32(az, bd, cd, 0, 0, 0);
+        sd += bd;
       }
     }
+    __builtin_amdgcn_wave_barrier();
   }
   // column sums: add the two row-parity halves
   sf += __shfl_xor(sf, 32);
   sgs += __shfl_xor(sgs, 32);
   sd += __shfl_xor(sd, 32);
+  __syncthreads();  // all waves done with their LDS tiles; reuse as `red`
+  float* red = lds;
   // cross-wave reduction through LDS, fixed order wave 0..3
   for (int w = 0; w < 4; ++w) {
     if (wave == w) {
@@ -266,6 +370,23 @@ __global__ __launch_bounds__(256) void layer_wgrad_kernel(
 // ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
+// one persistent workgroup per CU (fewer when there is less work)
+static int layer_grid(int B, int T) {
+  static int cus = 0;  // read-only after the first call
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) !=
+            hipSuccess || n <= 0)
+      n = 256;
+    cus = n;
+  }
+  const long ntiles = (long)B * ((T + 31) / 32);
+  long g = (ntiles + LAYER_WAVES - 1) / LAYER_WAVES;
+  if (g > cus) g = cus;
+  return (int)(g < 1 ? 1 : g);
+}
+
 extern "C" {
 
 int wn_layer_fwd(const float* x, float* x_out, float* z, float* th, float* sg,
@@ -280,12 +401,12 @@ int wn_layer_fwd(const float* x, float* x_out, float* z, float* th, float* sg,
       (x_out && !wn_aligned16(x_out)) || (th && !wn_aligned16(th)) ||
       (sg && !wn_aligned16(sg)))
     return WN_ERR_MISALIGNED;
-  dim3 grid((T + 127) / 128, B), block(256);
+  dim3 grid(layer_grid(B, T)), block(LAYER_WG);
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(HD, TS)                                                      \
   hipLaunchKernelGGL((layer_fwd_kernel<HD, TS>), grid, block, 0, s, x,      \
-                     x_out, z, th, sg, wblock, bias_fg, bias_clip_stride, T, \
-                     dilation)
+                     x_out, z, th, sg, wblock, bias_fg, bias_clip_stride, B, \
+                     T, dilation)
   if (has_dense && save_ts) LAUNCH(true, true);
   else if (has_dense) LAUNCH(true, false);
   else if (save_ts) LAUNCH(false, true);
@@ -308,13 +429,13 @@ int wn_layer_bwd(const float* daf_cur, const float* dag_cur, const float* dxin,
                         sg,      daf_next, dag_next};
   for (const void* p : ptrs)
     if (p && !wn_aligned16(p)) return WN_ERR_MISALIGNED;
-  dim3 grid((T + 127) / 128, B), block(256);
+  dim3 grid(layer_grid(B, T)), block(LAYER_WG);
   hipStream_t s = (hipStream_t)stream;
   const bool hx = dxin != nullptr;
 #define LAUNCH(DB, DA, HX)                                                   \
   hipLaunchKernelGGL((layer_bwd_kernel<DB, DA, HX>), grid, block, 0, s,      \
                      daf_cur, dag_cur, dxin, dx_out, wblock_b, dZ, th, sg,   \
-                     wblock_a, daf_next, dag_next, T, dilation)
+                     wblock_a, daf_next, dag_next, B, T, dilation)
   if (do_b && do_a) { if (hx) LAUNCH(true, true, true); else LAUNCH(true, true, false); }
   else if (do_b) { if (hx) LAUNCH(true, false, true); else LAUNCH(true, false, false); }
   else { if (hx) LAUNCH(false, true, true); else LAUNCH(false, true, false); }

@@ -58,6 +58,7 @@ SIGNATURES = {
                                c_int, P]),
     'wn_time_to_batch': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     'wn_batch_to_time': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    'wn_diag_mfma_peak': (c_int, [P, c_int, c_int, P]),
     'wn_axpy': (c_int, [P, P, c_float, P, c_long, P]),
     'wn_fill': (c_int, [P, c_long, c_float, P]),
     'wn_sum_rows': (c_int, [P, c_int, c_int, P, P]),

@@ -97,7 +97,7 @@ class _Workspace(object):
         self.w1t = torch.empty((S, S), **f32)
         self.wst = torch.empty((S, L * CH), **f32)
         ntiles = B * ((T + 31) // 32)
-        self.nslab = max(1, min(256, ntiles // 4))
+        self.nslab = max(1, min(512, ntiles // 4))
         self.lslabs = torch.empty((L, self.nslab, LAYER_BLOCK), **f32)
         lib = _lib.load()
         need = 0

@@ -1,0 +1,89 @@
+"""Per-kernel micro-benchmarks at the bench.py shapes (development aid).
+usage: python tools/kbench.py [peak] [nn] [tn] [layer]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'tensorflow-wavenet_amd'))
+import torch
+from wavenet import _lib
+lib = _lib.load()
+dev = torch.device('cuda')
+st = lambda: torch.cuda.current_stream().cuda_stream
+
+
+def timeit(fn, n=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n):
+        fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n * 1e-3
+
+
+def peak():
+    out = torch.empty(4096 * 256, device=dev)
+    for blocks in (1024, 2048):
+        iters = 2000
+        t = timeit(lambda: _lib.call('wn_diag_mfma_peak', out.data_ptr(), blocks, iters, st()), n=5)
+        fl = blocks * 4 * iters * 32 * 4096
+        print('mfma peak blocks=%d: %.1f TFLOP/s' % (blocks, fl / t / 1e12))
+
+
+def nn():
+    N = 128000
+    for (K, Nn, planes_a, planes_c, name) in [(1600, 512, 50, 0, 'skip'), (512, 512, 0, 0, 'post1'),
+                                               (512, 256, 0, 0, 'post2'), (256, 512, 0, 0, 'dh2'),
+                                               (512, 1600, 0, 50, 'dZ')]:
+        A = torch.randn(N * K, device=dev)
+        W = torch.randn(K * Nn, device=dev)
+        C = torch.empty(N * Nn, device=dev)
+        bias = torch.randn(Nn, device=dev)
+        def f():
+            _lib.call('wn_gemm_nn', A.data_ptr(), 0 if planes_a else K, planes_a, N * 32, W.data_ptr(), Nn,
+                      bias.data_ptr(), None, 0, None, 0, C.data_ptr(), 0 if planes_c else Nn, planes_c, N * 32,
+                      None, N, Nn, K, 1, st())
+        t = timeit(f)
+        print('nn %-6s K=%4d N=%4d: %7.1f us  %.1f TFLOP/s' % (name, K, Nn, t * 1e6, 2.0 * N * K * Nn / t / 1e12))
+
+
+def tn():
+    N = 128000
+    for (Mw, Nw, planes, name, sp) in [(1600, 512, 50, 'dWs', 64), (512, 512, 0, 'dW1', 128), (512, 256, 0, 'dW2', 256)]:
+        A = torch.randn(N * Mw, device=dev)
+        G = torch.randn(N * Nw, device=dev)
+        sl = lib.wn_gemm_tn_slab_floats(Mw, Nw)
+        slabs = torch.empty(sp * sl, device=dev)
+        def f():
+            _lib.call('wn_gemm_tn', A.data_ptr(), 0 if planes else Mw, planes, N * 32, None, 0, 16000, G.data_ptr(),
+                      Nw, slabs.data_ptr(), sp, N, Mw, Nw, 1, st())
+        t = timeit(f)
+        print('tn %-4s %dx%d splits=%d: %7.1f us  %.1f TFLOP/s' % (name, Mw, Nw, sp, t * 1e6, 2.0 * N * Mw * Nw / t / 1e12))
+
+
+def layer():
+    B, T = 8, 16000
+    N = B * T
+    mk = lambda: torch.randn(N * 32, device=dev)
+    x, xo, z, th, sg, dz, f, g, f2, g2, dx, dxo = [mk() for _ in range(12)]
+    w = torch.randn(5216, device=dev) * 0.1
+    nslab = 512
+    slabs = torch.empty(nslab * 5216, device=dev)
+    for d in (1, 64, 512):
+        t = timeit(lambda: _lib.call('wn_layer_fwd', x.data_ptr(), xo.data_ptr(), z.data_ptr(), th.data_ptr(),
+                                     sg.data_ptr(), w.data_ptr(), None, 0, B, T, d, 1, 1, st()), n=20)
+        print('layer_fwd d=%3d: %6.1f us  (%.2f TB/s of 640 B/sample)' % (d, t * 1e6, N * 640 / t / 1e12))
+        t = timeit(lambda: _lib.call('wn_layer_bwd', f.data_ptr(), g.data_ptr(), dx.data_ptr(), dxo.data_ptr(),
+                                     w.data_ptr(), dz.data_ptr(), th.data_ptr(), sg.data_ptr(), w.data_ptr(),
+                                     f2.data_ptr(), g2.data_ptr(), B, T, d, 1, 1, st()), n=20)
+        print('layer_bwd d=%3d: %6.1f us  (%.2f TB/s of 1152 B/sample)' % (d, t * 1e6, N * 1152 / t / 1e12))
+        t = timeit(lambda: _lib.call('wn_layer_wgrad', x.data_ptr(), f.data_ptr(), g.data_ptr(), z.data_ptr(),
+                                     dx.data_ptr(), slabs.data_ptr(), nslab, B, T, d, st()), n=20)
+        print('layer_wgrad d=%3d: %6.1f us  (%.2f TB/s of 640 B/sample)' % (d, t * 1e6, N * 640 / t / 1e12))
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['peak', 'nn', 'tn', 'layer']
+    for w in which:
+        globals()[w]()

@@ -115,6 +115,12 @@ def main():
     rank, world, local = parallel.init_from_env()
     if world != args.gpus and world > 1:
         raise SystemExit('WORLD_SIZE %d != --gpus %d' % (world, args.gpus))
+    # one rank per GPU; WN_SHARE_GPU=1 (rehearsal only) maps every rank to the
+    # devices that exist
+    ndev = torch.cuda.device_count()
+    if local >= ndev and os.environ.get('WN_SHARE_GPU') != '1':
+        raise SystemExit('rank %d has no GPU (found %d)' % (local, ndev))
+    local = local % max(ndev, 1)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 

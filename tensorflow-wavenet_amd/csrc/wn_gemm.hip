@@ -540,7 +540,8 @@ int wn_gemm_tn(const float* A, long lda, int a_planes, long a_plane_stride,
   const int m32 = (Mw + 31) / 32, n32 = (Nw + 31) / 32;
   int NF = (n32 % 2 == 0) ? 2 : 1;
   int MF;
-  if (m32 % 5 == 0) MF = 5;
+  if (codes) { NF = 1; MF = (m32 % 2 == 0) ? 2 : 1; }  // one-hot: A is free
+  else if (m32 % 5 == 0) MF = 5;
   else if (m32 % 4 == 0) MF = 4;
   else if (m32 % 2 == 0) MF = 2;
   else MF = 1;

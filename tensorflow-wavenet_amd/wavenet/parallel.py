@@ -39,7 +39,10 @@ def init_from_env(backend=None):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            # WN_DIST_BACKEND=gloo lets the N>1 path be rehearsed on a box
+            # with fewer GPUs than ranks (gloo stages CUDA tensors via host)
+            backend = os.environ.get('WN_DIST_BACKEND') or (
+                'nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

@@ -401,6 +401,130 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN g) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// TN, LDS-staged variant for wide outputs (dWs, dW1, dW2): one workgroup
+// owns a (MF*32) x (4*NF*32) output tile; the 4 waves share the A chunk
+// through LDS and each owns NF*32 columns of the G chunk.  A 32-row chunk is
+// 16*MF*NF MFMAs per wave (10 240 cycles at MF=5, NF=2) between barriers, the
+// next chunk's global loads (coalesced 16-byte) are in flight meanwhile.
+// ---------------------------------------------------------------------------
+template <int MF, int NF>
+__global__ __launch_bounds__(256, 2) void gemm_tn2_kernel(GemmTN g) {
+  constexpr int TM = MF * 32, TNW = 4 * NF * 32;
+  constexpr int A4 = TM / 4;            // float4 per A row
+  constexpr int G4 = TNW / 4;           // float4 per G row
+  constexpr int NA = (32 * A4 + 255) / 256, NG = (32 * G4) / 256;
+  __shared__ __attribute__((aligned(16))) float As[32 * TM];
+  __shared__ __attribute__((aligned(16))) float Gs[32 * TNW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int tn = blockIdx.x % g.tiles_n, tm = blockIdx.x / g.tiles_n;
+  const int m0 = tm * TM, n0 = tn * TNW;
+  const long r_begin = (long)blockIdx.y * g.rows_per_split;
+  long r_end = r_begin + g.rows_per_split;
+  if (r_end > g.rows) r_end = g.rows;
+
+  f32x16 acc[MF][NF];
+#pragma unroll
+  for (int a = 0; a < MF; ++a)
+#pragma unroll
+    for (int b = 0; b < NF; ++b) acc[a][b] = frag_zero();
+  float cs[NF];
+#pragma unroll
+  for (int b = 0; b < NF; ++b) cs[b] = 0.f;
+
+  f32x4 ra[NA], rg[NG];
+  auto gload = [&](long r0) {
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+      const int idx = tid + 256 * k;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (idx < 32 * A4) {
+        const int row = idx / A4, c4 = idx - row * A4;
+        const long r = r0 + row;
+        if (r < r_end) {
+          const int m = m0 + c4 * 4;
+          const float* p = g.a_planes
+                               ? g.A + (long)(m >> 5) * g.a_plane_stride + r * 32 + (m & 31)
+                               : g.A + r * g.lda + m;
+          v = *reinterpret_cast<const f32x4*>(p);
+        }
+      }
+      ra[k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+      const int idx = tid + 256 * k;
+      const int row = idx / G4, c4 = idx - row * G4;
+      const long r = r0 + row;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r < r_end)
+        v = *reinterpret_cast<const f32x4*>(g.G + r * g.ldg + n0 + c4 * 4);
+      rg[k] = v;
+    }
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+      const int idx = tid + 256 * k;
+      if (idx < 32 * A4) *reinterpret_cast<f32x4*>(&As[idx * 4]) = ra[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NG; ++k)
+      *reinterpret_cast<f32x4*>(&Gs[(tid + 256 * k) * 4]) = rg[k];
+  };
+
+  gload(r_begin);
+  sstore();
+  __syncthreads();
+  for (long r0 = r_begin; r0 < r_end; r0 += 32) {
+    const bool more = r0 + 32 < r_end;
+    if (more) gload(r0 + 32);
+    const float* al = As + h * TM + i;
+    const float* gl = Gs + h * TNW + wave * (NF * 32) + i;
+#pragma unroll 2
+    for (int s = 0; s < 16; ++s) {
+      float av[MF], bv[NF];
+#pragma unroll
+      for (int a = 0; a < MF; ++a) av[a] = al[2 * s * TM + a * 32];
+#pragma unroll
+      for (int b = 0; b < NF; ++b) {
+        bv[b] = gl[2 * s * TNW + b * 32];
+        cs[b] += bv[b];
+      }
+#pragma unroll
+      for (int a = 0; a < MF; ++a)
+#pragma unroll
+        for (int b = 0; b < NF; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
+    __syncthreads();
+    if (more) sstore();
+    __syncthreads();
+  }
+
+  float* slab = g.slabs + (long)blockIdx.y * g.slab_stride;
+#pragma unroll
+  for (int a = 0; a < MF; ++a)
+#pragma unroll
+    for (int b = 0; b < NF; ++b) {
+      const int n = n0 + wave * (NF * 32) + b * 32 + i;
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const int m = m0 + a * 32 + 8 * (rr >> 2) + 4 * h + (rr & 3);
+        slab[(long)m * g.Nw + n] = acc[a][b][rr];
+      }
+    }
+  if (g.want_colsum && tm == 0) {
+#pragma unroll
+    for (int b = 0; b < NF; ++b) {
+      float v = cs[b] + __shfl_xor(cs[b], 32);
+      const int n = n0 + wave * (NF * 32) + b * 32 + i;
+      if (h == 0) slab[(long)g.Mw * g.Nw + n] = v;
+    }
+  }
+}
+
 // out[b][rep][e] = sum_s slabs[b][s][offset + e]   (fixed order over s)
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs,
                                     int num_slabs, long slab_stride,
@@ -532,10 +656,31 @@ int wn_gemm_tn(const float* A, long lda, int a_planes, long a_plane_stride,
   g.slabs = slabs; g.slab_stride = wn_gemm_tn_slab_floats(Mw, Nw);
   g.rows = rows;
   long rps = (rows + splits - 1) / splits;
-  rps = (rps + 23) / 24 * 24;  // whole pipeline groups (6- or 8-row)
+  rps = (rps + 95) / 96 * 96;  // whole 32-row chunks and 6/8-row groups
   g.rows_per_split = rps;
   g.Mw = Mw; g.Nw = Nw; g.want_colsum = want_colsum;
   hipStream_t s = (hipStream_t)stream;
+  // LDS-staged workgroup-tile kernel when the output is wide and tile-aligned
+  if (!codes && (lda % 4 == 0) && (ldg % 4 == 0) && wn_aligned16(A) &&
+      wn_aligned16(G)) {
+    int mf2 = 0, nf2 = 0;
+    if (Nw % 256 == 0) nf2 = 2; else if (Nw % 128 == 0) nf2 = 1;
+    if (Mw % 160 == 0) mf2 = 5; else if (Mw % 128 == 0) mf2 = 4;
+    if (mf2 == 5 && nf2 == 2) nf2 = 1;  // <5,2> needs > 256 VGPRs: spills
+    if (mf2 && nf2) {
+      g.tiles_m = Mw / (mf2 * 32);
+      g.tiles_n = Nw / (4 * nf2 * 32);
+      dim3 grid2(g.tiles_m * g.tiles_n, splits), block2(256);
+#define LAUNCH2(mf, nf) \
+  hipLaunchKernelGGL((gemm_tn2_kernel<mf, nf>), grid2, block2, 0, s, g)
+      if (mf2 == 5 && nf2 == 2) LAUNCH2(5, 2);
+      else if (mf2 == 5) LAUNCH2(5, 1);
+      else if (nf2 == 2) LAUNCH2(4, 2);
+      else LAUNCH2(4, 1);
+#undef LAUNCH2
+      return wn_check_launch();
+    }
+  }
   // wave-tile shape: least padding waste, then largest tile
   const int m32 = (Mw + 31) / 32, n32 = (Nw + 31) / 32;
   int NF = (n32 % 2 == 0) ? 2 : 1;

@@ -99,6 +99,22 @@ def cpu_baseline(params, T, max_seconds=30.0):
                       '(%.2f s/step)' % (n, T, dt)}
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary
+    (profiles/*_pmc_traffic.json, written by tools/pmc_summary.py from separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, with
+    the gfx950 FETCH_SIZE x2 correction).  None when no summary exists."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            return json.load(f)[kernel]['hbm_bytes_per_launch']
+    except (KeyError, ValueError, OSError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -144,6 +160,8 @@ def main():
         gc_ids = torch.tensor([(37 * (rank * B + b)) % 377 for b in range(B)],
                               dtype=torch.int32, device=dev)
     net = WaveNetModel(seed=0, **kw)
+    if os.environ.get('WN_OVERLAP_WGRAD') is not None:   # A/B knob
+        net.overlap_wgrad = os.environ['WN_OVERLAP_WGRAD'] == '1'
     parallel.broadcast_parameters(net)
     opt = optimizer_factory['adam'](learning_rate=1e-3, momentum=0.9)
     audio = torch.from_numpy(synth_audio(B, T, first_clip=rank * B)).to(dev)
@@ -205,7 +223,8 @@ def main():
         'roofline': {'bound': 'mfma', 'kernel': 'gemm_nn_kernel',
                      'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS,
                      'unit': 'TFLOP/s', 'frac': achieved / FP32_MFMA_PEAK_TFLOPS,
-                     'traffic': None,
+                     'traffic': pmc_traffic('gemm_nn_kernel'),
+                     'traffic_unit': 'bytes per launch (rocprofv3 PMC pass)',
                      'launches_per_step': nlaunch // max(args.steps, 1),
                      'avg_launch_us': ktime / max(nlaunch, 1) * 1e6,
                      'flops_per_step': flops / max(args.steps, 1)},

@@ -568,14 +568,25 @@ __global__ void transpose_pad_kernel(const float* __restrict__ in, int rows,
   }
 }
 
-// Diagnostic: register-only fp32 MFMA loop (no memory traffic) -- calibrates
-// the clock-limited MFMA ceiling of the device the benchmark runs on.
+// Diagnostic: fp32 MFMA loop -- calibrates the MFMA ceiling of the device the
+// benchmark runs on.  mode 0: operands in registers (no memory traffic);
+// mode 1: the A operand pair of every 4-MFMA group is read from LDS right
+// before use (the pattern of the GEMM inner loops).
+template <int MODE>
 __global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters) {
+  __shared__ float lds[4096];
+  for (int k = threadIdx.x; k < 4096; k += 256) lds[k] = 1.0f + k * 1e-4f;
+  __syncthreads();
   f32x16 a0 = frag_zero(), a1 = frag_zero(), a2 = frag_zero(), a3 = frag_zero();
   float x = 1.0f + threadIdx.x * 1e-3f, y = 0.5f - threadIdx.x * 1e-3f;
+  const float* lp = lds + (threadIdx.x & 63);
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
+      if (MODE == 1) {
+        x = lp[(u * 128 + it) & 4095 & ~63];
+        y = lp[((u * 128 + 64 + it) & 4095) & ~63];
+      }
       a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
       a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, a1, 0, 0, 0);
       a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, x, a2, 0, 0, 0);
@@ -593,9 +604,13 @@ extern "C" {
 // Launches `blocks` x 4 waves, each issuing iters*32 MFMAs (4096 FLOP each).
 int wn_diag_mfma_peak(float* out, int blocks, int iters, void* stream) {
   if (!out) return WN_ERR_NULL;
-  if (blocks <= 0 || iters <= 0) return WN_ERR_BAD_SHAPE;
-  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0,
-                     (hipStream_t)stream, out, iters);
+  if (blocks <= 0 || iters == 0) return WN_ERR_BAD_SHAPE;
+  if (iters > 0)
+    hipLaunchKernelGGL(mfma_peak_kernel<0>, dim3(blocks), dim3(256), 0,
+                       (hipStream_t)stream, out, iters);
+  else  // negative iters: LDS-fed variant
+    hipLaunchKernelGGL(mfma_peak_kernel<1>, dim3(blocks), dim3(256), 0,
+                       (hipStream_t)stream, out, -iters);
   return wn_check_launch();
 }
 

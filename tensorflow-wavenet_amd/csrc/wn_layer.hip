@@ -123,8 +123,13 @@ __global__ __launch_bounds__(LAYER_WG) void layer_fwd_kernel(
 //   A(l-1): dz       = dZ_{l-1}[t] + dx_l[t]*Wd_{l-1}^T
 //           da_f     = dz * sig * (1 - tanh^2);  da_g = dz * tanh * sig*(1-sig)
 // da is stored as two planes: daf[rows][32], dag[rows][32].
+// 512-thread workgroups (8 waves, 85 KB LDS) so that layer_wgrad_kernel
+// (64 KB LDS) fits on the same CU and overlaps from a second stream.
+#define BWD_WG 512
+#define BWD_WAVES (BWD_WG / 64)
+
 template <bool DO_B, bool DO_A, bool HAS_DXIN>
-__global__ __launch_bounds__(LAYER_WG) void layer_bwd_kernel(
+__global__ __launch_bounds__(BWD_WG) void layer_bwd_kernel(
     const float* __restrict__ daf_cur, const float* __restrict__ dag_cur,
     const float* __restrict__ dxin, float* __restrict__ dx_out,
     const float* __restrict__ wblock_b,   // layer l block (phase B)
@@ -139,16 +144,16 @@ __global__ __launch_bounds__(LAYER_WG) void layer_bwd_kernel(
   // channel (contraction), col = dilation channel.
   constexpr int LDT = 33, MT = 32 * LDT;
   __shared__ float wl[5 * MT];
-  __shared__ __attribute__((aligned(16))) float tiles[LAYER_WAVES * 2 * 1024];
+  __shared__ __attribute__((aligned(16))) float tiles[BWD_WAVES * 2 * 1024];
   const int tid = threadIdx.x;
   if (DO_B) {
-    for (int i = tid; i < 4096; i += LAYER_WG) {
+    for (int i = tid; i < 4096; i += BWD_WG) {
       const int m = i >> 10, rr = (i >> 5) & 31, cc = i & 31;  // W[m][rr][cc]
       wl[m * MT + cc * LDT + rr] = wblock_b[i];
     }
   }
   if (DO_A) {
-    for (int i = tid; i < 1024; i += LAYER_WG) {
+    for (int i = tid; i < 1024; i += BWD_WG) {
       const int rr = i >> 5, cc = i & 31;  // Wd[dch rr][res cc]
       wl[4 * MT + cc * LDT + rr] = wblock_a[4096 + i];
     }
@@ -160,8 +165,8 @@ __global__ __launch_bounds__(LAYER_WG) void layer_bwd_kernel(
   float* tb = ta + 1024;
   const int tiles_per_clip = (T + 31) >> 5;
   const int ntiles = tiles_per_clip * B;
-  for (int tile = blockIdx.x * LAYER_WAVES + wave; tile < ntiles;
-       tile += gridDim.x * LAYER_WAVES) {
+  for (int tile = blockIdx.x * BWD_WAVES + wave; tile < ntiles;
+       tile += gridDim.x * BWD_WAVES) {
     int woff = j + 4 * h * LDT;  // opaque: no hoisting of the weight reads
     asm volatile("" : "+v"(woff));
     const float* wlane = wl + woff;
@@ -371,7 +376,7 @@ __global__ __launch_bounds__(256) void layer_wgrad_kernel(
 // C ABI
 // ---------------------------------------------------------------------------
 // one persistent workgroup per CU (fewer when there is less work)
-static int layer_grid(int B, int T) {
+static int layer_grid(int B, int T, int waves = LAYER_WAVES) {
   static int cus = 0;  // read-only after the first call
   if (cus == 0) {
     int dev = 0, n = 0;
@@ -382,7 +387,7 @@ static int layer_grid(int B, int T) {
     cus = n;
   }
   const long ntiles = (long)B * ((T + 31) / 32);
-  long g = (ntiles + LAYER_WAVES - 1) / LAYER_WAVES;
+  long g = (ntiles + waves - 1) / waves;
   if (g > cus) g = cus;
   return (int)(g < 1 ? 1 : g);
 }
@@ -429,7 +434,7 @@ int wn_layer_bwd(const float* daf_cur, const float* dag_cur, const float* dxin,
                         sg,      daf_next, dag_next};
   for (const void* p : ptrs)
     if (p && !wn_aligned16(p)) return WN_ERR_MISALIGNED;
-  dim3 grid(layer_grid(B, T)), block(LAYER_WG);
+  dim3 grid(layer_grid(B, T, BWD_WAVES)), block(BWD_WG);
   hipStream_t s = (hipStream_t)stream;
   const bool hx = dxin != nullptr;
 #define LAUNCH(DB, DA, HX)                                                   \

@@ -24,11 +24,12 @@ def timeit(fn, n=10, warm=3):
 
 def peak():
     out = torch.empty(4096 * 256, device=dev)
-    for blocks in (1024, 2048):
-        iters = 2000
-        t = timeit(lambda: _lib.call('wn_diag_mfma_peak', out.data_ptr(), blocks, iters, st()), n=5)
-        fl = blocks * 4 * iters * 32 * 4096
-        print('mfma peak blocks=%d: %.1f TFLOP/s' % (blocks, fl / t / 1e12))
+    for blocks in (256, 512, 1024, 2048):
+        for sign, nm in ((1, 'regs'), (-1, 'lds-fed')):
+            iters = 2000
+            t = timeit(lambda: _lib.call('wn_diag_mfma_peak', out.data_ptr(), blocks, sign * iters, st()), n=5)
+            fl = blocks * 4 * iters * 32 * 4096
+            print('mfma peak %-8s blocks=%4d (%d waves/SIMD): %.1f TFLOP/s' % (nm, blocks, max(1, blocks // 256), fl / t / 1e12))
 
 
 def nn():
@@ -83,7 +84,22 @@ def layer():
         print('layer_wgrad d=%3d: %6.1f us  (%.2f TB/s of 640 B/sample)' % (d, t * 1e6, N * 640 / t / 1e12))
 
 
+def nnsmall():
+    # same GEMM at sizes whose A operand fits the 256 MB Infinity Cache
+    for N in (65536, 128000, 131072, 128000 + 512):
+        K, Nn = 1600, 512
+        A = torch.randn(N * K, device=dev)
+        W = torch.randn(K * Nn, device=dev)
+        C = torch.empty(N * Nn, device=dev)
+        def f():
+            _lib.call('wn_gemm_nn', A.data_ptr(), 0, 50, N * 32, W.data_ptr(), Nn, None, None, 0, None, 0,
+                      C.data_ptr(), Nn, 0, 0, None, N, Nn, K, 1, st())
+        t = timeit(f, n=20)
+        print('nn skip M=%6d (A %4d MB): %7.1f us  %.1f TFLOP/s' % (N, N * K * 4 >> 20, t * 1e6, 2.0 * N * K * Nn / t / 1e12))
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['peak', 'nn', 'tn', 'layer']
     for w in which:
         globals()[w]()
+

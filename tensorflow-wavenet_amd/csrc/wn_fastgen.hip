@@ -20,7 +20,9 @@
 // (model.py:511 vs 436-437); queues start as zeros (net.init_ops).
 #include "wn_common.h"
 
-#define FG_THREADS 320
+#define FG_THREADS 256   // wave 0: chain; waves 1..3: skip / post (192 threads)
+#define FG_SKT 192       // skip threads
+#define FG_SKO 3         // skip outputs per skip thread (3 * 192 >= FG_MAXS)
 #define FG_MAXS 512
 #define FG_MAXQ 512
 
@@ -36,6 +38,8 @@ __device__ __forceinline__ float readlane_f(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
+#define FG_MAXL 64
+
 struct FastGen {
   const float* causal;   // [2][Q][32]
   const float* layer0;   // layer blocks
@@ -47,9 +51,8 @@ struct FastGen {
   const float* post2_w;  // [S][Q]
   const float* post2_b;  // [Q] or null
   const float* bias_fg;  // [L][64] filter|gate bias (+gc) or null
-  const int32_t* dil;    // [L] device
   int L, S, Q;
-  float* state;          // ring buffers, layer l at state_off(l)
+  float* state;          // ring buffers, layer l at state + roff[l]*32
   int32_t* cursors;      // [0] steps done so far, [1] previous code (-1: none)
   int32_t* samples;      // [n_steps + 1]
   int n_given, n_steps;
@@ -60,118 +63,223 @@ struct FastGen {
   int use_dense_bias;
   int push;              // 0: peek (do not advance the queues), like running
                          // the reference's proba op without net.push_ops
+  const int32_t* dil;    // [L] device
 };
 
-__global__ __launch_bounds__(FG_THREADS) void fastgen_kernel(FastGen g) {
+// Roles inside the workgroup (a producer / consumer split, one barrier per
+// layer):
+//   waves 1..3 ("loaders"): stream the NEXT layers' weights -- the 20 KB chain
+//     block through registers into a 2-deep LDS ring, their own skip-weight
+//     columns into registers -- and accumulate the skip outputs of the layer
+//     the chain finished before the last barrier;
+//   wave 0 ("chain"): the serial residual chain, weights read from the LDS
+//     ring (conflict-free, ~64-cycle latency instead of an L2 / Infinity-Cache
+//     round trip), state value and bias prefetched one layer ahead.
+// Nothing the loaders fetch depends on the data being computed, so all global
+// latency sits off the critical path.
+#define FG_CW LAYER_W_FLOATS   // chain weights per layer (floats)
+#define FG_CW4 (FG_CW / 4)
+#define FG_LDR ((FG_CW4 + FG_SKT - 1) / FG_SKT)   // float4 per loader thread
+
+__global__ __launch_bounds__(FG_THREADS, 1) void fastgen_kernel(FastGen g) {
+  __shared__ __attribute__((aligned(16))) float wring[2][FG_CW];
   __shared__ float zbuf[2][32];
-  __shared__ float hbuf[FG_MAXS];     // relu(total) then relu(conv1)
-  __shared__ float h2buf[FG_MAXS];
+  __shared__ float hbuf[FG_MAXS];     // relu(total)
+  __shared__ float h2buf[FG_MAXS];    // relu(conv1)
   __shared__ float part[FG_MAXS];     // post2 partial sums
   __shared__ double pd[FG_MAXQ];
   __shared__ int s_code;
+  __shared__ int pos[FG_MAXL];        // ring cursor of every layer
+  __shared__ int sdil[FG_MAXL], roff[FG_MAXL];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int S = g.S, Q = g.Q, L = g.L;
-  const int st = tid - 64;            // skip-thread index 0..255 (waves 1..4)
+  const int st = tid - 64;            // loader-thread index 0..191 (waves 1..3)
 
-  int steps_done = g.cursors[0];
+  const int steps_done = g.cursors[0];
   int prev_code = g.cursors[1];
   if (tid == 0) s_code = g.samples[0];
+  for (int l = tid; l < L; l += FG_THREADS) {
+    sdil[l] = g.dil[l];
+    pos[l] = steps_done % g.dil[l];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int off = 0;
+    for (int l = 0; l < L; ++l) { roff[l] = off; off += sdil[l]; }
+  }
   __syncthreads();
 
   for (int step = 0; step < g.n_steps; ++step) {
     const int code = s_code;
     const long tpos = (long)steps_done + step;
-    // ---------------- chain + skip, pipelined by one layer ----------------
-    float x = 0.f;  // wave 0, lanes < 32: residual stream
-    if (wave == 0 && lane < 32) {
-      float v = 0.f;
-      if (prev_code >= 0 && prev_code < Q) v = g.causal[(long)prev_code * 32 + lane];
-      if (code >= 0 && code < Q) v += g.causal[((long)Q + code) * 32 + lane];
-      x = v;
+    // ---------------- loaders: chain-weight ring + skip columns ------------
+    f32x4 cw[FG_LDR];
+    auto cw_load = [&](int l) {        // global -> registers
+      const f32x4* src = reinterpret_cast<const f32x4*>(
+          g.layer0 + (long)l * g.layer_stride);
+#pragma unroll
+      for (int k = 0; k < FG_LDR; ++k) {
+        const int i4 = st + FG_SKT * k;
+        if (i4 < FG_CW4) cw[k] = src[i4];
+      }
+    };
+    auto cw_store = [&](int buf) {     // registers -> LDS ring
+      f32x4* dst = reinterpret_cast<f32x4*>(wring[buf]);
+#pragma unroll
+      for (int k = 0; k < FG_LDR; ++k) {
+        const int i4 = st + FG_SKT * k;
+        if (i4 < FG_CW4) dst[i4] = cw[k];
+      }
+    };
+    float acc[FG_SKO], sw[FG_SKO][32];
+    bool son[FG_SKO];
+#pragma unroll
+    for (int o = 0; o < FG_SKO; ++o) {
+      acc[o] = 0.f;
+      son[o] = wave >= 1 && st + FG_SKT * o < S;
     }
-    float acc0 = 0.f, acc1 = 0.f;      // skip outputs st and st+256
-    long qbase = 0;
+    auto skip_load = [&](int l) {
+      const float* ws = g.skip_w + (long)l * 32 * S + st;
+#pragma unroll
+      for (int o = 0; o < FG_SKO; ++o)
+        if (son[o]) {
+#pragma unroll
+          for (int k = 0; k < 32; ++k) sw[o][k] = ws[(long)k * S + FG_SKT * o];
+        }
+    };
+    auto skip_fma = [&](const float* zl) {
+#pragma unroll
+      for (int o = 0; o < FG_SKO; ++o)
+        if (son[o]) {
+#pragma unroll
+          for (int k = 0; k < 32; ++k) acc[o] = fmaf(zl[k], sw[o][k], acc[o]);
+        }
+    };
+    // ---------------- chain state (wave 0) ---------------------------------
+    float x = 0.f;                     // residual stream on lanes < 32
+    float stv = 0.f, bias = 0.f, bdv = 0.f;  // prefetched for the coming layer
+    auto chain_prefetch = [&](int l) {
+      bias = g.bias_fg ? g.bias_fg[l * 64 + lane] : 0.f;
+      bdv = g.use_dense_bias
+                ? g.layer0[(long)l * g.layer_stride + LAYER_OFF_BD + (lane & 31)]
+                : 0.f;
+      stv = lane < 32 ? g.state[((long)roff[l] + pos[l]) * 32 + lane] : 0.f;
+    };
+    // prologue: layer 0 weights into ring[0]
+    if (wave >= 1) {
+      cw_load(0);
+      cw_store(0);
+      if (L > 1) cw_load(1);
+      skip_load(0);
+    } else {
+      chain_prefetch(0);
+      if (lane < 32) {
+        float v = 0.f;
+        if (prev_code >= 0 && prev_code < Q) v = g.causal[(long)prev_code * 32 + lane];
+        if (code >= 0 && code < Q) v += g.causal[((long)Q + code) * 32 + lane];
+        x = v;
+      }
+    }
+    __syncthreads();
     for (int l = 0; l <= L; ++l) {
       if (wave == 0) {
         if (l < L) {
-          const int d = g.dil[l];
-          const float* blk = g.layer0 + (long)l * g.layer_stride;
-          float* ring = g.state + qbase * 32 + (tpos % d) * 32;
-          qbase += d;
-          float stv = 0.f;
-          if (lane < 32) {
-            stv = ring[lane];   // dequeue: x_l[t - d]
-            if (g.push) ring[lane] = x;  // enqueue: x_l[t]
-          }
-          // conv: lane n -> filter ch n (n<32) / gate ch n-32
-          const float* wcol = blk + (lane < 32 ? 0 : 2048) + (lane & 31);
-          float a = g.bias_fg ? g.bias_fg[l * 64 + lane] : 0.f;
+          const float* wl = wring[l & 1];
+          const float cur_st = stv, cur_bias = bias, cur_bd = bdv;
+          if (g.push && lane < 32)       // enqueue x_l[t] (after the dequeue)
+            g.state[((long)roff[l] + pos[l]) * 32 + lane] = x;
+          if (l + 1 < L) chain_prefetch(l + 1);
+          const float* wcol = wl + (lane < 32 ? 0 : 2048) + (lane & 31);
+          float a = cur_bias;
 #pragma unroll
           for (int k = 0; k < 32; ++k) {
-            const float sk = readlane_f(stv, k);
-            const float xk = readlane_f(x, k);
-            a = fmaf(sk, wcol[k * 32], a);           // W[0]: past tap
-            a = fmaf(xk, wcol[1024 + k * 32], a);    // W[1]: current tap
+            a = fmaf(readlane_f(cur_st, k), wcol[k * 32], a);      // W[0]
+            a = fmaf(readlane_f(x, k), wcol[1024 + k * 32], a);    // W[1]
           }
           const float gate = __shfl(a, (lane & 31) + 32);
           const float z = wn_tanh(a) * wn_sigmoid(gate);  // valid on lanes < 32
           if (lane < 32) zbuf[l & 1][lane] = z;
           if (l + 1 < L) {
-            float dsum = g.use_dense_bias ? blk[LAYER_OFF_BD + (lane & 31)] : 0.f;
-            const float* wd = blk + 4096 + (lane & 31);
+            float dsum = cur_bd;
+            const float* wd = wl + 4096 + (lane & 31);
 #pragma unroll
-            for (int k = 0; k < 32; ++k) {
-              const float zk = readlane_f(z, k);
-              dsum = fmaf(zk, wd[k * 32], dsum);
-            }
+            for (int k = 0; k < 32; ++k) dsum = fmaf(readlane_f(z, k), wd[k * 32], dsum);
             if (lane < 32) x += dsum;
           }
         }
-      } else if (l >= 1) {
-        // skip accumulation for layer l-1 (z written before the last barrier)
-        const float* zl = zbuf[(l - 1) & 1];
-        const float* ws = g.skip_w + (long)(l - 1) * 32 * S;
-        if (st < S) {
-#pragma unroll 8
-          for (int k = 0; k < 32; ++k) acc0 = fmaf(zl[k], ws[(long)k * S + st], acc0);
-        }
-        if (st + 256 < S) {
-#pragma unroll 8
-          for (int k = 0; k < 32; ++k)
-            acc1 = fmaf(zl[k], ws[(long)k * S + st + 256], acc1);
-        }
+      } else {
+        // ring slot (l+1)&1 was last read in iteration l-1: free to refill
+        if (l + 1 < L) cw_store((l + 1) & 1);
+        if (l + 2 < L) cw_load(l + 2);
+        if (l >= 1) skip_fma(zbuf[(l - 1) & 1]);
+        if (l >= 1 && l < L) skip_load(l);
       }
       __syncthreads();
     }
+    // advance the ring cursors (after every wave is done with this step)
+    if (g.push) {
+      for (int l = tid; l < L; l += FG_THREADS) {
+        const int p = pos[l] + 1;
+        pos[l] = p == sdil[l] ? 0 : p;
+      }
+    }
     // ---------------- post-processing (model.py:505-514) -------------------
     if (wave >= 1) {
-      if (st < S) hbuf[st] = fmaxf(acc0 + (g.skip_bsum ? g.skip_bsum[st] : 0.f), 0.f);
-      if (st + 256 < S)
-        hbuf[st + 256] = fmaxf(acc1 + (g.skip_bsum ? g.skip_bsum[st + 256] : 0.f), 0.f);
+#pragma unroll
+      for (int o = 0; o < FG_SKO; ++o)
+        if (son[o]) {
+          const int sc = st + FG_SKT * o;
+          hbuf[sc] = fmaxf(acc[o] + (g.skip_bsum ? g.skip_bsum[sc] : 0.f), 0.f);
+        }
     }
     __syncthreads();
     if (wave >= 1) {
-      for (int s = st; s < S; s += 256) {
-        float c = g.post1_b ? g.post1_b[s] : 0.f;
+      for (int s = st; s < S; s += FG_SKT) {
+        float c0 = g.post1_b ? g.post1_b[s] : 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
         const float* w = g.post1_w + s;
-#pragma unroll 8
-        for (int k = 0; k < S; ++k) c = fmaf(hbuf[k], w[(long)k * S], c);
-        h2buf[s] = fmaxf(c, 0.f);
+        int k = 0;
+        for (; k + 64 <= S; k += 64) {
+          float wv[64];
+#pragma unroll
+          for (int u = 0; u < 64; ++u) wv[u] = w[(long)(k + u) * S];
+#pragma unroll
+          for (int u = 0; u < 64; u += 4) {
+            c0 = fmaf(hbuf[k + u], wv[u], c0);
+            c1 = fmaf(hbuf[k + u + 1], wv[u + 1], c1);
+            c2 = fmaf(hbuf[k + u + 2], wv[u + 2], c2);
+            c3 = fmaf(hbuf[k + u + 3], wv[u + 3], c3);
+          }
+        }
+        for (; k < S; ++k) c0 = fmaf(hbuf[k], w[(long)k * S], c0);
+        h2buf[s] = fmaxf((c0 + c1) + (c2 + c3), 0.f);
       }
     }
     __syncthreads();
-    // logits: thread (q, part) sums a k-range; parts = 256 / Qp
+    // logits: thread (q, part) sums a k-range; parts = 192 / Q
     {
-      int parts = 256 / Q;
+      int parts = FG_SKT / Q;
       if (parts < 1) parts = 1;
       if (wave >= 1) {
-        for (int o = st; o < Q * parts; o += 256) {
+        for (int o = st; o < Q * parts; o += FG_SKT) {
           const int q = o % Q, p = o / Q;
           const int k0 = (int)((long)S * p / parts), k1 = (int)((long)S * (p + 1) / parts);
-          float c = 0.f;
+          float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
           const float* w = g.post2_w + q;
-          for (int k = k0; k < k1; ++k) c = fmaf(h2buf[k], w[(long)k * Q], c);
-          part[o] = c;
+          int k = k0;
+          for (; k + 64 <= k1; k += 64) {
+            float wv[64];
+#pragma unroll
+            for (int u = 0; u < 64; ++u) wv[u] = w[(long)(k + u) * Q];
+#pragma unroll
+            for (int u = 0; u < 64; u += 4) {
+              c0 = fmaf(h2buf[k + u], wv[u], c0);
+              c1 = fmaf(h2buf[k + u + 1], wv[u + 1], c1);
+              c2 = fmaf(h2buf[k + u + 2], wv[u + 2], c2);
+              c3 = fmaf(h2buf[k + u + 3], wv[u + 3], c3);
+            }
+          }
+          for (; k < k1; ++k) c0 = fmaf(h2buf[k], w[(long)k * Q], c0);
+          part[o] = (c0 + c1) + (c2 + c3);
         }
       }
       __syncthreads();
@@ -201,27 +309,48 @@ __global__ __launch_bounds__(FG_THREADS) void fastgen_kernel(FastGen g) {
     }
     __syncthreads();
     if (step + 1 >= g.n_given) {
-      if (tid == 0) {
-        // temperature: exp(log(p)/tau - logsumexp) in float64
+      if (wave == 0) {
+        // temperature: exp(log(p)/tau - logsumexp) in float64, then inverse
+        // CDF with a counter-based uniform (np.random.choice equivalent)
         const double tau = (double)g.temperature;
         double mx = -1e300;
-        for (int q = 0; q < Q; ++q) {
+        for (int q = lane; q < Q; q += 64) {
           const double lp = log(pd[q] > 0.0 ? pd[q] : 1e-300) / tau;
           pd[q] = lp;
           mx = fmax(mx, lp);
         }
-        double se = 0.0;
-        for (int q = 0; q < Q; ++q) se += exp(pd[q] - mx);
-        const uint64_t r = splitmix64(g.seed ^ splitmix64((uint64_t)tpos));
-        const double u = (double)(r >> 11) * (1.0 / 9007199254740992.0) * se;
-        double c = 0.0;
-        int pick = Q - 1;
-        for (int q = 0; q < Q; ++q) {
-          c += exp(pd[q] - mx);
-          if (u < c) { pick = q; break; }
+        for (int o = 32; o >= 1; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+        // per-lane contiguous segment [q0, q1): segment sums -> prefix -> pick
+        const int per = (Q + 63) / 64;
+        const int q0 = lane * per, q1 = min(Q, q0 + per);
+        double seg = 0.0;
+        for (int q = q0; q < q1; ++q) seg += exp(pd[q] - mx);
+        double incl = seg;
+        for (int o = 1; o < 64; o <<= 1) {
+          const double v = __shfl_up(incl, o);
+          if (lane >= o) incl += v;
         }
-        g.samples[step + 1] = pick;
-        s_code = pick;
+        const double total = __shfl(incl, 63);
+        const uint64_t r = splitmix64(g.seed ^ splitmix64((uint64_t)tpos));
+        const double u = (double)(r >> 11) * (1.0 / 9007199254740992.0) * total;
+        const double excl = incl - seg;
+        int pick = -1;
+        if (u >= excl && u < incl) {
+          double c = excl;
+          pick = q1 - 1;
+          for (int q = q0; q < q1; ++q) {
+            c += exp(pd[q] - mx);
+            if (u < c) { pick = q; break; }
+          }
+        }
+        // exactly one lane holds the pick (u < total); fall back to Q-1
+        int best = pick;
+        for (int o = 32; o >= 1; o >>= 1) best = max(best, __shfl_xor(best, o));
+        if (best < 0) best = Q - 1;
+        if (lane == 0) {
+          g.samples[step + 1] = best;
+          s_code = best;
+        }
       }
     } else if (tid == 0) {
       s_code = g.samples[step + 1];
@@ -274,7 +403,7 @@ int wn_fastgen_run(const float* params_causal, const float* layer0,
     return WN_ERR_NULL;
   if (L <= 0 || S <= 0 || Q <= 0 || n_steps <= 0 || n_given < 1)
     return WN_ERR_BAD_SHAPE;
-  if (S > FG_MAXS || Q > FG_MAXQ) return WN_ERR_UNSUPPORTED;
+  if (S > FG_MAXS || Q > FG_MAXQ || L > FG_MAXL) return WN_ERR_UNSUPPORTED;
   if (!(temperature > 0.f)) return WN_ERR_BAD_SHAPE;
   FastGen g;
   g.causal = params_causal; g.layer0 = layer0; g.layer_stride = layer_stride;

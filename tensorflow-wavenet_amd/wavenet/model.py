@@ -826,3 +826,15 @@ class WaveNetModel(object):
                           pe if pe > 0 else 1, global_condition)
         out = io[:n_given + int(num_samples)]
         return (out, proba) if pe > 0 else out
+
+    def continue_generation(self, num_samples, last_sample, temperature=1.0,
+                            global_condition=None, seed=0):
+        """Draw `num_samples` more samples after `generate` (the queues stay
+        on the device; `last_sample` is the last code drawn so far, which has
+        not been pushed yet).  Returns the new int32 codes."""
+        self._check_supported()
+        n = int(num_samples)
+        io = torch.zeros(n + 1, dtype=torch.int32, device=self.device)
+        io[0] = int(last_sample)
+        self._gen_run(io, 1, n, temperature, seed, None, 1, global_condition)
+        return io[1:]

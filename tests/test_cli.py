@@ -1,0 +1,72 @@
+"""train.py / generate.py counterparts: flags, directory rules, checkpoint
+naming (reference train.py:37-180, generate.py:24-116).  CPU part."""
+import os
+import sys
+
+import pytest
+
+from util import ROOT
+
+sys.path.insert(0, ROOT)
+import train  # noqa: E402
+import generate  # noqa: E402
+
+
+def test_train_flag_defaults():
+    a = train.get_arguments([])
+    assert (a.batch_size, a.checkpoint_every, a.num_steps) == (1, 50, 100000)
+    assert (a.learning_rate, a.sample_size, a.optimizer) == (1e-3, 100000, 'adam')
+    assert (a.momentum, a.silence_threshold) == (0.9, 0.3)
+    assert a.l2_regularization_strength == 0 and a.gc_channels is None
+    assert a.data_dir == './VCTK-Corpus' and a.histograms is False
+
+
+def test_validate_directories_rules():
+    a = train.get_arguments(['--logdir', 'x', '--logdir_root', 'y'])
+    with pytest.raises(ValueError, match='cannot be specified at the same'):
+        train.validate_directories(a)
+    a = train.get_arguments(['--logdir', 'x', '--restore_from', 'y'])
+    with pytest.raises(ValueError, match='unexpected overwrites'):
+        train.validate_directories(a)
+    d = train.validate_directories(train.get_arguments(['--logdir', 'x']))
+    assert d == {'logdir': 'x', 'logdir_root': None, 'restore_from': 'x'}
+    d = train.validate_directories(train.get_arguments(
+        ['--logdir_root', 'r', '--restore_from', 'old']))
+    assert d['logdir'].startswith(os.path.join('r', 'train'))
+    assert d['restore_from'] == 'old' and d['logdir'] != d['restore_from']
+    d = train.validate_directories(train.get_arguments([]))
+    assert d['logdir'].startswith(os.path.join('./logdir', 'train'))
+
+
+def test_checkpoint_naming(tmp_path):
+    assert train.checkpoint_path('d', 150) == os.path.join('d', 'model.ckpt-150')
+    assert train.latest_checkpoint(str(tmp_path)) is None
+    for s in (3, 20, 100):
+        open(train.checkpoint_path(str(tmp_path), s), 'w').close()
+    assert train.latest_checkpoint(str(tmp_path)).endswith('model.ckpt-100')
+    with open(os.path.join(str(tmp_path), 'checkpoint'), 'w') as f:
+        f.write('model_checkpoint_path: "model.ckpt-20"\n')
+    assert train.latest_checkpoint(str(tmp_path)).endswith('model.ckpt-20')
+
+
+def test_generate_flags():
+    a = generate.get_arguments(['ck'])
+    assert (a.samples, a.temperature, a.window) == (16000, 1.0, 8000)
+    assert a.fast_generation is True and a.save_every is None
+    assert generate.get_arguments(['ck', '--fast_generation', 'false']
+                                  ).fast_generation is False
+    with pytest.raises(ValueError, match='gc_cardinality'):
+        generate.get_arguments(['ck', '--gc_channels', '32'])
+    with pytest.raises(ValueError, match='gc_id'):
+        generate.get_arguments(['ck', '--gc_channels', '32',
+                                '--gc_cardinality', '377'])
+    with pytest.raises(SystemExit):
+        generate.get_arguments(['ck', '--temperature', '-1'])
+
+
+def test_synthetic_reader():
+    r = train.SyntheticReader(1000, gc_cardinality=7)
+    a = r.dequeue(3)
+    g = r.dequeue_gc(3)
+    assert tuple(a.shape) == (3, 1000, 1) and float(a.abs().max()) <= 1
+    assert tuple(g.shape) == (3,) and int(g.max()) < 7

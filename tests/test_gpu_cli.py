@@ -1,0 +1,113 @@
+"""End-to-end: train.py (synthetic + wav data, checkpoint / resume) and
+generate.py (fast + naive, wav seed, save_every) on the GPU."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+from scipy.io import wavfile
+
+from util import ROOT
+
+sys.path.insert(0, ROOT)
+import train  # noqa: E402
+import generate  # noqa: E402
+from test_audio_reader import make_wavs  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+SMALL = {"filter_width": 2, "sample_rate": 16000,
+         "dilations": [1, 2, 4, 8, 16, 32, 1, 2, 4, 8, 16, 32],
+         "residual_channels": 32, "dilation_channels": 32,
+         "quantization_channels": 256, "skip_channels": 64,
+         "use_biases": True, "scalar_input": False,
+         "initial_filter_width": 32, "residual_postproc": False}
+
+
+@pytest.fixture()
+def params(tmp_path):
+    p = str(tmp_path / 'params.json')
+    json.dump(SMALL, open(p, 'w'))
+    return p
+
+
+def test_train_checkpoint_resume_and_generate(hip_lib, tmp_path, params, capsys):
+    logdir = str(tmp_path / 'run')
+    common = ['--synthetic', '--sample_size', '3000', '--batch_size', '2',
+              '--wavenet_params', params, '--logdir', logdir,
+              '--checkpoint_every', '2', '--learning_rate', '0.002']
+    assert train.main(common + ['--num_steps', '5']) == 0
+    out = capsys.readouterr().out
+    assert 'step 0 - loss = ' in out and 'sec/step)' in out
+    assert os.path.exists(os.path.join(logdir, 'model.ckpt-4'))
+    assert train.latest_checkpoint(logdir).endswith('model.ckpt-4')
+    ev = [json.loads(l) for l in open(os.path.join(logdir, 'events.jsonl'))]
+    assert [e['step'] for e in ev] == [0, 1, 2, 3, 4]
+    assert ev[-1]['loss'] < ev[0]['loss']
+    # resume: continues at step 5 from the restored weights
+    assert train.main(common + ['--num_steps', '7']) == 0
+    out = capsys.readouterr().out
+    assert 'Global step was: 4' in out and 'step 5 - loss' in out
+    assert 'step 4 - loss' not in out
+    ck = os.path.join(logdir, 'model.ckpt-6')
+    assert os.path.exists(ck)
+    sd = torch.load(ck, map_location='cpu')
+    assert sd['step'] == 6
+    assert 'wavenet/dilated_stack/layer3/filter' in sd['variables']
+    # generate: fast path with save_every chunks
+    wav = str(tmp_path / 'out.wav')
+    assert generate.main([ck, '--samples', '300', '--wavenet_params', params,
+                          '--wav_out_path', wav, '--save_every', '120',
+                          '--logdir', str(tmp_path / 'gen')]) == 0
+    rate, data = wavfile.read(wav)
+    assert rate == 16000 and data.shape[0] == 301 and np.abs(data).max() <= 1
+    # seeded by a wav file, naive windowed path
+    seed = str(tmp_path / 'seed.wav')
+    t = np.arange(4000) / 16000.0
+    wavfile.write(seed, 16000, (0.4 * np.sin(2 * np.pi * 330 * t)
+                                ).astype(np.float32))
+    wav2 = str(tmp_path / 'out2.wav')
+    assert generate.main([ck, '--samples', '20', '--wavenet_params', params,
+                          '--wav_out_path', wav2, '--wav_seed', seed,
+                          '--window', '200', '--fast_generation', 'false',
+                          '--logdir', str(tmp_path / 'gen')]) == 0
+    _, d2 = wavfile.read(wav2)
+    assert d2.shape[0] == 200 + 20
+    # and seeded fast path (priming in-kernel)
+    assert generate.main([ck, '--samples', '50', '--wavenet_params', params,
+                          '--wav_out_path', wav2, '--wav_seed', seed,
+                          '--window', '500',
+                          '--logdir', str(tmp_path / 'gen')]) == 0
+    _, d3 = wavfile.read(wav2)
+    assert d3.shape[0] == 500 + 50
+
+
+def test_chunked_generation_equals_single_call(hip_lib):
+    from wavenet import WaveNetModel
+    kw = {k: SMALL[k] for k in SMALL if k not in ('sample_rate',)}
+    net = WaveNetModel(batch_size=1, seed=4, **kw)
+    a = net.generate(200, seed_samples=[7, 9], seed=3).cpu().numpy()
+    b1 = net.generate(80, seed_samples=[7, 9], seed=3).cpu().numpy()
+    b2 = net.continue_generation(120, int(b1[-1]), 1.0, None, 3).cpu().numpy()
+    assert np.array_equal(a, np.concatenate([b1, b2]))
+
+
+def test_train_on_wav_directory_with_gc(hip_lib, tmp_path, params, capsys):
+    data = str(tmp_path / 'corpus')
+    os.makedirs(data)
+    make_wavs(data)
+    logdir = str(tmp_path / 'run2')
+    assert train.main(['--data_dir', data, '--sample_size', '4000',
+                       '--batch_size', '2', '--wavenet_params', params,
+                       '--logdir', logdir, '--num_steps', '3',
+                       '--gc_channels', '8', '--silence_threshold', '0.05',
+                       '--optimizer', 'sgd', '--learning_rate', '0.01',
+                       '--l2_regularization_strength', '1e-6']) == 0
+    out = capsys.readouterr().out
+    assert 'Detected --gc_cardinality=227' in out
+    assert 'step 2 - loss' in out
+    sd = torch.load(train.latest_checkpoint(logdir), map_location='cpu')
+    assert tuple(sd['variables']['wavenet/embeddings/gc_embedding'].shape) \
+        == (227, 8)

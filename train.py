@@ -1,0 +1,318 @@
+#!/usr/bin/env python
+"""Training script: MI355X counterpart of the reference's train.py.
+
+Same flags, defaults, logdir rules and progress line as the reference
+(train.py:22-101 flags, :142-180 directory validation, :104-134 checkpoint
+save / restore with the step parsed from the file name, :310-311
+`step N - loss = x, (y sec/step)`), driving the HIP WaveNetModel.  New:
+  * --synthetic : train on generated sine clips instead of --data_dir wavs;
+  * data-parallel when launched by torchrun (one rank per GPU, RCCL);
+  * --store_metadata dumps a kernel-level Chrome trace (torch.profiler) every
+    50th step in place of TF's RunMetadata timeline.
+Checkpoints are torch files `model.ckpt-<step>` holding {reference variable
+name: tensor}; scalars go to <logdir>/events.jsonl (TensorBoard is TF-only).
+"""
+from __future__ import print_function
+
+import argparse
+import glob
+import json
+import os
+import sys
+import time
+from datetime import datetime
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, 'tensorflow-wavenet_amd'))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+BATCH_SIZE = 1
+DATA_DIRECTORY = './VCTK-Corpus'
+LOGDIR_ROOT = './logdir'
+CHECKPOINT_EVERY = 50
+NUM_STEPS = int(1e5)
+LEARNING_RATE = 1e-3
+WAVENET_PARAMS = './wavenet_params.json'
+STARTED_DATESTRING = "{0:%Y-%m-%dT%H-%M-%S}".format(datetime.now())
+SAMPLE_SIZE = 100000
+L2_REGULARIZATION_STRENGTH = 0
+SILENCE_THRESHOLD = 0.3
+EPSILON = 0.001
+MOMENTUM = 0.9
+
+
+def _str_to_bool(s):
+    if s.lower() not in ('true', 'false'):
+        raise ValueError('Argument needs to be a boolean, got {}'.format(s))
+    return s.lower() == 'true'
+
+
+def get_arguments(argv=None):
+    p = argparse.ArgumentParser(description='WaveNet example network')
+    p.add_argument('--batch_size', type=int, default=BATCH_SIZE,
+                   help='How many wav files to process at once (per GPU).')
+    p.add_argument('--data_dir', type=str, default=DATA_DIRECTORY,
+                   help='The directory containing the VCTK corpus.')
+    p.add_argument('--store_metadata', type=bool, default=False,
+                   help='Store a kernel trace every 50 steps.')
+    p.add_argument('--logdir', type=str, default=None,
+                   help='Directory for logs / checkpoints; continues training '
+                   'if it holds a model. Not with --logdir_root / '
+                   '--restore_from.')
+    p.add_argument('--logdir_root', type=str, default=None,
+                   help='Root under which a dated logdir is created.')
+    p.add_argument('--restore_from', type=str, default=None,
+                   help='Directory to restore the model from (new logdir).')
+    p.add_argument('--checkpoint_every', type=int, default=CHECKPOINT_EVERY)
+    p.add_argument('--num_steps', type=int, default=NUM_STEPS)
+    p.add_argument('--learning_rate', type=float, default=LEARNING_RATE)
+    p.add_argument('--wavenet_params', type=str, default=WAVENET_PARAMS)
+    p.add_argument('--sample_size', type=int, default=SAMPLE_SIZE,
+                   help='Concatenate and cut audio samples to this many '
+                   'samples.')
+    p.add_argument('--l2_regularization_strength', type=float,
+                   default=L2_REGULARIZATION_STRENGTH)
+    p.add_argument('--silence_threshold', type=float,
+                   default=SILENCE_THRESHOLD)
+    p.add_argument('--optimizer', type=str, default='adam',
+                   choices=['adam', 'sgd', 'rmsprop'])
+    p.add_argument('--momentum', type=float, default=MOMENTUM)
+    p.add_argument('--histograms', type=_str_to_bool, default=False)
+    p.add_argument('--gc_channels', type=int, default=None,
+                   help='Number of global condition channels.')
+    p.add_argument('--synthetic', action='store_true',
+                   help='Train on synthetic sine clips (no --data_dir needed).')
+    p.add_argument('--gc_cardinality', type=int, default=None,
+                   help='Only with --synthetic: number of speaker ids.')
+    return p.parse_args(argv)
+
+
+def checkpoint_path(logdir, step):
+    return os.path.join(logdir, 'model.ckpt-{}'.format(step))
+
+
+def save(net, logdir, step):
+    print('Storing checkpoint to {} ...'.format(logdir), end="")
+    sys.stdout.flush()
+    os.makedirs(logdir, exist_ok=True)
+    path = checkpoint_path(logdir, step)
+    torch.save({'variables': net.state_dict(), 'step': step}, path)
+    with open(os.path.join(logdir, 'checkpoint'), 'w') as f:
+        f.write('model_checkpoint_path: "{}"\n'.format(os.path.basename(path)))
+    print(' Done.')
+
+
+def latest_checkpoint(logdir):
+    """Newest `model.ckpt-<step>` in logdir, or None."""
+    marker = os.path.join(logdir, 'checkpoint')
+    if os.path.exists(marker):
+        name = open(marker).read().split('"')[1]
+        path = os.path.join(logdir, name)
+        if os.path.exists(path):
+            return path
+    found = glob.glob(os.path.join(logdir, 'model.ckpt-*'))
+    found = [f for f in found if f.rsplit('-', 1)[-1].isdigit()]
+    return max(found, key=lambda f: int(f.rsplit('-', 1)[-1])) if found \
+        else None
+
+
+def load(net, logdir):
+    print("Trying to restore saved checkpoints from {} ...".format(logdir),
+          end="")
+    path = latest_checkpoint(logdir) if os.path.isdir(logdir) else None
+    if path is None:
+        print(" No checkpoint found.")
+        return None
+    print("  Checkpoint found: {}".format(path))
+    global_step = int(path.split('/')[-1].split('-')[-1])
+    print("  Global step was: {}".format(global_step))
+    print("  Restoring...", end="")
+    net.load_state_dict(torch.load(path, map_location='cpu')['variables'])
+    print(" Done.")
+    return global_step
+
+
+def get_default_logdir(logdir_root):
+    return os.path.join(logdir_root, 'train', STARTED_DATESTRING)
+
+
+def validate_directories(args):
+    """Validate and arrange directory related arguments (train.py:142-180)."""
+    if args.logdir and args.logdir_root:
+        raise ValueError("--logdir and --logdir_root cannot be "
+                         "specified at the same time.")
+    if args.logdir and args.restore_from:
+        raise ValueError(
+            "--logdir and --restore_from cannot be specified at the same "
+            "time. This is to keep your previous model from unexpected "
+            "overwrites.\nUse --logdir_root to specify the root of the "
+            "directory which will be automatically created with current date "
+            "and time, or use only --logdir to just continue the training "
+            "from the last checkpoint.")
+    logdir_root = args.logdir_root or LOGDIR_ROOT
+    logdir = args.logdir
+    if logdir is None:
+        logdir = get_default_logdir(logdir_root)
+        print('Using default logdir: {}'.format(logdir))
+    restore_from = args.restore_from or logdir
+    return {'logdir': logdir, 'logdir_root': args.logdir_root,
+            'restore_from': restore_from}
+
+
+class SyntheticReader(object):
+    """Sine-plus-noise clips of `sample_size` samples (BASELINE.md data)."""
+
+    def __init__(self, sample_size, gc_cardinality=None, rank=0, seed=1234):
+        self.T, self.card = sample_size, gc_cardinality
+        self.rng = np.random.default_rng(seed + rank)
+        self.gc_category_cardinality = gc_cardinality
+        self.count = rank * 1000003
+
+    def _clip(self):
+        self.count += 1
+        f = 110.0 * 2 ** ((self.count % 36) / 12.0)
+        t = np.arange(self.T)
+        x = 0.5 * np.sin(2 * np.pi * f * t / 16000.0) + \
+            0.05 * self.rng.standard_normal(self.T)
+        return np.clip(x, -1, 1).astype(np.float32), self.count
+
+    def dequeue(self, n):
+        clips = [self._clip() for _ in range(n)]
+        self._last_ids = [c[1] for c in clips]
+        return torch.from_numpy(np.stack([c[0] for c in clips]))[..., None]
+
+    def dequeue_gc(self, n):
+        return torch.tensor([(37 * i) % self.card for i in self._last_ids],
+                            dtype=torch.int32)
+
+    def start_threads(self, *a, **k):
+        return []
+
+
+def main(argv=None):
+    args = get_arguments(argv)
+    try:
+        directories = validate_directories(args)
+    except ValueError as e:
+        print("Some arguments are wrong:")
+        print(str(e))
+        return 1
+    logdir = directories['logdir']
+    restore_from = directories['restore_from']
+    # a restored model written somewhere else counts as a new training
+    is_overwritten_training = logdir != restore_from
+
+    from wavenet import WaveNetModel, AudioReader, optimizer_factory, parallel
+    from wavenet.audio_reader import Coordinator
+    rank, world, local = parallel.init_from_env()
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
+
+    with open(args.wavenet_params, 'r') as f:
+        wavenet_params = json.load(f)
+
+    coord = Coordinator()
+    # (the reference computes `silence_threshold = None if below EPSILON` and
+    # then passes the raw flag, train.py:211-220; the intent is kept here)
+    silence_threshold = args.silence_threshold \
+        if args.silence_threshold > EPSILON else None
+    gc_enabled = args.gc_channels is not None
+    if args.synthetic:
+        reader = SyntheticReader(args.sample_size,
+                                 args.gc_cardinality if gc_enabled else None,
+                                 rank=rank)
+    else:
+        reader = AudioReader(args.data_dir, coord,
+                             sample_rate=wavenet_params['sample_rate'],
+                             gc_enabled=gc_enabled,
+                             sample_size=args.sample_size,
+                             silence_threshold=silence_threshold,
+                             rank=rank, world=world, seed=rank)
+
+    net = WaveNetModel(
+        batch_size=args.batch_size,
+        dilations=wavenet_params["dilations"],
+        filter_width=wavenet_params["filter_width"],
+        residual_channels=wavenet_params["residual_channels"],
+        dilation_channels=wavenet_params["dilation_channels"],
+        skip_channels=wavenet_params["skip_channels"],
+        quantization_channels=wavenet_params["quantization_channels"],
+        use_biases=wavenet_params["use_biases"],
+        scalar_input=wavenet_params["scalar_input"],
+        initial_filter_width=wavenet_params["initial_filter_width"],
+        histograms=args.histograms,
+        global_condition_channels=args.gc_channels,
+        global_condition_cardinality=reader.gc_category_cardinality,
+        residual_postproc=wavenet_params.get("residual_postproc", False))
+    l2 = args.l2_regularization_strength or None
+    optimizer = optimizer_factory[args.optimizer](
+        learning_rate=args.learning_rate, momentum=args.momentum)
+
+    try:
+        saved_global_step = load(net, restore_from)
+        if is_overwritten_training or saved_global_step is None:
+            # the first training step will be saved_global_step + 1
+            saved_global_step = -1
+    except Exception:
+        print("Something went wrong while restoring checkpoint. "
+              "We will terminate training to avoid accidentally overwriting "
+              "the previous model.")
+        raise
+    parallel.broadcast_parameters(net)
+
+    threads = reader.start_threads()
+    events = None
+    if rank == 0:
+        os.makedirs(logdir, exist_ok=True)
+        events = open(os.path.join(logdir, 'events.jsonl'), 'a')
+
+    step = None
+    last_saved_step = saved_global_step
+    try:
+        for step in range(saved_global_step + 1, args.num_steps):
+            start_time = time.time()
+            audio = reader.dequeue(args.batch_size)
+            gc = reader.dequeue_gc(args.batch_size) if gc_enabled else None
+            if audio.shape[1] < 2:
+                continue
+            trace = args.store_metadata and step % 50 == 0 and rank == 0
+            if trace:
+                print('Storing metadata')
+                prof = torch.profiler.profile(
+                    activities=[torch.profiler.ProfilerActivity.CPU,
+                                torch.profiler.ProfilerActivity.CUDA])
+                prof.__enter__()
+            loss = net.loss(input_batch=audio, global_condition_batch=gc,
+                            l2_regularization_strength=l2)
+            optimizer.minimize(loss)
+            loss_value = float(parallel.allreduce_mean_scalar(loss))
+            if trace:
+                prof.__exit__(None, None, None)
+                prof.export_chrome_trace(os.path.join(logdir,
+                                                      'timeline.trace'))
+            duration = time.time() - start_time
+            if rank == 0:
+                print('step {:d} - loss = {:.3f}, ({:.3f} sec/step)'
+                      .format(step, loss_value, duration))
+                events.write(json.dumps({'step': step, 'loss': loss_value,
+                                         'sec_per_step': duration}) + '\n')
+                events.flush()
+                if step % args.checkpoint_every == 0:
+                    save(net, logdir, step)
+                    last_saved_step = step
+    except KeyboardInterrupt:
+        print()
+    finally:
+        if rank == 0 and step is not None and step > last_saved_step:
+            save(net, logdir, step)
+        coord.request_stop()
+        coord.join(threads)
+        if events:
+            events.close()
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())

@@ -55,6 +55,14 @@ int wn_mu_law_decode(const int32_t* codes, float* audio, long n,
 int wn_causal_gather(const int32_t* q, const float* Wc, float* x0, int B,
                      int T, int Q, void* stream);
 
+/* ---- causal layer on scalar input (scalar_input=True): wavenet/model.py:
+ * 143-153, 227-234, 646-648; W is [K0][32], K0 = initial_filter_width <= 32.
+ * The wgrad writes [splits][K0*32] slabs for wn_reduce_slabs. */
+int wn_scalar_causal_fwd(const float* audio, const float* W, float* x0, int B,
+                         int T, int K0, void* stream);
+int wn_scalar_causal_wgrad(const float* audio, const float* dx0, float* slabs,
+                           int splits, int B, int T, int K0, void* stream);
+
 /* ---- fused residual block: wavenet/model.py:236-330
  * (_create_dilation_layer) incl. both causal_conv calls, ops.py:46-62.
  * wblock = Wf[2][32][32] Wg[2][32][32] Wd[32][32] bf[32] bg[32] bd[32].

@@ -133,6 +133,53 @@ __global__ void causal_gather_kernel(const int32_t* __restrict__ q,
 }
 
 // ---------------------------------------------------------------------------
+// causal layer on scalar input (scalar_input=True, model.py:143-153, 646-648):
+//   x0[t][c] = sum_k audio[t - s_k] * W[k][0][c],  s_k = (K0-1-k) + (K0-1)/2
+// (dilation 1; the extra (K0-1)/2 delay is TF's 'SAME' centring inside
+// causal_conv for K0 > 2, ops.py:46-62).  W: [K0][32].
+// ---------------------------------------------------------------------------
+__global__ void scalar_causal_fwd_kernel(const float* __restrict__ audio,
+                                         const float* __restrict__ W,
+                                         float* __restrict__ x0, long rows,
+                                         int T, int K0) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long row = idx >> 3;
+  const int c4 = (idx & 7) * 4;
+  if (row >= rows) return;
+  const int t = (int)(row % T);
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  const int extra = (K0 - 1) / 2;
+  for (int k = 0; k < K0; ++k) {
+    const int s = (K0 - 1 - k) + extra;
+    if (t - s < 0) continue;
+    const float a = audio[row - s];
+    const f32x4 w = *reinterpret_cast<const f32x4*>(W + (long)k * 32 + c4);
+    v += a * w;
+  }
+  *reinterpret_cast<f32x4*>(x0 + row * 32 + c4) = v;
+}
+
+// dW[k][c] = sum_rows audio[row - s_k] * dx0[row][c] into slabs [splits][K0*32]
+__global__ __launch_bounds__(1024) void scalar_causal_wgrad_kernel(
+    const float* __restrict__ audio, const float* __restrict__ dx0,
+    float* __restrict__ slabs, long rows, long rows_per_split, int T, int K0) {
+  const int c = threadIdx.x & 31, k = threadIdx.x >> 5;   // k < 32
+  const long r0 = (long)blockIdx.x * rows_per_split;
+  long r1 = r0 + rows_per_split;
+  if (r1 > rows) r1 = rows;
+  const int s = (K0 - 1 - k) + (K0 - 1) / 2;
+  float acc = 0.f;
+  if (k < K0) {
+    int t = (int)(r0 % T);
+    for (long r = r0; r < r1; ++r) {
+      if (t >= s) acc = fmaf(audio[r - s], dx0[r * 32 + c], acc);
+      if (++t == T) t = 0;
+    }
+    slabs[(long)blockIdx.x * K0 * 32 + k * 32 + c] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // fused softmax cross-entropy, forward + backward   (model.py:654-666)
 // One wave per row.  target of row (b,t) = q[b][t+1]; the last row of every
 // clip has the all-zero label row the reference pads in (model.py:659): its
@@ -550,6 +597,30 @@ int wn_causal_gather(const int32_t* q, const float* Wc, float* x0, int B,
   const long threads = rows * 8;
   hipLaunchKernelGGL(causal_gather_kernel, dim3((unsigned)((threads + 255) / 256)),
                      dim3(256), 0, (hipStream_t)stream, q, Wc, x0, rows, T, Q);
+  return wn_check_launch();
+}
+
+int wn_scalar_causal_fwd(const float* audio, const float* W, float* x0, int B,
+                         int T, int K0, void* stream) {
+  if (!audio || !W || !x0) return WN_ERR_NULL;
+  if (B <= 0 || T <= 0 || K0 <= 0) return WN_ERR_BAD_SHAPE;
+  if (!wn_aligned16(W) || !wn_aligned16(x0)) return WN_ERR_MISALIGNED;
+  const long rows = (long)B * T, threads = rows * 8;
+  hipLaunchKernelGGL(scalar_causal_fwd_kernel,
+                     dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, audio, W, x0, rows, T, K0);
+  return wn_check_launch();
+}
+
+int wn_scalar_causal_wgrad(const float* audio, const float* dx0, float* slabs,
+                           int splits, int B, int T, int K0, void* stream) {
+  if (!audio || !dx0 || !slabs) return WN_ERR_NULL;
+  if (B <= 0 || T <= 0 || K0 <= 0 || splits <= 0) return WN_ERR_BAD_SHAPE;
+  if (K0 > 32) return WN_ERR_UNSUPPORTED;
+  const long rows = (long)B * T;
+  const long rps = (rows + splits - 1) / splits;
+  hipLaunchKernelGGL(scalar_causal_wgrad_kernel, dim3(splits), dim3(1024), 0,
+                     (hipStream_t)stream, audio, dx0, slabs, rows, rps, T, K0);
   return wn_check_launch();
 }
 

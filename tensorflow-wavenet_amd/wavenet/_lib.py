@@ -22,6 +22,9 @@ SIGNATURES = {
     'wn_mu_law_encode': (c_int, [P, P, c_long, P, c_int, P]),
     'wn_mu_law_decode': (c_int, [P, P, c_long, P, c_int, P]),
     'wn_causal_gather': (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    'wn_scalar_causal_fwd': (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    'wn_scalar_causal_wgrad': (c_int, [P, P, P, c_int, c_int, c_int, c_int,
+                                       P]),
     'wn_layer_fwd': (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int,
                              c_int, c_int, P]),
     'wn_layer_bwd': (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int,

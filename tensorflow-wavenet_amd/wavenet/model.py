@@ -73,6 +73,7 @@ class _Workspace(object):
         f32 = dict(dtype=torch.float32, device=dev)
         self.B, self.T, self.N, self.training = B, T, N, training
         self.q = torch.empty(N, dtype=torch.int32, device=dev)
+        self.audio = torch.empty(N, **f32) if net.scalar_input else None
         self.X = torch.empty((L, N, CH), **f32)
         self.Z = torch.empty((L, N, CH), **f32)
         self.h1 = torch.empty((N, S), **f32)
@@ -190,9 +191,8 @@ class WaveNetModel(object):
         if filter_width != 2:
             self._unsupported = ('filter_width != 2 is not on the HIP path yet '
                                  '(SURVEY 8f-4)')
-        elif scalar_input:
-            self._unsupported = ('scalar_input is not on the HIP path yet '
-                                 '(SURVEY 8f-4)')
+        elif scalar_input and initial_filter_width > 32:
+            self._unsupported = 'initial_filter_width > 32 not supported yet'
         elif self.R > CH or self.D > CH:
             self._unsupported = 'residual/dilation channels > 32 not supported yet'
         elif self.S % 4 or self.Q % 4:
@@ -224,7 +224,8 @@ class WaveNetModel(object):
             off = _align(off + n)
         if card is not None:
             add('emb', card * G)
-        add('causal', 2 * Q * CH)
+        add('causal', (self.initial_filter_width if self.scalar_input
+                       else 2 * Q) * CH)
         add('layers', L * self.layer_stride)
         add('skip_w', L * CH * S)
         add('skip_b', L * S)
@@ -251,8 +252,12 @@ class WaveNetModel(object):
         if card is not None:
             var['embeddings'] = {
                 'gc_embedding': self._seg(flat, 'emb').view(card, G)}
-        var['causal_layer'] = {
-            'filter': self._seg(flat, 'causal').view(2, Q, CH)[:, :, :R]}
+        if self.scalar_input:                               # model.py:143-153
+            var['causal_layer'] = {'filter': self._seg(flat, 'causal').view(
+                self.initial_filter_width, 1, CH)[:, :, :R]}
+        else:
+            var['causal_layer'] = {
+                'filter': self._seg(flat, 'causal').view(2, Q, CH)[:, :, :R]}
         layers = self._seg(flat, 'layers').view(L, self.layer_stride)
         skw = self._seg(flat, 'skip_w').view(L, 1, CH, S)
         skb = self._seg(flat, 'skip_b').view(L, S)
@@ -430,9 +435,14 @@ class WaveNetModel(object):
         st = _lib.stream()
         B, T, N, L, S, Q = ws.B, ws.T, ws.N, self.L, self.S, self.Q
         P = self.params
-        _lib.call('wn_causal_gather', _lib.ptr(ws.q),
-                  _lib.ptr(self._seg(P, 'causal')), _lib.ptr(ws.X[0]), B, T, Q,
-                  st)
+        if self.scalar_input:
+            _lib.call('wn_scalar_causal_fwd', _lib.ptr(ws.audio),
+                      _lib.ptr(self._seg(P, 'causal')), _lib.ptr(ws.X[0]), B,
+                      T, self.initial_filter_width, st)
+        else:
+            _lib.call('wn_causal_gather', _lib.ptr(ws.q),
+                      _lib.ptr(self._seg(P, 'causal')), _lib.ptr(ws.X[0]), B,
+                      T, Q, st)
         bias, bstride = self._bias_fg(ws.bias_fg, ids, B)
         for l, d in enumerate(self.dilations):
             last = l == L - 1
@@ -593,14 +603,22 @@ class WaveNetModel(object):
         # causal layer: dWc[1][v] = sum_t [q[t]==v] dx0[t]; dWc[0][v] likewise
         # with q[t-1]  (one-hot operand generated on the fly)
         gc_ = self._seg(Gr, 'causal')
-        for tap, shift in ((1, 0), (0, 1)):
+        if self.scalar_input:
+            K0 = self.initial_filter_width
             sp = ws.splits['causal']
-            sl = lib.wn_gemm_tn_slab_floats(Q, CH)
-            _lib.call('wn_gemm_tn', None, 0, 0, 0, _lib.ptr(ws.q), shift, T,
-                      _lib.ptr(dxin), CH, _lib.ptr(ws.slabs), sp, N, Q, CH, 0,
-                      st)
-            _lib.call('wn_reduce_slabs', _lib.ptr(ws.slabs), sp, sl, 1, 0, 0,
-                      Q * CH, _lib.ptr(gc_[tap * Q * CH:]), 0, 1, 0, st)
+            _lib.call('wn_scalar_causal_wgrad', _lib.ptr(ws.audio),
+                      _lib.ptr(dxin), _lib.ptr(ws.slabs), sp, B, T, K0, st)
+            _lib.call('wn_reduce_slabs', _lib.ptr(ws.slabs), sp, K0 * CH, 1,
+                      0, 0, K0 * CH, _lib.ptr(gc_), 0, 1, 0, st)
+        else:
+            for tap, shift in ((1, 0), (0, 1)):
+                sp = ws.splits['causal']
+                sl = lib.wn_gemm_tn_slab_floats(Q, CH)
+                _lib.call('wn_gemm_tn', None, 0, 0, 0, _lib.ptr(ws.q), shift,
+                          T, _lib.ptr(dxin), CH, _lib.ptr(ws.slabs), sp, N, Q,
+                          CH, 0, st)
+                _lib.call('wn_reduce_slabs', _lib.ptr(ws.slabs), sp, sl, 1, 0,
+                          0, Q * CH, _lib.ptr(gc_[tap * Q * CH:]), 0, 1, 0, st)
         if ws.dsum is not None:
             _lib.call('wn_gc_grad', _lib.ptr(self._layer_block(P, 0)),
                       self.layer_stride, OFF_GC, self.G,
@@ -632,12 +650,18 @@ class WaveNetModel(object):
         `self.grads` (the flat bucket `optimizer.minimize` consumes).'''
         self._check_supported()
         B = self.batch_size
-        q = self.encode(input_batch, B)
+        a = input_batch
+        if not isinstance(a, torch.Tensor):
+            a = torch.as_tensor(np.asarray(a), dtype=torch.float32)
+        a = a.to(device=self.device, dtype=torch.float32).reshape(B, -1)
+        q = mu_law_encode(a, self.Q)
         return self.loss_from_codes(q, global_condition_batch,
-                                    l2_regularization_strength, backward)
+                                    l2_regularization_strength, backward,
+                                    audio=a)
 
     def loss_from_codes(self, q, global_condition_batch=None,
-                        l2_regularization_strength=None, backward=True):
+                        l2_regularization_strength=None, backward=True,
+                        audio=None):
         self._check_supported()
         B = self.batch_size
         q = q.reshape(B, -1)
@@ -645,6 +669,11 @@ class WaveNetModel(object):
         N = B * T
         ws = self._workspace(B, T, backward)
         ws.q.copy_(q.reshape(-1))
+        if self.scalar_input:
+            # network input is the raw float audio (model.py:645-648)
+            if audio is None:
+                raise ValueError('scalar_input needs the float audio')
+            ws.audio.copy_(audio.reshape(-1))
         ids = self._gc_ids(global_condition_batch, B)
         st = _lib.stream()
         self._forward(ws, ids, save_ts=backward)
@@ -706,6 +735,9 @@ class WaveNetModel(object):
         T = w.shape[1]
         ws = self._workspace(B, T, False)
         ws.q.copy_(w.reshape(-1))
+        if self.scalar_input:
+            # decode the codes back to floats in [-1, 1] (model.py:570-576)
+            ws.audio.copy_(mu_law_decode(w, self.Q).reshape(-1))
         ids = self._gc_ids(global_condition, B)
         self._forward(ws, ids, save_ts=False)
         out = torch.empty(self.Q, dtype=torch.float32, device=self.device)

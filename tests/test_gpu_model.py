@@ -41,6 +41,12 @@ CASES = [
     ('r16', cfg_with(MID, batch_size=1, residual_channels=16,
                      dilation_channels=16, skip_channels=32,
                      quantization_channels=128), 200, False, None),
+    ('scalar_k4', cfg_with(TINY, batch_size=2, scalar_input=True,
+                           initial_filter_width=4), 70, False, None),
+    ('scalar_k32', cfg_with(MID, batch_size=2, scalar_input=True,
+                            initial_filter_width=32), 150, False, None),
+    ('scalar_T_lt_k', cfg_with(TINY, batch_size=1, scalar_input=True,
+                               initial_filter_width=32), 9, False, None),
     ('default', cfg_with(DEFAULT, batch_size=1), 1500, False, None),
     ('default_gc', cfg_with(DEFAULT, batch_size=2,
                             global_condition_channels=32,
@@ -171,6 +177,19 @@ def test_predict_proba_vs_oracle(hip_lib):
     assert np.abs(p - ref).max() < 1e-5
 
 
+def test_predict_proba_scalar_input(hip_lib):
+    # model.py:570-576: codes are decoded back to floats for the scalar net
+    cfg = cfg_with(TINY, batch_size=1, scalar_input=True,
+                   initial_filter_width=4)
+    net, var = build_pair(cfg)
+    data = np.random.default_rng(0).integers(0, 16, 60)
+    p = net.predict_proba(data).cpu().numpy()
+    ref = O.predict_proba(cfg, var, data, dtype=np.float64)
+    assert np.abs(p - ref).max() < 1e-5
+    with pytest.raises(NotImplementedError, match='Scalar input'):
+        net.predict_proba_incremental(3)
+
+
 def test_incremental_vs_oracle_and_naive(hip_lib):
     """test/test_generation.py:50-72 strengthened: compare over more than the
     receptive field (RF 32 -> 80 steps), against the golden trace, the oracle
@@ -231,8 +250,8 @@ def test_generate_sampling(hip_lib):
 
 def test_unsupported_configs_raise(hip_lib):
     from wavenet import WaveNetModel
-    for kw in (dict(filter_width=3), dict(scalar_input=True),
-               dict(residual_channels=64)):
+    for kw in (dict(filter_width=3), dict(residual_channels=64),
+               dict(scalar_input=True, initial_filter_width=64)):
         cfg = cfg_with(TINY, batch_size=1, **kw)
         net = WaveNetModel(**model_kwargs(cfg))
         with pytest.raises(NotImplementedError):

@@ -72,6 +72,14 @@ def test_small_channel_views_and_init(hip_lib):
     assert torch.equal(net.params, net2.params)
 
 
+def test_scalar_input_causal_filter_shape(hip_lib):
+    from wavenet import WaveNetModel
+    cfg = cfg_with(TINY, batch_size=1, scalar_input=True,
+                   initial_filter_width=4)
+    net = WaveNetModel(device='cpu', **model_kwargs(cfg))
+    assert tuple(net.variables['causal_layer']['filter'].shape) == (4, 1, 8)
+
+
 def test_identity_embedding_when_square(hip_lib):
     from wavenet import WaveNetModel
     cfg = cfg_with(TINY, batch_size=3, global_condition_channels=3,

@@ -144,3 +144,72 @@ def test_rmsprop_training_then_fast_generation_spectrum(hip_lib):
     near = lambda f: power[np.abs(freqs - f).argmin()]
     expected = near(155.56) + near(196.00) + near(233.08)
     assert expected > 0.7 * power.sum()
+
+
+def test_scalar_input_training_thresholds(hip_lib):
+    """test/test_model.py:359-381 (TestNetWithScalarInput): scalar input,
+    initial_filter_width 4, sgd lr 0.01, 1000 iterations."""
+    from wavenet import WaveNetModel, optimizer_factory
+    net = WaveNetModel(batch_size=1, dilations=[1, 2, 4, 8, 16, 32, 64] * 2,
+                       filter_width=2, residual_channels=32,
+                       dilation_channels=32, quantization_channels=256,
+                       use_biases=True, skip_channels=32, scalar_input=True,
+                       initial_filter_width=4, seed=1)
+    audio = make_sine_chord()
+    opt = optimizer_factory['sgd'](learning_rate=0.01, momentum=0.95)
+    initial = float(net.loss(audio, backward=False))
+    for i in range(1000):
+        loss = net.loss(audio)
+        opt.minimize(loss)
+    final = float(loss)
+    assert initial > 0.1 and final < 0.1 and final / initial < 0.02
+
+
+def test_global_conditioning_training_and_generation(hip_lib):
+    """test/test_model.py:384-405 + 159-172 (TestNetWithGlobalConditioning):
+    3 speakers, each a different sine; gc_channels = cardinality = 3 (identity
+    embedding); after training, the waveform generated (naive windowed path,
+    like the reference -- its fast-generation check is commented out,
+    test_model.py:293-298) for a speaker carries >= 10x the power at its own
+    frequency than at the other two."""
+    from wavenet import WaveNetModel, optimizer_factory, mu_law_decode
+    rate, n = 2000.0, 1000
+    t = np.arange(n) / rate
+    freqs = (155.56, 196.00, 233.08)
+    amps = (0.6, 0.5, 0.4)
+    lead = 64
+    audio = np.zeros((3, n), np.float32)
+    for i in range(3):
+        audio[i, lead:] = amps[i] * np.sin((t[lead:] - t[lead]) * 2 * np.pi * freqs[i])
+    ids = np.array([[0], [1], [2]])
+    net = WaveNetModel(batch_size=3, dilations=[1, 2, 4, 8, 16, 32, 64] * 2,
+                       filter_width=2, residual_channels=32,
+                       dilation_channels=32, quantization_channels=256,
+                       use_biases=True, skip_channels=256,
+                       global_condition_channels=3,
+                       global_condition_cardinality=3, seed=1)
+    opt = optimizer_factory['sgd'](learning_rate=0.01, momentum=0.95)
+    initial = float(net.loss(audio, ids, backward=False))
+    for i in range(1000):
+        loss = net.loss(audio, ids)
+        opt.minimize(loss)
+    assert float(loss) < 0.1 and float(loss) / initial < 0.02
+    net.batch_size = 1                  # test_model.py:102
+    rng = np.random.default_rng(0)
+    for spk in range(3):
+        # generate_waveform(fast_generation=False), test_model.py:61-95: naive
+        # windowed prediction (last 256 samples), host-side np.random.choice
+        waveform = [128]
+        for i in range(1000):
+            window = waveform[-256:]
+            p = net.predict_proba(np.asarray(window), [spk]).cpu().numpy()
+            p = p.astype(np.float64)
+            waveform.append(int(rng.choice(256, p=p / p.sum())))
+        wav = mu_law_decode(np.asarray(waveform[256:]), 256).cpu().numpy()
+        power = np.abs(np.fft.fft(wav)) ** 2
+        fr = np.fft.fftfreq(wav.size, 1.0 / rate)
+        sel = (fr >= 0) & (fr <= 500.0)
+        power, fr = power[sel], fr[sel]
+        near = [power[np.abs(fr - f).argmin()] for f in freqs]
+        others = sum(near) - near[spk]
+        assert near[spk] > 10.0 * others, (spk, near)

@@ -160,6 +160,8 @@ def main():
         gc_ids = torch.tensor([(37 * (rank * B + b)) % 377 for b in range(B)],
                               dtype=torch.int32, device=dev)
     net = WaveNetModel(seed=0, **kw)
+    if os.environ.get('WN_FUSED_BWD') is not None:       # A/B knob
+        net.fused_bwd = os.environ['WN_FUSED_BWD'] == '1'
     if os.environ.get('WN_OVERLAP_WGRAD') is not None:   # A/B knob
         net.overlap_wgrad = os.environ['WN_OVERLAP_WGRAD'] == '1'
     parallel.broadcast_parameters(net)

@@ -85,6 +85,16 @@ int wn_layer_wgrad(const float* x, const float* daf, const float* dag,
                    const float* z, const float* dxin, float* slabs,
                    int num_slabs, int B, int T, int dilation, void* stream);
 
+/* fused backward of one block: phase B + all weight gradients of layer l and
+ * phase A of layer l-1 in one pass (reads da_l / dx_{l+1} once). */
+int wn_layer_bwdw_slabs(int B, int T);
+int wn_layer_bwdw(const float* x, const float* z, const float* daf_cur,
+                  const float* dag_cur, const float* dxin, float* dx_out,
+                  const float* wblock_b, const float* dZ, const float* th,
+                  const float* sg, const float* wblock_a, float* daf_next,
+                  float* dag_next, float* slabs, int B, int T, int dilation,
+                  int do_a, void* stream);
+
 /* ---- fp32 MFMA GEMMs: the skip sum + post-processing of
  * wavenet/model.py:303-305, 430-440 (_create_network) and their gradients */
 int wn_gemm_nn(const float* A, long lda, int a_planes, long a_plane_stride,

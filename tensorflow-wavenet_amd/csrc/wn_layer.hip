@@ -373,6 +373,218 @@ __global__ __launch_bounds__(256) void layer_wgrad_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// Fused backward of one residual block: data gradient (phase B of layer l),
+// ALL weight gradients of layer l, and phase A of layer l-1, in one pass over
+// the rows.  Versus layer_bwd_kernel + layer_wgrad_kernel it reads da_l and
+// dx_{l+1} once instead of twice (-49 MB per layer at B*T = 128000) and saves
+// a launch.  One 512-thread workgroup per CU; every wave owns four 4 KB LDS
+// tiles that serve BOTH views of a tile: fragments (time on lanes, operands
+// of the data products) and transposed element reads (channel on lanes,
+// operands of the weight-gradient products).
+// ---------------------------------------------------------------------------
+#define BW_WG 512
+#define BW_WAVES (BW_WG / 64)
+
+template <bool DO_A, bool HAS_DXIN>
+__global__ __launch_bounds__(BW_WG) void layer_bwdw_kernel(
+    const float* __restrict__ x, const float* __restrict__ z,
+    const float* __restrict__ daf_cur, const float* __restrict__ dag_cur,
+    const float* __restrict__ dxin, float* __restrict__ dx_out,
+    const float* __restrict__ wblock_b, const float* __restrict__ dZ,
+    const float* __restrict__ th, const float* __restrict__ sg,
+    const float* __restrict__ wblock_a, float* __restrict__ daf_next,
+    float* __restrict__ dag_next, float* __restrict__ slabs, int B, int T,
+    int d) {
+  constexpr int LDT = 33, MT = 32 * LDT;
+  __shared__ float wl[5 * MT];
+  __shared__ __attribute__((aligned(16))) float tiles[BW_WAVES * 4 * 1024];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 4096; i += BW_WG) {
+    const int m = i >> 10, rr = (i >> 5) & 31, cc = i & 31;  // W[m][rr][cc]
+    wl[m * MT + cc * LDT + rr] = wblock_b[i];
+  }
+  if (DO_A) {
+    for (int i = tid; i < 1024; i += BW_WG) {
+      const int rr = i >> 5, cc = i & 31;  // Wd[dch rr][res cc]
+      wl[4 * MT + cc * LDT + rr] = wblock_a[4096 + i];
+    }
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  float* t0 = tiles + wave * 4096;
+  float* t1 = t0 + 1024;
+  float* t2 = t1 + 1024;
+  float* t3 = t2 + 1024;
+  const int tiles_per_clip = (T + 31) >> 5;
+  const int ntiles = tiles_per_clip * B;
+  f32x16 cf0 = frag_zero(), cf1 = frag_zero(), cg0 = frag_zero(),
+         cg1 = frag_zero(), cd = frag_zero();
+  float sf = 0.f, sgs = 0.f, sd = 0.f;
+  for (int tile = blockIdx.x * BW_WAVES + wave; tile < ntiles;
+       tile += gridDim.x * BW_WAVES) {
+    int woff = j + 4 * h * LDT;  // opaque: no hoisting of the weight reads
+    asm volatile("" : "+v"(woff));
+    const float* wlane = wl + woff;
+    const int b = tile / tiles_per_clip;
+    const int tt0 = (tile - b * tiles_per_clip) * 32;
+    const int hi = min(32, T - tt0);
+    const int hi_f = min(hi, T - d - tt0);  // rows whose t+d tap exists
+    const int lo_p = max(0, d - tt0);       // rows whose t-d tap exists
+    const size_t off0 = ((size_t)b * T + tt0) * WN_CH;
+    // ---- data gradient, current tap; weight gradients.  Global loads are
+    // issued at most ~3 tiles ahead of their LDS write to bound VGPR use.
+    f32x16 dx;
+    {
+      RowRegs rdx;
+      if (HAS_DXIN) rdx = rows_load(dxin + off0, lane, 0, hi);
+      const RowRegs rf0 = rows_load(daf_cur + off0, lane, 0, hi);
+      const RowRegs rg0 = rows_load(dag_cur + off0, lane, 0, hi);
+      const RowRegs rxc = rows_load(x + off0, lane, 0, hi);
+      if (HAS_DXIN) rows_to_lds(t0, lane, rdx);   // t0 keeps dx_{l+1}
+      rows_to_lds(t1, lane, rf0);
+      rows_to_lds(t2, lane, rg0);
+      rows_to_lds(t3, lane, rxc);
+    }
+    const RowRegs rxp = rows_load(x + off0 - (size_t)d * WN_CH, lane, lo_p, hi);
+    __builtin_amdgcn_wave_barrier();
+    if (HAS_DXIN) dx = frag_from_lds(t0, j, h); else dx = frag_zero();
+    {
+      const f32x16 f0 = frag_from_lds(t1, j, h);
+      const f32x16 g0 = frag_from_lds(t2, j, h);
+      mma32<LDT>(dx, f0, wlane + 1 * MT);  // da_f[t]   * Wf[1]^T
+      mma32<LDT>(dx, g0, wlane + 3 * MT);  // da_g[t]   * Wg[1]^T
+    }
+#pragma unroll 4
+    for (int s = 0; s < 16; ++s) {       // dW[1] += x[t]^T da[t]
+      const int row = 2 * s + h;
+      const float axc = tile_elem(t3, row, j);
+      const float bf = tile_elem(t1, row, j), bg = tile_elem(t2, row, j);
+      cf1 = __builtin_amdgcn_mfma_f32_32x32x2f32(axc, bf, cf1, 0, 0, 0);
+      cg1 = __builtin_amdgcn_mfma_f32_32x32x2f32(axc, bg, cg1, 0, 0, 0);
+      sf += bf;
+      sgs += bg;
+    }
+    __builtin_amdgcn_wave_barrier();
+    rows_to_lds(t3, lane, rxp);
+    __builtin_amdgcn_wave_barrier();
+    RowRegs rzz;
+    if (HAS_DXIN) rzz = rows_load(z + off0, lane, 0, hi);
+    const RowRegs rf1 = rows_load(daf_cur + off0 + (size_t)d * WN_CH, lane, 0, hi_f);
+#pragma unroll 4
+    for (int s = 0; s < 16; ++s) {       // dW[0] += x[t-d]^T da[t]
+      const int row = 2 * s + h;
+      const float axp = tile_elem(t3, row, j);
+      const float bf = tile_elem(t1, row, j), bg = tile_elem(t2, row, j);
+      cf0 = __builtin_amdgcn_mfma_f32_32x32x2f32(axp, bf, cf0, 0, 0, 0);
+      cg0 = __builtin_amdgcn_mfma_f32_32x32x2f32(axp, bg, cg0, 0, 0, 0);
+    }
+    const RowRegs rg1 = rows_load(dag_cur + off0 + (size_t)d * WN_CH, lane, 0, hi_f);
+    if (HAS_DXIN) {                      // dWd += z^T dx_{l+1}
+      __builtin_amdgcn_wave_barrier();
+      rows_to_lds(t3, lane, rzz);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+      for (int s = 0; s < 16; ++s) {
+        const int row = 2 * s + h;
+        const float az = tile_elem(t3, row, j), bd = tile_elem(t0, row, j);
+        cd = __builtin_amdgcn_mfma_f32_32x32x2f32(az, bd, cd, 0, 0, 0);
+        sd += bd;
+      }
+    }
+    // ---- data gradient, anti-causal tap
+    __builtin_amdgcn_wave_barrier();
+    rows_to_lds(t1, lane, rf1);
+    rows_to_lds(t2, lane, rg1);
+    __builtin_amdgcn_wave_barrier();
+    RowRegs rdz, rth;
+    if (DO_A) {
+      rdz = rows_load(dZ + off0, lane, 0, hi);
+      rth = rows_load(th + off0, lane, 0, hi);
+    }
+    {
+      const f32x16 f1 = frag_from_lds(t1, j, h);
+      const f32x16 g1 = frag_from_lds(t2, j, h);
+      mma32<LDT>(dx, f1, wlane + 0 * MT);  // da_f[t+d] * Wf[0]^T
+      mma32<LDT>(dx, g1, wlane + 2 * MT);  // da_g[t+d] * Wg[0]^T
+    }
+    __builtin_amdgcn_wave_barrier();
+    frag_to_lds(t3, j, h, dx);
+    __builtin_amdgcn_wave_barrier();
+    rows_store(dx_out + off0, lane, hi, rows_from_lds(t3, lane));
+    // ---- phase A of layer l-1
+    if (DO_A) {
+      const RowRegs rsg = rows_load(sg + off0, lane, 0, hi);
+      __builtin_amdgcn_wave_barrier();
+      rows_to_lds(t0, lane, rdz);
+      rows_to_lds(t1, lane, rth);
+      rows_to_lds(t2, lane, rsg);
+      __builtin_amdgcn_wave_barrier();
+      f32x16 dz = frag_from_lds(t0, j, h);
+      const f32x16 tt = frag_from_lds(t1, j, h);
+      const f32x16 ss = frag_from_lds(t2, j, h);
+      mma32<LDT>(dz, dx, wlane + 4 * MT);
+      f32x16 df, dg;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float zs = dz[r] * ss[r];
+        df[r] = zs * (1.f - tt[r] * tt[r]);
+        dg[r] = zs * tt[r] * (1.f - ss[r]);
+      }
+      __builtin_amdgcn_wave_barrier();
+      frag_to_lds(t0, j, h, df);
+      frag_to_lds(t1, j, h, dg);
+      __builtin_amdgcn_wave_barrier();
+      rows_store(daf_next + off0, lane, hi, rows_from_lds(t0, lane));
+      rows_store(dag_next + off0, lane, hi, rows_from_lds(t1, lane));
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // ---- weight-gradient slab of this workgroup (fixed-order wave reduction)
+  sf += __shfl_xor(sf, 32);
+  sgs += __shfl_xor(sgs, 32);
+  sd += __shfl_xor(sd, 32);
+  __syncthreads();
+  float* red = tiles;
+  for (int w = 0; w < BW_WAVES; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = 8 * (r >> 2) + 4 * h + (r & 3);
+        const int e = m * 32 + j;
+        if (w == 0) {
+          red[0 * 1024 + e] = cf0[r];
+          red[1 * 1024 + e] = cf1[r];
+          red[2 * 1024 + e] = cg0[r];
+          red[3 * 1024 + e] = cg1[r];
+          red[4 * 1024 + e] = cd[r];
+        } else {
+          red[0 * 1024 + e] += cf0[r];
+          red[1 * 1024 + e] += cf1[r];
+          red[2 * 1024 + e] += cg0[r];
+          red[3 * 1024 + e] += cg1[r];
+          red[4 * 1024 + e] += cd[r];
+        }
+      }
+      if (h == 0) {
+        if (w == 0) {
+          red[LAYER_W_FLOATS + j] = sf;
+          red[LAYER_W_FLOATS + 32 + j] = sgs;
+          red[LAYER_W_FLOATS + 64 + j] = sd;
+        } else {
+          red[LAYER_W_FLOATS + j] += sf;
+          red[LAYER_W_FLOATS + 32 + j] += sgs;
+          red[LAYER_W_FLOATS + 64 + j] += sd;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* out = slabs + (size_t)blockIdx.x * LAYER_BLOCK_FLOATS;
+  for (int e = tid; e < LAYER_BLOCK_FLOATS; e += BW_WG) out[e] = red[e];
+}
+
+// ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
 // one persistent workgroup per CU (fewer when there is less work)
@@ -449,6 +661,37 @@ int wn_layer_bwd(const float* daf_cur, const float* dag_cur, const float* dxin,
 }
 
 int wn_layer_wgrad_slab_floats(void) { return LAYER_BLOCK_FLOATS; }
+
+// number of slabs (workgroups) wn_layer_bwdw writes for this shape
+int wn_layer_bwdw_slabs(int B, int T) { return layer_grid(B, T, BW_WAVES); }
+
+int wn_layer_bwdw(const float* x, const float* z, const float* daf_cur,
+                  const float* dag_cur, const float* dxin, float* dx_out,
+                  const float* wblock_b, const float* dZ, const float* th,
+                  const float* sg, const float* wblock_a, float* daf_next,
+                  float* dag_next, float* slabs, int B, int T, int dilation,
+                  int do_a, void* stream) {
+  if (B <= 0 || T <= 0 || dilation <= 0) return WN_ERR_BAD_SHAPE;
+  if (!x || !daf_cur || !dag_cur || !dx_out || !wblock_b || !slabs)
+    return WN_ERR_NULL;
+  if ((dxin != nullptr) != (z != nullptr)) return WN_ERR_NULL;
+  if (do_a && (!dZ || !th || !sg || !wblock_a || !daf_next || !dag_next))
+    return WN_ERR_NULL;
+  const void* ptrs[] = {x, z, daf_cur, dag_cur, dxin, dx_out, dZ, th, sg,
+                        daf_next, dag_next};
+  for (const void* p : ptrs)
+    if (p && !wn_aligned16(p)) return WN_ERR_MISALIGNED;
+  dim3 grid(layer_grid(B, T, BW_WAVES)), block(BW_WG);
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(DA, HX)                                                        \
+  hipLaunchKernelGGL((layer_bwdw_kernel<DA, HX>), grid, block, 0, s, x, z,    \
+                     daf_cur, dag_cur, dxin, dx_out, wblock_b, dZ, th, sg,    \
+                     wblock_a, daf_next, dag_next, slabs, B, T, dilation)
+  if (do_a) { if (dxin) LAUNCH(true, true); else LAUNCH(true, false); }
+  else { if (dxin) LAUNCH(false, true); else LAUNCH(false, false); }
+#undef LAUNCH
+  return wn_check_launch();
+}
 
 int wn_layer_wgrad(const float* x, const float* daf, const float* dag,
                    const float* z, const float* dxin, float* slabs,

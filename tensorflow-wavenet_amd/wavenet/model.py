@@ -101,9 +101,11 @@ class _Workspace(object):
         self.w1t = torch.empty((S, S), **f32)
         self.wst = torch.empty((S, L * CH), **f32)
         ntiles = B * ((T + 31) // 32)
-        self.nslab = max(1, min(512, ntiles // 4))
-        self.lslabs = torch.empty((L, self.nslab, LAYER_BLOCK), **f32)
         lib = _lib.load()
+        self.nslab = max(1, min(512, ntiles // 4))
+        self.nslab_f = lib.wn_layer_bwdw_slabs(B, T)      # fused kernel
+        self.lslabs = torch.empty((L, max(self.nslab, self.nslab_f),
+                                   LAYER_BLOCK), **f32)
         need = 0
         self.splits = {}
         for key, (mw, nw) in dict(post2=(S, Q), post1=(S, S), skip=(L * CH, S),
@@ -173,6 +175,8 @@ class WaveNetModel(object):
         # 12.80 ms/step: 100 cross-stream event edges per step cost more than
         # the overlap recovers), so it is off by default.
         self.overlap_wgrad = False
+        # fused backward kernel (data + weight gradients in one pass)
+        self.fused_bwd = True
 
         _lib.load()
         if device is None:
@@ -552,9 +556,37 @@ class WaveNetModel(object):
         # data kernel of layer l-1 overwrites those buffers, so it waits for it.
         main = torch.cuda.current_stream()
         side = self._side_stream() if self.overlap_wgrad else main
+        fused = self.fused_bwd and side is main
+        nslab = ws.nslab_f if fused else ws.nslab
         for l in range(L - 1, -1, -1):
             d = int(self.dilations[l])
             f, g = da(cur)
+            dxo = ws.dx[xp]
+            if fused:
+                # one pass: dx_l, every weight gradient of layer l, da_{l-1}
+                if ws.dsum is not None:
+                    _lib.call('wn_colsum_clip', _lib.ptr(f), B, T,
+                              _lib.ptr(ws.dsum[l]), 64, st)
+                    _lib.call('wn_colsum_clip', _lib.ptr(g), B, T,
+                              _lib.ptr(ws.dsum[l].view(-1)[32:]), 64, st)
+                fn, gn = da(1 - cur) if l > 0 else (None, None)
+                _lib.call('wn_layer_bwdw', _lib.ptr(ws.X[l]),
+                          None if dxin is None else _lib.ptr(ws.Z[l]),
+                          _lib.ptr(f), _lib.ptr(g),
+                          None if dxin is None else _lib.ptr(dxin),
+                          _lib.ptr(dxo), _lib.ptr(self._layer_block(P, l)),
+                          _lib.ptr(ws.dZ[l - 1]) if l > 0 else None,
+                          _lib.ptr(ws.TH[l - 1]) if l > 0 else None,
+                          _lib.ptr(ws.SG[l - 1]) if l > 0 else None,
+                          _lib.ptr(self._layer_block(P, l - 1)) if l > 0
+                          else None,
+                          _lib.ptr(fn), _lib.ptr(gn), _lib.ptr(ws.lslabs[l]),
+                          B, T, d, 1 if l > 0 else 0, st)
+                if l > 0:
+                    cur = 1 - cur
+                dxin = dxo
+                xp = 1 - xp
+                continue
             if side is not main:
                 ws.ev_ready[l].record(main)
                 side.wait_event(ws.ev_ready[l])
@@ -573,7 +605,6 @@ class WaveNetModel(object):
                 ws.ev_done[l].record(side)
                 if l < L - 1:
                     main.wait_event(ws.ev_done[l + 1])
-            dxo = ws.dx[xp]
             if l > 0:
                 fn, gn = da(1 - cur)
                 _lib.call('wn_layer_bwd', _lib.ptr(f), _lib.ptr(g),
@@ -596,8 +627,8 @@ class WaveNetModel(object):
             main.wait_event(ws.ev_done[0])
         # layer-block gradients: fixed-order sum of the per-workgroup slabs
         lo, _ = self.segments['layers']
-        _lib.call('wn_reduce_slabs', _lib.ptr(ws.lslabs), ws.nslab,
-                  LAYER_BLOCK, L, ws.nslab * LAYER_BLOCK, 0,
+        _lib.call('wn_reduce_slabs', _lib.ptr(ws.lslabs), nslab,
+                  LAYER_BLOCK, L, ws.lslabs.shape[1] * LAYER_BLOCK, 0,
                   LAYER_BLOCK if ub else LAYER_W, _lib.ptr(Gr[lo:]),
                   self.layer_stride, 1, 0, st)
         # causal layer: dWc[1][v] = sum_t [q[t]==v] dx0[t]; dWc[0][v] likewise

@@ -51,9 +51,10 @@ int wn_mu_law_decode(const int32_t* codes, float* audio, long n,
                      const float* lut_dev, int Q, void* stream);
 
 /* ---- causal layer on one-hot input as a gather: wavenet/model.py:227-234
- * (_create_causal_layer) + :518-531 (_one_hot).  Wc is [2][Q][32]. */
+ * (_create_causal_layer) + :518-531 (_one_hot).  Wc is [K][Q][32],
+ * K = filter_width taps at shifts (K-1-k) + (K-1)/2. */
 int wn_causal_gather(const int32_t* q, const float* Wc, float* x0, int B,
-                     int T, int Q, void* stream);
+                     int T, int Q, int K, void* stream);
 
 /* ---- causal layer on scalar input (scalar_input=True): wavenet/model.py:
  * 143-153, 227-234, 646-648; W is [K0][32], K0 = initial_filter_width <= 32.
@@ -84,6 +85,24 @@ int wn_layer_wgrad_slab_floats(void);
 int wn_layer_wgrad(const float* x, const float* daf, const float* dag,
                    const float* z, const float* dxin, float* slabs,
                    int num_slabs, int B, int T, int dilation, void* stream);
+
+/* generic filter width K >= 2 (off-default; the K = 2 kernels above are the
+ * tuned path): block = Wf[K][32][32] Wg[K][32][32] Wd[32][32] bf bg bd,
+ * tap k reads x[t - (K-1-k + (K-1)/2) * dilation] (ops.py:46-62). */
+int wn_layer_fwd_k(const float* x, float* x_out, float* z, float* th,
+                   float* sg, const float* wblock, const float* bias_fg,
+                   int bias_clip_stride, int B, int T, int dilation, int K,
+                   int has_dense, int save_ts, void* stream);
+int wn_layer_bwd_k(const float* daf_cur, const float* dag_cur,
+                   const float* dxin, float* dx_out, const float* wblock_b,
+                   const float* dZ, const float* th, const float* sg,
+                   const float* wblock_a, float* daf_next, float* dag_next,
+                   int B, int T, int dilation, int K, int do_b, int do_a,
+                   void* stream);
+int wn_layer_wgrad_k(const float* x, const float* daf, const float* dag,
+                     const float* z, const float* dxin, float* slabs,
+                     int num_slabs, int B, int T, int dilation, int K,
+                     void* stream);
 
 /* fused backward of one block: phase B + all weight gradients of layer l and
  * phase A of layer l-1 in one pass (reads da_l / dx_{l+1} once). */

@@ -585,6 +585,313 @@ __global__ __launch_bounds__(BW_WG) void layer_bwdw_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// Generic tap count (filter_width K >= 2, runtime): the off-default variant
+// of the three layer kernels.  Layer block = Wf[K][32][32] Wg[K][32][32]
+// Wd[32][32] bf bg bd.  Tap k reads x[t - s_k], s_k = (K-1-k + (K-1)/2) * d
+// (TF 'SAME' centring inside causal_conv for K > 2, ops.py:46-62), so for
+// K > 2 no tap has shift 0 and the residual x[t] is a separate load.
+// Same tile machinery as the K = 2 kernels; correctness-first (taps are
+// processed one after another, the weight-gradient kernel re-reads da per
+// tap).
+// ---------------------------------------------------------------------------
+#define GEN_WG 512
+#define GEN_WAVES (GEN_WG / 64)
+
+__device__ __forceinline__ int tap_shift(int K, int k, int d) {
+  return (K - 1 - k + (K - 1) / 2) * d;
+}
+
+template <bool HAS_DENSE, bool SAVE_TS>
+__global__ __launch_bounds__(GEN_WG) void layer_fwd_gen_kernel(
+    const float* __restrict__ x, float* __restrict__ xo, float* __restrict__ z,
+    float* __restrict__ th, float* __restrict__ sg,
+    const float* __restrict__ wblock, const float* __restrict__ bias_fg,
+    int bias_clip_stride, int B, int T, int d, int K) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int WF = (2 * K + 1) * 1024;
+  float* wl = smem;                 // weights + bd[32]
+  float* tiles = smem + WF + 32;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < WF / 4; i += GEN_WG)
+    reinterpret_cast<f32x4*>(wl)[i] = reinterpret_cast<const f32x4*>(wblock)[i];
+  if (tid < 32) wl[WF + tid] = wblock[WF + 64 + tid];   // bd
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  float* ta = tiles + wave * 1024;
+  const int tiles_per_clip = (T + 31) >> 5;
+  const int ntiles = tiles_per_clip * B;
+  for (int tile = blockIdx.x * GEN_WAVES + wave; tile < ntiles;
+       tile += gridDim.x * GEN_WAVES) {
+    int woff = j + 4 * h * 32;
+    asm volatile("" : "+v"(woff));
+    const float* wlane = wl + woff;
+    const int b = tile / tiles_per_clip;
+    const int t0 = (tile - b * tiles_per_clip) * 32;
+    const int hi = min(32, T - t0);
+    const size_t off0 = ((size_t)b * T + t0) * WN_CH;
+    f32x16 af, ag;
+    if (bias_fg) {
+      const float* bp = bias_fg + (size_t)b * bias_clip_stride;
+      af = frag_bcast(bp, h);
+      ag = frag_bcast(bp + 32, h);
+    } else {
+      af = frag_zero();
+      ag = frag_zero();
+    }
+    for (int k = 0; k < K; ++k) {
+      const int sh = tap_shift(K, k, d);
+      const RowRegs r = rows_load(x + off0 - (size_t)sh * WN_CH, lane,
+                                  max(0, sh - t0), hi);
+      __builtin_amdgcn_wave_barrier();
+      rows_to_lds(ta, lane, r);
+      __builtin_amdgcn_wave_barrier();
+      const f32x16 xk = frag_from_lds(ta, j, h);
+      mma32<32>(af, xk, wlane + k * 1024);
+      mma32<32>(ag, xk, wlane + (K + k) * 1024);
+    }
+    f32x16 zz;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      af[r] = wn_tanh(af[r]);
+      ag[r] = wn_sigmoid(ag[r]);
+      zz[r] = af[r] * ag[r];
+    }
+    __builtin_amdgcn_wave_barrier();
+    frag_to_lds(ta, j, h, zz);
+    __builtin_amdgcn_wave_barrier();
+    rows_store(z + off0, lane, hi, rows_from_lds(ta, lane));
+    if (SAVE_TS) {
+      __builtin_amdgcn_wave_barrier();
+      frag_to_lds(ta, j, h, af);
+      __builtin_amdgcn_wave_barrier();
+      rows_store(th + off0, lane, hi, rows_from_lds(ta, lane));
+      __builtin_amdgcn_wave_barrier();
+      frag_to_lds(ta, j, h, ag);
+      __builtin_amdgcn_wave_barrier();
+      rows_store(sg + off0, lane, hi, rows_from_lds(ta, lane));
+    }
+    if (HAS_DENSE) {
+      __builtin_amdgcn_wave_barrier();
+      rows_to_lds(ta, lane, rows_load(x + off0, lane, 0, hi));
+      __builtin_amdgcn_wave_barrier();
+      f32x16 acc = frag_from_lds(ta, j, h);
+      const f32x16 bd = frag_bcast(wl + WF + (woff - j - 128 * h), h);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += bd[r];
+      mma32<32>(acc, zz, wlane + 2 * K * 1024);
+      __builtin_amdgcn_wave_barrier();
+      frag_to_lds(ta, j, h, acc);
+      __builtin_amdgcn_wave_barrier();
+      rows_store(xo + off0, lane, hi, rows_from_lds(ta, lane));
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <bool DO_B, bool DO_A, bool HAS_DXIN>
+__global__ __launch_bounds__(GEN_WG) void layer_bwd_gen_kernel(
+    const float* __restrict__ daf_cur, const float* __restrict__ dag_cur,
+    const float* __restrict__ dxin, float* __restrict__ dx_out,
+    const float* __restrict__ wblock_b, const float* __restrict__ dZ,
+    const float* __restrict__ th, const float* __restrict__ sg,
+    const float* __restrict__ wblock_a, float* __restrict__ daf_next,
+    float* __restrict__ dag_next, int B, int T, int d, int K) {
+  constexpr int LDT = 33, MT = 32 * LDT;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* wl = smem;                         // (2K+1) transposed matrices
+  float* tiles = smem + ((2 * K + 1) * MT + 3) / 4 * 4;
+  const int tid = threadIdx.x;
+  if (DO_B) {
+    for (int i = tid; i < 2 * K * 1024; i += GEN_WG) {
+      const int m = i >> 10, rr = (i >> 5) & 31, cc = i & 31;
+      wl[m * MT + cc * LDT + rr] = wblock_b[i];
+    }
+  }
+  if (DO_A) {
+    for (int i = tid; i < 1024; i += GEN_WG) {
+      const int rr = i >> 5, cc = i & 31;
+      wl[2 * K * MT + cc * LDT + rr] = wblock_a[2 * K * 1024 + i];
+    }
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  float* ta = tiles + wave * 2048;
+  float* tb = ta + 1024;
+  const int tiles_per_clip = (T + 31) >> 5;
+  const int ntiles = tiles_per_clip * B;
+  for (int tile = blockIdx.x * GEN_WAVES + wave; tile < ntiles;
+       tile += gridDim.x * GEN_WAVES) {
+    int woff = j + 4 * h * LDT;
+    asm volatile("" : "+v"(woff));
+    const float* wlane = wl + woff;
+    const int b = tile / tiles_per_clip;
+    const int t0 = (tile - b * tiles_per_clip) * 32;
+    const int hi = min(32, T - t0);
+    const size_t off0 = ((size_t)b * T + t0) * WN_CH;
+    f32x16 dx;
+    if (HAS_DXIN) {
+      rows_to_lds(ta, lane, rows_load(dxin + off0, lane, 0, hi));
+      __builtin_amdgcn_wave_barrier();
+      dx = frag_from_lds(ta, j, h);
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      dx = frag_zero();
+    }
+    if (DO_B) {
+      for (int k = 0; k < K; ++k) {
+        const int sh = tap_shift(K, k, d);
+        const int hi_f = min(hi, T - sh - t0);
+        const RowRegs rf = rows_load(daf_cur + off0 + (size_t)sh * WN_CH, lane, 0, hi_f);
+        const RowRegs rg = rows_load(dag_cur + off0 + (size_t)sh * WN_CH, lane, 0, hi_f);
+        __builtin_amdgcn_wave_barrier();
+        rows_to_lds(ta, lane, rf);
+        rows_to_lds(tb, lane, rg);
+        __builtin_amdgcn_wave_barrier();
+        const f32x16 fk = frag_from_lds(ta, j, h);
+        const f32x16 gk = frag_from_lds(tb, j, h);
+        mma32<LDT>(dx, fk, wlane + k * MT);
+        mma32<LDT>(dx, gk, wlane + (K + k) * MT);
+      }
+      __builtin_amdgcn_wave_barrier();
+      frag_to_lds(ta, j, h, dx);
+      __builtin_amdgcn_wave_barrier();
+      rows_store(dx_out + off0, lane, hi, rows_from_lds(ta, lane));
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (DO_A) {
+      const RowRegs rz = rows_load(dZ + off0, lane, 0, hi);
+      const RowRegs rt = rows_load(th + off0, lane, 0, hi);
+      const RowRegs rs = rows_load(sg + off0, lane, 0, hi);
+      rows_to_lds(ta, lane, rz);
+      rows_to_lds(tb, lane, rt);
+      __builtin_amdgcn_wave_barrier();
+      f32x16 dz = frag_from_lds(ta, j, h);
+      const f32x16 tt = frag_from_lds(tb, j, h);
+      __builtin_amdgcn_wave_barrier();
+      rows_to_lds(ta, lane, rs);
+      __builtin_amdgcn_wave_barrier();
+      const f32x16 ss = frag_from_lds(ta, j, h);
+      if (DO_B || HAS_DXIN) mma32<LDT>(dz, dx, wlane + 2 * K * MT);
+      f32x16 df, dg;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float zs = dz[r] * ss[r];
+        df[r] = zs * (1.f - tt[r] * tt[r]);
+        dg[r] = zs * tt[r] * (1.f - ss[r]);
+      }
+      __builtin_amdgcn_wave_barrier();
+      frag_to_lds(ta, j, h, df);
+      frag_to_lds(tb, j, h, dg);
+      __builtin_amdgcn_wave_barrier();
+      rows_store(daf_next + off0, lane, hi, rows_from_lds(ta, lane));
+      rows_store(dag_next + off0, lane, hi, rows_from_lds(tb, lane));
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// weight gradients, one tap per pass; slab layout == layer block layout
+template <bool HAS_DENSE>
+__global__ __launch_bounds__(256) void layer_wgrad_gen_kernel(
+    const float* __restrict__ x, const float* __restrict__ daf,
+    const float* __restrict__ dag, const float* __restrict__ z,
+    const float* __restrict__ dxin, float* __restrict__ slabs, int B, int T,
+    int d, int K) {
+  __shared__ __attribute__((aligned(16))) float lds[4 * 3 * 1024];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  float* t_x = lds + wave * 3 * 1024;
+  float* t_f = t_x + 1024;
+  float* t_g = t_f + 1024;
+  const int tiles_per_clip = (T + 31) >> 5;
+  const int ntiles = tiles_per_clip * B;
+  const int nwaves = gridDim.x * 4;
+  const int WF = (2 * K + 1) * 1024;
+  float* out = slabs + (size_t)blockIdx.x * (WF + 96);
+  for (int k = 0; k < K; ++k) {
+    const int sh = tap_shift(K, k, d);
+    f32x16 cf = frag_zero(), cg = frag_zero(), cd = frag_zero();
+    float sf = 0.f, sgs = 0.f, sd = 0.f;
+    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += nwaves) {
+      const int b = tile / tiles_per_clip;
+      const int t0 = (tile - b * tiles_per_clip) * 32;
+      const int hi = min(32, T - t0);
+      const size_t off0 = ((size_t)b * T + t0) * WN_CH;
+      const RowRegs rx = rows_load(x + off0 - (size_t)sh * WN_CH, lane,
+                                   max(0, sh - t0), hi);
+      const RowRegs rf = rows_load(daf + off0, lane, 0, hi);
+      const RowRegs rg = rows_load(dag + off0, lane, 0, hi);
+      __builtin_amdgcn_wave_barrier();
+      rows_to_lds(t_x, lane, rx);
+      rows_to_lds(t_f, lane, rf);
+      rows_to_lds(t_g, lane, rg);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+      for (int s = 0; s < 16; ++s) {
+        const int row = 2 * s + h;
+        const float ax = tile_elem(t_x, row, i);
+        const float bf = tile_elem(t_f, row, i), bg = tile_elem(t_g, row, i);
+        cf = __builtin_amdgcn_mfma_f32_32x32x2f32(ax, bf, cf, 0, 0, 0);
+        cg = __builtin_amdgcn_mfma_f32_32x32x2f32(ax, bg, cg, 0, 0, 0);
+        sf += bf;
+        sgs += bg;
+      }
+      if (HAS_DENSE && k == 0) {
+        const RowRegs rz = rows_load(z + off0, lane, 0, hi);
+        const RowRegs rd = rows_load(dxin + off0, lane, 0, hi);
+        __builtin_amdgcn_wave_barrier();
+        rows_to_lds(t_x, lane, rz);
+        rows_to_lds(t_f, lane, rd);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) {
+          const int row = 2 * s + h;
+          const float az = tile_elem(t_x, row, i), bd = tile_elem(t_f, row, i);
+          cd = __builtin_amdgcn_mfma_f32_32x32x2f32(az, bd, cd, 0, 0, 0);
+          sd += bd;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    sf += __shfl_xor(sf, 32);
+    sgs += __shfl_xor(sgs, 32);
+    sd += __shfl_xor(sd, 32);
+    __syncthreads();
+    float* red = lds;   // [0] cf, [1] cg, [2] cd, then 96 sums
+    for (int w = 0; w < 4; ++w) {
+      if (wave == w) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int e = (8 * (r >> 2) + 4 * h + (r & 3)) * 32 + i;
+          if (w == 0) {
+            red[e] = cf[r]; red[1024 + e] = cg[r]; red[2048 + e] = cd[r];
+          } else {
+            red[e] += cf[r]; red[1024 + e] += cg[r]; red[2048 + e] += cd[r];
+          }
+        }
+        if (h == 0) {
+          if (w == 0) {
+            red[3072 + i] = sf; red[3104 + i] = sgs; red[3136 + i] = sd;
+          } else {
+            red[3072 + i] += sf; red[3104 + i] += sgs; red[3136 + i] += sd;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    for (int e = tid; e < 1024; e += 256) {
+      out[k * 1024 + e] = red[e];
+      out[(K + k) * 1024 + e] = red[1024 + e];
+      if (k == 0) out[2 * K * 1024 + e] = red[2048 + e];
+    }
+    if (k == 0 && tid < 96) out[WF + tid] = red[3072 + tid];
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
 // one persistent workgroup per CU (fewer when there is less work)
@@ -661,6 +968,87 @@ int wn_layer_bwd(const float* daf_cur, const float* dag_cur, const float* dxin,
 }
 
 int wn_layer_wgrad_slab_floats(void) { return LAYER_BLOCK_FLOATS; }
+
+// ---- generic filter width (K taps); block = (2K+1)*1024 + 96 floats
+int wn_layer_fwd_k(const float* x, float* x_out, float* z, float* th,
+                   float* sg, const float* wblock, const float* bias_fg,
+                   int bias_clip_stride, int B, int T, int dilation, int K,
+                   int has_dense, int save_ts, void* stream) {
+  if (!x || !z || !wblock) return WN_ERR_NULL;
+  if (B <= 0 || T <= 0 || dilation <= 0 || K < 2) return WN_ERR_BAD_SHAPE;
+  if (K > 8) return WN_ERR_UNSUPPORTED;
+  if (has_dense && !x_out) return WN_ERR_NULL;
+  if (save_ts && (!th || !sg)) return WN_ERR_NULL;
+  dim3 grid(layer_grid(B, T, GEN_WAVES)), block(GEN_WG);
+  const size_t lds = ((size_t)(2 * K + 1) * 1024 + 32 + GEN_WAVES * 1024) * 4;
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(HD, TS)                                                       \
+  if (hipFuncSetAttribute((const void*)layer_fwd_gen_kernel<HD, TS>,         \
+                          hipFuncAttributeMaxDynamicSharedMemorySize,        \
+                          (int)lds) != hipSuccess)                           \
+    return WN_ERR_LAUNCH;                                                    \
+  hipLaunchKernelGGL((layer_fwd_gen_kernel<HD, TS>), grid, block, lds, s, x, \
+                     x_out, z, th, sg, wblock, bias_fg, bias_clip_stride, B, \
+                     T, dilation, K)
+  if (has_dense && save_ts) { LAUNCH(true, true); }
+  else if (has_dense) { LAUNCH(true, false); }
+  else if (save_ts) { LAUNCH(false, true); }
+  else { LAUNCH(false, false); }
+#undef LAUNCH
+  return wn_check_launch();
+}
+
+int wn_layer_bwd_k(const float* daf_cur, const float* dag_cur,
+                   const float* dxin, float* dx_out, const float* wblock_b,
+                   const float* dZ, const float* th, const float* sg,
+                   const float* wblock_a, float* daf_next, float* dag_next,
+                   int B, int T, int dilation, int K, int do_b, int do_a,
+                   void* stream) {
+  if (B <= 0 || T <= 0 || dilation <= 0 || K < 2) return WN_ERR_BAD_SHAPE;
+  if (K > 8) return WN_ERR_UNSUPPORTED;
+  if (!do_a && !do_b) return WN_ERR_BAD_SHAPE;
+  if (do_b && (!daf_cur || !dag_cur || !dx_out || !wblock_b)) return WN_ERR_NULL;
+  if (do_a && (!dZ || !th || !sg || !wblock_a || !daf_next || !dag_next))
+    return WN_ERR_NULL;
+  dim3 grid(layer_grid(B, T, GEN_WAVES)), block(GEN_WG);
+  const size_t lds = (((size_t)(2 * K + 1) * 33 * 32 + 3) / 4 * 4 +
+                      GEN_WAVES * 2048) * 4;
+  hipStream_t s = (hipStream_t)stream;
+  const bool hx = dxin != nullptr;
+#define LAUNCH(DB, DA, HX)                                                    \
+  if (hipFuncSetAttribute((const void*)layer_bwd_gen_kernel<DB, DA, HX>,      \
+                          hipFuncAttributeMaxDynamicSharedMemorySize,         \
+                          (int)lds) != hipSuccess)                            \
+    return WN_ERR_LAUNCH;                                                     \
+  hipLaunchKernelGGL((layer_bwd_gen_kernel<DB, DA, HX>), grid, block, lds, s, \
+                     daf_cur, dag_cur, dxin, dx_out, wblock_b, dZ, th, sg,    \
+                     wblock_a, daf_next, dag_next, B, T, dilation, K)
+  if (do_b && do_a) { if (hx) { LAUNCH(true, true, true); } else { LAUNCH(true, true, false); } }
+  else if (do_b) { if (hx) { LAUNCH(true, false, true); } else { LAUNCH(true, false, false); } }
+  else { if (hx) { LAUNCH(false, true, true); } else { LAUNCH(false, true, false); } }
+#undef LAUNCH
+  return wn_check_launch();
+}
+
+int wn_layer_wgrad_k(const float* x, const float* daf, const float* dag,
+                     const float* z, const float* dxin, float* slabs,
+                     int num_slabs, int B, int T, int dilation, int K,
+                     void* stream) {
+  if (!x || !daf || !dag || !slabs) return WN_ERR_NULL;
+  if (B <= 0 || T <= 0 || dilation <= 0 || num_slabs <= 0 || K < 2)
+    return WN_ERR_BAD_SHAPE;
+  if (K > 8) return WN_ERR_UNSUPPORTED;
+  if ((dxin != nullptr) != (z != nullptr)) return WN_ERR_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(num_slabs), block(256);
+  if (dxin)
+    hipLaunchKernelGGL((layer_wgrad_gen_kernel<true>), grid, block, 0, s, x,
+                       daf, dag, z, dxin, slabs, B, T, dilation, K);
+  else
+    hipLaunchKernelGGL((layer_wgrad_gen_kernel<false>), grid, block, 0, s, x,
+                       daf, dag, z, dxin, slabs, B, T, dilation, K);
+  return wn_check_launch();
+}
 
 // number of slabs (workgroups) wn_layer_bwdw writes for this shape
 int wn_layer_bwdw_slabs(int B, int T) { return layer_grid(B, T, BW_WAVES); }

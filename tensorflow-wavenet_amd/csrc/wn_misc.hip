@@ -107,28 +107,29 @@ __global__ void mu_law_decode_kernel(const int32_t* __restrict__ codes,
 
 // ---------------------------------------------------------------------------
 // causal layer on one-hot input == gather   (model.py:227-234, 518-531)
-//   x0[t] = Wc[0][q[t-1]] + Wc[1][q[t]]   (first term 0 at t = 0; an
-//   out-of-range code is an all-zero one-hot row)
-// Wc: [2][Q][32] (R padded to 32).  8 threads x 16 B per row.
+//   x0[t] = sum_k Wc[k][q[t - s_k]],  s_k = (K-1-k) + (K-1)/2
+//   (K = filter_width; K = 2: Wc[0][q[t-1]] + Wc[1][q[t]]; terms with t < s_k
+//   vanish; an out-of-range code is an all-zero one-hot row)
+// Wc: [K][Q][32] (R padded to 32).  8 threads x 16 B per row.
 // ---------------------------------------------------------------------------
 __global__ void causal_gather_kernel(const int32_t* __restrict__ q,
                                      const float* __restrict__ Wc,
                                      float* __restrict__ x0, long rows, int T,
-                                     int Q) {
+                                     int Q, int K) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long row = idx >> 3;
   const int c4 = (idx & 7) * 4;
   if (row >= rows) return;
   const int t = (int)(row % T);
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if (t >= 1) {
-    const int qp = q[row - 1];
-    if (qp >= 0 && qp < Q)
-      v = *reinterpret_cast<const f32x4*>(Wc + (long)qp * 32 + c4);
+  const int extra = (K - 1) / 2;       // TF 'SAME' centring for K > 2
+  for (int k = 0; k < K; ++k) {
+    const int s = (K - 1 - k) + extra;
+    if (t < s) continue;
+    const int code = q[row - s];
+    if (code >= 0 && code < Q)
+      v += *reinterpret_cast<const f32x4*>(Wc + ((long)k * Q + code) * 32 + c4);
   }
-  const int qc = q[row];
-  if (qc >= 0 && qc < Q)
-    v += *reinterpret_cast<const f32x4*>(Wc + ((long)Q + qc) * 32 + c4);
   *reinterpret_cast<f32x4*>(x0 + row * 32 + c4) = v;
 }
 
@@ -589,14 +590,15 @@ int wn_mu_law_decode(const int32_t* codes, float* audio, long n,
 }
 
 int wn_causal_gather(const int32_t* q, const float* Wc, float* x0, int B,
-                     int T, int Q, void* stream) {
+                     int T, int Q, int K, void* stream) {
   if (!q || !Wc || !x0) return WN_ERR_NULL;
-  if (B <= 0 || T <= 0 || Q <= 0) return WN_ERR_BAD_SHAPE;
+  if (B <= 0 || T <= 0 || Q <= 0 || K <= 0) return WN_ERR_BAD_SHAPE;
   if (!wn_aligned16(Wc) || !wn_aligned16(x0)) return WN_ERR_MISALIGNED;
   const long rows = (long)B * T;
   const long threads = rows * 8;
   hipLaunchKernelGGL(causal_gather_kernel, dim3((unsigned)((threads + 255) / 256)),
-                     dim3(256), 0, (hipStream_t)stream, q, Wc, x0, rows, T, Q);
+                     dim3(256), 0, (hipStream_t)stream, q, Wc, x0, rows, T, Q,
+                     K);
   return wn_check_launch();
 }
 

@@ -21,7 +21,7 @@ SIGNATURES = {
     'wn_mu_law_decode_table_host': (c_int, [c_int, P]),
     'wn_mu_law_encode': (c_int, [P, P, c_long, P, c_int, P]),
     'wn_mu_law_decode': (c_int, [P, P, c_long, P, c_int, P]),
-    'wn_causal_gather': (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    'wn_causal_gather': (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     'wn_scalar_causal_fwd': (c_int, [P, P, P, c_int, c_int, c_int, P]),
     'wn_scalar_causal_wgrad': (c_int, [P, P, P, c_int, c_int, c_int, c_int,
                                        P]),
@@ -32,6 +32,12 @@ SIGNATURES = {
     'wn_layer_wgrad_slab_floats': (c_int, []),
     'wn_layer_wgrad': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int,
                                P]),
+    'wn_layer_fwd_k': (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int,
+                               c_int, c_int, c_int, P]),
+    'wn_layer_bwd_k': (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int,
+                               c_int, c_int, c_int, c_int, P]),
+    'wn_layer_wgrad_k': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int,
+                                 c_int, P]),
     'wn_layer_bwdw_slabs': (c_int, [c_int, c_int]),
     'wn_layer_bwdw': (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int,
                               c_int, c_int, c_int, P]),

@@ -25,10 +25,12 @@ from . import _lib
 from .ops import mu_law_encode, mu_law_decode, mu_law_tables
 
 CH = 32                      # padded residual / dilation channels per plane
-LAYER_W = 5 * 1024           # Wf[2][32][32] Wg[2][32][32] Wd[32][32]
-OFF_BF, OFF_BG, OFF_BD = 5120, 5152, 5184
-LAYER_BLOCK = LAYER_W + 96
-OFF_GC = LAYER_BLOCK
+# layer block (floats) for filter width K:
+#   Wf[K][32][32] Wg[K][32][32] Wd[32][32] bf[32] bg[32] bd[32] (+ gc weights)
+
+
+def layer_w(K):
+    return (2 * K + 1) * 1024
 
 
 def _align(n, a=32):
@@ -105,7 +107,7 @@ class _Workspace(object):
         self.nslab = max(1, min(512, ntiles // 4))
         self.nslab_f = lib.wn_layer_bwdw_slabs(B, T)      # fused kernel
         self.lslabs = torch.empty((L, max(self.nslab, self.nslab_f),
-                                   LAYER_BLOCK), **f32)
+                                   net.LAYER_BLOCK), **f32)
         need = 0
         self.splits = {}
         for key, (mw, nw) in dict(post2=(S, Q), post1=(S, S), skip=(L * CH, S),
@@ -192,9 +194,8 @@ class WaveNetModel(object):
         self.G = global_condition_channels
         self.card = global_condition_cardinality
         self._unsupported = None
-        if filter_width != 2:
-            self._unsupported = ('filter_width != 2 is not on the HIP path yet '
-                                 '(SURVEY 8f-4)')
+        if filter_width < 2 or filter_width > 8:
+            self._unsupported = 'filter_width must be in [2, 8] on the HIP path'
         elif scalar_input and initial_filter_width > 32:
             self._unsupported = 'initial_filter_width > 32 not supported yet'
         elif self.R > CH or self.D > CH:
@@ -204,6 +205,16 @@ class WaveNetModel(object):
         elif self.G is not None and self.card is None:
             self._unsupported = ('dense-vector global conditioning cannot run in '
                                  'the reference either (model.py:547,553)')
+        self.KW = K = int(filter_width)
+        # K = 2 runs the tuned kernels; other widths (or forcing it, for
+        # tests) the generic-tap kernels
+        self.generic_layers = K != 2
+        self.LAYER_W = layer_w(K)
+        self.OFF_BF = self.LAYER_W
+        self.OFF_BG = self.LAYER_W + 32
+        self.OFF_BD = self.LAYER_W + 64
+        self.LAYER_BLOCK = self.LAYER_W + 96
+        self.OFF_GC = self.LAYER_BLOCK
         self._ws = {}
         self._gen = None
         self.init_ops = []
@@ -220,7 +231,7 @@ class WaveNetModel(object):
             self.params = torch.zeros(4, device=self.device)
             self.grads = torch.zeros(4, device=self.device)
             return {}
-        self.layer_stride = LAYER_BLOCK + (2 * G * CH if G else 0)
+        self.layer_stride = self.LAYER_BLOCK + (2 * G * CH if G else 0)
         seg, off = {}, 0
         def add(name, n):
             nonlocal off
@@ -229,7 +240,7 @@ class WaveNetModel(object):
         if card is not None:
             add('emb', card * G)
         add('causal', (self.initial_filter_width if self.scalar_input
-                       else 2 * Q) * CH)
+                       else self.KW * Q) * CH)
         add('layers', L * self.layer_stride)
         add('skip_w', L * CH * S)
         add('skip_b', L * S)
@@ -261,7 +272,8 @@ class WaveNetModel(object):
                 self.initial_filter_width, 1, CH)[:, :, :R]}
         else:
             var['causal_layer'] = {
-                'filter': self._seg(flat, 'causal').view(2, Q, CH)[:, :, :R]}
+                'filter': self._seg(flat, 'causal').view(self.KW, Q, CH)[
+                    :, :, :R]}
         layers = self._seg(flat, 'layers').view(L, self.layer_stride)
         skw = self._seg(flat, 'skip_w').view(L, 1, CH, S)
         skb = self._seg(flat, 'skip_b').view(L, S)
@@ -269,9 +281,13 @@ class WaveNetModel(object):
         for i in range(L):
             blk = layers[i]
             cur = dict()
-            cur['filter'] = blk[0:2048].view(2, CH, CH)[:, :R, :D]
-            cur['gate'] = blk[2048:4096].view(2, CH, CH)[:, :R, :D]
-            cur['dense'] = blk[4096:5120].view(1, CH, CH)[:, :D, :R]
+            K = self.KW
+            OFF_GC, OFF_BF, OFF_BG, OFF_BD = (self.OFF_GC, self.OFF_BF,
+                                              self.OFF_BG, self.OFF_BD)
+            cur['filter'] = blk[0:K * 1024].view(K, CH, CH)[:, :R, :D]
+            cur['gate'] = blk[K * 1024:2 * K * 1024].view(K, CH, CH)[:, :R, :D]
+            cur['dense'] = blk[2 * K * 1024:(2 * K + 1) * 1024].view(
+                1, CH, CH)[:, :D, :R]
             cur['skip'] = skw[i][:, :D, :]
             if G is not None:
                 gcf = blk[OFF_GC:OFF_GC + G * CH].view(1, G, CH)
@@ -414,7 +430,7 @@ class WaveNetModel(object):
         out = ws_bias.view(-1)[:self.L * nb * 64].view(self.L, nb, 64)
         emb = self._seg(self.params, 'emb') if ids is not None else None
         _lib.call('wn_gc_bias', _lib.ptr(self._layer_block(self.params, 0)),
-                  self.layer_stride, OFF_BF, OFF_GC, self.G or 0,
+                  self.layer_stride, self.OFF_BF, self.OFF_GC, self.G or 0,
                   _lib.ptr(emb), self.card or 0, _lib.ptr(ids), _lib.ptr(out),
                   self.L, nb, _lib.stream())
         return out, (64 if ids is not None else 0)
@@ -446,18 +462,24 @@ class WaveNetModel(object):
         else:
             _lib.call('wn_causal_gather', _lib.ptr(ws.q),
                       _lib.ptr(self._seg(P, 'causal')), _lib.ptr(ws.X[0]), B,
-                      T, Q, st)
+                      T, Q, self.KW, st)
         bias, bstride = self._bias_fg(ws.bias_fg, ids, B)
         for l, d in enumerate(self.dilations):
             last = l == L - 1
-            _lib.call('wn_layer_fwd', _lib.ptr(ws.X[l]),
-                      None if last else _lib.ptr(ws.X[l + 1]),
-                      _lib.ptr(ws.Z[l]),
-                      _lib.ptr(ws.TH[l]) if save_ts else None,
-                      _lib.ptr(ws.SG[l]) if save_ts else None,
-                      _lib.ptr(self._layer_block(P, l)),
-                      None if bias is None else _lib.ptr(bias[l]), bstride,
-                      B, T, int(d), 0 if last else 1, 1 if save_ts else 0, st)
+            fargs = (_lib.ptr(ws.X[l]),
+                     None if last else _lib.ptr(ws.X[l + 1]),
+                     _lib.ptr(ws.Z[l]),
+                     _lib.ptr(ws.TH[l]) if save_ts else None,
+                     _lib.ptr(ws.SG[l]) if save_ts else None,
+                     _lib.ptr(self._layer_block(P, l)),
+                     None if bias is None else _lib.ptr(bias[l]), bstride,
+                     B, T, int(d))
+            if self.generic_layers:
+                _lib.call('wn_layer_fwd_k', *fargs, self.KW,
+                          0 if last else 1, 1 if save_ts else 0, st)
+            else:
+                _lib.call('wn_layer_fwd', *fargs, 0 if last else 1,
+                          1 if save_ts else 0, st)
         bsum = None
         if self.use_biases:
             _lib.call('wn_sum_rows', _lib.ptr(self._seg(P, 'skip_b')), L, S,
@@ -540,10 +562,23 @@ class WaveNetModel(object):
         # residual stack, last layer first
         def da(p):
             return ws.da[p][0], ws.da[p][1]
+        gen = self.generic_layers
+
+        def layer_bwd(*a):           # (..., B, T, d, do_b, do_a, stream)
+            if gen:
+                _lib.call('wn_layer_bwd_k', *a[:14], self.KW, *a[14:])
+            else:
+                _lib.call('wn_layer_bwd', *a)
+
+        def layer_wgrad(*a):         # (..., nslab, B, T, d, stream)
+            if gen:
+                _lib.call('wn_layer_wgrad_k', *a[:10], self.KW, a[10])
+            else:
+                _lib.call('wn_layer_wgrad', *a)
         cur = 0
         f, g = da(cur)
         # phase A of the last layer (no gradient flows into its x' output)
-        _lib.call('wn_layer_bwd', None, None, None, None, None,
+        layer_bwd(None, None, None, None, None,
                   _lib.ptr(ws.dZ[L - 1]), _lib.ptr(ws.TH[L - 1]),
                   _lib.ptr(ws.SG[L - 1]),
                   _lib.ptr(self._layer_block(P, L - 1)), _lib.ptr(f),
@@ -556,7 +591,7 @@ class WaveNetModel(object):
         # data kernel of layer l-1 overwrites those buffers, so it waits for it.
         main = torch.cuda.current_stream()
         side = self._side_stream() if self.overlap_wgrad else main
-        fused = self.fused_bwd and side is main
+        fused = self.fused_bwd and side is main and not gen
         nslab = ws.nslab_f if fused else ws.nslab
         for l in range(L - 1, -1, -1):
             d = int(self.dilations[l])
@@ -591,11 +626,10 @@ class WaveNetModel(object):
                 ws.ev_ready[l].record(main)
                 side.wait_event(ws.ev_ready[l])
             sst = side.cuda_stream
-            _lib.call('wn_layer_wgrad', _lib.ptr(ws.X[l]), _lib.ptr(f),
-                      _lib.ptr(g),
-                      None if dxin is None else _lib.ptr(ws.Z[l]),
-                      None if dxin is None else _lib.ptr(dxin),
-                      _lib.ptr(ws.lslabs[l]), ws.nslab, B, T, d, sst)
+            layer_wgrad(_lib.ptr(ws.X[l]), _lib.ptr(f), _lib.ptr(g),
+                        None if dxin is None else _lib.ptr(ws.Z[l]),
+                        None if dxin is None else _lib.ptr(dxin),
+                        _lib.ptr(ws.lslabs[l]), ws.nslab, B, T, d, sst)
             if ws.dsum is not None:
                 _lib.call('wn_colsum_clip', _lib.ptr(f), B, T,
                           _lib.ptr(ws.dsum[l]), 64, sst)
@@ -607,7 +641,7 @@ class WaveNetModel(object):
                     main.wait_event(ws.ev_done[l + 1])
             if l > 0:
                 fn, gn = da(1 - cur)
-                _lib.call('wn_layer_bwd', _lib.ptr(f), _lib.ptr(g),
+                layer_bwd(_lib.ptr(f), _lib.ptr(g),
                           None if dxin is None else _lib.ptr(dxin),
                           _lib.ptr(dxo), _lib.ptr(self._layer_block(P, l)),
                           _lib.ptr(ws.dZ[l - 1]), _lib.ptr(ws.TH[l - 1]),
@@ -616,7 +650,7 @@ class WaveNetModel(object):
                           _lib.ptr(gn), B, T, d, 1, 1, st)
                 cur = 1 - cur
             else:
-                _lib.call('wn_layer_bwd', _lib.ptr(f), _lib.ptr(g),
+                layer_bwd(_lib.ptr(f), _lib.ptr(g),
                           None if dxin is None else _lib.ptr(dxin),
                           _lib.ptr(dxo), _lib.ptr(self._layer_block(P, l)),
                           None, None, None, None, None, None, B, T, d, 1, 0,
@@ -628,8 +662,9 @@ class WaveNetModel(object):
         # layer-block gradients: fixed-order sum of the per-workgroup slabs
         lo, _ = self.segments['layers']
         _lib.call('wn_reduce_slabs', _lib.ptr(ws.lslabs), nslab,
-                  LAYER_BLOCK, L, ws.lslabs.shape[1] * LAYER_BLOCK, 0,
-                  LAYER_BLOCK if ub else LAYER_W, _lib.ptr(Gr[lo:]),
+                  self.LAYER_BLOCK, L, ws.lslabs.shape[1] * self.LAYER_BLOCK,
+                  0, self.LAYER_BLOCK if ub else self.LAYER_W,
+                  _lib.ptr(Gr[lo:]),
                   self.layer_stride, 1, 0, st)
         # causal layer: dWc[1][v] = sum_t [q[t]==v] dx0[t]; dWc[0][v] likewise
         # with q[t-1]  (one-hot operand generated on the fly)
@@ -642,7 +677,9 @@ class WaveNetModel(object):
             _lib.call('wn_reduce_slabs', _lib.ptr(ws.slabs), sp, K0 * CH, 1,
                       0, 0, K0 * CH, _lib.ptr(gc_), 0, 1, 0, st)
         else:
-            for tap, shift in ((1, 0), (0, 1)):
+            K = self.KW
+            for tap in range(K):
+                shift = (K - 1 - tap) + (K - 1) // 2
                 sp = ws.splits['causal']
                 sl = lib.wn_gemm_tn_slab_floats(Q, CH)
                 _lib.call('wn_gemm_tn', None, 0, 0, 0, _lib.ptr(ws.q), shift,
@@ -652,7 +689,7 @@ class WaveNetModel(object):
                           0, Q * CH, _lib.ptr(gc_[tap * Q * CH:]), 0, 1, 0, st)
         if ws.dsum is not None:
             _lib.call('wn_gc_grad', _lib.ptr(self._layer_block(P, 0)),
-                      self.layer_stride, OFF_GC, self.G,
+                      self.layer_stride, self.OFF_GC, self.G,
                       _lib.ptr(self._seg(P, 'emb')), self.card, _lib.ptr(ids),
                       _lib.ptr(ws.dsum), L, B,
                       _lib.ptr(self._layer_block(Gr, 0)),

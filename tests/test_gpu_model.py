@@ -47,6 +47,12 @@ CASES = [
                             initial_filter_width=32), 150, False, None),
     ('scalar_T_lt_k', cfg_with(TINY, batch_size=1, scalar_input=True,
                                initial_filter_width=32), 9, False, None),
+    ('k3', cfg_with(TINY, batch_size=2, filter_width=3), 90, False, None),
+    ('k3_mid_gc', cfg_with(MID, batch_size=2, filter_width=3,
+                           global_condition_channels=4,
+                           global_condition_cardinality=5), 300, True, None),
+    ('k4_T_lt_shift', cfg_with(TINY, batch_size=2, filter_width=4), 11, False,
+     None),
     ('default', cfg_with(DEFAULT, batch_size=1), 1500, False, None),
     ('default_gc', cfg_with(DEFAULT, batch_size=2,
                             global_condition_channels=32,
@@ -78,6 +84,19 @@ def test_loss_and_gradients_vs_oracle(hip_lib, name, cfg, T, gc, l2):
     assert abs(float(loss2) - ref_loss) < TOL
     logits = ws.logits.cpu().numpy().reshape(B, T, -1)
     assert np.abs(logits - c['logits']).max() < TOL
+
+
+def test_generic_tap_kernels_at_k2(hip_lib):
+    """The generic-filter-width kernels forced on a K = 2 model must give the
+    same loss / gradients as the oracle (and hence the tuned kernels)."""
+    cfg = cfg_with(MID, batch_size=2)
+    net, var = build_pair(cfg)
+    net.generic_layers = True
+    audio = np.random.default_rng(5).uniform(-1, 1, (2, 333)).astype(np.float32)
+    ref_loss, ref_g = O.loss_and_grads(cfg, var, audio, dtype=np.float64)
+    loss = net.loss(audio)
+    assert abs(float(loss) - ref_loss) < TOL
+    check_grads(net, ref_g)
 
 
 def test_xent_quirk_switch(hip_lib):
@@ -250,7 +269,7 @@ def test_generate_sampling(hip_lib):
 
 def test_unsupported_configs_raise(hip_lib):
     from wavenet import WaveNetModel
-    for kw in (dict(filter_width=3), dict(residual_channels=64),
+    for kw in (dict(filter_width=9), dict(residual_channels=64),
                dict(scalar_input=True, initial_filter_width=64)):
         cfg = cfg_with(TINY, batch_size=1, **kw)
         net = WaveNetModel(**model_kwargs(cfg))

@@ -72,6 +72,18 @@ def test_small_channel_views_and_init(hip_lib):
     assert torch.equal(net.params, net2.params)
 
 
+def test_filter_width_3_shapes(hip_lib):
+    from wavenet import WaveNetModel
+    cfg = cfg_with(TINY, batch_size=1, filter_width=3)
+    net = WaveNetModel(device='cpu', **model_kwargs(cfg))
+    v = net.variables['dilated_stack'][0]
+    assert tuple(v['filter'].shape) == (3, 8, 8)
+    assert tuple(v['gate'].shape) == (3, 8, 8)
+    assert tuple(v['dense'].shape) == (1, 8, 8)
+    # causal layer keeps filter_width taps on the one-hot input (model.py:148)
+    assert tuple(net.variables['causal_layer']['filter'].shape) == (3, 16, 8)
+
+
 def test_scalar_input_causal_filter_shape(hip_lib):
     from wavenet import WaveNetModel
     cfg = cfg_with(TINY, batch_size=1, scalar_input=True,

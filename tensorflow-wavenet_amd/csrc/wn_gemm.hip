@@ -53,6 +53,62 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + idx;
 }
 
+// Coalesced epilogue shared by gemm_nn_kernel / gemm_nt_kernel.  An
+// accumulator fragment store touches 32 rows x 32 B per instruction; instead
+// each wave passes its 64 x 64 result through a private LDS tile (two halves
+// of 32 rows, row stride 68 floats: conflict-free both ways) and writes / reads
+// C, Cpre, mask and addend as 256-byte row segments (lane -> row l>>4, 16-byte
+// chunk l&15).  Must be called after a __syncthreads() that retires every
+// read of the operand tiles (the LDS is reused).
+#define EP_LD 68
+__device__ __forceinline__ void gemm_epilogue(const GemmNN& g, f32x16 (&acc)[2][2],
+                                              float* lds, long m0, int n0,
+                                              int wm, int wn, int wave, int lane) {
+  const int j = lane & 31, h = lane >> 5;
+  float* tile = lds + wave * (32 * EP_LD);
+  const int rr = lane >> 4, cc = (lane & 15) * 4;   // row-in-group, column
+  const int n = n0 + wn * 64 + cc;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (g.bias && n < g.N) bias4 = *reinterpret_cast<const f32x4*>(g.bias + n);
+#pragma unroll
+  for (int fm = 0; fm < 2; ++fm) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int fn = 0; fn < 2; ++fn)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v = {acc[fn][fm][4 * q], acc[fn][fm][4 * q + 1],
+                   acc[fn][fm][4 * q + 2], acc[fn][fm][4 * q + 3]};
+        *reinterpret_cast<f32x4*>(tile + j * EP_LD + fn * 32 + 8 * q + 4 * h) = v;
+      }
+    __builtin_amdgcn_wave_barrier();
+    const long mbase = m0 + wm * 64 + fm * 32;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 4 + rr;
+      const long m = mbase + row;
+      f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * EP_LD + cc);
+      if (m >= g.M || n >= g.N) continue;
+      v += bias4;
+      if (g.Cpre) *reinterpret_cast<f32x4*>(g.Cpre + m * g.ldc + n) = v;
+      if (g.relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      if (g.mask) {
+        const f32x4 mk = *reinterpret_cast<const f32x4*>(g.mask + m * g.ld_mask + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
+      }
+      if (g.addend) v += *reinterpret_cast<const f32x4*>(g.addend + m * g.ld_add + n);
+      float* dst = g.c_planes
+                       ? g.C + (long)(n >> 5) * g.c_plane_stride + m * 32 + (n & 31)
+                       : g.C + m * g.ldc + n;
+      *reinterpret_cast<f32x4*>(dst) = v;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmNN g) {
   __shared__ __attribute__((aligned(16))) float As[2][NN_TM * NN_KC];
   __shared__ __attribute__((aligned(16))) float Bs[2][NN_KC * NN_TN];
@@ -168,40 +224,8 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmNN g) {
     __syncthreads();
   }
 
-  // epilogue
-#pragma unroll
-  for (int fn = 0; fn < 2; ++fn) {
-#pragma unroll
-    for (int fm = 0; fm < 2; ++fm) {
-      const long m = m0 + wm * 64 + fm * 32 + j;
-      if (m >= g.M) continue;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = n0 + wn * 64 + fn * 32 + 8 * q + 4 * h;
-        if (n >= g.N) continue;
-        f32x4 v = {acc[fn][fm][4 * q], acc[fn][fm][4 * q + 1],
-                   acc[fn][fm][4 * q + 2], acc[fn][fm][4 * q + 3]};
-        if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + n);
-        if (g.Cpre) *reinterpret_cast<f32x4*>(g.Cpre + m * g.ldc + n) = v;
-        if (g.relu) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        if (g.mask) {
-          const f32x4 mk =
-              *reinterpret_cast<const f32x4*>(g.mask + m * g.ld_mask + n);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
-        }
-        if (g.addend)
-          v += *reinterpret_cast<const f32x4*>(g.addend + m * g.ld_add + n);
-        float* dst = g.c_planes
-                         ? g.C + (long)(n >> 5) * g.c_plane_stride + m * 32 + (n & 31)
-                         : g.C + m * g.ldc + n;
-        *reinterpret_cast<f32x4*>(dst) = v;
-      }
-    }
-  }
+  // coalesced epilogue through LDS (the K loop ended with a barrier)
+  gemm_epilogue(g, acc, &As[0][0], m0, n0, wm, wn, wave, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -614,7 +638,7 @@ int wn_diag_mfma_peak(float* out, int blocks, int iters, void* stream) {
   return wn_check_launch();
 }
 
-int wn_gemm_nn(const float* A, long lda, int a_planes, long a_plane_stride,
+static int gemm_nn_launch(const float* A, long lda, int a_planes, long a_plane_stride,
                const float* W, int ldw, const float* bias, const float* mask,
                long ld_mask, const float* addend, long ld_add, float* C,
                long ldc, int c_planes, long c_plane_stride, float* Cpre,
@@ -651,6 +675,16 @@ int wn_gemm_nn(const float* A, long lda, int a_planes, long a_plane_stride,
   hipLaunchKernelGGL(gemm_nn_kernel, dim3((unsigned)nwg), dim3(256), 0,
                      (hipStream_t)stream, g);
   return wn_check_launch();
+}
+
+int wn_gemm_nn(const float* A, long lda, int a_planes, long a_plane_stride,
+               const float* W, int ldw, const float* bias, const float* mask,
+               long ld_mask, const float* addend, long ld_add, float* C,
+               long ldc, int c_planes, long c_plane_stride, float* Cpre,
+               long M, int N, int K, int relu, void* stream) {
+  return gemm_nn_launch(A, lda, a_planes, a_plane_stride, W, ldw, bias, mask,
+                        ld_mask, addend, ld_add, C, ldc, c_planes,
+                        c_plane_stride, Cpre, M, N, K, relu, stream);
 }
 
 // Number of floats one slab needs for wn_gemm_tn.

@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'libwavenet_hip.so')
+LIB_PATH = os.environ.get('WN_LIB_PATH') or os.path.join(
+    os.path.dirname(_HERE), 'libwavenet_hip.so')   # WN_LIB_PATH: A/B builds
 
 c_int, c_long, c_float = ctypes.c_int, ctypes.c_long, ctypes.c_float
 c_void_p, c_u64 = ctypes.c_void_p, ctypes.c_uint64

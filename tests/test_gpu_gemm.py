@@ -1,0 +1,137 @@
+"""Direct parity of the fp32 MFMA GEMM entry points (wn_gemm_nn,
+wn_gemm_tn + wn_reduce_slabs) against float64 numpy, through the C ABI:
+ragged M, partial tiles in N and K, plane-mode operands, every epilogue."""
+import numpy as np
+import pytest
+import torch
+
+from util import PKG  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).cuda()
+
+
+@pytest.mark.parametrize('kind', ['nn'])
+@pytest.mark.parametrize('M,N,K', [(1, 4, 4), (37, 16, 16), (300, 132, 68),
+                                   (5000, 256, 512), (129, 512, 96)])
+def test_gemm_dense_epilogues(hip_lib, kind, M, N, K):
+    from wavenet import _lib
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = rng.standard_normal((K, N)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    mask = rng.standard_normal((M, N)).astype(np.float32)
+    add = rng.standard_normal((M, N)).astype(np.float32)
+    dA, dW = dev(A), dev(W if kind == 'nn' else W.T)
+    db, dm, dadd = dev(bias), dev(mask), dev(add)
+    C = torch.empty((M, N), device='cuda')
+    Cpre = torch.empty((M, N), device='cuda')
+    st = torch.cuda.current_stream().cuda_stream
+    ldw = N if kind == 'nn' else K
+    ref0 = A.astype(np.float64) @ W.astype(np.float64) + bias
+    for relu, use_mask, use_add in [(0, 0, 0), (1, 0, 0), (0, 1, 0), (1, 0, 1)]:
+        _lib.call('wn_gemm_' + kind, dA.data_ptr(), K, 0, 0, dW.data_ptr(), ldw,
+                  db.data_ptr(), dm.data_ptr() if use_mask else None, N,
+                  dadd.data_ptr() if use_add else None, N, C.data_ptr(), N, 0,
+                  0, Cpre.data_ptr(), M, N, K, relu, st)
+        ref = ref0.copy()
+        if relu:
+            ref = np.maximum(ref, 0)
+        if use_mask:
+            ref = np.where(mask > 0, ref, 0)
+        if use_add:
+            ref = ref + add
+        tol = 1e-4 * max(1.0, np.abs(ref0).max())
+        assert np.abs(C.cpu().numpy() - ref).max() < tol
+        assert np.abs(Cpre.cpu().numpy() - ref0).max() < tol
+
+
+@pytest.mark.parametrize('kind', ['nn'])
+def test_gemm_plane_operands(hip_lib, kind):
+    """A as [P][M][32] planes (the z planes of the skip sum) and C as planes
+    (dZ): K = P*32 / N = P*32."""
+    from wavenet import _lib
+    rng = np.random.default_rng(3)
+    M, P, N = 777, 5, 64
+    Ap = rng.standard_normal((P, M, 32)).astype(np.float32)
+    W = rng.standard_normal((P * 32, N)).astype(np.float32)
+    A = Ap.transpose(1, 0, 2).reshape(M, P * 32)
+    dA, dW = dev(Ap), dev(W if kind == 'nn' else W.T)
+    C = torch.empty((M, N), device='cuda')
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.call('wn_gemm_' + kind, dA.data_ptr(), 0, P, M * 32, dW.data_ptr(),
+              N if kind == 'nn' else P * 32, None, None, 0, None, 0,
+              C.data_ptr(), N, 0, 0, None, M, N, P * 32, 0, st)
+    ref = A.astype(np.float64) @ W.astype(np.float64)
+    assert np.abs(C.cpu().numpy() - ref).max() < 1e-3
+    # planes out: C2[p][m][32] = (X @ W2)[:, p*32:(p+1)*32]
+    X = rng.standard_normal((M, 48)).astype(np.float32)
+    W2 = rng.standard_normal((48, P * 32)).astype(np.float32)
+    Cp = torch.empty((P, M, 32), device='cuda')
+    dX, dW2 = dev(X), dev(W2 if kind == 'nn' else W2.T)   # keep alive
+    _lib.call('wn_gemm_' + kind, dX.data_ptr(), 48, 0, 0,
+              dW2.data_ptr(),
+              P * 32 if kind == 'nn' else 48, None, None, 0, None, 0,
+              Cp.data_ptr(), 0, P, M * 32, None, M, P * 32, 48, 0, st)
+    ref2 = (X.astype(np.float64) @ W2.astype(np.float64)).reshape(M, P, 32)
+    assert np.abs(Cp.cpu().numpy().transpose(1, 0, 2) - ref2).max() < 1e-3
+
+
+@pytest.mark.parametrize('rows,Mw,Nw,splits', [(100, 32, 32, 3), (1000, 64, 96, 7),
+                                               (5000, 160, 128, 9), (3333, 512, 256, 5),
+                                               (777, 96, 64, 1)])
+def test_gemm_tn_and_reduce(hip_lib, rows, Mw, Nw, splits):
+    from wavenet import _lib
+    lib = hip_lib
+    rng = np.random.default_rng(rows)
+    A = rng.standard_normal((rows, Mw)).astype(np.float32)
+    G = rng.standard_normal((rows, Nw)).astype(np.float32)
+    sl = lib.wn_gemm_tn_slab_floats(Mw, Nw)
+    slabs = torch.zeros(splits * sl, device='cuda')
+    out = torch.empty(Mw * Nw, device='cuda')
+    cs = torch.empty(Nw, device='cuda')
+    st = torch.cuda.current_stream().cuda_stream
+    dA, dG = dev(A), dev(G)                                # keep alive
+    _lib.call('wn_gemm_tn', dA.data_ptr(), Mw, 0, 0, None, 0, 1,
+              dG.data_ptr(), Nw, slabs.data_ptr(), splits, rows, Mw, Nw, 1,
+              st)
+    _lib.call('wn_reduce_slabs', slabs.data_ptr(), splits, sl, 1, 0, 0,
+              Mw * Nw, out.data_ptr(), 0, 1, 0, st)
+    _lib.call('wn_reduce_slabs', slabs.data_ptr(), splits, sl, 1, 0, Mw * Nw,
+              Nw, cs.data_ptr(), 0, 1, 0, st)
+    ref = A.astype(np.float64).T @ G.astype(np.float64)
+    assert np.abs(out.cpu().numpy().reshape(Mw, Nw) - ref).max() < \
+        1e-4 * max(1.0, np.abs(ref).max())
+    assert np.abs(cs.cpu().numpy() - G.astype(np.float64).sum(0)).max() < 1e-2
+
+
+def test_gemm_tn_one_hot(hip_lib):
+    """one-hot A generated from int codes with a per-clip shift (the causal
+    layer's weight gradient)."""
+    from wavenet import _lib
+    lib = hip_lib
+    rng = np.random.default_rng(9)
+    B, T, Q = 3, 50, 16
+    q = rng.integers(0, Q, (B, T)).astype(np.int32)
+    G = rng.standard_normal((B * T, 32)).astype(np.float32)
+    sl = lib.wn_gemm_tn_slab_floats(Q, 32)
+    st = torch.cuda.current_stream().cuda_stream
+    dq = torch.as_tensor(q).cuda()
+    dG = dev(G)
+    for shift in (0, 1, 3):
+        slabs = torch.zeros(4 * sl, device='cuda')
+        out = torch.empty(Q * 32, device='cuda')
+        _lib.call('wn_gemm_tn', None, 0, 0, 0, dq.data_ptr(), shift, T,
+                  dG.data_ptr(), 32, slabs.data_ptr(), 4, B * T, Q, 32, 0,
+                  st)
+        _lib.call('wn_reduce_slabs', slabs.data_ptr(), 4, sl, 1, 0, 0, Q * 32,
+                  out.data_ptr(), 0, 1, 0, st)
+        ref = np.zeros((Q, 32))
+        Gr = G.reshape(B, T, 32)
+        for b in range(B):
+            for t in range(shift, T):
+                ref[q[b, t - shift]] += Gr[b, t]
+        assert np.abs(out.cpu().numpy().reshape(Q, 32) - ref).max() < 1e-4

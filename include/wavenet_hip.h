@@ -211,6 +211,21 @@ int wn_fastgen_run(const float* params_causal, const float* layer0,
                    float* proba_out, int proba_every, int use_biases,
                    int push, void* stream);
 
+/* Multi-CU variant: enqueues ONE generation step as four kernels (chain on
+ * one CU; skip sum and conv1 on S/32 CUs; logits + float64 softmax + draw).
+ * Everything step-dependent lives in device memory (cursors), so the host
+ * captures a few hundred calls into a hipGraph and replays it. */
+int wn_fastgen_step(const float* params_causal, const float* layer0,
+                    long layer_stride, const float* skip_w,
+                    const float* skip_bsum, const float* post1_w,
+                    const float* post1_b, const float* post2_w,
+                    const float* post2_b, const float* gc_bias_fg,
+                    const int32_t* dilations_dev, int L, int S, int Q,
+                    float* state, int32_t* cursors, int32_t* samples_io,
+                    int base, int n_given, float temperature, uint64_t seed,
+                    float* proba_out, int proba_every, int use_biases,
+                    float* z_all, float* h1, float* h2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -214,7 +214,11 @@ __global__ __launch_bounds__(FG_THREADS, 1) void fastgen_kernel(FastGen g) {
         if (l >= 1) skip_fma(zbuf[(l - 1) & 1]);
         if (l >= 1 && l < L) skip_load(l);
       }
-      __syncthreads();
+      // raw barrier: only LDS traffic is drained.  __syncthreads() would also
+      // wait vmcnt(0), i.e. for the weight loads just issued for the NEXT
+      // layers -- exposing a full L2 / Infinity-Cache round trip per layer.
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
     }
     // advance the ring cursors (after every wave is done with this step)
     if (g.push) {
@@ -364,6 +368,329 @@ __global__ __launch_bounds__(FG_THREADS, 1) void fastgen_kernel(FastGen g) {
   }
 }
 
+// ===========================================================================
+// Multi-CU fast generation: one generated sample = four small kernels on the
+// stream (captured into a hipGraph by the host, hundreds of samples per
+// replay):
+//   A fg_chain_kernel   1 workgroup : the serial residual chain; four loader
+//                        waves stream the 20 KB/layer chain weights through a
+//                        4-slot LDS ring three layers ahead of the chain wave
+//   B fg_skip_kernel    S/32 WGs    : total = sum_l z_l Ws_l (+bias), ReLU
+//   C fg_post1_kernel   S/32 WGs    : conv1 (+bias), ReLU
+//   D fg_post2_kernel   1 workgroup : logits, float64 softmax, temperature,
+//                        inverse-CDF draw, cursor update
+// Kernel boundaries are the grid-wide synchronisation (about 1.5 us each):
+// no in-launch flags, nothing that can hang.  The 3.3 MB skip and 1 MB conv1
+// weights are read by S/32 CUs in parallel instead of one CU's load path.
+// ===========================================================================
+struct FgStep {
+  const float* causal;
+  const float* layer0;
+  long layer_stride;
+  const float* skip_w;
+  const float* skip_bsum;
+  const float* post1_w;
+  const float* post1_b;
+  const float* post2_w;
+  const float* post2_b;
+  const float* bias_fg;
+  const int32_t* dil;
+  int L, S, Q;
+  float* state;
+  int32_t* cursors;      // [0] steps done, [1] previous code
+  int32_t* samples;      // indexed by (cursors[0] - base)
+  int base;              // cursors[0] at the start of this generate() call
+  int n_given;
+  float temperature;
+  uint64_t seed;
+  float* proba_out;
+  int proba_every;
+  int use_dense_bias;
+  float* z_all;          // [L][32]
+  float* h1;             // [S]
+  float* h2;             // [S]
+};
+
+#define FGC_THREADS 320
+#define FGC_SLOTS 4
+
+__global__ __launch_bounds__(FGC_THREADS) void fg_chain_kernel(FgStep g) {
+  __shared__ __attribute__((aligned(16))) float wring[FGC_SLOTS][FG_CW];
+  __shared__ int pos[FG_MAXL], roff[FG_MAXL], sdil[FG_MAXL];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int L = g.L, Q = g.Q;
+  const int lt = tid - 64;                       // loader thread 0..255
+  const int steps_done = g.cursors[0];
+  const int prev_code = g.cursors[1];
+  const int code = g.samples[steps_done - g.base];
+  for (int l = tid; l < L; l += FGC_THREADS) {
+    sdil[l] = g.dil[l];
+    pos[l] = steps_done % g.dil[l];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int off = 0;
+    for (int l = 0; l < L; ++l) { roff[l] = off; off += sdil[l]; }
+  }
+  // loaders: 256 threads x 5 float4 = one layer (5120 floats)
+  f32x4 s0[5], s1[5], s2[5];
+  auto ld = [&](f32x4 (&r)[5], int l) {
+    if (l < L) {
+      const f32x4* src = reinterpret_cast<const f32x4*>(g.layer0 + (long)l * g.layer_stride);
+#pragma unroll
+      for (int k = 0; k < 5; ++k) r[k] = src[lt + 256 * k];
+    }
+  };
+  auto stl = [&](const f32x4 (&r)[5], int l) {
+    if (l < L) {
+      f32x4* dst = reinterpret_cast<f32x4*>(wring[l % FGC_SLOTS]);
+#pragma unroll
+      for (int k = 0; k < 5; ++k) dst[lt + 256 * k] = r[k];
+    }
+  };
+  float x = 0.f, stv = 0.f, bias = 0.f, bdv = 0.f;
+  auto chain_prefetch = [&](int l) {
+    bias = g.bias_fg ? g.bias_fg[l * 64 + lane] : 0.f;
+    bdv = g.use_dense_bias
+              ? g.layer0[(long)l * g.layer_stride + LAYER_OFF_BD + (lane & 31)]
+              : 0.f;
+    stv = lane < 32 ? g.state[((long)roff[l] + pos[l]) * 32 + lane] : 0.f;
+  };
+  __syncthreads();
+  if (wave >= 1) {
+    ld(s0, 0);
+    ld(s1, 1);
+    ld(s2, 2);
+    stl(s0, 0);
+    ld(s0, 3);
+  } else {
+    chain_prefetch(0);
+    if (lane < 32) {
+      float v = 0.f;
+      if (prev_code >= 0 && prev_code < Q) v = g.causal[(long)prev_code * 32 + lane];
+      if (code >= 0 && code < Q) v += g.causal[((long)Q + code) * 32 + lane];
+      x = v;
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  // one chain layer (wave 0) / one ring refill (loaders); `set` holds layer
+  // l+1, is stored to its slot and re-issued for layer l+4
+  auto body = [&](int l, f32x4 (&set)[5]) {
+    if (wave == 0) {
+      if (l < L) {
+        const float* wl = wring[l % FGC_SLOTS];
+        const float cur_st = stv, cur_bias = bias, cur_bd = bdv;
+        if (lane < 32) g.state[((long)roff[l] + pos[l]) * 32 + lane] = x;
+        if (l + 1 < L) chain_prefetch(l + 1);
+        const float* wcol = wl + (lane < 32 ? 0 : 2048) + (lane & 31);
+        float a = cur_bias;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+          a = fmaf(readlane_f(cur_st, k), wcol[k * 32], a);
+          a = fmaf(readlane_f(x, k), wcol[1024 + k * 32], a);
+        }
+        const float gate = __shfl(a, (lane & 31) + 32);
+        const float z = wn_tanh(a) * wn_sigmoid(gate);
+        if (lane < 32) g.z_all[l * 32 + lane] = z;
+        if (l + 1 < L) {
+          float dsum = cur_bd;
+          const float* wd = wl + 4096 + (lane & 31);
+#pragma unroll
+          for (int k = 0; k < 32; ++k) dsum = fmaf(readlane_f(z, k), wd[k * 32], dsum);
+          if (lane < 32) x += dsum;
+        }
+      }
+    } else {
+      stl(set, l + 1);
+      ld(set, l + 4);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  for (int l = 0; l < L; l += 3) {
+    body(l, s1);          // stores layer l+1 (set (l+1)%3 == 1 when l%3 == 0)
+    body(l + 1, s2);
+    body(l + 2, s0);
+  }
+}
+
+// total[s] = sum_{l,k} z[l][k] Ws[l][k][s] + bsum[s]; h1 = relu(total)
+__global__ __launch_bounds__(256) void fg_skip_kernel(FgStep g) {
+  __shared__ float zs[FG_MAXL * 32];
+  __shared__ float red[8][32];
+  const int tid = threadIdx.x, o = tid & 31, part = tid >> 5;
+  const int s = blockIdx.x * 32 + o;
+  const int KK = g.L * 32;
+  for (int i = tid; i < KK; i += 256) zs[i] = g.z_all[i];
+  __syncthreads();
+  const int per = (KK + 7) / 8, k0 = part * per, k1 = min(KK, k0 + per);
+  float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+  if (s < g.S) {
+    const float* w = g.skip_w + s;
+    int k = k0;
+    for (; k + 40 <= k1; k += 40) {
+      float wv[40];
+#pragma unroll
+      for (int u = 0; u < 40; ++u) wv[u] = w[(long)(k + u) * g.S];
+#pragma unroll
+      for (int u = 0; u < 40; u += 4) {
+        c0 = fmaf(zs[k + u], wv[u], c0);
+        c1 = fmaf(zs[k + u + 1], wv[u + 1], c1);
+        c2 = fmaf(zs[k + u + 2], wv[u + 2], c2);
+        c3 = fmaf(zs[k + u + 3], wv[u + 3], c3);
+      }
+    }
+    for (; k < k1; ++k) c0 = fmaf(zs[k], w[(long)k * g.S], c0);
+  }
+  red[part][o] = (c0 + c1) + (c2 + c3);
+  __syncthreads();
+  if (part == 0 && s < g.S) {
+    float t = g.skip_bsum ? g.skip_bsum[s] : 0.f;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) t += red[p][o];
+    g.h1[s] = fmaxf(t, 0.f);
+  }
+}
+
+// h2[s] = relu(sum_k h1[k] W1[k][s] + b1[s])
+__global__ __launch_bounds__(256) void fg_post1_kernel(FgStep g) {
+  __shared__ float hs[FG_MAXS];
+  __shared__ float red[8][32];
+  const int tid = threadIdx.x, o = tid & 31, part = tid >> 5;
+  const int s = blockIdx.x * 32 + o;
+  const int S = g.S;
+  for (int i = tid; i < S; i += 256) hs[i] = g.h1[i];
+  __syncthreads();
+  const int per = (S + 7) / 8, k0 = part * per, k1 = min(S, k0 + per);
+  float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+  if (s < S) {
+    const float* w = g.post1_w + s;
+    int k = k0;
+    for (; k + 32 <= k1; k += 32) {
+      float wv[32];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) wv[u] = w[(long)(k + u) * S];
+#pragma unroll
+      for (int u = 0; u < 32; u += 4) {
+        c0 = fmaf(hs[k + u], wv[u], c0);
+        c1 = fmaf(hs[k + u + 1], wv[u + 1], c1);
+        c2 = fmaf(hs[k + u + 2], wv[u + 2], c2);
+        c3 = fmaf(hs[k + u + 3], wv[u + 3], c3);
+      }
+    }
+    for (; k < k1; ++k) c0 = fmaf(hs[k], w[(long)k * S], c0);
+  }
+  red[part][o] = (c0 + c1) + (c2 + c3);
+  __syncthreads();
+  if (part == 0 && s < S) {
+    float t = g.post1_b ? g.post1_b[s] : 0.f;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) t += red[p][o];
+    g.h2[s] = fmaxf(t, 0.f);
+  }
+}
+
+// logits, softmax (float64), temperature, draw, cursor update
+__global__ __launch_bounds__(256) void fg_post2_kernel(FgStep g) {
+  __shared__ float hs[FG_MAXS];
+  __shared__ float part[1024];
+  __shared__ double pd[FG_MAXQ];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int S = g.S, Q = g.Q;
+  const int steps_done = g.cursors[0];
+  const int local = steps_done - g.base;
+  const int code = g.samples[local];
+  for (int i = tid; i < S; i += 256) hs[i] = g.h2[i];
+  __syncthreads();
+  int parts = 256 / Q;
+  if (parts < 1) parts = 1;
+  if (parts > 4) parts = 4;
+  for (int o = tid; o < Q * parts; o += 256) {
+    const int q = o % Q, p = o / Q;
+    const int k0 = (int)((long)S * p / parts), k1 = (int)((long)S * (p + 1) / parts);
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+    const float* w = g.post2_w + q;
+    int k = k0;
+    for (; k + 64 <= k1; k += 64) {
+      float wv[64];
+#pragma unroll
+      for (int u = 0; u < 64; ++u) wv[u] = w[(long)(k + u) * Q];
+#pragma unroll
+      for (int u = 0; u < 64; u += 4) {
+        c0 = fmaf(hs[k + u], wv[u], c0);
+        c1 = fmaf(hs[k + u + 1], wv[u + 1], c1);
+        c2 = fmaf(hs[k + u + 2], wv[u + 2], c2);
+        c3 = fmaf(hs[k + u + 3], wv[u + 3], c3);
+      }
+    }
+    for (; k < k1; ++k) c0 = fmaf(hs[k], w[(long)k * Q], c0);
+    part[o] = (c0 + c1) + (c2 + c3);
+  }
+  __syncthreads();
+  for (int q = tid; q < Q; q += 256) {
+    float c = g.post2_b ? g.post2_b[q] : 0.f;
+    for (int p = 0; p < parts; ++p) c += part[p * Q + q];
+    pd[q] = (double)c;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    double m = -1e300;
+    for (int q = lane; q < Q; q += 64) m = fmax(m, pd[q]);
+    for (int o = 32; o >= 1; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+    double se = 0.0;
+    for (int q = lane; q < Q; q += 64) se += exp(pd[q] - m);
+    for (int o = 32; o >= 1; o >>= 1) se += __shfl_xor(se, o);
+    const bool want_p = g.proba_out && (local % g.proba_every == 0);
+    float* po = want_p ? g.proba_out + (long)(local / g.proba_every) * Q : nullptr;
+    for (int q = lane; q < Q; q += 64) {
+      const float p32 = (float)(exp(pd[q] - m) / se);
+      if (po) po[q] = p32;
+      pd[q] = (double)p32;
+    }
+    if (local + 1 >= g.n_given) {
+      const double tau = (double)g.temperature;
+      double mx = -1e300;
+      for (int q = lane; q < Q; q += 64) {
+        const double lp = log(pd[q] > 0.0 ? pd[q] : 1e-300) / tau;
+        pd[q] = lp;
+        mx = fmax(mx, lp);
+      }
+      for (int o = 32; o >= 1; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+      const int per = (Q + 63) / 64;
+      const int q0 = lane * per, q1 = min(Q, q0 + per);
+      double seg = 0.0;
+      for (int q = q0; q < q1; ++q) seg += exp(pd[q] - mx);
+      double incl = seg;
+      for (int o = 1; o < 64; o <<= 1) {
+        const double v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+      }
+      const double total = __shfl(incl, 63);
+      const uint64_t r = splitmix64(g.seed ^ splitmix64((uint64_t)steps_done));
+      const double u = (double)(r >> 11) * (1.0 / 9007199254740992.0) * total;
+      const double excl = incl - seg;
+      int pick = -1;
+      if (u >= excl && u < incl) {
+        double c = excl;
+        pick = q1 - 1;
+        for (int q = q0; q < q1; ++q) {
+          c += exp(pd[q] - mx);
+          if (u < c) { pick = q; break; }
+        }
+      }
+      int best = pick;
+      for (int o = 32; o >= 1; o >>= 1) best = max(best, __shfl_xor(best, o));
+      if (best < 0) best = Q - 1;
+      if (lane == 0) g.samples[local + 1] = best;
+    }
+    if (lane == 0) {
+      g.cursors[0] = steps_done + 1;
+      g.cursors[1] = code;
+    }
+  }
+}
+
 extern "C" {
 
 long wn_fastgen_state_floats(const int32_t* dilations_host, int L) {
@@ -419,6 +746,46 @@ int wn_fastgen_run(const float* params_causal, const float* layer0,
   if (!push && n_steps != 1) return WN_ERR_BAD_SHAPE;
   hipLaunchKernelGGL(fastgen_kernel, dim3(1), dim3(FG_THREADS), 0,
                      (hipStream_t)stream, g);
+  return wn_check_launch();
+}
+
+
+// Enqueue ONE generation step (4 kernels) on `stream`.  `base` = value of
+// cursors[0] when this generate() call started (samples_io / proba_out are
+// indexed relative to it); everything step-dependent is read from device
+// memory, so the call can be captured into a hipGraph and replayed.
+int wn_fastgen_step(const float* params_causal, const float* layer0,
+                    long layer_stride, const float* skip_w,
+                    const float* skip_bsum, const float* post1_w,
+                    const float* post1_b, const float* post2_w,
+                    const float* post2_b, const float* gc_bias_fg,
+                    const int32_t* dilations_dev, int L, int S, int Q,
+                    float* state, int32_t* cursors, int32_t* samples_io,
+                    int base, int n_given, float temperature, uint64_t seed,
+                    float* proba_out, int proba_every, int use_biases,
+                    float* z_all, float* h1, float* h2, void* stream) {
+  if (!params_causal || !layer0 || !skip_w || !post1_w || !post2_w ||
+      !dilations_dev || !state || !cursors || !samples_io || !z_all || !h1 ||
+      !h2)
+    return WN_ERR_NULL;
+  if (L <= 0 || S <= 0 || Q <= 0 || n_given < 1) return WN_ERR_BAD_SHAPE;
+  if (S > FG_MAXS || Q > FG_MAXQ || L > FG_MAXL) return WN_ERR_UNSUPPORTED;
+  if (!(temperature > 0.f)) return WN_ERR_BAD_SHAPE;
+  FgStep g;
+  g.causal = params_causal; g.layer0 = layer0; g.layer_stride = layer_stride;
+  g.skip_w = skip_w; g.skip_bsum = skip_bsum; g.post1_w = post1_w;
+  g.post1_b = post1_b; g.post2_w = post2_w; g.post2_b = post2_b;
+  g.bias_fg = gc_bias_fg; g.dil = dilations_dev; g.L = L; g.S = S; g.Q = Q;
+  g.state = state; g.cursors = cursors; g.samples = samples_io; g.base = base;
+  g.n_given = n_given; g.temperature = temperature; g.seed = seed;
+  g.proba_out = proba_out; g.proba_every = proba_every > 0 ? proba_every : 1;
+  g.use_dense_bias = use_biases; g.z_all = z_all; g.h1 = h1; g.h2 = h2;
+  hipStream_t s = (hipStream_t)stream;
+  const int wgs = (S + 31) / 32;
+  hipLaunchKernelGGL(fg_chain_kernel, dim3(1), dim3(FGC_THREADS), 0, s, g);
+  hipLaunchKernelGGL(fg_skip_kernel, dim3(wgs), dim3(256), 0, s, g);
+  hipLaunchKernelGGL(fg_post1_kernel, dim3(wgs), dim3(256), 0, s, g);
+  hipLaunchKernelGGL(fg_post2_kernel, dim3(1), dim3(256), 0, s, g);
   return wn_check_launch();
 }
 

@@ -80,6 +80,9 @@ SIGNATURES = {
     'wn_fastgen_run': (c_int, [P, P, c_long, P, P, P, P, P, P, P, P, c_int,
                                c_int, c_int, P, P, P, c_int, c_int, c_float,
                                c_u64, P, c_int, c_int, c_int, P]),
+    'wn_fastgen_step': (c_int, [P, P, c_long, P, P, P, P, P, P, P, P, c_int,
+                                c_int, c_int, P, P, P, c_int, c_int, c_float,
+                                c_u64, P, c_int, c_int, P, P, P, P]),
 }
 
 _lib = None

@@ -179,6 +179,10 @@ class WaveNetModel(object):
         self.overlap_wgrad = False
         # fused backward kernel (data + weight gradients in one pass)
         self.fused_bwd = True
+        # generate(): four kernels per sample over many CUs, replayed from a
+        # hipGraph, instead of the single-workgroup persistent kernel
+        self.fastgen_multi_cu = True
+        self.fastgen_graph_steps = 200
 
         _lib.load()
         if device is None:
@@ -831,6 +835,13 @@ class WaveNetModel(object):
                                  device=self.device),
                 proba=torch.empty(self.Q, dtype=torch.float32,
                                   device=self.device),
+                z_all=torch.zeros(self.L * CH, dtype=torch.float32,
+                                  device=self.device),
+                h1=torch.zeros(self.S, dtype=torch.float32,
+                               device=self.device),
+                h2=torch.zeros(self.S, dtype=torch.float32,
+                               device=self.device),
+                steps=0,
                 io=torch.zeros(2, dtype=torch.int32, device=self.device))
             self._gen = g
             self._gen_reset()
@@ -840,9 +851,15 @@ class WaveNetModel(object):
         g = self._gen
         _lib.call('wn_fastgen_init', _lib.ptr(g['state']), g['state'].numel(),
                   _lib.ptr(g['cursors']), self.L, _lib.stream())
+        g['steps'] = 0
 
     def _gen_run(self, samples_io, n_given, n_steps, temperature, seed,
-                 proba_out, proba_every, global_condition, push=True):
+                 proba_out, proba_every, global_condition, push=True,
+                 multi_cu=False):
+        """Run `n_steps` generation steps.  multi_cu=False: ONE persistent
+        single-workgroup kernel (also the push=False peek).  multi_cu=True:
+        four kernels per step spread over many CUs, captured into a hipGraph
+        and replayed (config 5 throughput path)."""
         g = self._generator(global_condition)
         ids = self._gc_ids(global_condition, 1) if self.card is not None \
             else None
@@ -854,7 +871,7 @@ class WaveNetModel(object):
                       self.S, _lib.ptr(g['bsum']), _lib.stream())
             bsum = g['bsum']
         ub = self.use_biases
-        _lib.call('wn_fastgen_run', _lib.ptr(self._seg(P, 'causal')),
+        common = (_lib.ptr(self._seg(P, 'causal')),
                   _lib.ptr(self._layer_block(P, 0)), self.layer_stride,
                   _lib.ptr(self._seg(P, 'skip_w')), _lib.ptr(bsum),
                   _lib.ptr(self._seg(P, 'post1_w')),
@@ -863,10 +880,38 @@ class WaveNetModel(object):
                   _lib.ptr(self._seg(P, 'post2_b')) if ub else None,
                   None if bias is None else _lib.ptr(bias), _lib.ptr(g['dil']),
                   self.L, self.S, self.Q, _lib.ptr(g['state']),
-                  _lib.ptr(g['cursors']), _lib.ptr(samples_io), int(n_given),
-                  int(n_steps), float(temperature), int(seed) & (2**64 - 1),
-                  _lib.ptr(proba_out), int(proba_every), 1 if ub else 0,
-                  1 if push else 0, _lib.stream())
+                  _lib.ptr(g['cursors']), _lib.ptr(samples_io))
+        sd = int(seed) & (2**64 - 1)
+        if not multi_cu or not push:
+            _lib.call('wn_fastgen_run', *common, int(n_given), int(n_steps),
+                      float(temperature), sd, _lib.ptr(proba_out),
+                      int(proba_every), 1 if ub else 0, 1 if push else 0,
+                      _lib.stream())
+            if push:
+                g['steps'] += int(n_steps)
+            return
+        base = g['steps']
+        tail = (base, int(n_given), float(temperature), sd,
+                _lib.ptr(proba_out), int(proba_every), 1 if ub else 0,
+                _lib.ptr(g['z_all']), _lib.ptr(g['h1']), _lib.ptr(g['h2']))
+
+        def one():
+            _lib.call('wn_fastgen_step', *common, *tail, _lib.stream())
+        per = self.fastgen_graph_steps
+        done = 0
+        if n_steps >= 2 * per:
+            one()                      # warm-up outside the capture
+            done = 1
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for _ in range(per):
+                    one()
+            while n_steps - done >= per:
+                graph.replay()
+                done += per
+        for _ in range(n_steps - done):
+            one()
+        g['steps'] += int(n_steps)
 
     def predict_proba_incremental(self, waveform, global_condition=None,
                                   name='wavenet', push=True):
@@ -923,7 +968,8 @@ class WaveNetModel(object):
                                 dtype=torch.float32, device=self.device)
         if n_steps > 0:
             self._gen_run(io, n_given, n_steps, temperature, seed, proba,
-                          pe if pe > 0 else 1, global_condition)
+                          pe if pe > 0 else 1, global_condition,
+                          multi_cu=self.fastgen_multi_cu)
         out = io[:n_given + int(num_samples)]
         return (out, proba) if pe > 0 else out
 
@@ -936,5 +982,6 @@ class WaveNetModel(object):
         n = int(num_samples)
         io = torch.zeros(n + 1, dtype=torch.int32, device=self.device)
         io[0] = int(last_sample)
-        self._gen_run(io, 1, n, temperature, seed, None, 1, global_condition)
+        self._gen_run(io, 1, n, temperature, seed, None, 1, global_condition,
+                      multi_cu=self.fastgen_multi_cu)
         return io[1:]

@@ -234,15 +234,21 @@ def test_incremental_vs_oracle_and_naive(hip_lib):
     naive = net.predict_proba(wave).cpu().numpy()
     assert np.abs(naive - z['inc/naive_last']).max() < 1e-5
     assert np.abs(naive - p).max() < 1e-5
-    # the persistent kernel in one launch (teacher forced) gives the same trace
-    out, pr = net.generate(0, seed_samples=wave, return_proba_every=1)
-    assert np.array_equal(out.cpu().numpy(), wave)
-    assert np.abs(pr.cpu().numpy() - probs[:len(wave) - 1]).max() < 1e-5
+    # teacher-forced generate() gives the same trace on both device paths:
+    # the single-workgroup persistent kernel and the multi-CU step kernels
+    for multi in (False, True):
+        net.fastgen_multi_cu = multi
+        out, pr = net.generate(0, seed_samples=wave, return_proba_every=1)
+        assert np.array_equal(out.cpu().numpy(), wave)
+        assert np.abs(pr.cpu().numpy() - probs[:len(wave) - 1]).max() < 1e-5
 
 
-def test_generate_sampling(hip_lib):
+@pytest.mark.parametrize('multi', [False, True])
+def test_generate_sampling(hip_lib, multi):
     cfg = cfg_with(MID, batch_size=1)
     net, var = build_pair(cfg)
+    net.fastgen_multi_cu = multi
+    net.fastgen_graph_steps = 50          # exercise graph capture + replay
     a = net.generate(300, seed_samples=[128], seed=11).cpu().numpy()
     b = net.generate(300, seed_samples=[128], seed=11).cpu().numpy()
     c = net.generate(300, seed_samples=[128], seed=12).cpu().numpy()

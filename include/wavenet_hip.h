@@ -211,8 +211,9 @@ int wn_fastgen_run(const float* params_causal, const float* layer0,
                    float* proba_out, int proba_every, int use_biases,
                    int push, void* stream);
 
-/* Multi-CU variant: enqueues ONE generation step as four kernels (chain on
- * one CU; skip sum and conv1 on S/32 CUs; logits + float64 softmax + draw).
+/* Multi-CU variant: enqueues ONE generation step as five kernels (chain on
+ * one CU; skip sum, conv1 and conv2 on S/32 / Q/32 CUs; float64 softmax +
+ * draw).
  * Everything step-dependent lives in device memory (cursors), so the host
  * captures a few hundred calls into a hipGraph and replays it. */
 int wn_fastgen_step(const float* params_causal, const float* layer0,
@@ -224,7 +225,11 @@ int wn_fastgen_step(const float* params_causal, const float* layer0,
                     float* state, int32_t* cursors, int32_t* samples_io,
                     int base, int n_given, float temperature, uint64_t seed,
                     float* proba_out, int proba_every, int use_biases,
-                    float* z_all, float* h1, float* h2, void* stream);
+                    const float* cw_img, float* z_all, float* h1, float* h2,
+                    float* logits, void* stream);
+/* cw_img [L][5120]: the chain weights transposed + swizzled for the LDS ring */
+int wn_fastgen_pack(const float* layer0, long layer_stride, float* img, int L,
+                    void* stream);
 
 #ifdef __cplusplus
 }

@@ -369,7 +369,7 @@ __global__ __launch_bounds__(FG_THREADS, 1) void fastgen_kernel(FastGen g) {
 }
 
 // ===========================================================================
-// Multi-CU fast generation: one generated sample = four small kernels on the
+// Multi-CU fast generation: one generated sample = five small kernels on the
 // stream (captured into a hipGraph by the host, hundreds of samples per
 // replay):
 //   A fg_chain_kernel   1 workgroup : the serial residual chain; four loader
@@ -377,7 +377,8 @@ __global__ __launch_bounds__(FG_THREADS, 1) void fastgen_kernel(FastGen g) {
 //                        4-slot LDS ring three layers ahead of the chain wave
 //   B fg_skip_kernel    S/32 WGs    : total = sum_l z_l Ws_l (+bias), ReLU
 //   C fg_post1_kernel   S/32 WGs    : conv1 (+bias), ReLU
-//   D fg_post2_kernel   1 workgroup : logits, float64 softmax, temperature,
+//   D fg_logits_kernel  Q/32 WGs    : conv2 logits
+//   E fg_draw_kernel    1 wave      : float64 softmax, temperature,
 //                        inverse-CDF draw, cursor update
 // Kernel boundaries are the grid-wide synchronisation (about 1.5 us each):
 // no in-launch flags, nothing that can hang.  The 3.3 MB skip and 1 MB conv1
@@ -406,16 +407,42 @@ struct FgStep {
   float* proba_out;
   int proba_every;
   int use_dense_bias;
+  const float* cw_img;   // [L][5120] chain weights, transposed + swizzled
   float* z_all;          // [L][32]
   float* h1;             // [S]
   float* h2;             // [S]
+  float* logits;         // [Q]
 };
 
 #define FGC_THREADS 320
 #define FGC_SLOTS 4
 
+// Ring-slot image: the five 32x32 matrices TRANSPOSED ([out n][in k], k
+// contiguous) with the 16-byte chunk c of row n stored at chunk c ^ (n & 7).
+// The chain lane that owns output n then reads its whole weight row with
+// eight ds_read_b128 per matrix (2-way conflicts at worst), and the 64 input
+// values are broadcast from LDS with 16 ds_read_b128 instead of 64
+// v_readlane: ~170 instructions per layer instead of ~350.
+__device__ __forceinline__ int fgc_widx(int m, int n, int k) {
+  return m * 1024 + n * 32 + ((((k >> 2) ^ (n & 7)) << 2) | (k & 3));
+}
+
+// one-off: layer blocks -> ring-slot images (weights are constant while
+// generating)
+__global__ void fg_pack_kernel(const float* __restrict__ layer0, long layer_stride,
+                               float* __restrict__ img, int L) {
+  const int l = blockIdx.x;
+  const float* blk = layer0 + (long)l * layer_stride;
+  for (int i = threadIdx.x; i < FG_CW; i += blockDim.x) {
+    const int m = i >> 10, k = (i >> 5) & 31, n = i & 31;   // W[m][k][n]
+    img[(long)l * FG_CW + fgc_widx(m, n, k)] = blk[i];
+  }
+}
+
 __global__ __launch_bounds__(FGC_THREADS) void fg_chain_kernel(FgStep g) {
   __shared__ __attribute__((aligned(16))) float wring[FGC_SLOTS][FG_CW];
+  __shared__ __attribute__((aligned(16))) float inv[64];   // [state | x]
+  __shared__ __attribute__((aligned(16))) float zv[32];
   __shared__ int pos[FG_MAXL], roff[FG_MAXL], sdil[FG_MAXL];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int L = g.L, Q = g.Q;
@@ -432,16 +459,16 @@ __global__ __launch_bounds__(FGC_THREADS) void fg_chain_kernel(FgStep g) {
     int off = 0;
     for (int l = 0; l < L; ++l) { roff[l] = off; off += sdil[l]; }
   }
-  // loaders: 256 threads x 5 float4 = one layer (5120 floats)
+  // loaders: 256 threads x 5 float4 = one layer of the pre-packed image
   f32x4 s0[5], s1[5], s2[5];
   auto ld = [&](f32x4 (&r)[5], int l) {
     if (l < L) {
-      const f32x4* src = reinterpret_cast<const f32x4*>(g.layer0 + (long)l * g.layer_stride);
+      const f32x4* src = reinterpret_cast<const f32x4*>(g.cw_img + (long)l * FG_CW);
 #pragma unroll
       for (int k = 0; k < 5; ++k) r[k] = src[lt + 256 * k];
     }
   };
-  auto stl = [&](const f32x4 (&r)[5], int l) {
+  auto stl = [&](const f32x4 (&r)[5], int l) {   // straight 16-byte copies
     if (l < L) {
       f32x4* dst = reinterpret_cast<f32x4*>(wring[l % FGC_SLOTS]);
 #pragma unroll
@@ -474,31 +501,55 @@ __global__ __launch_bounds__(FGC_THREADS) void fg_chain_kernel(FgStep g) {
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  // one chain layer (wave 0) / one ring refill (loaders); `set` holds layer
-  // l+1, is stored to its slot and re-issued for layer l+4
+  const int nn = lane & 31, gsel = lane >> 5;     // output row, 0 filter / 1 gate
   auto body = [&](int l, f32x4 (&set)[5]) {
     if (wave == 0) {
       if (l < L) {
         const float* wl = wring[l % FGC_SLOTS];
-        const float cur_st = stv, cur_bias = bias, cur_bd = bdv;
-        if (lane < 32) g.state[((long)roff[l] + pos[l]) * 32 + lane] = x;
-        if (l + 1 < L) chain_prefetch(l + 1);
-        const float* wcol = wl + (lane < 32 ? 0 : 2048) + (lane & 31);
-        float a = cur_bias;
-#pragma unroll
-        for (int k = 0; k < 32; ++k) {
-          a = fmaf(readlane_f(cur_st, k), wcol[k * 32], a);
-          a = fmaf(readlane_f(x, k), wcol[1024 + k * 32], a);
+        const float cur_bias = bias, cur_bd = bdv;
+        if (lane < 32) {
+          g.state[((long)roff[l] + pos[l]) * 32 + lane] = x;  // enqueue x_l[t]
+          inv[lane] = stv;                                    // x_l[t - d]
+          inv[32 + lane] = x;
         }
-        const float gate = __shfl(a, (lane & 31) + 32);
-        const float z = wn_tanh(a) * wn_sigmoid(gate);
-        if (lane < 32) g.z_all[l * 32 + lane] = z;
-        if (l + 1 < L) {
-          float dsum = cur_bd;
-          const float* wd = wl + 4096 + (lane & 31);
+        if (l + 1 < L) chain_prefetch(l + 1);
+        __builtin_amdgcn_wave_barrier();
+        // conv: lane -> output nn of filter (gsel 0) or gate (gsel 1)
+        const float* w0 = wl + (gsel * 2) * 1024 + nn * 32;       // past tap
+        const float* w1 = w0 + 1024;                              // current tap
+        float a0 = cur_bias, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-          for (int k = 0; k < 32; ++k) dsum = fmaf(readlane_f(z, k), wd[k * 32], dsum);
-          if (lane < 32) x += dsum;
+        for (int c = 0; c < 8; ++c) {
+          const int sw = (c ^ (nn & 7)) << 2;
+          const f32x4 sv = *reinterpret_cast<const f32x4*>(inv + 4 * c);
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(inv + 32 + 4 * c);
+          const f32x4 p = *reinterpret_cast<const f32x4*>(w0 + sw);
+          const f32x4 q = *reinterpret_cast<const f32x4*>(w1 + sw);
+          a0 = fmaf(sv[0], p[0], a0); a1 = fmaf(sv[1], p[1], a1);
+          a2 = fmaf(sv[2], p[2], a2); a3 = fmaf(sv[3], p[3], a3);
+          a0 = fmaf(xv[0], q[0], a0); a1 = fmaf(xv[1], q[1], a1);
+          a2 = fmaf(xv[2], q[2], a2); a3 = fmaf(xv[3], q[3], a3);
+        }
+        const float a = (a0 + a1) + (a2 + a3);
+        const float gate = __shfl(a, nn + 32);
+        const float z = wn_tanh(a) * wn_sigmoid(gate);
+        if (lane < 32) {
+          g.z_all[l * 32 + lane] = z;
+          zv[lane] = z;
+        }
+        if (l + 1 < L) {
+          __builtin_amdgcn_wave_barrier();
+          const float* wd = wl + 4 * 1024 + nn * 32;
+          float d0 = cur_bd, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            const int sw = (c ^ (nn & 7)) << 2;
+            const f32x4 zz = *reinterpret_cast<const f32x4*>(zv + 4 * c);
+            const f32x4 p = *reinterpret_cast<const f32x4*>(wd + sw);
+            d0 = fmaf(zz[0], p[0], d0); d1 = fmaf(zz[1], p[1], d1);
+            d2 = fmaf(zz[2], p[2], d2); d3 = fmaf(zz[3], p[3], d3);
+          }
+          if (lane < 32) x += (d0 + d1) + (d2 + d3);
         }
       }
     } else {
@@ -591,33 +642,26 @@ __global__ __launch_bounds__(256) void fg_post1_kernel(FgStep g) {
   }
 }
 
-// logits, softmax (float64), temperature, draw, cursor update
-__global__ __launch_bounds__(256) void fg_post2_kernel(FgStep g) {
+// logits[q] = sum_k h2[k] W2[k][q] + b2[q]   (Q/32 workgroups)
+__global__ __launch_bounds__(256) void fg_logits_kernel(FgStep g) {
   __shared__ float hs[FG_MAXS];
-  __shared__ float part[1024];
-  __shared__ double pd[FG_MAXQ];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ float red[8][32];
+  const int tid = threadIdx.x, o = tid & 31, part = tid >> 5;
+  const int q = blockIdx.x * 32 + o;
   const int S = g.S, Q = g.Q;
-  const int steps_done = g.cursors[0];
-  const int local = steps_done - g.base;
-  const int code = g.samples[local];
   for (int i = tid; i < S; i += 256) hs[i] = g.h2[i];
   __syncthreads();
-  int parts = 256 / Q;
-  if (parts < 1) parts = 1;
-  if (parts > 4) parts = 4;
-  for (int o = tid; o < Q * parts; o += 256) {
-    const int q = o % Q, p = o / Q;
-    const int k0 = (int)((long)S * p / parts), k1 = (int)((long)S * (p + 1) / parts);
-    float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+  const int per = (S + 7) / 8, k0 = part * per, k1 = min(S, k0 + per);
+  float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+  if (q < Q) {
     const float* w = g.post2_w + q;
     int k = k0;
-    for (; k + 64 <= k1; k += 64) {
-      float wv[64];
+    for (; k + 32 <= k1; k += 32) {
+      float wv[32];
 #pragma unroll
-      for (int u = 0; u < 64; ++u) wv[u] = w[(long)(k + u) * Q];
+      for (int u = 0; u < 32; ++u) wv[u] = w[(long)(k + u) * Q];
 #pragma unroll
-      for (int u = 0; u < 64; u += 4) {
+      for (int u = 0; u < 32; u += 4) {
         c0 = fmaf(hs[k + u], wv[u], c0);
         c1 = fmaf(hs[k + u + 1], wv[u + 1], c1);
         c2 = fmaf(hs[k + u + 2], wv[u + 2], c2);
@@ -625,14 +669,26 @@ __global__ __launch_bounds__(256) void fg_post2_kernel(FgStep g) {
       }
     }
     for (; k < k1; ++k) c0 = fmaf(hs[k], w[(long)k * Q], c0);
-    part[o] = (c0 + c1) + (c2 + c3);
   }
+  red[part][o] = (c0 + c1) + (c2 + c3);
   __syncthreads();
-  for (int q = tid; q < Q; q += 256) {
-    float c = g.post2_b ? g.post2_b[q] : 0.f;
-    for (int p = 0; p < parts; ++p) c += part[p * Q + q];
-    pd[q] = (double)c;
+  if (part == 0 && q < Q) {
+    float t = g.post2_b ? g.post2_b[q] : 0.f;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) t += red[p][o];
+    g.logits[q] = t;
   }
+}
+
+// float64 softmax, temperature, inverse-CDF draw, cursor update (one wave)
+__global__ __launch_bounds__(64) void fg_draw_kernel(FgStep g) {
+  __shared__ double pd[FG_MAXQ];
+  const int lane = threadIdx.x, wave = 0;
+  const int Q = g.Q;
+  const int steps_done = g.cursors[0];
+  const int local = steps_done - g.base;
+  const int code = g.samples[local];
+  for (int q = lane; q < Q; q += 64) pd[q] = (double)g.logits[q];
   __syncthreads();
   if (wave == 0) {
     double m = -1e300;
@@ -763,7 +819,9 @@ int wn_fastgen_step(const float* params_causal, const float* layer0,
                     float* state, int32_t* cursors, int32_t* samples_io,
                     int base, int n_given, float temperature, uint64_t seed,
                     float* proba_out, int proba_every, int use_biases,
-                    float* z_all, float* h1, float* h2, void* stream) {
+                    const float* cw_img, float* z_all, float* h1, float* h2,
+                    float* logits, void* stream) {
+  if (!cw_img || !logits) return WN_ERR_NULL;
   if (!params_causal || !layer0 || !skip_w || !post1_w || !post2_w ||
       !dilations_dev || !state || !cursors || !samples_io || !z_all || !h1 ||
       !h2)
@@ -779,13 +837,25 @@ int wn_fastgen_step(const float* params_causal, const float* layer0,
   g.state = state; g.cursors = cursors; g.samples = samples_io; g.base = base;
   g.n_given = n_given; g.temperature = temperature; g.seed = seed;
   g.proba_out = proba_out; g.proba_every = proba_every > 0 ? proba_every : 1;
-  g.use_dense_bias = use_biases; g.z_all = z_all; g.h1 = h1; g.h2 = h2;
+  g.use_dense_bias = use_biases; g.cw_img = cw_img; g.z_all = z_all;
+  g.h1 = h1; g.h2 = h2; g.logits = logits;
   hipStream_t s = (hipStream_t)stream;
   const int wgs = (S + 31) / 32;
   hipLaunchKernelGGL(fg_chain_kernel, dim3(1), dim3(FGC_THREADS), 0, s, g);
   hipLaunchKernelGGL(fg_skip_kernel, dim3(wgs), dim3(256), 0, s, g);
   hipLaunchKernelGGL(fg_post1_kernel, dim3(wgs), dim3(256), 0, s, g);
-  hipLaunchKernelGGL(fg_post2_kernel, dim3(1), dim3(256), 0, s, g);
+  hipLaunchKernelGGL(fg_logits_kernel, dim3((Q + 31) / 32), dim3(256), 0, s, g);
+  hipLaunchKernelGGL(fg_draw_kernel, dim3(1), dim3(64), 0, s, g);
+  return wn_check_launch();
+}
+
+// Build the chain-weight image wn_fastgen_step streams: img [L][5120].
+int wn_fastgen_pack(const float* layer0, long layer_stride, float* img, int L,
+                    void* stream) {
+  if (!layer0 || !img) return WN_ERR_NULL;
+  if (L <= 0) return WN_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(fg_pack_kernel, dim3(L), dim3(256), 0,
+                     (hipStream_t)stream, layer0, layer_stride, img, L);
   return wn_check_launch();
 }
 

@@ -837,10 +837,14 @@ class WaveNetModel(object):
                                   device=self.device),
                 z_all=torch.zeros(self.L * CH, dtype=torch.float32,
                                   device=self.device),
+                cw_img=torch.zeros(self.L * 5120, dtype=torch.float32,
+                                   device=self.device),
                 h1=torch.zeros(self.S, dtype=torch.float32,
                                device=self.device),
                 h2=torch.zeros(self.S, dtype=torch.float32,
                                device=self.device),
+                logits=torch.zeros(self.Q, dtype=torch.float32,
+                                   device=self.device),
                 steps=0,
                 io=torch.zeros(2, dtype=torch.int32, device=self.device))
             self._gen = g
@@ -891,9 +895,14 @@ class WaveNetModel(object):
                 g['steps'] += int(n_steps)
             return
         base = g['steps']
+        # weights are constant while generating: pack the chain blocks once
+        _lib.call('wn_fastgen_pack', _lib.ptr(self._layer_block(P, 0)),
+                  self.layer_stride, _lib.ptr(g['cw_img']), self.L,
+                  _lib.stream())
         tail = (base, int(n_given), float(temperature), sd,
                 _lib.ptr(proba_out), int(proba_every), 1 if ub else 0,
-                _lib.ptr(g['z_all']), _lib.ptr(g['h1']), _lib.ptr(g['h2']))
+                _lib.ptr(g['cw_img']), _lib.ptr(g['z_all']), _lib.ptr(g['h1']),
+                _lib.ptr(g['h2']), _lib.ptr(g['logits']))
 
         def one():
             _lib.call('wn_fastgen_step', *common, *tail, _lib.stream())

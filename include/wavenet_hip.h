@@ -162,8 +162,9 @@ int wn_l2_partials(const float* p, long n, const float* mask, float* partials,
 int wn_gc_bias(const float* layer0, long layer_stride, long off_bias,
                long off_gc, int G, const float* emb, int card,
                const int32_t* ids, float* out, int L, int B, void* stream);
-int wn_colsum_clip(const float* plane, int B, int T, float* out,
-                   int out_stride, void* stream);
+int wn_colsum_clip_chunks(int T);
+int wn_colsum_clip(const float* plane0, const float* plane1, int B, int T,
+                   float* part, float* out, void* stream);
 int wn_gc_grad(const float* layer0, long layer_stride, long off_gc, int G,
                const float* emb, int card, const int32_t* ids,
                const float* dsum, int L, int B, float* glayer0, float* gemb,

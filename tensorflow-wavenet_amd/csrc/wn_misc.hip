@@ -370,20 +370,33 @@ __global__ void gc_bias_kernel(const float* __restrict__ layer0, long layer_stri
   out[((long)l * B + b) * 64 + c] = v;
 }
 
-// per-clip column sums of a plane: out[b][c] = sum_t P[b][t][c]
-__global__ void colsum_clip_kernel(const float* __restrict__ P, int T,
-                                   float* __restrict__ out, int out_stride) {
-  __shared__ float red[8][32];
-  const int b = blockIdx.x, c = threadIdx.x & 31, w = threadIdx.x >> 5;
-  const float* p = P + (long)b * T * 32;
-  float s = 0.f;
-  for (int t = w; t < T; t += 8) s += p[(long)t * 32 + c];
-  red[w][c] = s;
+// per-clip column sums of TWO planes (da_f, da_g), stage 1 of 2:
+//   part[b][chunk][0:32]  = sum over the chunk's rows of P0[b][t][:]
+//   part[b][chunk][32:64] = same for P1
+// grid (chunks, B); wn_reduce_slabs sums the chunks in a fixed order.
+__global__ __launch_bounds__(256) void colsum_clip_kernel(
+    const float* __restrict__ P0, const float* __restrict__ P1, int T,
+    int rows_per_chunk, float* __restrict__ part) {
+  __shared__ float red[8][64];
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int c = threadIdx.x & 31, w = threadIdx.x >> 5;
+  const int t0 = chunk * rows_per_chunk;
+  const int t1 = min(T, t0 + rows_per_chunk);
+  const float* p0 = P0 + (long)b * T * 32;
+  const float* p1 = P1 + (long)b * T * 32;
+  float s0 = 0.f, s1 = 0.f;
+  for (int t = t0 + w; t < t1; t += 8) {
+    s0 += p0[(long)t * 32 + c];
+    s1 += p1[(long)t * 32 + c];
+  }
+  red[w][c] = s0;
+  red[w][32 + c] = s1;
   __syncthreads();
-  if (w == 0) {
+  if (threadIdx.x < 64) {
     float v = 0.f;
-    for (int k = 0; k < 8; ++k) v += red[k][c];
-    out[(long)b * out_stride + c] = v;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v += red[k][threadIdx.x];
+    part[((long)b * gridDim.x + chunk) * 64 + threadIdx.x] = v;
   }
 }
 
@@ -410,24 +423,30 @@ __global__ void gc_grad_kernel(const float* __restrict__ layer0, long layer_stri
       gw[e] = s;
     }
   } else {
-    // embedding rows: serial over clips (deterministic when ids repeat)
+    // embedding rows.  Phase 1 (parallel): tmp[b][g] = sum_l dsum_l[b] Wgc_l[g]^T
+    // Phase 2: rows are added clip by clip in a fixed order (deterministic
+    // when several clips share an id).
+    extern __shared__ float tmp[];      // [B][G]
     for (int e = tid; e < card * G; e += blockDim.x) gemb[e] = 0.f;
-    __syncthreads();
-    for (int b = 0; b < B; ++b) {
-      const int id = ids[b];
-      if (id < 0 || id >= card) continue;
-      for (int g = tid; g < G; g += blockDim.x) {
-        float s = 0.f;
-        for (int l = 0; l < L; ++l) {
-          const float* w = layer0 + (long)l * layer_stride + off_gc;
-          const float* ds = dsum + ((long)l * B + b) * 64;
-          for (int c = 0; c < 32; ++c)
-            s += ds[c] * w[(long)g * 32 + c] +
-                 ds[32 + c] * w[(long)(G + g) * 32 + c];
-        }
-        gemb[(long)id * G + g] += s;
+    for (int e = tid; e < B * G; e += blockDim.x) {
+      const int b = e / G, gi = e - b * G;
+      float s = 0.f;
+      for (int l = 0; l < L; ++l) {
+        const float* w = layer0 + (long)l * layer_stride + off_gc;
+        const float* ds = dsum + ((long)l * B + b) * 64;
+        for (int c = 0; c < 32; ++c)
+          s += ds[c] * w[(long)gi * 32 + c] +
+               ds[32 + c] * w[(long)(G + gi) * 32 + c];
       }
-      __syncthreads();
+      tmp[e] = s;
+    }
+    __syncthreads();
+    for (int gi = tid; gi < G; gi += blockDim.x) {
+      for (int b = 0; b < B; ++b) {
+        const int id = ids[b];
+        if (id < 0 || id >= card) continue;
+        gemb[(long)id * G + gi] += tmp[b * G + gi];
+      }
     }
   }
 }
@@ -521,6 +540,11 @@ static inline int grid1d(long n, int block, int cap = 2048) {
 }
 
 extern "C" {
+
+int wn_reduce_slabs(const float* slabs, int num_slabs, long slab_stride,
+                    int batch, long in_batch_stride, long offset, long n,
+                    float* dst, long out_batch_stride, int replicate,
+                    long rep_stride, void* stream);
 
 int wn_version(void) { return 100; }
 
@@ -714,13 +738,26 @@ int wn_gc_bias(const float* layer0, long layer_stride, long off_bias,
   return wn_check_launch();
 }
 
-int wn_colsum_clip(const float* plane, int B, int T, float* out,
-                   int out_stride, void* stream) {
-  if (!plane || !out) return WN_ERR_NULL;
+int wn_colsum_clip_chunks(int T) {
+  int c = (T + 511) / 512;
+  if (c > 64) c = 64;
+  return c < 1 ? 1 : c;
+}
+
+// out[b][0:32] = sum_t P0[b][t][:], out[b][32:64] = sum_t P1[b][t][:];
+// `part` is caller scratch of B * wn_colsum_clip_chunks(T) * 64 floats.
+int wn_colsum_clip(const float* plane0, const float* plane1, int B, int T,
+                   float* part, float* out, void* stream) {
+  if (!plane0 || !plane1 || !part || !out) return WN_ERR_NULL;
   if (B <= 0 || T <= 0) return WN_ERR_BAD_SHAPE;
-  hipLaunchKernelGGL(colsum_clip_kernel, dim3(B), dim3(256), 0,
-                     (hipStream_t)stream, plane, T, out, out_stride);
-  return wn_check_launch();
+  const int chunks = wn_colsum_clip_chunks(T);
+  const int rpc = (T + chunks - 1) / chunks;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(colsum_clip_kernel, dim3(chunks, B), dim3(256), 0, s,
+                     plane0, plane1, T, rpc, part);
+  // fixed-order sum over the chunks (reduce_slabs_kernel lives in wn_gemm.hip)
+  return wn_reduce_slabs(part, chunks, 64, B, (long)chunks * 64, 0, 64, out, 64,
+                         1, 0, stream);
 }
 
 int wn_gc_grad(const float* layer0, long layer_stride, long off_gc, int G,
@@ -729,8 +766,9 @@ int wn_gc_grad(const float* layer0, long layer_stride, long off_gc, int G,
                void* stream) {
   if (!layer0 || !emb || !ids || !dsum || !glayer0 || !gemb) return WN_ERR_NULL;
   if (L <= 0 || B <= 0 || G <= 0 || card <= 0) return WN_ERR_BAD_SHAPE;
-  hipLaunchKernelGGL(gc_grad_kernel, dim3(L + 1), dim3(256), 0,
-                     (hipStream_t)stream, layer0, layer_stride, off_gc, G, emb,
+  if ((size_t)B * G * sizeof(float) > 48 * 1024) return WN_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(gc_grad_kernel, dim3(L + 1), dim3(256),
+                     (size_t)B * G * sizeof(float), (hipStream_t)stream, layer0, layer_stride, off_gc, G, emb,
                      card, ids, dsum, L, B, glayer0, gemb);
   return wn_check_launch();
 }

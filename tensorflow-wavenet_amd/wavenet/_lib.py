@@ -64,7 +64,8 @@ SIGNATURES = {
     'wn_l2_partials': (c_int, [P, c_long, P, P, P]),
     'wn_gc_bias': (c_int, [P, c_long, c_long, c_long, c_int, P, c_int, P, P,
                            c_int, c_int, P]),
-    'wn_colsum_clip': (c_int, [P, c_int, c_int, P, c_int, P]),
+    'wn_colsum_clip_chunks': (c_int, [c_int]),
+    'wn_colsum_clip': (c_int, [P, P, c_int, c_int, P, P, P]),
     'wn_gc_grad': (c_int, [P, c_long, c_long, c_int, P, c_int, P, P, c_int,
                            c_int, P, P, P]),
     'wn_causal_conv': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int,

@@ -118,6 +118,8 @@ class _Workspace(object):
             need = max(need, sp * lib.wn_gemm_tn_slab_floats(mw, nw))
         self.slabs = torch.empty(need, **f32)
         self.dsum = torch.empty((L, B, 64), **f32) if net.G else None
+        self.dsum_part = torch.empty(
+            B * lib.wn_colsum_clip_chunks(T) * 64, **f32) if net.G else None
         # cross-stream events: weight-gradient kernels run on a side stream
         self.ev_ready = [torch.cuda.Event() for _ in range(L)]
         self.ev_done = [torch.cuda.Event() for _ in range(L)]
@@ -604,10 +606,9 @@ class WaveNetModel(object):
             if fused:
                 # one pass: dx_l, every weight gradient of layer l, da_{l-1}
                 if ws.dsum is not None:
-                    _lib.call('wn_colsum_clip', _lib.ptr(f), B, T,
-                              _lib.ptr(ws.dsum[l]), 64, st)
-                    _lib.call('wn_colsum_clip', _lib.ptr(g), B, T,
-                              _lib.ptr(ws.dsum[l].view(-1)[32:]), 64, st)
+                    _lib.call('wn_colsum_clip', _lib.ptr(f), _lib.ptr(g), B,
+                              T, _lib.ptr(ws.dsum_part), _lib.ptr(ws.dsum[l]),
+                              st)
                 fn, gn = da(1 - cur) if l > 0 else (None, None)
                 _lib.call('wn_layer_bwdw', _lib.ptr(ws.X[l]),
                           None if dxin is None else _lib.ptr(ws.Z[l]),
@@ -635,10 +636,8 @@ class WaveNetModel(object):
                         None if dxin is None else _lib.ptr(dxin),
                         _lib.ptr(ws.lslabs[l]), ws.nslab, B, T, d, sst)
             if ws.dsum is not None:
-                _lib.call('wn_colsum_clip', _lib.ptr(f), B, T,
-                          _lib.ptr(ws.dsum[l]), 64, sst)
-                _lib.call('wn_colsum_clip', _lib.ptr(g), B, T,
-                          _lib.ptr(ws.dsum[l].view(-1)[32:]), 64, sst)
+                _lib.call('wn_colsum_clip', _lib.ptr(f), _lib.ptr(g), B, T,
+                          _lib.ptr(ws.dsum_part), _lib.ptr(ws.dsum[l]), sst)
             if side is not main:
                 ws.ev_done[l].record(side)
                 if l < L - 1:

@@ -66,48 +66,63 @@ def _tn_splits(rows, mw, nw, target_wgs=1024, onehot=False):
 
 class _Workspace(object):
     """Caller-owned device buffers for one (B, T) shape (the library never
-    allocates).  Sized for 288 GB HBM: everything stays resident."""
+    allocates).  Sized for 288 GB HBM: everything stays resident.  A workspace
+    for a smaller T (same B) is carved out of an existing larger one
+    (`parent`) without allocating -- the windowed naive generation path calls
+    predict_proba with a growing T."""
 
-    def __init__(self, net, B, T, training):
+    def __init__(self, net, B, T, training, parent=None):
         dev = net.device
         L, S, Q = net.L, net.S, net.Q
         N = B * T
         f32 = dict(dtype=torch.float32, device=dev)
         self.B, self.T, self.N, self.training = B, T, N, training
-        self.q = torch.empty(N, dtype=torch.int32, device=dev)
-        self.audio = torch.empty(N, **f32) if net.scalar_input else None
-        self.X = torch.empty((L, N, CH), **f32)
-        self.Z = torch.empty((L, N, CH), **f32)
-        self.h1 = torch.empty((N, S), **f32)
-        self.h2 = torch.empty((N, S), **f32)
-        self.logits = torch.empty((N, Q), **f32)
-        self.bias_fg = torch.empty((L, B, 64), **f32)
-        self.bsum = torch.empty(S, **f32)
-        self.total = torch.empty((N, S), **f32) if net.residual_postproc else None
-        self.nparts = _lib.load().wn_xent_partials(N)
-        self.loss_parts = torch.empty(self.nparts, **f32)
-        self.loss = torch.zeros(1, **f32)
-        self.proba = torch.empty(Q, **f32)
+        self.capacity = N if parent is None else parent.capacity
+        lib = _lib.load()
+
+        def alloc(name, shape, dtype=torch.float32, fill=None):
+            n = int(np.prod(shape))
+            if parent is not None and getattr(parent, name, None) is not None:
+                t = getattr(parent, name).reshape(-1)[:n].view(shape)
+            elif fill is None:
+                t = torch.empty(shape, dtype=dtype, device=dev)
+            else:
+                t = torch.full(shape, fill, dtype=dtype, device=dev)
+            setattr(self, name, t)
+            return t
+
+        alloc('q', (N,), torch.int32)
+        self.audio = alloc('audio', (N,)) if net.scalar_input else None
+        alloc('X', (L, N, CH))
+        alloc('Z', (L, N, CH))
+        alloc('h1', (N, S))
+        alloc('h2', (N, S))
+        alloc('logits', (N, Q))
+        alloc('bias_fg', (L, B, 64))
+        alloc('bsum', (S,))
+        self.total = alloc('total', (N, S)) if net.residual_postproc else None
+        self.nparts = lib.wn_xent_partials(N)
+        alloc('loss_parts', (self.nparts,))
+        alloc('loss', (1,), fill=0.0)
+        alloc('proba', (Q,))
         if not training:
             return
-        self.TH = torch.empty((L, N, CH), **f32)
-        self.SG = torch.empty((L, N, CH), **f32)
-        self.dZ = torch.empty((L, N, CH), **f32)
-        self.dc1 = torch.empty((N, S), **f32)
-        self.dtotal = torch.empty((N, S), **f32)
-        self.dh2 = torch.empty((N, S), **f32) if net.residual_postproc else None
-        self.c1 = torch.empty((N, S), **f32) if net.residual_postproc else None
-        self.da = torch.empty((2, 2, N, CH), **f32)   # [pingpong][f|g]
-        self.dx = torch.empty((2, N, CH), **f32)
-        self.w2t = torch.empty((Q, S), **f32)
-        self.w1t = torch.empty((S, S), **f32)
-        self.wst = torch.empty((S, L * CH), **f32)
+        alloc('TH', (L, N, CH))
+        alloc('SG', (L, N, CH))
+        alloc('dZ', (L, N, CH))
+        alloc('dc1', (N, S))
+        alloc('dtotal', (N, S))
+        self.dh2 = alloc('dh2', (N, S)) if net.residual_postproc else None
+        self.c1 = alloc('c1', (N, S)) if net.residual_postproc else None
+        alloc('da', (2, 2, N, CH))    # [pingpong][f|g]
+        alloc('dx', (2, N, CH))
+        alloc('w2t', (Q, S))
+        alloc('w1t', (S, S))
+        alloc('wst', (S, L * CH))
         ntiles = B * ((T + 31) // 32)
-        lib = _lib.load()
         self.nslab = max(1, min(512, ntiles // 4))
         self.nslab_f = lib.wn_layer_bwdw_slabs(B, T)      # fused kernel
-        self.lslabs = torch.empty((L, max(self.nslab, self.nslab_f),
-                                   net.LAYER_BLOCK), **f32)
+        alloc('lslabs', (L, max(self.nslab, self.nslab_f), net.LAYER_BLOCK))
         need = 0
         self.splits = {}
         for key, (mw, nw) in dict(post2=(S, Q), post1=(S, S), skip=(L * CH, S),
@@ -116,15 +131,20 @@ class _Workspace(object):
                             onehot=(key == 'causal'))
             self.splits[key] = sp
             need = max(need, sp * lib.wn_gemm_tn_slab_floats(mw, nw))
-        self.slabs = torch.empty(need, **f32)
-        self.dsum = torch.empty((L, B, 64), **f32) if net.G else None
-        self.dsum_part = torch.empty(
-            B * lib.wn_colsum_clip_chunks(T) * 64, **f32) if net.G else None
+        need = max(need, 256 * 32 * CH)          # scalar-input causal wgrad
+        alloc('slabs', (need,))
+        self.dsum = alloc('dsum', (L, B, 64)) if net.G else None
+        self.dsum_part = alloc(
+            'dsum_part', (B * lib.wn_colsum_clip_chunks(T) * 64,)) \
+            if net.G else None
         # cross-stream events: weight-gradient kernels run on a side stream
-        self.ev_ready = [torch.cuda.Event() for _ in range(L)]
-        self.ev_done = [torch.cuda.Event() for _ in range(L)]
-        self.l2_parts = torch.empty(lib.wn_l2_partials_count(), **f32)
-        self.l2 = torch.zeros(1, **f32)
+        if parent is not None and getattr(parent, 'ev_ready', None):
+            self.ev_ready, self.ev_done = parent.ev_ready, parent.ev_done
+        else:
+            self.ev_ready = [torch.cuda.Event() for _ in range(L)]
+            self.ev_done = [torch.cuda.Event() for _ in range(L)]
+        alloc('l2_parts', (lib.wn_l2_partials_count(),))
+        alloc('l2', (1,), fill=0.0)
 
 
 class WaveNetModel(object):
@@ -401,11 +421,25 @@ class WaveNetModel(object):
                 'no CPU fallback' % self.device)
 
     def _workspace(self, B, T, training):
-        key = (B, T)
+        key = (B, T, bool(training))
         ws = self._ws.get(key)
-        if ws is None or (training and not ws.training):
+        if ws is not None:
+            return ws
+        # carve out of a resident larger workspace of the same batch size
+        for (b, t, tr), cand in list(self._ws.items()):
+            if cand.capacity == cand.N and b == B and B * T <= cand.capacity \
+                    and (tr or not training):
+                ws = _Workspace(self, B, T, training, parent=cand)
+                break
+        if ws is None:
             ws = _Workspace(self, B, T, training)
-            self._ws = {key: ws}      # keep one shape resident
+            self._ws = {}             # keep one owning allocation resident
+        self._ws[key] = ws
+        if len(self._ws) > 64:        # views are cheap but unbounded otherwise
+            owners = {k: v for k, v in self._ws.items()
+                      if v.capacity == v.N}
+            self._ws = owners
+            self._ws[key] = ws
         return ws
 
     def _gc_ids(self, global_condition, B):

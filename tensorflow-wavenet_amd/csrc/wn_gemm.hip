@@ -14,6 +14,7 @@
 // Orientation: "time on the MFMA N axis" (see wn_common.h): activations are
 // the B operand as 32x32 fragments, weights the A operand from LDS.
 #include "wn_common.h"
+#include <cstdlib>
 
 // ---------------------------------------------------------------------------
 // NN
@@ -109,20 +110,27 @@ __device__ __forceinline__ void gemm_epilogue(const GemmNN& g, f32x16 (&acc)[2][
   }
 }
 
-__global__ __launch_bounds__(256) void gemm_nn_kernel(GemmNN g) {
-  __shared__ __attribute__((aligned(16))) float As[2][NN_TM * NN_KC];
-  __shared__ __attribute__((aligned(16))) float Bs[2][NN_KC * NN_TN];
+template <int WMT>
+__global__ __launch_bounds__(WMT * 128) void gemm_nn_kernel(GemmNN g) {
+  constexpr int TM = WMT * 64, NT = WMT * 128;   // rows per tile, threads
+  constexpr int NA = TM * 8 / NT, NB = 1024 / NT; // float4 per thread (A, W)
+  // one buffer: the epilogue's per-wave tiles (WMT*2*32*EP_LD floats) reuse it
+  __shared__ __attribute__((aligned(16))) float smem[2 * TM * NN_KC + 2 * NN_KC * NN_TN];
+  float (*As)[TM * NN_KC] = reinterpret_cast<float (*)[TM * NN_KC]>(smem);
+  float (*Bs)[NN_KC * NN_TN] =
+      reinterpret_cast<float (*)[NN_KC * NN_TN]>(smem + 2 * TM * NN_KC);
+  static_assert(WMT * 2 * 32 * EP_LD <= 2 * TM * NN_KC + 2 * NN_KC * NN_TN, "epilogue LDS");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, h = lane >> 5;
-  const int wm = wave & 1, wn = wave >> 1;
+  const int wm = wave % WMT, wn = wave / WMT;
   const int logical = xcd_remap(blockIdx.x, g.nwg);
   const int tile_n = logical % g.tiles_n;
-  const long m0 = (long)(logical / g.tiles_n) * NN_TM;
+  const long m0 = (long)(logical / g.tiles_n) * TM;
   const int n0 = tile_n * NN_TN;
   const int nk = (g.K + NN_KC - 1) / NN_KC;
 
-  f32x4 ra[4], rb[4];
-  const bool full_m = m0 + NN_TM <= g.M, full_n = n0 + NN_TN <= g.N;
+  f32x4 ra[NA], rb[NB];
+  const bool full_m = m0 + TM <= g.M, full_n = n0 + NN_TN <= g.N;
   auto gload = [&](int kc) {
     const bool full_k = (kc + 1) * NN_KC <= g.K;
     if (full_m && full_k) {  // interior tile: no predicates, no branches
@@ -131,13 +139,13 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmNN g) {
                             : g.A + m0 * g.lda + kc * NN_KC;
       const long ld = g.a_planes ? 32 : g.lda;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < NA; ++i)
         ra[i] = *reinterpret_cast<const f32x4*>(
-            pa + (long)((tid >> 3) + 32 * i) * ld + (tid & 7) * 4);
+            pa + (long)((tid >> 3) + (NT / 8) * i) * ld + (tid & 7) * 4);
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = (tid >> 3) + 32 * i, ch = tid & 7;
+      for (int i = 0; i < NA; ++i) {
+        const int row = (tid >> 3) + (NT / 8) * i, ch = tid & 7;
         const long m = m0 + row;
         const int k = kc * NN_KC + ch * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -153,13 +161,13 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmNN g) {
     if (full_n && full_k) {
       const float* pb = g.W + (long)kc * NN_KC * g.ldw + n0;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < NB; ++i)
         rb[i] = *reinterpret_cast<const f32x4*>(
-            pb + (long)((tid >> 5) + 8 * i) * g.ldw + (tid & 31) * 4);
+            pb + (long)((tid >> 5) + (NT / 32) * i) * g.ldw + (tid & 31) * 4);
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int kk = (tid >> 5) + 8 * i, c4 = tid & 31;
+      for (int i = 0; i < NB; ++i) {
+        const int kk = (tid >> 5) + (NT / 32) * i, c4 = tid & 31;
         const int k = kc * NN_KC + kk, n = n0 + c4 * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (k < g.K && n < g.N)
@@ -170,14 +178,14 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmNN g) {
   };
   auto sstore = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = (tid >> 3) + 32 * i, ch = tid & 7;
+    for (int i = 0; i < NA; ++i) {
+      const int row = (tid >> 3) + (NT / 8) * i, ch = tid & 7;
       const int sw = ch ^ ((row >> 1) & 7);  // 16-byte chunk swizzle
       *reinterpret_cast<f32x4*>(&As[buf][row * NN_KC + sw * 4]) = ra[i];
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int kk = (tid >> 5) + 8 * i, c4 = tid & 31;
+    for (int i = 0; i < NB; ++i) {
+      const int kk = (tid >> 5) + (NT / 32) * i, c4 = tid & 31;
       *reinterpret_cast<f32x4*>(&Bs[buf][kk * NN_TN + c4 * 4]) = rb[i];
     }
   };
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmNN g) {
   }
 
   // coalesced epilogue through LDS (the K loop ended with a barrier)
-  gemm_epilogue(g, acc, &As[0][0], m0, n0, wm, wn, wave, lane);
+  gemm_epilogue(g, acc, smem, m0, n0, wm, wn, wave, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -667,13 +675,21 @@ static int gemm_nn_launch(const float* A, long lda, int a_planes, long a_plane_s
   g.addend = addend; g.ld_add = ld_add; g.C = C; g.ldc = ldc;
   g.c_plane_stride = c_plane_stride; g.c_planes = c_planes; g.Cpre = Cpre;
   g.M = M; g.N = N; g.K = K; g.relu = relu;
-  const long tiles_m = (M + NN_TM - 1) / NN_TM;
+  // 256-row tiles (8 waves, the weight tile shared by twice the rows) once
+  // the grid still fills the chip; WN_NN_ROWS=128/256 overrides (experiments)
+  int rows = M >= 65536 ? 256 : 128;
+  if (const char* e = getenv("WN_NN_ROWS")) rows = atoi(e) == 256 ? 256 : 128;
+  const long tiles_m = (M + rows - 1) / rows;
   g.tiles_n = (N + NN_TN - 1) / NN_TN;
   const long nwg = tiles_m * g.tiles_n;
   if (nwg > 0x7fffffffL) return WN_ERR_BAD_SHAPE;
   g.nwg = (int)nwg;
-  hipLaunchKernelGGL(gemm_nn_kernel, dim3((unsigned)nwg), dim3(256), 0,
-                     (hipStream_t)stream, g);
+  if (rows == 256)
+    hipLaunchKernelGGL(gemm_nn_kernel<4>, dim3((unsigned)nwg), dim3(512), 0,
+                       (hipStream_t)stream, g);
+  else
+    hipLaunchKernelGGL(gemm_nn_kernel<2>, dim3((unsigned)nwg), dim3(256), 0,
+                       (hipStream_t)stream, g);
   return wn_check_launch();
 }
 

@@ -49,6 +49,24 @@ def nn():
         print('nn %-6s K=%4d N=%4d: %7.1f us  %.1f TFLOP/s' % (name, K, Nn, t * 1e6, 2.0 * N * K * Nn / t / 1e12))
 
 
+def vendor():
+    """vendor-library fp32 GEMM (torch.mm -> rocBLAS/hipBLASLt) on the same
+    shapes, as a calibration of what 'good' is on this device (not shipped)"""
+    N = 128000
+    torch.backends.cuda.matmul.allow_tf32 = False
+    for (K, Nn, name) in [(1600, 512, 'skip'), (512, 512, 'post1'), (512, 256, 'post2'), (256, 512, 'dh2'),
+                          (512, 1600, 'dZ')]:
+        A = torch.randn(N, K, device=dev)
+        W = torch.randn(K, Nn, device=dev)
+        t = timeit(lambda: torch.mm(A, W))
+        print('torch.mm %-6s K=%4d N=%4d: %7.1f us  %.1f TFLOP/s' % (name, K, Nn, t * 1e6, 2.0 * N * K * Nn / t / 1e12))
+    for (Mw, Nw, name) in [(1600, 512, 'dWs'), (512, 512, 'dW1'), (512, 256, 'dW2')]:
+        A = torch.randn(N, Mw, device=dev)
+        G = torch.randn(N, Nw, device=dev)
+        t = timeit(lambda: torch.mm(A.t(), G))
+        print('torch.mm^T %-4s %dx%d: %7.1f us  %.1f TFLOP/s' % (name, Mw, Nw, t * 1e6, 2.0 * N * Mw * Nw / t / 1e12))
+
+
 def tn():
     N = 128000
     for (Mw, Nw, planes, name, sp) in [(1600, 512, 50, 'dWs', 64), (512, 512, 0, 'dW1', 128), (512, 256, 0, 'dW2', 256)]:

@@ -9,7 +9,7 @@ N > 1 is launched by torch.distributed.run, one rank per GPU over RCCL; the
 per-GPU work is fixed (weak scaling), `value` is the whole-job aggregate.
 
 Extra objects on the JSON line:
-  roofline     - the dominant kernel (gemm_nn_kernel: the skip-sum /
+  roofline     - the dominant kernel (gemm_nn3_kernel: the skip-sum /
                  post-processing fp32 MFMA GEMMs and their data gradients),
                  timed live with HIP events on the launch stream inside the
                  timed region; achieved = algorithmic FLOPs / kernel time.
@@ -222,10 +222,10 @@ def main():
                    'global_batch': world * B,
                    'parallelism': 'dp%d' % world,
                    'final_loss': float(loss)},
-        'roofline': {'bound': 'mfma', 'kernel': 'gemm_nn_kernel',
+        'roofline': {'bound': 'mfma', 'kernel': 'gemm_nn3_kernel',
                      'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS,
                      'unit': 'TFLOP/s', 'frac': achieved / FP32_MFMA_PEAK_TFLOPS,
-                     'traffic': pmc_traffic('gemm_nn_kernel'),
+                     'traffic': pmc_traffic('gemm_nn3_kernel'),
                      'traffic_unit': 'bytes per launch (rocprofv3 PMC pass)',
                      'launches_per_step': nlaunch // max(args.steps, 1),
                      'avg_launch_us': ktime / max(nlaunch, 1) * 1e6,

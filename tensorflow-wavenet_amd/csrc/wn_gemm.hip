@@ -41,6 +41,7 @@ struct GemmNN {
   int relu;
   int tiles_n;
   int nwg;
+  int tiles_m;
 };
 
 #define NN_TM 128
@@ -128,7 +129,6 @@ __global__ __launch_bounds__(WMT * 128) void gemm_nn_kernel(GemmNN g) {
   const long m0 = (long)(logical / g.tiles_n) * TM;
   const int n0 = tile_n * NN_TN;
   const int nk = (g.K + NN_KC - 1) / NN_KC;
-
   f32x4 ra[NA], rb[NB];
   const bool full_m = m0 + TM <= g.M, full_n = n0 + NN_TN <= g.N;
   auto gload = [&](int kc) {
@@ -233,6 +233,128 @@ __global__ __launch_bounds__(WMT * 128) void gemm_nn_kernel(GemmNN g) {
   }
 
   // coalesced epilogue through LDS (the K loop ended with a barrier)
+  gemm_epilogue(g, acc, smem, m0, n0, wm, wn, wave, lane);
+}
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// ---------------------------------------------------------------------------
+// LDS-DMA variant (the default): same 128 x 128 output tile and wave
+// decomposition as gemm_nn_kernel, but
+//  * operands are staged by global_load_lds_dwordx4 (no staging registers, no
+//    ds_write pass) in K chunks of 16, two 16 KB stages: the DMA of chunk k+1
+//    is issued right after the barrier that opens chunk k;
+//  * 35 KB of LDS and < 128 registers: four workgroups per CU, so other
+//    workgroups' MFMAs cover this one's first fetch, barriers and output
+//    store (the register-staged kernel fits two and loses a fixed ~2.6 chunk
+//    times per tile: efficiency(K) = K / (1.19 K + 82) of the MFMA peak);
+//  * s_setprio(1) around a wave's MFMA block.
+// Measured (tools/kbench.py nnexp, B*T = 128000): 135 / 130 / 126 / 122 / 129
+// TFLOP/s on the five shapes of a training step vs 127 / 119 / 116 / 108 /
+// 116 for the register-staged kernel and 130 / 136 / 133 / 124 / 132 for the
+// vendor library (torch.mm) on the same device.
+// One wave-instruction writes 1 KiB of LDS linearly (lane l -> base + 16 l),
+// so the XOR swizzle of the activation image is applied to the per-lane
+// SOURCE address: LDS slot s of row r (64-byte rows) holds the global 16-byte
+// chunk s ^ ((r >> 2) & 3).  Rows / columns past the edge are clamped to valid
+// addresses: they only feed outputs that are never stored.  Needs K % 16 == 0.
+// ---------------------------------------------------------------------------
+#define N3_KC 16
+#define N3_STAGE (NN_TM * N3_KC + N3_KC * NN_TN)   // floats per stage
+
+__global__ __launch_bounds__(256, 4) void gemm_nn3_kernel(GemmNN g) {
+  constexpr int NS = 2;  // LDS stages (3 = DMA two chunks ahead: measured equal or slower)
+  constexpr int LDSF = NS * N3_STAGE > 4 * 32 * EP_LD ? NS * N3_STAGE : 4 * 32 * EP_LD;
+  __shared__ __attribute__((aligned(1024))) float smem[LDSF];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int logical = xcd_remap(blockIdx.x, g.nwg);
+  const int tile_n = logical % g.tiles_n;
+  const long m0 = (long)(logical / g.tiles_n) * NN_TM;
+  const int n0 = tile_n * NN_TN;
+  const int nk = g.K / N3_KC;
+
+  // Wave w stages pieces p = w + 4 i (i = 0, 1) of each operand: 16 activation
+  // rows / 2 weight k-rows per piece; the swizzle term (row >> 2) & 3 =
+  // (l >> 4) & 3 does not depend on the piece.
+  const int a_slot = lane & 3;
+  const int a_chunk = a_slot ^ ((lane >> 4) & 3);
+  long am0 = m0 + 16 * wave + (lane >> 2), am1 = am0 + 64;
+  am0 = am0 < g.M ? am0 : g.M - 1;
+  am1 = am1 < g.M ? am1 : g.M - 1;
+  const long lda = g.a_planes ? 32 : g.lda;
+  const float* a0 = g.A + am0 * lda + a_chunk * 4;
+  const float* a1 = g.A + am1 * lda + a_chunk * 4;
+  int wcol = n0 + (lane & 31) * 4;
+  wcol = wcol < g.N ? wcol : 0;
+  const float* w0p = g.W + (long)(2 * wave + (lane >> 5)) * g.ldw + wcol;
+  const long w_piece = 8L * g.ldw, w_chunk = (long)N3_KC * g.ldw;
+  auto stage = [&](int kc, int st) {
+    float* base = smem + st * N3_STAGE;
+    // plane mode: chunk kc is half (kc & 1) of plane kc >> 1
+    const long aoff = g.a_planes ? (long)(kc >> 1) * g.a_plane_stride + (kc & 1) * 16
+                                 : (long)kc * N3_KC;
+    __builtin_amdgcn_global_load_lds((gptr_t)(a0 + aoff), (lptr_t)(base + wave * 256), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(a1 + aoff), (lptr_t)(base + (wave + 4) * 256), 16, 0, 0);
+    const float* wp = w0p + kc * w_chunk;
+    float* wb = base + NN_TM * N3_KC;
+    __builtin_amdgcn_global_load_lds((gptr_t)wp, (lptr_t)(wb + wave * 256), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(wp + w_piece), (lptr_t)(wb + (wave + 4) * 256), 16, 0, 0);
+  };
+
+  f32x16 acc[2][2];  // [fn][fm]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = frag_zero();
+
+  stage(0, 0);
+  if (NS == 3 && nk > 1) stage(1, 1);
+  int st = 0;
+  for (int kc = 0; kc < nk; ++kc) {
+    // chunk kc landed (this wave's pieces), then everybody's; the barrier
+    // also retires every wave's reads of the stage that is refilled next
+    if (NS == 3 && kc + 1 < nk) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (NS == 3) {
+      if (kc + 2 < nk) stage(kc + 2, st >= 1 ? st - 1 : 2);  // (st + 2) % 3
+    } else {
+      if (kc + 1 < nk) stage(kc + 1, st ^ 1);
+    }
+    const float* As = smem + st * N3_STAGE;
+    const float* Bs = As + NN_TM * N3_KC;
+    f32x4 fa[2][2];
+#pragma unroll
+    for (int fm = 0; fm < 2; ++fm) {
+      const int row = wm * 64 + fm * 32 + j;
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        fa[fm][q] = *reinterpret_cast<const f32x4*>(
+            As + row * N3_KC + (((2 * q + h) ^ ((row >> 2) & 3)) << 2));
+    }
+    const float* bl = Bs + 4 * h * NN_TN + wn * 64 + j;
+    // raised priority while this wave feeds the matrix pipe: the other
+    // workgroups' waves on the SIMD do their staging / barrier work in the gaps
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int ko = (8 * (r >> 2) + (r & 3)) * NN_TN;
+      const float w0 = bl[ko], w1 = bl[ko + 32];
+      const float x0 = fa[0][r >> 2][r & 3], x1 = fa[1][r >> 2][r & 3];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, x0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, x1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, x0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, x1, acc[1][1], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    st = st == NS - 1 ? 0 : st + 1;
+  }
+  // every wave is done with the operand stages before they become the
+  // epilogue's staging tiles
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   gemm_epilogue(g, acc, smem, m0, n0, wm, wn, wave, lane);
 }
 
@@ -675,20 +797,20 @@ static int gemm_nn_launch(const float* A, long lda, int a_planes, long a_plane_s
   g.addend = addend; g.ld_add = ld_add; g.C = C; g.ldc = ldc;
   g.c_plane_stride = c_plane_stride; g.c_planes = c_planes; g.Cpre = Cpre;
   g.M = M; g.N = N; g.K = K; g.relu = relu;
-  // 256-row tiles (8 waves, the weight tile shared by twice the rows) once
-  // the grid still fills the chip; WN_NN_ROWS=128/256 overrides (experiments)
-  int rows = M >= 65536 ? 256 : 128;
-  if (const char* e = getenv("WN_NN_ROWS")) rows = atoi(e) == 256 ? 256 : 128;
-  const long tiles_m = (M + rows - 1) / rows;
+  const long tiles_m = (M + NN_TM - 1) / NN_TM;
   g.tiles_n = (N + NN_TN - 1) / NN_TN;
   const long nwg = tiles_m * g.tiles_n;
   if (nwg > 0x7fffffffL) return WN_ERR_BAD_SHAPE;
   g.nwg = (int)nwg;
-  if (rows == 256)
-    hipLaunchKernelGGL(gemm_nn_kernel<4>, dim3((unsigned)nwg), dim3(512), 0,
+  g.tiles_m = (int)tiles_m;
+  // default: three-stage LDS-DMA kernel, 3 workgroups / CU; WN_NN_MODE=tile
+  // (or K % 16 != 0): register-staged two-stage kernel
+  const char* me = getenv("WN_NN_MODE");
+  if ((me && me[0] == 't') || (K % N3_KC) != 0)
+    hipLaunchKernelGGL(gemm_nn_kernel<2>, dim3((unsigned)nwg), dim3(256), 0,
                        (hipStream_t)stream, g);
   else
-    hipLaunchKernelGGL(gemm_nn_kernel<2>, dim3((unsigned)nwg), dim3(256), 0,
+    hipLaunchKernelGGL(gemm_nn3_kernel, dim3((unsigned)nwg), dim3(256), 0,
                        (hipStream_t)stream, g);
   return wn_check_launch();
 }

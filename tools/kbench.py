@@ -49,6 +49,48 @@ def nn():
         print('nn %-6s K=%4d N=%4d: %7.1f us  %.1f TFLOP/s' % (name, K, Nn, t * 1e6, 2.0 * N * K * Nn / t / 1e12))
 
 
+def nnab():
+    """128- vs 256-row NN tiles, interleaved in one process (WN_NN_ROWS)"""
+    for rep in range(2):
+        for rows in ('128', '256'):
+            os.environ['WN_NN_ROWS'] = rows
+            print('--- WN_NN_ROWS=%s' % rows)
+            nn()
+    del os.environ['WN_NN_ROWS']
+
+
+def nnexp():
+    """A/B of WN_NN_MODE[:WN_NN_EXP] configs (KB_EXPS), interleaved per shape;
+    prints the median of 5 interleaved repetitions"""
+    N = 128000
+    for (K, Nn, planes_a, planes_c, name) in [(1600, 512, 50, 0, 'skip'), (512, 512, 0, 0, 'post1'),
+                                               (512, 256, 0, 0, 'post2'), (256, 512, 0, 0, 'dh2'),
+                                               (512, 1600, 0, 50, 'dZ')]:
+        A = torch.randn(N * K, device=dev)
+        W = torch.randn(K * Nn, device=dev)
+        C = torch.empty(N * Nn, device=dev)
+        bias = torch.randn(Nn, device=dev)
+        def f():
+            _lib.call('wn_gemm_nn', A.data_ptr(), 0 if planes_a else K, planes_a, N * 32, W.data_ptr(), Nn,
+                      bias.data_ptr(), None, 0, None, 0, C.data_ptr(), 0 if planes_c else Nn, planes_c, N * 32,
+                      None, N, Nn, K, 1, st())
+        res = {v: [] for v in sys_exp}
+        for rep in range(5):
+            for v in sys_exp:
+                os.environ['WN_NN_MODE'] = v.split(':')[0]
+                os.environ['WN_NN_EXP'] = (v.split(':') + ['0'])[1]
+                res[v].append(timeit(f, n=8, warm=2))
+        line = 'nn %-6s K=%4d N=%4d:' % (name, K, Nn)
+        for v in sys_exp:
+            t = sorted(res[v])[2]
+            line += '  %s %6.1f us %5.1f TF' % (v, t * 1e6, 2.0 * N * K * Nn / t / 1e12)
+        print(line, flush=True)
+    del os.environ['WN_NN_MODE'], os.environ['WN_NN_EXP']
+
+
+sys_exp = os.environ.get('KB_EXPS', 'tile,stream').split(',')
+
+
 def vendor():
     """vendor-library fp32 GEMM (torch.mm -> rocBLAS/hipBLASLt) on the same
     shapes, as a calibration of what 'good' is on this device (not shipped)"""

@@ -122,6 +122,8 @@ int wn_gemm_nn(const float* A, long lda, int a_planes, long a_plane_stride,
                long ldc, int c_planes, long c_plane_stride, float* Cpre,
                long M, int N, int K, int relu, void* stream);
 long wn_gemm_tn_slab_floats(int Mw, int Nw);
+/* recommended `splits` for wn_gemm_tn (grid = one resident wave of workgroups) */
+int wn_gemm_tn_splits(long rows, int Mw, int Nw, int onehot);
 int wn_gemm_tn(const float* A, long lda, int a_planes, long a_plane_stride,
                const int32_t* codes, int shift, int T, const float* G,
                long ldg, float* slabs, int splits, long rows, int Mw, int Nw,

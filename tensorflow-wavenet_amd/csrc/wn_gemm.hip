@@ -44,6 +44,10 @@ struct GemmNN {
   int tiles_m;
 };
 
+// address-space-qualified pointers of __builtin_amdgcn_global_load_lds
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
 #define NN_TM 128
 #define NN_TN 128
 #define NN_KC 32
@@ -235,9 +239,6 @@ __global__ __launch_bounds__(WMT * 128) void gemm_nn_kernel(GemmNN g) {
   // coalesced epilogue through LDS (the K loop ended with a barrier)
   gemm_epilogue(g, acc, smem, m0, n0, wm, wn, wave, lane);
 }
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
 
 // ---------------------------------------------------------------------------
 // LDS-DMA variant (the default): same 128 x 128 output tile and wave
@@ -679,6 +680,114 @@ __global__ __launch_bounds__(256, 2) void gemm_tn2_kernel(GemmTN g) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// TN, LDS-DMA variant of gemm_tn2_kernel (the default for dWs / dW1 / dW2):
+// same output tile per workgroup, but 16-row chunks staged by
+// global_load_lds_dwordx4 into two stages (no staging registers, one barrier
+// per chunk), 36 / 48 KB of LDS -> 4 / 3 workgroups per CU, s_setprio(1)
+// around the MFMA block.  Both operands are k-major in memory ([row][m],
+// [row][n]) which is what the MFMA A/B operand reads want, so the LDS image is
+// the plain [row][TM] / [row][TNW] array and a DMA piece is 1 KiB of it.
+// Needs whole 16-row chunks (rows and rows_per_split multiples of 16).
+// ---------------------------------------------------------------------------
+template <int MF, int NF>
+__global__ __launch_bounds__(256, (MF * NF >= 10 ? 2 : MF * NF > 5 ? 3 : 4)) void gemm_tn3_kernel(GemmTN g) {
+  constexpr int TM = MF * 32, TNW = 4 * NF * 32, KR = 16;
+  constexpr int STAGE = KR * TM + KR * TNW;     // floats
+  constexpr int PA = KR * TM / 256, PG = KR * TNW / 256;  // 1 KiB pieces
+  __shared__ __attribute__((aligned(1024))) float smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 31, h = lane >> 5;
+  const int tn = blockIdx.x % g.tiles_n, tm = blockIdx.x / g.tiles_n;
+  const int m0 = tm * TM, n0 = tn * TNW;
+  const long r_begin = (long)blockIdx.y * g.rows_per_split;
+  long r_end = r_begin + g.rows_per_split;
+  if (r_end > g.rows) r_end = g.rows;
+  const int nchunks = r_end > r_begin ? (int)((r_end - r_begin) / KR) : 0;
+
+  auto stage = [&](int c, int st) {
+    float* base = smem + st * STAGE;
+    const long r0 = r_begin + (long)c * KR;
+#pragma unroll
+    for (int p = wave; p < PA; p += 4) {
+      const int e = p * 256 + lane * 4;
+      const int row = e / TM, col = e - row * TM;
+      const int m = m0 + col;
+      const float* src = g.a_planes
+                             ? g.A + (long)(m >> 5) * g.a_plane_stride + (r0 + row) * 32 + (m & 31)
+                             : g.A + (r0 + row) * g.lda + m;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + p * 256), 16, 0, 0);
+    }
+    float* gb = base + KR * TM;
+#pragma unroll
+    for (int p = wave; p < PG; p += 4) {
+      const int e = p * 256 + lane * 4;
+      const int row = e / TNW, col = e - row * TNW;
+      const float* src = g.G + (r0 + row) * g.ldg + n0 + col;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(gb + p * 256), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[MF][NF];
+#pragma unroll
+  for (int a = 0; a < MF; ++a)
+#pragma unroll
+    for (int b = 0; b < NF; ++b) acc[a][b] = frag_zero();
+  float cs[NF];
+#pragma unroll
+  for (int b = 0; b < NF; ++b) cs[b] = 0.f;
+
+  if (nchunks > 0) stage(0, 0);
+  for (int c = 0; c < nchunks; ++c) {
+    const int st = c & 1;
+    // chunk c landed for every wave; all reads of the other stage retired
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (c + 1 < nchunks) stage(c + 1, st ^ 1);
+    const float* al = smem + st * STAGE + h * TM + i;
+    const float* gl = smem + st * STAGE + KR * TM + h * TNW + wave * (NF * 32) + i;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s = 0; s < KR / 2; ++s) {
+      float av[MF], bv[NF];
+#pragma unroll
+      for (int a = 0; a < MF; ++a) av[a] = al[2 * s * TM + a * 32];
+#pragma unroll
+      for (int b = 0; b < NF; ++b) {
+        bv[b] = gl[2 * s * TNW + b * 32];
+        cs[b] += bv[b];
+      }
+#pragma unroll
+      for (int a = 0; a < MF; ++a)
+#pragma unroll
+        for (int b = 0; b < NF; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  }
+
+  float* slab = g.slabs + (long)blockIdx.y * g.slab_stride;
+#pragma unroll
+  for (int a = 0; a < MF; ++a)
+#pragma unroll
+    for (int b = 0; b < NF; ++b) {
+      const int n = n0 + wave * (NF * 32) + b * 32 + i;
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const int m = m0 + a * 32 + 8 * (rr >> 2) + 4 * h + (rr & 3);
+        slab[(long)m * g.Nw + n] = acc[a][b][rr];
+      }
+    }
+  if (g.want_colsum && tm == 0) {
+#pragma unroll
+    for (int b = 0; b < NF; ++b) {
+      float v = cs[b] + __shfl_xor(cs[b], 32);
+      const int n = n0 + wave * (NF * 32) + b * 32 + i;
+      if (h == 0) slab[(long)g.Mw * g.Nw + n] = v;
+    }
+  }
+}
+
 // out[b][rep][e] = sum_s slabs[b][s][offset + e]   (fixed order over s)
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs,
                                     int num_slabs, long slab_stride,
@@ -828,6 +937,53 @@ int wn_gemm_nn(const float* A, long lda, int a_planes, long a_plane_stride,
 // Number of floats one slab needs for wn_gemm_tn.
 long wn_gemm_tn_slab_floats(int Mw, int Nw) { return (long)Mw * Nw + Nw; }
 
+static int tn_device_cus() {
+  static int cus = 0;  // read-only after the first call
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) !=
+            hipSuccess || n <= 0)
+      n = 256;
+    cus = n;
+  }
+  return cus;
+}
+
+// Workgroup-tile shape of the LDS-staged TN kernels for an output, or false.
+static bool tn_wg_tile(int Mw, int Nw, int* mf, int* nf) {
+  int m = 0, n = 0;
+  if (Nw % 256 == 0) n = 2; else if (Nw % 128 == 0) n = 1;
+  if (Mw % 160 == 0) m = 5; else if (Mw % 128 == 0) m = 4;
+  if (m == 5 && n == 2) n = 1;  // <5,2>: 160 accumulators, 2 waves / SIMD
+  *mf = m; *nf = n;
+  return m && n;
+}
+
+// Recommended split count: the grid (tiles x splits) should fill the CUs'
+// resident-workgroup capacity exactly once (measured: 768 / 1000 workgroups
+// for dW1 / dWs run 129-130 TFLOP/s, 1.33 x that capacity 98); every extra
+// split also costs a slab write + read.
+int wn_gemm_tn_splits(long rows, int Mw, int Nw, int onehot) {
+  if (rows <= 0 || Mw <= 0 || Nw <= 0) return 1;
+  int mf, nf;
+  long s;
+  if (!onehot && tn_wg_tile(Mw, Nw, &mf, &nf)) {
+    const int tiles = (Mw / (mf * 32)) * (Nw / (4 * nf * 32));
+    const int occ = mf * nf > 5 ? 3 : 4;
+    s = (long)occ * tn_device_cus() / tiles;
+  } else {
+    const int m32 = (Mw + 31) / 32, n32 = (Nw + 31) / 32;
+    int f = (n32 % 2 == 0) ? 2 : 1, e;
+    if (onehot) { f = 1; e = (m32 % 2 == 0) ? 2 : 1; }
+    else e = m32 % 5 == 0 ? 5 : m32 % 4 == 0 ? 4 : m32 % 2 == 0 ? 2 : 1;
+    const int wtiles = ((m32 + e - 1) / e) * ((n32 + f - 1) / f);
+    s = (onehot ? 256 : 1024) / ((wtiles + 3) / 4);
+  }
+  if (s > rows / 64) s = rows / 64;
+  return (int)(s < 1 ? 1 : s);
+}
+
 int wn_gemm_tn(const float* A, long lda, int a_planes, long a_plane_stride,
                const int32_t* codes, int shift, int T, const float* G,
                long ldg, float* slabs, int splits, long rows, int Mw, int Nw,
@@ -851,15 +1007,20 @@ int wn_gemm_tn(const float* A, long lda, int a_planes, long a_plane_stride,
   if (!codes && (lda % 4 == 0) && (ldg % 4 == 0) && wn_aligned16(A) &&
       wn_aligned16(G)) {
     int mf2 = 0, nf2 = 0;
-    if (Nw % 256 == 0) nf2 = 2; else if (Nw % 128 == 0) nf2 = 1;
-    if (Mw % 160 == 0) mf2 = 5; else if (Mw % 128 == 0) mf2 = 4;
-    if (mf2 == 5 && nf2 == 2) nf2 = 1;  // <5,2> needs > 256 VGPRs: spills
+    tn_wg_tile(Mw, Nw, &mf2, &nf2);
     if (mf2 && nf2) {
       g.tiles_m = Mw / (mf2 * 32);
       g.tiles_n = Nw / (4 * nf2 * 32);
       dim3 grid2(g.tiles_m * g.tiles_n, splits), block2(256);
-#define LAUNCH2(mf, nf) \
-  hipLaunchKernelGGL((gemm_tn2_kernel<mf, nf>), grid2, block2, 0, s, g)
+      // LDS-DMA kernel when every split is whole 16-row chunks
+      // (WN_TN_MODE=reg selects the register-staged kernel)
+      const char* tme = getenv("WN_TN_MODE");
+      const bool dma = (rows % 16 == 0) && !(tme && tme[0] == 'r');
+#define LAUNCH2(mf, nf)                                                          \
+  do {                                                                           \
+    if (dma) hipLaunchKernelGGL((gemm_tn3_kernel<mf, nf>), grid2, block2, 0, s, g); \
+    else hipLaunchKernelGGL((gemm_tn2_kernel<mf, nf>), grid2, block2, 0, s, g);  \
+  } while (0)
       if (mf2 == 5 && nf2 == 2) LAUNCH2(5, 2);
       else if (mf2 == 5) LAUNCH2(5, 1);
       else if (nf2 == 2) LAUNCH2(4, 2);

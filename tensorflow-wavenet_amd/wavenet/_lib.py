@@ -46,6 +46,7 @@ SIGNATURES = {
                            P, c_long, P, c_long, c_int, c_long, P, c_long,
                            c_int, c_int, c_int, P]),
     'wn_gemm_tn_slab_floats': (c_long, [c_int, c_int]),
+    'wn_gemm_tn_splits': (c_int, [c_long, c_int, c_int, c_int]),
     'wn_gemm_tn': (c_int, [P, c_long, c_int, c_long, P, c_int, c_int, P,
                            c_long, P, c_int, c_long, c_int, c_int, c_int, P]),
     'wn_reduce_slabs': (c_int, [P, c_int, c_long, c_int, c_long, c_long,

@@ -47,23 +47,6 @@ def _xavier_(t, gen):
     t.copy_(vals.to(t.device))
 
 
-def _tn_tiles(mw, nw, onehot=False):
-    """wave tiles of wn_gemm_tn (mirrors the selection in csrc/wn_gemm.hip)"""
-    m32, n32 = (mw + 31) // 32, (nw + 31) // 32
-    nf = 2 if n32 % 2 == 0 else 1
-    mf = 5 if m32 % 5 == 0 else 4 if m32 % 4 == 0 else 2 if m32 % 2 == 0 else 1
-    if onehot:
-        nf, mf = 1, (2 if m32 % 2 == 0 else 1)
-    return ((m32 + mf - 1) // mf) * ((n32 + nf - 1) // nf)
-
-
-def _tn_splits(rows, mw, nw, target_wgs=1024, onehot=False):
-    wgs = (_tn_tiles(mw, nw, onehot) + 3) // 4
-    s = max(1, target_wgs // wgs)
-    s = min(s, max(1, rows // 64))
-    return int(s)
-
-
 class _Workspace(object):
     """Caller-owned device buffers for one (B, T) shape (the library never
     allocates).  Sized for 288 GB HBM: everything stays resident.  A workspace
@@ -127,8 +110,7 @@ class _Workspace(object):
         self.splits = {}
         for key, (mw, nw) in dict(post2=(S, Q), post1=(S, S), skip=(L * CH, S),
                                   causal=(Q, CH)).items():
-            sp = _tn_splits(N, mw, nw, 256 if key == 'causal' else 1024,
-                            onehot=(key == 'causal'))
+            sp = lib.wn_gemm_tn_splits(N, mw, nw, 1 if key == 'causal' else 0)
             self.splits[key] = sp
             need = max(need, sp * lib.wn_gemm_tn_slab_floats(mw, nw))
         need = max(need, 256 * 32 * CH)          # scalar-input causal wgrad

@@ -110,17 +110,31 @@ def vendor():
 
 
 def tn():
+    """weight-gradient GEMMs; WN_TN_MODE variants (KB_TN, default 'reg,dma')
+    interleaved, median of 5; splits as the model picks them and a few more"""
     N = 128000
-    for (Mw, Nw, planes, name, sp) in [(1600, 512, 50, 'dWs', 64), (512, 512, 0, 'dW1', 128), (512, 256, 0, 'dW2', 256)]:
+    modes = os.environ.get('KB_TN', 'reg,dma').split(',')
+    for (Mw, Nw, planes, name, sps) in [(1600, 512, 50, 'dWs', (13, 19, 25, 38, 51)), (512, 512, 0, 'dW1', (32, 48, 64, 96, 128)),
+                                        (512, 256, 0, 'dW2', (64, 96, 128, 192))]:
         A = torch.randn(N * Mw, device=dev)
         G = torch.randn(N * Nw, device=dev)
         sl = lib.wn_gemm_tn_slab_floats(Mw, Nw)
-        slabs = torch.empty(sp * sl, device=dev)
-        def f():
-            _lib.call('wn_gemm_tn', A.data_ptr(), 0 if planes else Mw, planes, N * 32, None, 0, 16000, G.data_ptr(),
-                      Nw, slabs.data_ptr(), sp, N, Mw, Nw, 1, st())
-        t = timeit(f)
-        print('tn %-4s %dx%d splits=%d: %7.1f us  %.1f TFLOP/s' % (name, Mw, Nw, sp, t * 1e6, 2.0 * N * Mw * Nw / t / 1e12))
+        for sp in sps:
+            slabs = torch.empty(sp * sl, device=dev)
+            def f():
+                _lib.call('wn_gemm_tn', A.data_ptr(), 0 if planes else Mw, planes, N * 32, None, 0, 16000,
+                          G.data_ptr(), Nw, slabs.data_ptr(), sp, N, Mw, Nw, 1, st())
+            res = {m: [] for m in modes}
+            for rep in range(5):
+                for m in modes:
+                    os.environ['WN_TN_MODE'] = m
+                    res[m].append(timeit(f, n=6, warm=2))
+            line = 'tn %-4s %dx%d splits=%3d:' % (name, Mw, Nw, sp)
+            for m in modes:
+                t = sorted(res[m])[2]
+                line += '  %s %7.1f us %5.1f TF' % (m, t * 1e6, 2.0 * N * Mw * Nw / t / 1e12)
+            print(line, flush=True)
+    del os.environ['WN_TN_MODE']
 
 
 def layer():

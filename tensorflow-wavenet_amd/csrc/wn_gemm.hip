@@ -699,9 +699,16 @@ __global__ __launch_bounds__(256, (MF * NF >= 10 ? 2 : MF * NF > 5 ? 3 : 4)) voi
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 31, h = lane >> 5;
-  const int tn = blockIdx.x % g.tiles_n, tm = blockIdx.x / g.tiles_n;
+  // XCD-aware order: the tiles of one split (same rows of A and G) are given
+  // to blocks of the SAME XCD (contiguous logical ids per XCD), so each operand
+  // chunk is fetched from HBM once per XCD instead of once per tile
+  // (measured 4.1 GB -> see DESIGN.md per dWs launch before the remap).
+  const int ntile = gridDim.x;
+  const int logical = xcd_remap(blockIdx.x + ntile * blockIdx.y, ntile * gridDim.y);
+  const int tile = logical % ntile, split = logical / ntile;
+  const int tn = tile % g.tiles_n, tm = tile / g.tiles_n;
   const int m0 = tm * TM, n0 = tn * TNW;
-  const long r_begin = (long)blockIdx.y * g.rows_per_split;
+  const long r_begin = (long)split * g.rows_per_split;
   long r_end = r_begin + g.rows_per_split;
   if (r_end > g.rows) r_end = g.rows;
   const int nchunks = r_end > r_begin ? (int)((r_end - r_begin) / KR) : 0;
@@ -766,7 +773,7 @@ __global__ __launch_bounds__(256, (MF * NF >= 10 ? 2 : MF * NF > 5 ? 3 : 4)) voi
     __builtin_amdgcn_s_setprio(0);
   }
 
-  float* slab = g.slabs + (long)blockIdx.y * g.slab_stride;
+  float* slab = g.slabs + (long)split * g.slab_stride;
 #pragma unroll
   for (int a = 0; a < MF; ++a)
 #pragma unroll

@@ -148,14 +148,15 @@ def layer():
     for d in (1, 64, 512):
         t = timeit(lambda: _lib.call('wn_layer_fwd', x.data_ptr(), xo.data_ptr(), z.data_ptr(), th.data_ptr(),
                                      sg.data_ptr(), w.data_ptr(), None, 0, B, T, d, 1, 1, st()), n=20)
-        print('layer_fwd d=%3d: %6.1f us  (%.2f TB/s of 640 B/sample)' % (d, t * 1e6, N * 640 / t / 1e12))
-        t = timeit(lambda: _lib.call('wn_layer_bwd', f.data_ptr(), g.data_ptr(), dx.data_ptr(), dxo.data_ptr(),
-                                     w.data_ptr(), dz.data_ptr(), th.data_ptr(), sg.data_ptr(), w.data_ptr(),
-                                     f2.data_ptr(), g2.data_ptr(), B, T, d, 1, 1, st()), n=20)
-        print('layer_bwd d=%3d: %6.1f us  (%.2f TB/s of 1152 B/sample)' % (d, t * 1e6, N * 1152 / t / 1e12))
-        t = timeit(lambda: _lib.call('wn_layer_wgrad', x.data_ptr(), f.data_ptr(), g.data_ptr(), z.data_ptr(),
-                                     dx.data_ptr(), slabs.data_ptr(), nslab, B, T, d, st()), n=20)
-        print('layer_wgrad d=%3d: %6.1f us  (%.2f TB/s of 640 B/sample)' % (d, t * 1e6, N * 640 / t / 1e12))
+        print('layer_fwd d=%3d: %6.1f us' % (d, t * 1e6), flush=True)
+    nsl = lib.wn_layer_bwdw_slabs(B, T)
+    slabs2 = torch.empty(max(nsl, 1) * 5216, device=dev)
+    for d in (1, 64, 512):
+        t = timeit(lambda: _lib.call('wn_layer_bwdw', x.data_ptr(), z.data_ptr(), f.data_ptr(), g.data_ptr(),
+                                     dx.data_ptr(), dxo.data_ptr(), w.data_ptr(), dz.data_ptr(), th.data_ptr(),
+                                     sg.data_ptr(), w.data_ptr(), f2.data_ptr(), g2.data_ptr(), slabs2.data_ptr(),
+                                     B, T, d, 1, st()), n=20)
+        print('layer_bwdw d=%3d: %6.1f us' % (d, t * 1e6), flush=True)
 
 
 def nnsmall():

@@ -16,7 +16,8 @@ def dev(a):
 
 @pytest.mark.parametrize('kind', ['nn'])
 @pytest.mark.parametrize('M,N,K', [(1, 4, 4), (37, 16, 16), (300, 132, 68),
-                                   (5000, 256, 512), (129, 512, 96)])
+                                   (5000, 256, 512), (129, 512, 96),
+                                   (256, 200, 64), (1031, 1600, 32)])
 def test_gemm_dense_epilogues(hip_lib, kind, M, N, K):
     from wavenet import _lib
     rng = np.random.default_rng(M + N + K)
@@ -82,7 +83,11 @@ def test_gemm_plane_operands(hip_lib, kind):
 
 @pytest.mark.parametrize('rows,Mw,Nw,splits', [(100, 32, 32, 3), (1000, 64, 96, 7),
                                                (5000, 160, 128, 9), (3333, 512, 256, 5),
-                                               (777, 96, 64, 1)])
+                                               (777, 96, 64, 1),
+                                               # whole 16-row chunks: LDS-DMA kernel
+                                               (4800, 160, 128, 9), (3328, 512, 256, 5),
+                                               (2048, 512, 512, 3), (1600, 128, 128, 40),
+                                               (96, 160, 256, 2)])
 def test_gemm_tn_and_reduce(hip_lib, rows, Mw, Nw, splits):
     from wavenet import _lib
     lib = hip_lib
@@ -106,6 +111,43 @@ def test_gemm_tn_and_reduce(hip_lib, rows, Mw, Nw, splits):
     assert np.abs(out.cpu().numpy().reshape(Mw, Nw) - ref).max() < \
         1e-4 * max(1.0, np.abs(ref).max())
     assert np.abs(cs.cpu().numpy() - G.astype(np.float64).sum(0)).max() < 1e-2
+
+
+def test_gemm_tn_plane_operand(hip_lib):
+    """A given as [P][rows][32] planes (dWs = Z^T dtotal), both TN kernels
+    (rows % 16 == 0 -> LDS-DMA, else register-staged)."""
+    from wavenet import _lib
+    lib = hip_lib
+    rng = np.random.default_rng(11)
+    for rows, splits in ((1600, 6), (1000, 4)):
+        P, Nw = 5, 128
+        Ap = rng.standard_normal((P, rows, 32)).astype(np.float32)
+        G = rng.standard_normal((rows, Nw)).astype(np.float32)
+        A = Ap.transpose(1, 0, 2).reshape(rows, P * 32)
+        sl = lib.wn_gemm_tn_slab_floats(P * 32, Nw)
+        slabs = torch.zeros(splits * sl, device='cuda')
+        out = torch.empty(P * 32 * Nw, device='cuda')
+        st = torch.cuda.current_stream().cuda_stream
+        dA, dG = dev(Ap), dev(G)
+        _lib.call('wn_gemm_tn', dA.data_ptr(), 0, P, rows * 32, None, 0, 1,
+                  dG.data_ptr(), Nw, slabs.data_ptr(), splits, rows, P * 32,
+                  Nw, 1, st)
+        _lib.call('wn_reduce_slabs', slabs.data_ptr(), splits, sl, 1, 0, 0,
+                  P * 32 * Nw, out.data_ptr(), 0, 1, 0, st)
+        ref = A.astype(np.float64).T @ G.astype(np.float64)
+        assert np.abs(out.cpu().numpy().reshape(P * 32, Nw) - ref).max() < \
+            1e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_gemm_tn_splits_policy(hip_lib):
+    """wn_gemm_tn_splits: >= 1, never more than rows / 64, and a grid of at
+    most one resident wave of workgroups for the LDS-staged shapes."""
+    lib = hip_lib
+    assert lib.wn_gemm_tn_splits(128000, 1600, 512, 0) in range(1, 2001)
+    assert lib.wn_gemm_tn_splits(64, 512, 512, 0) == 1
+    assert lib.wn_gemm_tn_splits(100, 256, 32, 1) == 1
+    assert lib.wn_gemm_tn_splits(128000, 512, 512, 0) * 8 <= 4 * 304
+    assert lib.wn_gemm_tn_splits(0, 512, 512, 0) == 1
 
 
 def test_gemm_tn_one_hot(hip_lib):

@@ -115,6 +115,38 @@ def pmc_traffic(kernel):
         return None
 
 
+def secondary(net, audio, gc_ids, kw, B, T, gen_samples=4000):
+    """SURVEY 8(d) secondary figures (rank 0, N = 1, after the timed region):
+    forward-only samples/s on the same batch, and fast generation
+    (BASELINE.json configs[4]: batch 1, seed 128, temperature 1)."""
+    from wavenet import WaveNetModel
+    for _ in range(2):
+        net.loss(audio, gc_ids, backward=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        net.loss(audio, gc_ids, backward=False)
+    torch.cuda.synchronize()
+    fwd = B * T * 10 / (time.perf_counter() - t0)
+    log('forward only: %.0f samples/s' % fwd)
+    kw1 = dict(kw)
+    kw1['batch_size'] = 1
+    gen = WaveNetModel(seed=0, **kw1)
+    gc = 5 if kw.get('global_condition_channels') else None
+    gen.generate(200, seed_samples=[128], seed=1, global_condition=gc)  # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    gen.generate(gen_samples, seed_samples=[128], temperature=1.0, seed=2,
+                 global_condition=gc)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    log('fast generation: %.0f samples/s' % (gen_samples / dt))
+    return {'forward_only_samples_per_s': fwd,
+            'fastgen_samples_per_s': gen_samples / dt,
+            'fastgen_us_per_sample': dt / gen_samples * 1e6,
+            'fastgen_samples': gen_samples}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -125,6 +157,8 @@ def main():
     ap.add_argument('--gc', action='store_true',
                     help='config[3]: global conditioning 32 x 377')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true',
+                    help='skip the forward-only and fast-generation figures')
     args = ap.parse_args()
 
     from wavenet import WaveNetModel, optimizer_factory, parallel
@@ -231,6 +265,8 @@ def main():
                      'avg_launch_us': ktime / max(nlaunch, 1) * 1e6,
                      'flops_per_step': flops / max(args.steps, 1)},
     }
+    if world == 1 and not args.no_secondary:
+        out['secondary'] = secondary(net, audio, gc_ids, kw, B, T)
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(params, T)
         out['gpu_over_cpu'] = value / out['cpu_baseline']['value']

@@ -187,6 +187,9 @@ class WaveNetModel(object):
         # hipGraph, instead of the single-workgroup persistent kernel
         self.fastgen_multi_cu = True
         self.fastgen_graph_steps = 200
+        # seeds longer than this are primed from ONE batch forward pass
+        # instead of one incremental step per seed sample
+        self.fastgen_prime_forward_min = 64
 
         _lib.load()
         if device is None:
@@ -990,12 +993,56 @@ class WaveNetModel(object):
         if pe > 0:
             proba = torch.empty(((n_steps + pe - 1) // pe, self.Q),
                                 dtype=torch.float32, device=self.device)
-        if n_steps > 0:
+        if pe == 0 and n_given - 1 >= self.fastgen_prime_forward_min and \
+                int(num_samples) > 0:
+            # the reference's own TODO (generate.py:199-201): fill the queues
+            # from a forward pass over the seed instead of stepping through it
+            self.prime_generator(io[:n_given - 1], global_condition)
+            io2 = io[n_given - 1:].clone()     # [last seed | generated ...]
+            self._gen_run(io2, 1, int(num_samples), temperature, seed, None,
+                          1, global_condition, multi_cu=self.fastgen_multi_cu)
+            io[n_given - 1:] = io2
+        elif n_steps > 0:
             self._gen_run(io, n_given, n_steps, temperature, seed, proba,
                           pe if pe > 0 else 1, global_condition,
                           multi_cu=self.fastgen_multi_cu)
         out = io[:n_given + int(num_samples)]
         return (out, proba) if pe > 0 else out
+
+    def prime_generator(self, codes, global_condition=None):
+        """Set the incremental-generation queues to the state they have after
+        `codes` were pushed one by one from a fresh `reset_generator()`, using
+        ONE batch forward pass: layer l's queue (capacity d_l) holds the last
+        d_l inputs x_l[t] of that layer (model.py:473-484), which are rows of
+        the forward pass's per-layer activation planes."""
+        if self.filter_width > 2 or self.scalar_input:
+            raise NotImplementedError('fast generation needs filter_width 2 '
+                                      'and one-hot input')
+        self._check_supported()
+        g = self._generator(global_condition)
+        self._gen_reset()
+        w = torch.as_tensor(codes).to(device=self.device,
+                                      dtype=torch.int32).reshape(-1)
+        n0 = int(w.numel())
+        if n0 == 0:
+            return
+        ws = self._workspace(1, n0, False)
+        ws.q.copy_(w)
+        ids = self._gc_ids(global_condition, 1)
+        self._forward(ws, ids, save_ts=False)
+        src, dst, roff = [], [], 0
+        for l, d in enumerate(self.dilations):
+            t = np.arange(max(0, n0 - d), n0, dtype=np.int64)
+            src.append(l * n0 + t)
+            dst.append(roff + t % d)
+            roff += d
+        src = torch.from_numpy(np.concatenate(src)).to(self.device)
+        dst = torch.from_numpy(np.concatenate(dst)).to(self.device)
+        X = ws.X.reshape(-1, CH)[:self.L * n0]
+        g['state'].view(-1, CH).index_copy_(0, dst, X.index_select(0, src))
+        g['cursors'][0] = n0
+        g['cursors'][1:2].copy_(w[-1:])
+        g['steps'] = n0
 
     def continue_generation(self, num_samples, last_sample, temperature=1.0,
                             global_condition=None, seed=0):

@@ -273,6 +273,42 @@ def test_generate_sampling(hip_lib, multi):
             p[g[i + 1]] > 0.999 * p.max()
 
 
+@pytest.mark.parametrize('n0', [5, 40, 150])
+def test_prime_generator_from_forward_pass(hip_lib, n0):
+    """prime_generator (one batch forward pass; the reference's TODO at
+    generate.py:199-201) leaves the queues in the state that n0 incremental
+    pushes produce: same ring contents, cursor, and next-step distribution;
+    also against the float64 oracle.  n0 below / above the largest dilation
+    and the receptive field."""
+    cfg = cfg_with(MID, batch_size=1)
+    net, var = build_pair(cfg)
+    rng = np.random.default_rng(n0)
+    codes = rng.integers(0, cfg['quantization_channels'], n0).astype(np.int32)
+    nxt = int(rng.integers(0, cfg['quantization_channels']))
+    net.reset_generator()
+    for c in codes:
+        net.predict_proba_incremental(int(c))
+    st_ref = net._gen['state'].clone()
+    cur_ref = net._gen['cursors'].clone()
+    p_ref = net.predict_proba_incremental(nxt, push=False).cpu().numpy()
+    net.prime_generator(codes)
+    assert torch.equal(net._gen['cursors'], cur_ref)
+    assert (net._gen['state'] - st_ref).abs().max().item() < 1e-5
+    p = net.predict_proba_incremental(nxt, push=False).cpu().numpy()
+    assert np.abs(p - p_ref).max() < 1e-5
+    gen = O.IncrementalGenerator(cfg, var, dtype=np.float64)
+    for c in codes:
+        gen.step(int(c))
+    assert np.abs(p - gen.step(nxt)).max() < 1e-5
+    # generate() with a long seed takes the forward-priming path and still
+    # returns seed + drawn samples, deterministically
+    net.fastgen_prime_forward_min = 16
+    a = net.generate(30, seed_samples=codes, seed=3).cpu().numpy()
+    b = net.generate(30, seed_samples=codes, seed=3).cpu().numpy()
+    assert a.shape == (n0 + 30,) and np.array_equal(a[:n0], codes)
+    assert np.array_equal(a, b)
+
+
 def test_unsupported_configs_raise(hip_lib):
     from wavenet import WaveNetModel
     for kw in (dict(filter_width=9), dict(residual_channels=64),

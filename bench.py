@@ -157,6 +157,9 @@ def main():
     ap.add_argument('--gc', action='store_true',
                     help='config[3]: global conditioning 32 x 377')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--gemm-mode', default='fp32',
+                    choices=['fp32', 'bf16x3', 'bf16x6', 'bf16x9'],
+                    help='opt-in split-bf16 NN GEMMs (default: fp32 MFMA)')
     ap.add_argument('--no-secondary', action='store_true',
                     help='skip the forward-only and fast-generation figures')
     args = ap.parse_args()
@@ -194,6 +197,7 @@ def main():
         gc_ids = torch.tensor([(37 * (rank * B + b)) % 377 for b in range(B)],
                               dtype=torch.int32, device=dev)
     net = WaveNetModel(seed=0, **kw)
+    net.gemm_mode = args.gemm_mode
     if os.environ.get('WN_FUSED_BWD') is not None:       # A/B knob
         net.fused_bwd = os.environ['WN_FUSED_BWD'] == '1'
     if os.environ.get('WN_OVERLAP_WGRAD') is not None:   # A/B knob
@@ -240,12 +244,17 @@ def main():
     ktime = sum(e[0].elapsed_time(e[1]) for e in events) * 1e-3
     achieved = flops / ktime / 1e12 if ktime > 0 else 0.0
     nlaunch = len(events)
+    peak = FP32_MFMA_PEAK_TFLOPS if args.gemm_mode == 'fp32' else \
+        2500.0 / int(args.gemm_mode[-1])
     out = {
         'metric': 'audio samples/sec (train, default wavenet_params.json)',
         'value': value, 'unit': 'audio samples/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+        'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32' if args.gemm_mode == 'fp32' else
+                 'f32 (NN GEMM products rebuilt from %s split pieces on bf16 '
+                 'MFMA, fp32 accumulate; opt-in)' % args.gemm_mode,
         'data': 'synthetic',
         'config': {'workload': 'default wavenet_params.json stack (50 dilation '
                                'layers, R=D=32, S=512, Q=256), full training '
@@ -256,9 +265,14 @@ def main():
                    'global_batch': world * B,
                    'parallelism': 'dp%d' % world,
                    'final_loss': float(loss)},
-        'roofline': {'bound': 'mfma', 'kernel': 'gemm_nn3_kernel',
-                     'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS,
-                     'unit': 'TFLOP/s', 'frac': achieved / FP32_MFMA_PEAK_TFLOPS,
+        'roofline': {'bound': 'mfma',
+                     'kernel': 'gemm_nn3_kernel' if args.gemm_mode == 'fp32'
+                     else 'gemm_nn_split_kernel',
+                     'achieved': achieved, 'peak': peak,
+                     'unit': 'TFLOP/s' if args.gemm_mode == 'fp32' else
+                             'TFLOP/s (fp32-equivalent; peak = bf16 dense '
+                             '2500 / piece products)',
+                     'frac': achieved / peak,
                      'traffic': pmc_traffic('gemm_nn3_kernel'),
                      'traffic_unit': 'bytes per launch (rocprofv3 PMC pass)',
                      'launches_per_step': nlaunch // max(args.steps, 1),

@@ -121,6 +121,19 @@ int wn_gemm_nn(const float* A, long lda, int a_planes, long a_plane_stride,
                long ld_mask, const float* addend, long ld_add, float* C,
                long ldc, int c_planes, long c_plane_stride, float* Cpre,
                long M, int N, int K, int relu, void* stream);
+/* opt-in: same contraction with fp32 accuracy rebuilt from bf16 matrix
+ * instructions (every operand split exactly into three bf16 pieces, nprod =
+ * 3 / 6 / 9 piece products; 6 is as accurate as the fp32 MFMA path).
+ * w_scratch: wn_gemm_split_w_bytes(K, N) bytes, caller-owned.  Not used unless
+ * the host asks for it (WaveNetModel.gemm_mode). */
+long wn_gemm_split_w_bytes(int K, int N);
+int wn_gemm_nn_split(const float* A, long lda, int a_planes,
+                     long a_plane_stride, const float* W, int ldw,
+                     const float* bias, const float* mask, long ld_mask,
+                     const float* addend, long ld_add, float* C, long ldc,
+                     int c_planes, long c_plane_stride, float* Cpre, long M,
+                     int N, int K, int relu, void* w_scratch, int nprod,
+                     void* stream);
 long wn_gemm_tn_slab_floats(int Mw, int Nw);
 /* recommended `splits` for wn_gemm_tn (grid = one resident wave of workgroups) */
 int wn_gemm_tn_splits(long rows, int Mw, int Nw, int onehot);

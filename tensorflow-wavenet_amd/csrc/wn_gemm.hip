@@ -264,8 +264,66 @@ __global__ __launch_bounds__(WMT * 128) void gemm_nn_kernel(GemmNN g) {
 #define N3_KC 16
 #define N3_STAGE (NN_TM * N3_KC + N3_KC * NN_TN)   // floats per stage
 
+// fp32 accuracy from bf16 matrix instructions (opt-in, WN_GEMM_MODE=bf16x6 /
+// bf16x9 / bf16x3): every fp32 operand is split EXACTLY into three bf16 pieces
+// x = x1 + x2 + x3 (8 + 8 + 8 significant bits, by truncation: two AND, two
+// exact SUB), and the fp32 product is rebuilt from piecewise products on
+// v_mfma_f32_32x32x16_bf16 (exact 16-bit products, fp32 accumulation):
+//   x6: x1y1 + x1y2 + x2y1 + x1y3 + x3y1 + x2y2   (dropped terms <= 3 * 2^-24 |xy|)
+//   x9: all nine (error-free products);  x3: x1y1 + x1y2 + x2y1 (~2^-16 |xy|).
+// The bf16 instruction does 8x the MACs of v_mfma_f32_32x32x2_f32 in half the
+// cycles, so x6 costs 6/16 of the fp32 MFMA time plus ~5.5 VALU per element.
+// NOT the default: BASELINE's configuration names fp32 arithmetic, and this
+// changes the summation order and the instruction class.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct Split3 {
+  bf16x8 p[3];  // high, middle, low pieces of 8 consecutive-k values
+};
+
+__device__ __forceinline__ Split3 split3(const float (&v)[8]) {
+  unsigned int hi[8], mi[8], lo[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const unsigned int u = __float_as_uint(v[e]) & 0xffff0000u;
+    const float r = v[e] - __uint_as_float(u);           // exact
+    const unsigned int m = __float_as_uint(r) & 0xffff0000u;
+    const float r2 = r - __uint_as_float(m);              // exact, <= 8 bits
+    hi[e] = u;
+    mi[e] = m;
+    lo[e] = __float_as_uint(r2);
+  }
+  Split3 s;
+  u32x4 ph, pm, pl;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {  // pack the top halves of two floats
+    ph[w] = __builtin_amdgcn_perm(hi[2 * w + 1], hi[2 * w], 0x07060302u);
+    pm[w] = __builtin_amdgcn_perm(mi[2 * w + 1], mi[2 * w], 0x07060302u);
+    pl[w] = __builtin_amdgcn_perm(lo[2 * w + 1], lo[2 * w], 0x07060302u);
+  }
+  s.p[0] = __builtin_bit_cast(bf16x8, ph);
+  s.p[1] = __builtin_bit_cast(bf16x8, pm);
+  s.p[2] = __builtin_bit_cast(bf16x8, pl);
+  return s;
+}
+
+// acc += A (rows on lanes) * B (columns on lanes) with NPROD piece products,
+// smallest terms first
+template <int NPROD>
+__device__ __forceinline__ void mma_split(f32x16& acc, const Split3& a, const Split3& b) {
+#define WN_MM(i, k) \
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[i], b.p[k], acc, 0, 0, 0)
+  if (NPROD >= 9) { WN_MM(2, 2); WN_MM(1, 2); WN_MM(2, 1); }
+  if (NPROD >= 6) { WN_MM(1, 1); WN_MM(0, 2); WN_MM(2, 0); }
+  WN_MM(0, 1);
+  WN_MM(1, 0);
+  WN_MM(0, 0);
+#undef WN_MM
+}
+
 __global__ __launch_bounds__(256, 4) void gemm_nn3_kernel(GemmNN g) {
-  constexpr int NS = 2;  // LDS stages (3 = DMA two chunks ahead: measured equal or slower)
+  constexpr int NS = 2;  // LDS stages (3 with a counted vmcnt: measured equal or slower)
   constexpr int LDSF = NS * N3_STAGE > 4 * 32 * EP_LD ? NS * N3_STAGE : 4 * 32 * EP_LD;
   __shared__ __attribute__((aligned(1024))) float smem[LDSF];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -313,18 +371,12 @@ __global__ __launch_bounds__(256, 4) void gemm_nn3_kernel(GemmNN g) {
     for (int b = 0; b < 2; ++b) acc[a][b] = frag_zero();
 
   stage(0, 0);
-  if (NS == 3 && nk > 1) stage(1, 1);
   int st = 0;
   for (int kc = 0; kc < nk; ++kc) {
     // chunk kc landed (this wave's pieces), then everybody's; the barrier
     // also retires every wave's reads of the stage that is refilled next
-    if (NS == 3 && kc + 1 < nk) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    if (NS == 3) {
-      if (kc + 2 < nk) stage(kc + 2, st >= 1 ? st - 1 : 2);  // (st + 2) % 3
-    } else {
-      if (kc + 1 < nk) stage(kc + 1, st ^ 1);
-    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (kc + 1 < nk) stage(kc + 1, st ^ 1);
     const float* As = smem + st * N3_STAGE;
     const float* Bs = As + NN_TM * N3_KC;
     f32x4 fa[2][2];
@@ -351,10 +403,135 @@ __global__ __launch_bounds__(256, 4) void gemm_nn3_kernel(GemmNN g) {
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, x1, acc[1][1], 0, 0, 0);
     }
     __builtin_amdgcn_s_setprio(0);
-    st = st == NS - 1 ? 0 : st + 1;
+    st ^= 1;
   }
   // every wave is done with the operand stages before they become the
   // epilogue's staging tiles
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  gemm_epilogue(g, acc, smem, m0, n0, wm, wn, wave, lane);
+}
+
+// ---------------------------------------------------------------------------
+// Split-bf16 NN GEMM (wn_gemm_nn_split): same tile / staging structure as
+// gemm_nn3_kernel.  The weights are split ONCE per call by split_w_kernel
+// into MFMA-fragment order ([k/16][n/32][piece][lane][8 bf16], 1 KiB per
+// piece fragment) and DMA-staged as they are, so a weight fragment is three
+// ds_read_b128 and no VALU; activations are staged as fp32 and split after the
+// LDS read (44 VALU per fragment).  Stage = 8 KB activations + 12 KB weight
+// pieces.
+// ---------------------------------------------------------------------------
+#define NSP_STAGE (NN_TM * N3_KC + 4 * 3 * 256)   // floats per stage
+
+__global__ void split_w_kernel(const float* __restrict__ W, int ldw, int K, int N,
+                               unsigned int* __restrict__ out, int nt32) {
+  const int kc = blockIdx.y, nt = blockIdx.x, lane = threadIdx.x;
+  const int i = lane & 31, h = lane >> 5;
+  const int n = nt * 32 + i;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = kc * 16 + 8 * h + e;
+    v[e] = (k < K && n < N) ? W[(long)k * ldw + n] : 0.f;
+  }
+  const Split3 s = split3(v);
+  u32x4* dst = reinterpret_cast<u32x4*>(out) + ((long)(kc * nt32 + nt) * 3) * 64 + lane;
+#pragma unroll
+  for (int p = 0; p < 3; ++p) dst[p * 64] = __builtin_bit_cast(u32x4, s.p[p]);
+}
+
+template <int NPROD>
+__global__ __launch_bounds__(256, 3) void gemm_nn_split_kernel(GemmNN g, const unsigned int* wp,
+                                                               int nt32) {
+  constexpr int LDSF = 2 * NSP_STAGE > 4 * 32 * EP_LD ? 2 * NSP_STAGE : 4 * 32 * EP_LD;
+  __shared__ __attribute__((aligned(1024))) float smem[LDSF];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int logical = xcd_remap(blockIdx.x, g.nwg);
+  const int tile_n = logical % g.tiles_n;
+  const long m0 = (long)(logical / g.tiles_n) * NN_TM;
+  const int n0 = tile_n * NN_TN;
+  const int nk = g.K / N3_KC;
+
+  const int a_chunk = (lane & 3) ^ ((lane >> 4) & 3);
+  long am0 = m0 + 16 * wave + (lane >> 2), am1 = am0 + 64;
+  am0 = am0 < g.M ? am0 : g.M - 1;
+  am1 = am1 < g.M ? am1 : g.M - 1;
+  const long lda = g.a_planes ? 32 : g.lda;
+  const float* a0 = g.A + am0 * lda + a_chunk * 4;
+  const float* a1 = g.A + am1 * lda + a_chunk * 4;
+  // weight pieces: wave w stages pieces p = w, w+4, w+8 of the 12 (4 n-tiles x
+  // 3) of a chunk; n-tiles past the matrix are clamped (never stored)
+  const int nt0 = n0 >> 5;
+  const unsigned int* wsrc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int p = wave + 4 * i;
+    int nt = nt0 + p / 3;
+    nt = nt < nt32 ? nt : nt32 - 1;
+    wsrc[i] = wp + ((long)nt * 3 + p % 3) * 256 + lane * 4;
+  }
+  const long w_chunk = (long)nt32 * 3 * 256;   // uint32 per k chunk
+  auto stage = [&](int kc, int st) {
+    float* base = smem + st * NSP_STAGE;
+    const long aoff = g.a_planes ? (long)(kc >> 1) * g.a_plane_stride + (kc & 1) * 16
+                                 : (long)kc * N3_KC;
+    __builtin_amdgcn_global_load_lds((gptr_t)(a0 + aoff), (lptr_t)(base + wave * 256), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(a1 + aoff), (lptr_t)(base + (wave + 4) * 256), 16, 0, 0);
+    float* wb = base + NN_TM * N3_KC;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + kc * w_chunk),
+                                       (lptr_t)(wb + (wave + 4 * i) * 256), 16, 0, 0);
+  };
+
+  f32x16 acc[2][2];  // [fn][fm]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = frag_zero();
+
+  stage(0, 0);
+  int st = 0;
+  for (int kc = 0; kc < nk; ++kc) {
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (kc + 1 < nk) stage(kc + 1, st ^ 1);
+    const float* As = smem + st * NSP_STAGE;
+    const float* Ws = As + NN_TM * N3_KC;
+    Split3 xs[2], ws[2];
+#pragma unroll
+    for (int fn = 0; fn < 2; ++fn) {
+      const u32x4* q = reinterpret_cast<const u32x4*>(Ws + ((wn * 2 + fn) * 3) * 256) + lane;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) ws[fn].p[p] = __builtin_bit_cast(bf16x8, q[p * 64]);
+    }
+    auto load_x = [&](int fm) {
+      const int row = wm * 64 + fm * 32 + j;
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(
+            As + row * N3_KC + (((2 * h + u) ^ ((row >> 2) & 3)) << 2));
+        v[4 * u] = t[0]; v[4 * u + 1] = t[1]; v[4 * u + 2] = t[2]; v[4 * u + 3] = t[3];
+      }
+      xs[fm] = split3(v);
+    };
+    load_x(0);
+    mma_split<NPROD>(acc[0][0], ws[0], xs[0]);
+    mma_split<NPROD>(acc[1][0], ws[1], xs[0]);
+    load_x(1);
+    // the second fragment's split (44 VALU) goes into the gaps of the first
+    // fragment's 2 * NPROD MFMAs: 1 MFMA, then 4 VALU, repeated
+#pragma unroll
+    for (int i = 0; i < 2 * NPROD; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, (44 + 2 * NPROD - 1) / (2 * NPROD), 0);
+    }
+    mma_split<NPROD>(acc[0][1], ws[0], xs[1]);
+    mma_split<NPROD>(acc[1][1], ws[1], xs[1]);
+    st ^= 1;
+  }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   gemm_epilogue(g, acc, smem, m0, n0, wm, wn, wave, lane);
 }
@@ -888,7 +1065,8 @@ static int gemm_nn_launch(const float* A, long lda, int a_planes, long a_plane_s
                const float* W, int ldw, const float* bias, const float* mask,
                long ld_mask, const float* addend, long ld_add, float* C,
                long ldc, int c_planes, long c_plane_stride, float* Cpre,
-               long M, int N, int K, int relu, void* stream) {
+               long M, int N, int K, int relu, void* stream,
+               void* wsplit = nullptr, int nprod = 0) {
   if (!A || !W || !C) return WN_ERR_NULL;
   if (M <= 0 || N <= 0 || K <= 0) return WN_ERR_BAD_SHAPE;
   if ((N & 3) || (K & 3) || (ldw & 3)) return WN_ERR_UNSUPPORTED;
@@ -922,10 +1100,22 @@ static int gemm_nn_launch(const float* A, long lda, int a_planes, long a_plane_s
   // default: three-stage LDS-DMA kernel, 3 workgroups / CU; WN_NN_MODE=tile
   // (or K % 16 != 0): register-staged two-stage kernel
   const char* me = getenv("WN_NN_MODE");
-  if ((me && me[0] == 't') || (K % N3_KC) != 0)
+  if (wsplit && (K % N3_KC) != 0) return WN_ERR_UNSUPPORTED;
+  if (wsplit && !wn_aligned16(wsplit)) return WN_ERR_MISALIGNED;
+  if (!wsplit && ((me && me[0] == 't') || (K % N3_KC) != 0))
     hipLaunchKernelGGL(gemm_nn_kernel<2>, dim3((unsigned)nwg), dim3(256), 0,
                        (hipStream_t)stream, g);
-  else
+  else if (wsplit) {
+    const int nt32 = (N + 31) / 32;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(split_w_kernel, dim3(nt32, K / N3_KC), dim3(64), 0, s, W, ldw, K, N,
+                       (unsigned int*)wsplit, nt32);
+    dim3 gr((unsigned)nwg), bl(256);
+    const unsigned int* wp = (const unsigned int*)wsplit;
+    if (nprod == 3) hipLaunchKernelGGL(gemm_nn_split_kernel<3>, gr, bl, 0, s, g, wp, nt32);
+    else if (nprod == 9) hipLaunchKernelGGL(gemm_nn_split_kernel<9>, gr, bl, 0, s, g, wp, nt32);
+    else hipLaunchKernelGGL(gemm_nn_split_kernel<6>, gr, bl, 0, s, g, wp, nt32);
+  } else
     hipLaunchKernelGGL(gemm_nn3_kernel, dim3((unsigned)nwg), dim3(256), 0,
                        (hipStream_t)stream, g);
   return wn_check_launch();
@@ -939,6 +1129,28 @@ int wn_gemm_nn(const float* A, long lda, int a_planes, long a_plane_stride,
   return gemm_nn_launch(A, lda, a_planes, a_plane_stride, W, ldw, bias, mask,
                         ld_mask, addend, ld_add, C, ldc, c_planes,
                         c_plane_stride, Cpre, M, N, K, relu, stream);
+}
+
+// Split-bf16 variant of wn_gemm_nn (opt-in): fp32 accuracy from bf16 matrix
+// instructions, see gemm_nn_split_kernel.  `w_scratch` (wn_gemm_split_w_bytes
+// bytes, 16-byte aligned) receives the weight pieces; nprod = 3, 6 or 9.
+long wn_gemm_split_w_bytes(int K, int N) {
+  if (K <= 0 || N <= 0) return 0;
+  return (long)((K + 15) / 16) * ((N + 31) / 32) * 3 * 1024;
+}
+
+int wn_gemm_nn_split(const float* A, long lda, int a_planes, long a_plane_stride,
+                     const float* W, int ldw, const float* bias, const float* mask,
+                     long ld_mask, const float* addend, long ld_add, float* C,
+                     long ldc, int c_planes, long c_plane_stride, float* Cpre,
+                     long M, int N, int K, int relu, void* w_scratch, int nprod,
+                     void* stream) {
+  if (!w_scratch) return WN_ERR_NULL;
+  if (nprod != 3 && nprod != 6 && nprod != 9) return WN_ERR_BAD_SHAPE;
+  return gemm_nn_launch(A, lda, a_planes, a_plane_stride, W, ldw, bias, mask,
+                        ld_mask, addend, ld_add, C, ldc, c_planes,
+                        c_plane_stride, Cpre, M, N, K, relu, stream, w_scratch,
+                        nprod);
 }
 
 // Number of floats one slab needs for wn_gemm_tn.

@@ -45,6 +45,10 @@ SIGNATURES = {
     'wn_gemm_nn': (c_int, [P, c_long, c_int, c_long, P, c_int, P, P, c_long,
                            P, c_long, P, c_long, c_int, c_long, P, c_long,
                            c_int, c_int, c_int, P]),
+    'wn_gemm_split_w_bytes': (c_long, [c_int, c_int]),
+    'wn_gemm_nn_split': (c_int, [P, c_long, c_int, c_long, P, c_int, P, P,
+                                 c_long, P, c_long, P, c_long, c_int, c_long,
+                                 P, c_long, c_int, c_int, c_int, P, c_int, P]),
     'wn_gemm_tn_slab_floats': (c_long, [c_int, c_int]),
     'wn_gemm_tn_splits': (c_int, [c_long, c_int, c_int, c_int]),
     'wn_gemm_tn': (c_int, [P, c_long, c_int, c_long, P, c_int, c_int, P,

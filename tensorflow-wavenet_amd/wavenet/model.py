@@ -187,6 +187,11 @@ class WaveNetModel(object):
         # hipGraph, instead of the single-workgroup persistent kernel
         self.fastgen_multi_cu = True
         self.fastgen_graph_steps = 200
+        # 'fp32' (default): fp32 MFMA GEMMs.  'bf16x6' / 'bf16x9' / 'bf16x3':
+        # opt-in split-bf16 products for the six NN GEMMs (wn_gemm_nn_split;
+        # x6 measures the same error vs float64 as the fp32 MFMA path)
+        self.gemm_mode = 'fp32'
+        self._wsplit = {}
         # seeds longer than this are primed from ONE batch forward pass
         # instead of one incremental step per seed sample
         self.fastgen_prime_forward_min = 64
@@ -461,18 +466,34 @@ class WaveNetModel(object):
         return out, (64 if ids is not None else 0)
 
     def _nn(self, *args):
-        """wn_gemm_nn, optionally bracketed by HIP events on the launch stream
-        (bench.py's live roofline measurement)."""
+        """wn_gemm_nn (or, when `gemm_mode` asks for it, wn_gemm_nn_split),
+        optionally bracketed by HIP events on the launch stream (bench.py's
+        live roofline measurement)."""
+        name = 'wn_gemm_nn'
+        if self.gemm_mode != 'fp32':
+            nprod = {'bf16x3': 3, 'bf16x6': 6, 'bf16x9': 9}[self.gemm_mode]
+            M, N, K = args[-5], args[-4], args[-3]
+            if K % 16 == 0:
+                key = (K, N)
+                buf = self._wsplit.get(key)
+                if buf is None:
+                    nb = _lib.load().wn_gemm_split_w_bytes(K, N)
+                    buf = torch.empty(nb // 4, dtype=torch.int32,
+                                      device=self.device)
+                    self._wsplit[key] = buf
+                name = 'wn_gemm_nn_split'
+                args = args[:-1] + (_lib.ptr(buf), nprod, args[-1])
         ev = getattr(self, '_gemm_events', None)
         if ev is None:
-            _lib.call('wn_gemm_nn', *args)
+            _lib.call(name, *args)
             return
         s = torch.cuda.Event(enable_timing=True)
         e = torch.cuda.Event(enable_timing=True)
         s.record()
-        _lib.call('wn_gemm_nn', *args)
+        _lib.call(name, *args)
         e.record()
-        ev.append((s, e, 2.0 * args[-5] * args[-4] * args[-3]))
+        k = -7 if name == 'wn_gemm_nn_split' else -5
+        ev.append((s, e, 2.0 * args[k] * args[k + 1] * args[k + 2]))
 
     # ------------------------------------------------------------------ forward
     def _forward(self, ws, ids, save_ts):

@@ -113,6 +113,41 @@ def test_gemm_tn_and_reduce(hip_lib, rows, Mw, Nw, splits):
     assert np.abs(cs.cpu().numpy() - G.astype(np.float64).sum(0)).max() < 1e-2
 
 
+@pytest.mark.parametrize('nprod,tol', [(6, 1e-5), (9, 1e-5), (3, 2e-3)])
+@pytest.mark.parametrize('M,N,K', [(37, 16, 16), (5000, 256, 512), (129, 512, 96),
+                                   (256, 200, 64), (1031, 1600, 32)])
+def test_gemm_nn_split(hip_lib, nprod, tol, M, N, K):
+    """wn_gemm_nn_split (opt-in): fp32 products rebuilt from exact bf16 pieces.
+    nprod 6 / 9 must be as close to float64 as an fp32 GEMM (1e-5 of the
+    result scale here), nprod 3 only ~2^-16; epilogues shared with wn_gemm_nn."""
+    from wavenet import _lib
+    lib = hip_lib
+    rng = np.random.default_rng(M + N + K + nprod)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = rng.standard_normal((K, N)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    mask = rng.standard_normal((M, N)).astype(np.float32)
+    dA, dW, db, dm = dev(A), dev(W), dev(bias), dev(mask)
+    C = torch.empty((M, N), device='cuda')
+    Cpre = torch.empty((M, N), device='cuda')
+    scratch = torch.empty(lib.wn_gemm_split_w_bytes(K, N) // 4,
+                          dtype=torch.int32, device='cuda')
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.call('wn_gemm_nn_split', dA.data_ptr(), K, 0, 0, dW.data_ptr(), N,
+              db.data_ptr(), dm.data_ptr(), N, None, 0, C.data_ptr(), N, 0, 0,
+              Cpre.data_ptr(), M, N, K, 1, scratch.data_ptr(), nprod, st)
+    ref0 = A.astype(np.float64) @ W.astype(np.float64) + bias
+    ref = np.where(mask > 0, np.maximum(ref0, 0), 0)
+    scale = max(1.0, np.abs(ref0).max())
+    assert np.abs(Cpre.cpu().numpy() - ref0).max() < tol * scale
+    assert np.abs(C.cpu().numpy() - ref).max() < tol * scale
+    # K not a multiple of 16 is refused, not silently mis-computed
+    assert lib.wn_gemm_nn_split(dA.data_ptr(), K, 0, 0, dW.data_ptr(), N, None,
+                                None, 0, None, 0, C.data_ptr(), N, 0, 0, None,
+                                M, N, K - 4, 0, scratch.data_ptr(), nprod,
+                                st) != 0
+
+
 def test_gemm_tn_plane_operand(hip_lib):
     """A given as [P][rows][32] planes (dWs = Z^T dtotal), both TN kernels
     (rows % 16 == 0 -> LDS-DMA, else register-staged)."""

@@ -86,6 +86,25 @@ def test_loss_and_gradients_vs_oracle(hip_lib, name, cfg, T, gc, l2):
     assert np.abs(logits - c['logits']).max() < TOL
 
 
+@pytest.mark.parametrize('mode', ['bf16x6', 'bf16x9'])
+@pytest.mark.parametrize('case', ['mid', 'rp_l2', 'default'])
+def test_split_bf16_gemm_mode_parity(hip_lib, mode, case):
+    """Opt-in `gemm_mode` (NN GEMM products rebuilt from three exact bf16
+    pieces per operand on bf16 MFMA, fp32 accumulation): same 1e-4 bar against
+    the float64 oracle as the fp32 MFMA path."""
+    name, cfg, T, gc, l2 = [c for c in CASES if c[0] == case][0]
+    B = cfg['batch_size']
+    net, var = build_pair(cfg)
+    net.gemm_mode = mode
+    audio = np.random.default_rng(7).uniform(-1, 1, (B, T)).astype(np.float32)
+    ref_loss, ref_g = O.loss_and_grads(cfg, var, audio, None, l2=l2,
+                                       dtype=np.float64)
+    loss = net.loss(audio, None, l2)
+    assert net._wsplit, 'split path not taken'
+    assert abs(float(loss) - ref_loss) < TOL
+    check_grads(net, ref_g)
+
+
 def test_generic_tap_kernels_at_k2(hip_lib):
     """The generic-filter-width kernels forced on a K = 2 model must give the
     same loss / gradients as the oracle (and hence the tuned kernels)."""

@@ -91,6 +91,40 @@ def nnexp():
 sys_exp = os.environ.get('KB_EXPS', 'tile,stream').split(',')
 
 
+def nnacc():
+    """speed and accuracy (vs float64) of the NN GEMM: fp32 MFMA vs the
+    split-bf16 variants (wn_gemm_nn_split, nprod 3 / 6 / 9)"""
+    N = 128000
+    modes = [int(m) for m in os.environ.get('KB_MODES', '0,3,6,9').split(',')]
+    for (K, Nn, name) in [(1600, 512, 'skip'), (512, 512, 'post1'), (256, 512, 'dh2'), (512, 1600, 'dZ')]:
+        A = torch.randn(N, K, device=dev)
+        W = torch.randn(K, Nn, device=dev) * 0.05
+        C = torch.empty(N, Nn, device=dev)
+        scratch = torch.empty(lib.wn_gemm_split_w_bytes(K, Nn) // 4, dtype=torch.int32, device=dev)
+        ref = A[:8192].double() @ W.double()
+        def f(m):
+            if m == 0:
+                _lib.call('wn_gemm_nn', A.data_ptr(), K, 0, 0, W.data_ptr(), Nn, None, None, 0, None, 0,
+                          C.data_ptr(), Nn, 0, 0, None, N, Nn, K, 0, st())
+            else:
+                _lib.call('wn_gemm_nn_split', A.data_ptr(), K, 0, 0, W.data_ptr(), Nn, None, None, 0, None, 0,
+                          C.data_ptr(), Nn, 0, 0, None, N, Nn, K, 0, scratch.data_ptr(), m, st())
+        res = {m: [] for m in modes}
+        err = {}
+        for rep in range(5):
+            for m in modes:
+                res[m].append(timeit(lambda: f(m), n=8, warm=2))
+                if rep == 0:
+                    d = (C[:8192].double() - ref)
+                    err[m] = (d.abs().max().item(), (d.norm() / ref.norm()).item())
+        line = 'nn %-6s K=%4d N=%4d:' % (name, K, Nn)
+        for m in modes:
+            t = sorted(res[m])[2]
+            line += '  x%d %6.1f us %5.1f TF err max %.2e rel %.2e |' % (m, t * 1e6, 2.0 * N * K * Nn / t / 1e12,
+                                                                     err[m][0], err[m][1])
+        print(line, flush=True)
+
+
 def vendor():
     """vendor-library fp32 GEMM (torch.mm -> rocBLAS/hipBLASLt) on the same
     shapes, as a calibration of what 'good' is on this device (not shipped)"""

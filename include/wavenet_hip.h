@@ -135,8 +135,15 @@ int wn_gemm_nn_split(const float* A, long lda, int a_planes,
                      int N, int K, int relu, void* w_scratch, int nprod,
                      void* stream);
 long wn_gemm_tn_slab_floats(int Mw, int Nw);
-/* recommended `splits` for wn_gemm_tn (grid = one resident wave of workgroups) */
-int wn_gemm_tn_splits(long rows, int Mw, int Nw, int onehot);
+/* recommended `splits` for wn_gemm_tn (grid = one resident wave of
+ * workgroups); kind: 0 dense A, 1 one-hot A, 2 wn_gemm_tn_split */
+int wn_gemm_tn_splits(long rows, int Mw, int Nw, int kind);
+/* opt-in split-bf16 variant of wn_gemm_tn (see wn_gemm_nn_split); dense or
+ * plane A, rows % 16 == 0 */
+int wn_gemm_tn_split(const float* A, long lda, int a_planes,
+                     long a_plane_stride, const float* G, long ldg,
+                     float* slabs, int splits, long rows, int Mw, int Nw,
+                     int want_colsum, int nprod, void* stream);
 int wn_gemm_tn(const float* A, long lda, int a_planes, long a_plane_stride,
                const int32_t* codes, int shift, int T, const float* G,
                long ldg, float* slabs, int splits, long rows, int Mw, int Nw,

@@ -972,6 +972,117 @@ __global__ __launch_bounds__(256, (MF * NF >= 10 ? 2 : MF * NF > 5 ? 3 : 4)) voi
   }
 }
 
+// ---------------------------------------------------------------------------
+// Split-bf16 TN GEMM (wn_gemm_tn_split, opt-in): workgroup tile 128 x 128,
+// 2 x 2 waves of 64 x 64, 16-row chunks of both operands staged as fp32 by
+// LDS-DMA and split into bf16 pieces after the LDS read (both operands are
+// activations, nothing can be pre-split).  Lane (i, h) of an operand fragment
+// holds rows 8h .. 8h+7 of column i: eight ds_read_b32 of consecutive floats
+// across lanes.
+// ---------------------------------------------------------------------------
+template <int NPROD>
+__global__ __launch_bounds__(256, 3) void gemm_tn_split_kernel(GemmTN g) {
+  constexpr int KR = 16, TT = 128;
+  constexpr int STAGE = 2 * KR * TT;   // floats: A chunk then G chunk
+  __shared__ __attribute__((aligned(1024))) float smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 31, h = lane >> 5;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int ntile = gridDim.x;
+  const int logical = xcd_remap(blockIdx.x + ntile * blockIdx.y, ntile * gridDim.y);
+  const int tile = logical % ntile, split = logical / ntile;
+  const int tn = tile % g.tiles_n, tm = tile / g.tiles_n;
+  const int m0 = tm * TT, n0 = tn * TT;
+  const long r_begin = (long)split * g.rows_per_split;
+  long r_end = r_begin + g.rows_per_split;
+  if (r_end > g.rows) r_end = g.rows;
+  const int nchunks = r_end > r_begin ? (int)((r_end - r_begin) / KR) : 0;
+
+  // wave w stages pieces w and w + 4 (2 rows x 128 floats each) of A and of G;
+  // columns past the matrix are clamped (they feed outputs never stored)
+  const int prow = lane >> 5, pcol = (lane & 31) * 4;
+  int am = m0 + pcol;
+  am = am < g.Mw ? am : g.Mw - 4;
+  int gn = n0 + pcol;
+  gn = gn < g.Nw ? gn : g.Nw - 4;
+  auto stage = [&](int c, int st) {
+    float* base = smem + st * STAGE;
+    const long r0 = r_begin + (long)c * KR;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int p = wave + 4 * q;
+      const long row = r0 + 2 * p + prow;
+      const float* src = g.a_planes
+                             ? g.A + (long)(am >> 5) * g.a_plane_stride + row * 32 + (am & 31)
+                             : g.A + row * g.lda + am;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + p * 256), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(g.G + row * g.ldg + gn),
+                                       (lptr_t)(base + KR * TT + p * 256), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];  // [fm][fn]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = frag_zero();
+  float cs[2] = {0.f, 0.f};
+
+  if (nchunks > 0) stage(0, 0);
+  for (int c = 0; c < nchunks; ++c) {
+    const int st = c & 1;
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (c + 1 < nchunks) stage(c + 1, st ^ 1);
+    const float* al = smem + st * STAGE + 8 * h * TT + wm * 64 + i;
+    const float* gl = smem + st * STAGE + KR * TT + 8 * h * TT + wn * 64 + i;
+    Split3 as[2], gs[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = al[e * TT + f * 32];
+      as[f] = split3(v);
+    }
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[e] = gl[e * TT + f * 32];
+        cs[f] += v[e];
+      }
+      gs[f] = split3(v);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) mma_split<NPROD>(acc[a][b], as[a], gs[b]);
+  }
+
+  float* slab = g.slabs + (long)split * g.slab_stride;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int n = n0 + wn * 64 + b * 32 + i;
+      if (n >= g.Nw) continue;
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const int m = m0 + wm * 64 + a * 32 + 8 * (rr >> 2) + 4 * h + (rr & 3);
+        if (m < g.Mw) slab[(long)m * g.Nw + n] = acc[a][b][rr];
+      }
+    }
+  if (g.want_colsum && tm == 0 && wm == 0) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const float v = cs[b] + __shfl_xor(cs[b], 32);
+      const int n = n0 + wn * 64 + b * 32 + i;
+      if (h == 0 && n < g.Nw) slab[(long)g.Mw * g.Nw + n] = v;
+    }
+  }
+}
+
 // out[b][rep][e] = sum_s slabs[b][s][offset + e]   (fixed order over s)
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs,
                                     int num_slabs, long slab_stride,
@@ -1187,7 +1298,10 @@ int wn_gemm_tn_splits(long rows, int Mw, int Nw, int onehot) {
   if (rows <= 0 || Mw <= 0 || Nw <= 0) return 1;
   int mf, nf;
   long s;
-  if (!onehot && tn_wg_tile(Mw, Nw, &mf, &nf)) {
+  if (onehot == 2) {  // split-bf16 kernel: 128 x 128 tiles, 3 workgroups / CU
+    const int tiles = ((Mw + 127) / 128) * ((Nw + 127) / 128);
+    s = 3L * tn_device_cus() / tiles;
+  } else if (!onehot && tn_wg_tile(Mw, Nw, &mf, &nf)) {
     const int tiles = (Mw / (mf * 32)) * (Nw / (4 * nf * 32));
     const int occ = mf * nf > 5 ? 3 : 4;
     s = (long)occ * tn_device_cus() / tiles;
@@ -1201,6 +1315,37 @@ int wn_gemm_tn_splits(long rows, int Mw, int Nw, int onehot) {
   }
   if (s > rows / 64) s = rows / 64;
   return (int)(s < 1 ? 1 : s);
+}
+
+// Split-bf16 variant of wn_gemm_tn (dense / plane A only; opt-in).  Needs
+// rows % 16 == 0, Mw % 4 == 0, Nw % 4 == 0, 16-byte aligned operands.
+int wn_gemm_tn_split(const float* A, long lda, int a_planes, long a_plane_stride,
+                     const float* G, long ldg, float* slabs, int splits,
+                     long rows, int Mw, int Nw, int want_colsum, int nprod,
+                     void* stream) {
+  if (!A || !G || !slabs) return WN_ERR_NULL;
+  if (rows <= 0 || Mw <= 0 || Nw <= 0 || splits <= 0) return WN_ERR_BAD_SHAPE;
+  if (nprod != 3 && nprod != 6 && nprod != 9) return WN_ERR_BAD_SHAPE;
+  if (a_planes && Mw != a_planes * 32) return WN_ERR_BAD_SHAPE;
+  if ((rows % 16) || (Mw & 3) || (Nw & 3) || (ldg & 3) || (!a_planes && (lda & 3)))
+    return WN_ERR_UNSUPPORTED;
+  if (!wn_aligned16(A) || !wn_aligned16(G)) return WN_ERR_MISALIGNED;
+  GemmTN g;
+  g.A = A; g.lda = lda; g.a_plane_stride = a_plane_stride; g.a_planes = a_planes;
+  g.codes = nullptr; g.shift = 0; g.T = 1; g.G = G; g.ldg = ldg;
+  g.slabs = slabs; g.slab_stride = wn_gemm_tn_slab_floats(Mw, Nw);
+  g.rows = rows;
+  long rps = (rows + splits - 1) / splits;
+  g.rows_per_split = (rps + 15) / 16 * 16;
+  g.Mw = Mw; g.Nw = Nw; g.want_colsum = want_colsum;
+  g.tiles_m = (Mw + 127) / 128;
+  g.tiles_n = (Nw + 127) / 128;
+  dim3 grid(g.tiles_m * g.tiles_n, splits), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (nprod == 3) hipLaunchKernelGGL(gemm_tn_split_kernel<3>, grid, block, 0, s, g);
+  else if (nprod == 9) hipLaunchKernelGGL(gemm_tn_split_kernel<9>, grid, block, 0, s, g);
+  else hipLaunchKernelGGL(gemm_tn_split_kernel<6>, grid, block, 0, s, g);
+  return wn_check_launch();
 }
 
 int wn_gemm_tn(const float* A, long lda, int a_planes, long a_plane_stride,

@@ -51,6 +51,8 @@ SIGNATURES = {
                                  P, c_long, c_int, c_int, c_int, P, c_int, P]),
     'wn_gemm_tn_slab_floats': (c_long, [c_int, c_int]),
     'wn_gemm_tn_splits': (c_int, [c_long, c_int, c_int, c_int]),
+    'wn_gemm_tn_split': (c_int, [P, c_long, c_int, c_long, P, c_long, P, c_int,
+                                 c_long, c_int, c_int, c_int, c_int, P]),
     'wn_gemm_tn': (c_int, [P, c_long, c_int, c_long, P, c_int, c_int, P,
                            c_long, P, c_int, c_long, c_int, c_int, c_int, P]),
     'wn_reduce_slabs': (c_int, [P, c_int, c_long, c_int, c_long, c_long,
@@ -125,11 +127,77 @@ def check(code, what=''):
         raise WaveNetHipError('%s failed: %s (code %d)' % (what, msg, code))
 
 
+# ---- launch plans --------------------------------------------------------
+# A training step is ~235 kernel launches whose arguments (raw device
+# addresses and ints) do not change from step to step.  Re-deriving them in
+# Python every step (tensor views, data_ptr(), current_stream()) costs about as
+# much host time as the GPU needs for the step, so the host records the
+# (function, args) sequence once per workspace and replays it.
+_rec = None
+
+
+class record(object):
+    """Context manager: every `call` inside is executed AND appended to
+    `self.plan` as (ctypes function, args, name, flops-or-None)."""
+
+    def __enter__(self):
+        global _rec
+        self._outer = _rec
+        self.plan = []
+        _rec = self.plan
+        return self
+
+    def __exit__(self, *exc):
+        global _rec
+        _rec = self._outer
+        return False
+
+
 def call(name, *args):
     """Call an int-returning entry point and raise on a non-zero code."""
     lib = load()
-    code = getattr(lib, name)(*args)
-    check(code, name)
+    fn = getattr(lib, name)
+    if _rec is not None:
+        _rec.append((fn, args, name, None))
+    code = fn(*args)
+    if code != 0:
+        check(code, name)
+
+
+def call_timed(name, args, flops, events):
+    """`call` for the GEMMs; with `events` (a list) the launch is bracketed by
+    HIP events on torch's current stream and (start, end, flops) is appended
+    (bench.py's live roofline measurement)."""
+    lib = load()
+    fn = getattr(lib, name)
+    if _rec is not None:
+        _rec.append((fn, args, name, flops))
+    _timed(fn, args, name, flops, events)
+
+
+def _timed(fn, args, name, flops, events):
+    if events is None:
+        code = fn(*args)
+    else:
+        import torch
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        code = fn(*args)
+        e.record()
+        events.append((s, e, flops))
+    if code != 0:
+        check(code, name)
+
+
+def replay(plan, events=None):
+    for fn, args, name, flops in plan:
+        if flops is not None and events is not None:
+            _timed(fn, args, name, flops, events)
+        else:
+            code = fn(*args)
+            if code != 0:
+                check(code, name)
 
 
 def ptr(t):

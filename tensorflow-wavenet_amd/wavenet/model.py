@@ -74,7 +74,10 @@ class _Workspace(object):
             setattr(self, name, t)
             return t
 
+        self.plans = {}
         alloc('q', (N,), torch.int32)
+        self.gc_ids = alloc('gc_ids', (B,), torch.int32) \
+            if net.card is not None else None
         self.audio = alloc('audio', (N,)) if net.scalar_input else None
         alloc('X', (L, N, CH))
         alloc('Z', (L, N, CH))
@@ -192,6 +195,9 @@ class WaveNetModel(object):
         # x6 measures the same error vs float64 as the fp32 MFMA path)
         self.gemm_mode = 'fp32'
         self._wsplit = {}
+        # replay recorded (function, args) launch sequences instead of
+        # re-deriving ~235 argument lists per step in Python
+        self.use_launch_plans = True
         # seeds longer than this are primed from ONE batch forward pass
         # instead of one incremental step per seed sample
         self.fastgen_prime_forward_min = 64
@@ -483,20 +489,60 @@ class WaveNetModel(object):
                     self._wsplit[key] = buf
                 name = 'wn_gemm_nn_split'
                 args = args[:-1] + (_lib.ptr(buf), nprod, args[-1])
-        ev = getattr(self, '_gemm_events', None)
-        if ev is None:
-            _lib.call(name, *args)
-            return
-        s = torch.cuda.Event(enable_timing=True)
-        e = torch.cuda.Event(enable_timing=True)
-        s.record()
-        _lib.call(name, *args)
-        e.record()
         k = -7 if name == 'wn_gemm_nn_split' else -5
-        ev.append((s, e, 2.0 * args[k] * args[k + 1] * args[k + 2]))
+        _lib.call_timed(name, args, 2.0 * args[k] * args[k + 1] * args[k + 2],
+                        getattr(self, '_gemm_events', None))
+
+    # ------------------------------------------------------------ launch plans
+    def _plan_key(self, tag, ws, ids, extra):
+        return (tag, extra, ids is not None, self.generic_layers,
+                self.fused_bwd, self.gemm_mode, self.tf_xent_zero_label_quirk,
+                _lib.stream(), self.params.data_ptr(), self.grads.data_ptr())
+
+    def _stage_ids(self, ws, ids):
+        """GC ids into a workspace-owned buffer, so that recorded launch
+        arguments never point at a caller's temporary."""
+        if ids is None:
+            return None
+        if ids.data_ptr() != ws.gc_ids.data_ptr():
+            ws.gc_ids.copy_(ids)
+        return ws.gc_ids
+
+    def _forward(self, ws, ids, save_ts):
+        """Forward pass through a recorded launch plan (see _lib.record)."""
+        ids = self._stage_ids(ws, ids)
+        if not self.use_launch_plans:
+            return self._forward_eager(ws, ids, save_ts)
+        key = self._plan_key('fwd', ws, ids, save_ts)
+        plan = ws.plans.get(key, 0)
+        if plan == 0:                 # first use of this workspace: eager
+            ws.plans[key] = None
+            self._forward_eager(ws, ids, save_ts)
+        elif plan is None:            # second use: record while executing
+            with _lib.record() as rec:
+                self._forward_eager(ws, ids, save_ts)
+            ws.plans[key] = rec.plan
+        else:
+            _lib.replay(plan, getattr(self, '_gemm_events', None))
+
+    def _backward(self, ws, ids):
+        ids = self._stage_ids(ws, ids)
+        if not self.use_launch_plans or self.overlap_wgrad:
+            return self._backward_eager(ws, ids)   # side stream: torch events
+        key = self._plan_key('bwd', ws, ids, None)
+        plan = ws.plans.get(key, 0)
+        if plan == 0:
+            ws.plans[key] = None
+            self._backward_eager(ws, ids)
+        elif plan is None:
+            with _lib.record() as rec:
+                self._backward_eager(ws, ids)
+            ws.plans[key] = rec.plan
+        else:
+            _lib.replay(plan, getattr(self, '_gemm_events', None))
 
     # ------------------------------------------------------------------ forward
-    def _forward(self, ws, ids, save_ts):
+    def _forward_eager(self, ws, ids, save_ts):
         """_create_network (model.py:389-442) on codes ws.q -> ws.logits."""
         st = _lib.stream()
         B, T, N, L, S, Q = ws.B, ws.T, ws.N, self.L, self.S, self.Q
@@ -550,7 +596,7 @@ class WaveNetModel(object):
                   None, 0, _lib.ptr(ws.logits), Q, 0, 0, None, N, Q, S, 0, st)
 
     # ------------------------------------------------------------------ backward
-    def _backward(self, ws, ids):
+    def _backward_eager(self, ws, ids):
         """Hand-written gradient of loss() (the reference uses TF autodiff of
         model.py:628-685).  Consumes ws.logits == dlogits (in place)."""
         st = _lib.stream()
@@ -565,8 +611,16 @@ class WaveNetModel(object):
                dst, dst_bias, replicate=1, rep_stride=0):
             sp = ws.splits[key]
             sl = lib.wn_gemm_tn_slab_floats(mw, nw)
-            _lib.call('wn_gemm_tn', A, lda, a_planes, a_pstride, codes, shift,
-                      T, Gm, ldg, _lib.ptr(ws.slabs), sp, N, mw, nw, ub, st)
+            if self.gemm_mode != 'fp32' and codes is None and N % 16 == 0:
+                # opt-in split-bf16 products (fewer, larger splits)
+                sp = min(sp, lib.wn_gemm_tn_splits(N, mw, nw, 2))
+                _lib.call('wn_gemm_tn_split', A, lda, a_planes, a_pstride, Gm,
+                          ldg, _lib.ptr(ws.slabs), sp, N, mw, nw, ub,
+                          int(self.gemm_mode[-1]), st)
+            else:
+                _lib.call('wn_gemm_tn', A, lda, a_planes, a_pstride, codes,
+                          shift, T, Gm, ldg, _lib.ptr(ws.slabs), sp, N, mw, nw,
+                          ub, st)
             _lib.call('wn_reduce_slabs', _lib.ptr(ws.slabs), sp, sl, 1, 0, 0,
                       mw * nw, dst, 0, 1, 0, st)
             if ub and dst_bias is not None:

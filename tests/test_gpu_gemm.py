@@ -148,6 +148,44 @@ def test_gemm_nn_split(hip_lib, nprod, tol, M, N, K):
                                 st) != 0
 
 
+@pytest.mark.parametrize('nprod', [6, 9])
+@pytest.mark.parametrize('rows,Mw,Nw,splits,planes', [(96, 32, 32, 2, 0), (4800, 160, 128, 9, 5),
+                                                      (3328, 512, 256, 5, 0), (1600, 200, 132, 3, 0)])
+def test_gemm_tn_split(hip_lib, nprod, rows, Mw, Nw, splits, planes):
+    """wn_gemm_tn_split (opt-in) + wn_reduce_slabs vs float64, dense and
+    plane-mode A, partial 128-tiles in both output dimensions, column sums."""
+    from wavenet import _lib
+    lib = hip_lib
+    rng = np.random.default_rng(rows + nprod)
+    A = rng.standard_normal((rows, Mw)).astype(np.float32)
+    G = rng.standard_normal((rows, Nw)).astype(np.float32)
+    if planes:
+        dA = dev(A.reshape(rows, planes, 32).transpose(1, 0, 2))
+        a_args = (dA.data_ptr(), 0, planes, rows * 32)
+    else:
+        dA = dev(A)
+        a_args = (dA.data_ptr(), Mw, 0, 0)
+    dG = dev(G)
+    sl = lib.wn_gemm_tn_slab_floats(Mw, Nw)
+    slabs = torch.zeros(splits * sl, device='cuda')
+    out = torch.empty(Mw * Nw, device='cuda')
+    cs = torch.empty(Nw, device='cuda')
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.call('wn_gemm_tn_split', *a_args, dG.data_ptr(), Nw, slabs.data_ptr(),
+              splits, rows, Mw, Nw, 1, nprod, st)
+    _lib.call('wn_reduce_slabs', slabs.data_ptr(), splits, sl, 1, 0, 0,
+              Mw * Nw, out.data_ptr(), 0, 1, 0, st)
+    _lib.call('wn_reduce_slabs', slabs.data_ptr(), splits, sl, 1, 0, Mw * Nw,
+              Nw, cs.data_ptr(), 0, 1, 0, st)
+    ref = A.astype(np.float64).T @ G.astype(np.float64)
+    assert np.abs(out.cpu().numpy().reshape(Mw, Nw) - ref).max() < \
+        1e-5 * max(1.0, np.abs(ref).max())
+    assert np.abs(cs.cpu().numpy() - G.astype(np.float64).sum(0)).max() < 1e-2
+    # ragged row counts are refused (the caller falls back to wn_gemm_tn)
+    assert lib.wn_gemm_tn_split(*a_args, dG.data_ptr(), Nw, slabs.data_ptr(),
+                                splits, rows - 3, Mw, Nw, 1, nprod, st) != 0
+
+
 def test_gemm_tn_plane_operand(hip_lib):
     """A given as [P][rows][32] planes (dWs = Z^T dtotal), both TN kernels
     (rows % 16 == 0 -> LDS-DMA, else register-staged)."""

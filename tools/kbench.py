@@ -125,6 +125,44 @@ def nnacc():
         print(line, flush=True)
 
 
+def tnacc():
+    """speed and accuracy (vs float64) of the TN GEMM: fp32 MFMA vs
+    wn_gemm_tn_split"""
+    N = 128000
+    modes = [int(m) for m in os.environ.get('KB_MODES', '0,3,6,9').split(',')]
+    for (Mw, Nw, name) in [(1600, 512, 'dWs'), (512, 512, 'dW1'), (512, 256, 'dW2')]:
+        A = torch.randn(N, Mw, device=dev)
+        G = torch.randn(N, Nw, device=dev) * 0.05
+        sl = lib.wn_gemm_tn_slab_floats(Mw, Nw)
+        sp0, sp2 = lib.wn_gemm_tn_splits(N, Mw, Nw, 0), lib.wn_gemm_tn_splits(N, Mw, Nw, 2)
+        slabs = torch.empty(max(sp0, sp2) * sl, device=dev)
+        out = torch.empty(Mw * Nw, device=dev)
+        ref = A.double().t() @ G.double()
+        def f(m):
+            sp = sp0 if m == 0 else sp2
+            if m == 0:
+                _lib.call('wn_gemm_tn', A.data_ptr(), Mw, 0, 0, None, 0, 16000, G.data_ptr(), Nw,
+                          slabs.data_ptr(), sp, N, Mw, Nw, 1, st())
+            else:
+                _lib.call('wn_gemm_tn_split', A.data_ptr(), Mw, 0, 0, G.data_ptr(), Nw, slabs.data_ptr(), sp, N,
+                          Mw, Nw, 1, m, st())
+            _lib.call('wn_reduce_slabs', slabs.data_ptr(), sp, sl, 1, 0, 0, Mw * Nw, out.data_ptr(), 0, 1, 0, st())
+        res = {m: [] for m in modes}
+        err = {}
+        for rep in range(5):
+            for m in modes:
+                res[m].append(timeit(lambda: f(m), n=6, warm=2))
+                if rep == 0:
+                    d = out.double().view(Mw, Nw) - ref
+                    err[m] = (d.abs().max().item(), (d.norm() / ref.norm()).item())
+        line = 'tn %-4s %dx%d (incl. slab reduce):' % (name, Mw, Nw)
+        for m in modes:
+            t = sorted(res[m])[2]
+            line += '  x%d %6.1f us %5.1f TF err max %.2e rel %.2e |' % (m, t * 1e6, 2.0 * N * Mw * Nw / t / 1e12,
+                                                                     err[m][0], err[m][1])
+        print(line, flush=True)
+
+
 def vendor():
     """vendor-library fp32 GEMM (torch.mm -> rocBLAS/hipBLASLt) on the same
     shapes, as a calibration of what 'good' is on this device (not shipped)"""

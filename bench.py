@@ -198,6 +198,8 @@ def main():
                               dtype=torch.int32, device=dev)
     net = WaveNetModel(seed=0, **kw)
     net.gemm_mode = args.gemm_mode
+    if os.environ.get('WN_LAUNCH_PLANS') is not None:    # A/B knob
+        net.use_launch_plans = os.environ['WN_LAUNCH_PLANS'] == '1'
     if os.environ.get('WN_FUSED_BWD') is not None:       # A/B knob
         net.fused_bwd = os.environ['WN_FUSED_BWD'] == '1'
     if os.environ.get('WN_OVERLAP_WGRAD') is not None:   # A/B knob
@@ -222,14 +224,14 @@ def main():
         step()
     torch.cuda.synchronize()
     log('warm-up done, timing %d steps' % args.steps)
-    net._gemm_events = []                    # live HIP-event timing of the GEMMs
+    net._gemm_events = None if os.environ.get('WN_NO_EVENTS') else []  # live HIP-event timing of the GEMMs
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     sync_all()
     dt = time.perf_counter() - t0
-    events = net._gemm_events
+    events = net._gemm_events or []
     net._gemm_events = None
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)

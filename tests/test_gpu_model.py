@@ -105,6 +105,43 @@ def test_split_bf16_gemm_mode_parity(hip_lib, mode, case):
     check_grads(net, ref_g)
 
 
+def test_launch_plan_replay_tracks_new_inputs(hip_lib):
+    """Steps 1 (eager), 2 (recorded) and 3+ (replayed launch plan) on the SAME
+    workspace with different audio, different GC ids (fresh tensors every
+    step) and a weight update in between must each match the oracle: nothing a
+    plan holds may point at a caller's temporary or a stale value."""
+    cfg = cfg_with(MID, batch_size=2, global_condition_channels=4,
+                   global_condition_cardinality=5)
+    net, var = build_pair(cfg)
+    assert net.use_launch_plans
+    rng = np.random.default_rng(21)
+    for step in range(5):
+        audio = rng.uniform(-1, 1, (2, 200)).astype(np.float32)
+        ids = rng.integers(0, 5, 2)
+        if step == 3:   # perturb the weights in place (same flat buffer)
+            with torch.no_grad():
+                net.params.mul_(1.01)
+            var = tree_to_numpy(net.variables)
+        ref_loss, ref_g = O.loss_and_grads(cfg, var, audio, ids,
+                                           dtype=np.float64)
+        loss = net.loss(torch.from_numpy(audio).cuda(),
+                        torch.as_tensor(ids).cuda())
+        assert abs(float(loss) - ref_loss) < TOL, step
+        check_grads(net, ref_g)
+    ws = list(net._ws.values())[0]
+    assert any(isinstance(p, list) and len(p) > 10 for p in ws.plans.values())
+    # switching a flag that changes the launch sequence takes a new plan
+    net.fused_bwd = False
+    loss = net.loss(audio, ids)
+    assert abs(float(loss) - ref_loss) < TOL
+    check_grads(net, ref_g)
+    # and the eager path agrees
+    net.use_launch_plans = False
+    loss = net.loss(audio, ids)
+    assert abs(float(loss) - ref_loss) < TOL
+    check_grads(net, ref_g)
+
+
 def test_generic_tap_kernels_at_k2(hip_lib):
     """The generic-filter-width kernels forced on a K = 2 model must give the
     same loss / gradients as the oracle (and hence the tuned kernels)."""

@@ -351,6 +351,35 @@ class WaveNetModel(object):
             _xavier_(v['postprocessing']['postprocess2'], gen)
             # biases: zeros (model.py:27)
 
+    def histogram_summaries(self, bins=30):
+        """Counterpart of the `histograms=True` summaries of
+        _create_dilation_layer (model.py:314-325): per layer, histograms of the
+        filter / gate / dense (not for the last layer) / skip weights and,
+        with biases, of the four bias vectors, under the reference's tags
+        (`layer3_filter`, `layer3_biases_gate`, ...).  Returns
+        {tag: (counts int64[bins], lo, hi)}; empty unless the model was built
+        with histograms=True."""
+        out = {}
+        if not self.histograms:
+            return out
+        L = self.L
+        tags = [('filter', '_filter'), ('gate', '_gate'), ('dense', '_dense'),
+                ('skip', '_skip'), ('filter_bias', '_biases_filter'),
+                ('gate_bias', '_biases_gate'), ('dense_bias', '_biases_dense'),
+                ('skip_bias', '_biases_skip')]
+        for i, cur in enumerate(self.variables['dilated_stack']):
+            for k, suffix in tags:
+                if k not in cur or (k == 'dense' and i == L - 1):
+                    continue
+                v = cur[k].detach().float().reshape(-1)
+                lo, hi = float(v.min()), float(v.max())
+                if hi <= lo:
+                    hi = lo + 1e-12
+                counts = torch.histc(v, bins=bins, min=lo, max=hi)
+                out['layer%d%s' % (i, suffix)] = (
+                    counts.to(torch.int64).cpu().numpy(), lo, hi)
+        return out
+
     def named_variables(self, tree=None, prefix='wavenet'):
         """(reference variable name, view) pairs, creation order."""
         tree = self.variables if tree is None else tree

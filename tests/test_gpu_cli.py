@@ -112,3 +112,24 @@ def test_train_on_wav_directory_with_gc(hip_lib, tmp_path, params, capsys):
     sd = torch.load(train.latest_checkpoint(logdir), map_location='cpu')
     assert tuple(sd['variables']['wavenet/embeddings/gc_embedding'].shape) \
         == (227, 8)
+
+
+def test_train_histogram_summaries(hip_lib, tmp_path, params):
+    """--histograms True: the reference's per-layer weight histograms
+    (model.py:314-325 tags) are written next to each checkpoint."""
+    logdir = str(tmp_path / 'run_h')
+    assert train.main(['--synthetic', '--sample_size', '2000', '--batch_size',
+                       '1', '--wavenet_params', params, '--logdir', logdir,
+                       '--checkpoint_every', '2', '--num_steps', '3',
+                       '--histograms', 'True']) == 0
+    z = np.load(os.path.join(logdir, 'histograms-2.npz'))
+    L = len(SMALL['dilations'])
+    for tag in ('layer0_filter', 'layer0_gate', 'layer0_dense', 'layer0_skip',
+                'layer3_biases_filter', 'layer3_biases_skip',
+                'layer%d_skip' % (L - 1)):
+        c = z[tag + '/counts']
+        assert c.shape == (30,) and c.sum() > 0
+        lo, hi = z[tag + '/range']
+        assert hi > lo
+    assert 'layer%d_dense/counts' % (L - 1) not in z.files   # model.py:318
+    assert z['layer0_filter/counts'].sum() == 2 * 32 * 32

@@ -302,6 +302,15 @@ def main(argv=None):
                 if step % args.checkpoint_every == 0:
                     save(net, logdir, step)
                     last_saved_step = step
+                    if args.histograms:
+                        # the reference's histogram summaries (model.py:314-325)
+                        # as an .npz next to the checkpoint
+                        hs = net.histogram_summaries()
+                        np.savez(os.path.join(
+                            logdir, 'histograms-%d.npz' % step),
+                            **{k + '/counts': v[0] for k, v in hs.items()},
+                            **{k + '/range': np.asarray(v[1:])
+                               for k, v in hs.items()})
     except KeyboardInterrupt:
         print()
     finally:

@@ -63,6 +63,12 @@ int wn_scalar_causal_fwd(const float* audio, const float* W, float* x0, int B,
                          int T, int K0, void* stream);
 int wn_scalar_causal_wgrad(const float* audio, const float* dx0, float* slabs,
                            int splits, int B, int T, int K0, void* stream);
+/* one-hot causal layer, filter width 2: dWc[tap][v][32] as per-wave slabs
+ * [num_slabs][2][Q][32] (reduce with wn_reduce_slabs, slab stride 2*Q*32);
+ * Q <= 256, num_slabs = wn_causal_wgrad_slabs(B*T) */
+int wn_causal_wgrad_slabs(long rows);
+int wn_causal_wgrad(const int32_t* q, const float* dx0, float* slabs,
+                    int num_slabs, int B, int T, int Q, void* stream);
 
 /* ---- fused residual block: wavenet/model.py:236-330
  * (_create_dilation_layer) incl. both causal_conv calls, ops.py:46-62.

@@ -650,6 +650,76 @@ int wn_scalar_causal_wgrad(const float* audio, const float* dx0, float* slabs,
   return wn_check_launch();
 }
 
+// ---------------------------------------------------------------------------
+// Causal-layer weight gradient for one-hot input, filter width 2
+// (model.py:227-234 under autodiff): dWc[tap][v][:] = sum over rows whose code
+// q[t - (1 - tap)] == v of dx0[t][:].  It is a segmented sum, not a GEMM: 16 MB
+// of dx0 are read once.  Every wave owns a private [2 taps][Q][32] table in
+// LDS and walks a contiguous range of rows IN ORDER (half-wave h = tap h, lane
+// c = channel c, so no two lanes ever touch one address), which keeps the
+// result independent of scheduling; the per-wave tables go out as slabs for
+// wn_reduce_slabs.  Replaces two one-hot MFMA contractions (2 x 110 us at
+// B*T = 128000).
+// ---------------------------------------------------------------------------
+#define CWG_QMAX 256
+__global__ __launch_bounds__(128) void causal_wgrad_kernel(
+    const int32_t* __restrict__ q, const float* __restrict__ dx0,
+    float* __restrict__ slabs, long rows, long rows_per_slab, int T, int Q) {
+  __shared__ float tab[2 * 2 * CWG_QMAX * 32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 31, h = lane >> 5;
+  float* mine = tab + (wave * 2 + h) * Q * 32;   // this half-wave's tap table
+  for (int i = c; i < Q * 32; i += 32) mine[i] = 0.f;
+  __builtin_amdgcn_wave_barrier();
+  const long slab = (long)blockIdx.x * 2 + wave;
+  const long r0 = slab * rows_per_slab;
+  long r1 = r0 + rows_per_slab;
+  if (r1 > rows) r1 = rows;
+  const int shift = 1 - h;                       // tap 0: previous sample
+  for (long r = r0; r < r1; r += 8) {
+    float v[8];
+    int code[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long rr = r + u;
+      code[u] = -1;
+      v[u] = 0.f;
+      if (rr < r1) {
+        const int t = (int)(rr % T);
+        if (t - shift >= 0) code[u] = q[rr - shift];
+        v[u] = dx0[rr * 32 + c];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (code[u] >= 0 && code[u] < Q) mine[code[u] * 32 + c] += v[u];
+  }
+  __builtin_amdgcn_wave_barrier();
+  // (a slab whose row range is empty still writes its zeros)
+  float* out = slabs + slab * (2L * Q * 32) + (long)h * Q * 32;
+  for (int i = c; i < Q * 32; i += 32) out[i] = mine[i];
+}
+
+int wn_causal_wgrad_slabs(long rows) {
+  long n = rows / 256;           // >= 256 rows per wave
+  if (n > 256) n = 256;
+  if (n < 2) n = 2;
+  return (int)(n & ~1L);         // two waves per workgroup
+}
+
+int wn_causal_wgrad(const int32_t* q, const float* dx0, float* slabs,
+                    int num_slabs, int B, int T, int Q, void* stream) {
+  if (!q || !dx0 || !slabs) return WN_ERR_NULL;
+  if (B <= 0 || T <= 0 || Q <= 0 || num_slabs < 2 || (num_slabs & 1))
+    return WN_ERR_BAD_SHAPE;
+  if (Q > CWG_QMAX) return WN_ERR_UNSUPPORTED;
+  const long rows = (long)B * T;
+  const long rps = (rows + num_slabs - 1) / num_slabs;
+  hipLaunchKernelGGL(causal_wgrad_kernel, dim3(num_slabs / 2), dim3(128), 0,
+                     (hipStream_t)stream, q, dx0, slabs, rows, rps, T, Q);
+  return wn_check_launch();
+}
+
 int wn_xent_partials(long rows) {
   long g = (rows + 3) / 4;
   if (g > 1024) g = 1024;

@@ -26,6 +26,8 @@ SIGNATURES = {
     'wn_scalar_causal_fwd': (c_int, [P, P, P, c_int, c_int, c_int, P]),
     'wn_scalar_causal_wgrad': (c_int, [P, P, P, c_int, c_int, c_int, c_int,
                                        P]),
+    'wn_causal_wgrad_slabs': (c_int, [c_long]),
+    'wn_causal_wgrad': (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     'wn_layer_fwd': (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int,
                              c_int, c_int, P]),
     'wn_layer_bwd': (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int,

@@ -117,6 +117,8 @@ class _Workspace(object):
             self.splits[key] = sp
             need = max(need, sp * lib.wn_gemm_tn_slab_floats(mw, nw))
         need = max(need, 256 * 32 * CH)          # scalar-input causal wgrad
+        self.nslab_c = lib.wn_causal_wgrad_slabs(N)
+        need = max(need, self.nslab_c * 2 * Q * CH)
         alloc('slabs', (need,))
         self.dsum = alloc('dsum', (L, B, 64)) if net.G else None
         self.dsum_part = alloc(
@@ -198,6 +200,9 @@ class WaveNetModel(object):
         # replay recorded (function, args) launch sequences instead of
         # re-deriving ~235 argument lists per step in Python
         self.use_launch_plans = True
+        # causal-layer weight gradient as a segmented sum (K = 2, Q <= 256)
+        # instead of two one-hot MFMA contractions
+        self.causal_wgrad_segsum = True
         # seeds longer than this are primed from ONE batch forward pass
         # instead of one incremental step per seed sample
         self.fastgen_prime_forward_min = 64
@@ -525,7 +530,7 @@ class WaveNetModel(object):
     # ------------------------------------------------------------ launch plans
     def _plan_key(self, tag, ws, ids, extra):
         return (tag, extra, ids is not None, self.generic_layers,
-                self.fused_bwd, self.gemm_mode, self.tf_xent_zero_label_quirk,
+                self.fused_bwd, self.gemm_mode, self.causal_wgrad_segsum, self.tf_xent_zero_label_quirk,
                 _lib.stream(), self.params.data_ptr(), self.grads.data_ptr())
 
     def _stage_ids(self, ws, ids):
@@ -802,6 +807,13 @@ class WaveNetModel(object):
                       _lib.ptr(dxin), _lib.ptr(ws.slabs), sp, B, T, K0, st)
             _lib.call('wn_reduce_slabs', _lib.ptr(ws.slabs), sp, K0 * CH, 1,
                       0, 0, K0 * CH, _lib.ptr(gc_), 0, 1, 0, st)
+        elif self.KW == 2 and Q <= 256 and self.causal_wgrad_segsum:
+            # segmented sum over the codes (no one-hot contraction)
+            ns = ws.nslab_c
+            _lib.call('wn_causal_wgrad', _lib.ptr(ws.q), _lib.ptr(dxin),
+                      _lib.ptr(ws.slabs), ns, B, T, Q, st)
+            _lib.call('wn_reduce_slabs', _lib.ptr(ws.slabs), ns, 2 * Q * CH,
+                      1, 0, 0, 2 * Q * CH, _lib.ptr(gc_), 0, 1, 0, st)
         else:
             K = self.KW
             for tap in range(K):

@@ -250,3 +250,37 @@ def test_gemm_tn_one_hot(hip_lib):
             for t in range(shift, T):
                 ref[q[b, t - shift]] += Gr[b, t]
         assert np.abs(out.cpu().numpy().reshape(Q, 32) - ref).max() < 1e-4
+
+
+@pytest.mark.parametrize('B,T,Q', [(3, 50, 16), (1, 1, 256), (2, 700, 256), (5, 333, 123)])
+def test_causal_wgrad_segmented_sum(hip_lib, B, T, Q):
+    """wn_causal_wgrad: both taps of the one-hot causal layer's weight
+    gradient as a segmented sum; clip boundaries (tap 0 has no t-1 at t = 0),
+    ragged slab ranges, deterministic."""
+    from wavenet import _lib
+    lib = hip_lib
+    rng = np.random.default_rng(B * T + Q)
+    q = rng.integers(0, Q, (B, T)).astype(np.int32)
+    G = rng.standard_normal((B * T, 32)).astype(np.float32)
+    ns = lib.wn_causal_wgrad_slabs(B * T)
+    assert ns >= 2 and ns % 2 == 0
+    st = torch.cuda.current_stream().cuda_stream
+    dq, dG = torch.as_tensor(q).cuda(), dev(G)
+    outs = []
+    for _ in range(2):
+        slabs = torch.full((ns * 2 * Q * 32,), float('nan'), device='cuda')
+        out = torch.empty(2 * Q * 32, device='cuda')
+        _lib.call('wn_causal_wgrad', dq.data_ptr(), dG.data_ptr(),
+                  slabs.data_ptr(), ns, B, T, Q, st)
+        _lib.call('wn_reduce_slabs', slabs.data_ptr(), ns, 2 * Q * 32, 1, 0, 0,
+                  2 * Q * 32, out.data_ptr(), 0, 1, 0, st)
+        outs.append(out.cpu().numpy().reshape(2, Q, 32))
+    assert np.array_equal(outs[0], outs[1])
+    ref = np.zeros((2, Q, 32))
+    Gr = G.reshape(B, T, 32).astype(np.float64)
+    for b in range(B):
+        for t in range(T):
+            ref[1, q[b, t]] += Gr[b, t]
+            if t >= 1:
+                ref[0, q[b, t - 1]] += Gr[b, t]
+    assert np.abs(outs[0] - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())

@@ -231,6 +231,28 @@ def layer():
         print('layer_bwdw d=%3d: %6.1f us' % (d, t * 1e6), flush=True)
 
 
+def layerpad():
+    """are the layer kernels sensitive to the relative alignment of their
+    planes?  (12 planes carved from one buffer at stride N*32 + pad floats)"""
+    B, T = 8, 16000
+    N = B * T
+    w = torch.randn(5216, device=dev) * 0.1
+    nsl = lib.wn_layer_bwdw_slabs(B, T)
+    slabs2 = torch.empty(max(nsl, 1) * 5216, device=dev)
+    for pad in (0, 64, 1088, 8256, 65600, 524352):
+        big = torch.randn(12 * (N * 32 + pad) + 64, device=dev)
+        pl = [big[i * (N * 32 + pad): i * (N * 32 + pad) + N * 32] for i in range(12)]
+        x, xo, z, th, sg, dz, f, g, f2, g2, dx, dxo = pl
+        d = 64
+        tf = timeit(lambda: _lib.call('wn_layer_fwd', x.data_ptr(), xo.data_ptr(), z.data_ptr(), th.data_ptr(),
+                                      sg.data_ptr(), w.data_ptr(), None, 0, B, T, d, 1, 1, st()), n=30)
+        tb = timeit(lambda: _lib.call('wn_layer_bwdw', x.data_ptr(), z.data_ptr(), f.data_ptr(), g.data_ptr(),
+                                      dx.data_ptr(), dxo.data_ptr(), w.data_ptr(), dz.data_ptr(), th.data_ptr(),
+                                      sg.data_ptr(), w.data_ptr(), f2.data_ptr(), g2.data_ptr(), slabs2.data_ptr(),
+                                      B, T, d, 1, st()), n=30)
+        print('pad %7d floats: fwd %5.1f us  bwdw %5.1f us' % (pad, tf * 1e6, tb * 1e6), flush=True)
+
+
 def nnsmall():
     # same GEMM at sizes whose A operand fits the 256 MB Infinity Cache
     for N in (65536, 128000, 131072, 128000 + 512):

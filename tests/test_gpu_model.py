@@ -365,6 +365,30 @@ def test_prime_generator_from_forward_pass(hip_lib, n0):
     assert np.array_equal(a, b)
 
 
+def test_prime_generator_with_global_condition(hip_lib):
+    """forward-pass priming with a speaker id: same queues / distribution as
+    stepping, and different from another speaker's."""
+    cfg = cfg_with(MID, batch_size=1, global_condition_channels=4,
+                   global_condition_cardinality=5)
+    net, var = build_pair(cfg)
+    codes = np.random.default_rng(4).integers(0, 256, 90).astype(np.int32)
+    net.reset_generator()
+    for c in codes:
+        net.predict_proba_incremental(int(c), global_condition=3)
+    st_ref = net._gen['state'].clone()
+    p_ref = net.predict_proba_incremental(7, global_condition=3,
+                                          push=False).cpu().numpy()
+    net.prime_generator(codes, global_condition=3)
+    assert (net._gen['state'] - st_ref).abs().max().item() < 1e-5
+    p = net.predict_proba_incremental(7, global_condition=3,
+                                      push=False).cpu().numpy()
+    assert np.abs(p - p_ref).max() < 1e-5
+    net.prime_generator(codes, global_condition=1)
+    p_other = net.predict_proba_incremental(7, global_condition=1,
+                                            push=False).cpu().numpy()
+    assert np.abs(p_other - p_ref).max() > 1e-4
+
+
 def test_unsupported_configs_raise(hip_lib):
     from wavenet import WaveNetModel
     for kw in (dict(filter_width=9), dict(residual_channels=64),

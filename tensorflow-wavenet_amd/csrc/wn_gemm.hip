@@ -13,6 +13,17 @@
 //
 // Orientation: "time on the MFMA N axis" (see wn_common.h): activations are
 // the B operand as 32x32 fragments, weights the A operand from LDS.
+//
+// Kernels in this file
+//   gemm_nn3_kernel      default NN: LDS-DMA staging, 4 workgroups / CU
+//   gemm_nn_kernel       NN fallback (K % 16 != 0, WN_NN_MODE=tile): register
+//                        staging, K chunks of 32, every edge predicated
+//   gemm_tn3_kernel      default TN for wide outputs (dWs / dW1 / dW2)
+//   gemm_tn2_kernel      its register-staged fallback (ragged row counts)
+//   gemm_tn_kernel       LDS-free TN for narrow / one-hot operands
+//   gemm_nn_split_kernel, gemm_tn_split_kernel, split_w_kernel
+//                        opt-in split-bf16 products (wn_gemm_*_split)
+//   reduce_slabs_kernel, transpose_pad_kernel, mfma_peak_kernel
 #include "wn_common.h"
 #include <cstdlib>
 
@@ -59,7 +70,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + idx;
 }
 
-// Coalesced epilogue shared by gemm_nn_kernel / gemm_nt_kernel.  An
+// Coalesced epilogue shared by the NN kernels.  An
 // accumulator fragment store touches 32 rows x 32 B per instruction; instead
 // each wave passes its 64 x 64 result through a private LDS tile (two halves
 // of 32 rows, row stride 68 floats: conflict-free both ways) and writes / reads
@@ -115,7 +126,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmNN& g, f32x16 (&acc)[2][
   }
 }
 
-template <int WMT>
+template <int WMT>   // time-waves per workgroup: 2 -> 128-row tile, 256 threads
 __global__ __launch_bounds__(WMT * 128) void gemm_nn_kernel(GemmNN g) {
   constexpr int TM = WMT * 64, NT = WMT * 128;   // rows per tile, threads
   constexpr int NA = TM * 8 / NT, NB = 1024 / NT; // float4 per thread (A, W)

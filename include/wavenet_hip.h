@@ -111,14 +111,16 @@ int wn_layer_wgrad_k(const float* x, const float* daf, const float* dag,
                      void* stream);
 
 /* fused backward of one block: phase B + all weight gradients of layer l and
- * phase A of layer l-1 in one pass (reads da_l / dx_{l+1} once). */
+ * phase A of layer l-1 in one pass (reads da_l / dx_{l+1} once).
+ * tile_colsum (optional): [B * ceil(T/32)][64] per-tile column sums of
+ * da_f | da_g, reduced per clip for the global-conditioning gradients. */
 int wn_layer_bwdw_slabs(int B, int T);
 int wn_layer_bwdw(const float* x, const float* z, const float* daf_cur,
                   const float* dag_cur, const float* dxin, float* dx_out,
                   const float* wblock_b, const float* dZ, const float* th,
                   const float* sg, const float* wblock_a, float* daf_next,
-                  float* dag_next, float* slabs, int B, int T, int dilation,
-                  int do_a, void* stream);
+                  float* dag_next, float* slabs, float* tile_colsum, int B,
+                  int T, int dilation, int do_a, void* stream);
 
 /* ---- fp32 MFMA GEMMs: the skip sum + post-processing of
  * wavenet/model.py:303-305, 430-440 (_create_network) and their gradients */

@@ -393,8 +393,8 @@ __global__ __launch_bounds__(BW_WG) void layer_bwdw_kernel(
     const float* __restrict__ wblock_b, const float* __restrict__ dZ,
     const float* __restrict__ th, const float* __restrict__ sg,
     const float* __restrict__ wblock_a, float* __restrict__ daf_next,
-    float* __restrict__ dag_next, float* __restrict__ slabs, int B, int T,
-    int d) {
+    float* __restrict__ dag_next, float* __restrict__ slabs,
+    float* __restrict__ tile_colsum, int B, int T, int d) {
   constexpr int LDT = 33, MT = 32 * LDT;
   __shared__ float wl[5 * MT];
   __shared__ __attribute__((aligned(16))) float tiles[BW_WAVES * 4 * 1024];
@@ -455,6 +455,7 @@ __global__ __launch_bounds__(BW_WG) void layer_bwdw_kernel(
       mma32<LDT>(dx, f0, wlane + 1 * MT);  // da_f[t]   * Wf[1]^T
       mma32<LDT>(dx, g0, wlane + 3 * MT);  // da_g[t]   * Wg[1]^T
     }
+    float tsf = 0.f, tsg = 0.f;          // this tile's column sums of da
 #pragma unroll 4
     for (int s = 0; s < 16; ++s) {       // dW[1] += x[t]^T da[t]
       const int row = 2 * s + h;
@@ -462,8 +463,20 @@ __global__ __launch_bounds__(BW_WG) void layer_bwdw_kernel(
       const float bf = tile_elem(t1, row, j), bg = tile_elem(t2, row, j);
       cf1 = __builtin_amdgcn_mfma_f32_32x32x2f32(axc, bf, cf1, 0, 0, 0);
       cg1 = __builtin_amdgcn_mfma_f32_32x32x2f32(axc, bg, cg1, 0, 0, 0);
-      sf += bf;
-      sgs += bg;
+      tsf += bf;
+      tsg += bg;
+    }
+    sf += tsf;
+    sgs += tsg;
+    if (tile_colsum) {
+      // per-tile column sums (a tile lies inside one clip): the per-clip sums
+      // the global-conditioning gradients need (model.py:272-284 under
+      // autodiff) without a separate pass over da
+      const float a = tsf + __shfl_xor(tsf, 32), b2 = tsg + __shfl_xor(tsg, 32);
+      if (h == 0) {
+        tile_colsum[(size_t)tile * 64 + j] = a;
+        tile_colsum[(size_t)tile * 64 + 32 + j] = b2;
+      }
     }
     __builtin_amdgcn_wave_barrier();
     rows_to_lds(t3, lane, rxp);
@@ -1057,8 +1070,8 @@ int wn_layer_bwdw(const float* x, const float* z, const float* daf_cur,
                   const float* dag_cur, const float* dxin, float* dx_out,
                   const float* wblock_b, const float* dZ, const float* th,
                   const float* sg, const float* wblock_a, float* daf_next,
-                  float* dag_next, float* slabs, int B, int T, int dilation,
-                  int do_a, void* stream) {
+                  float* dag_next, float* slabs, float* tile_colsum, int B,
+                  int T, int dilation, int do_a, void* stream) {
   if (B <= 0 || T <= 0 || dilation <= 0) return WN_ERR_BAD_SHAPE;
   if (!x || !daf_cur || !dag_cur || !dx_out || !wblock_b || !slabs)
     return WN_ERR_NULL;
@@ -1074,7 +1087,8 @@ int wn_layer_bwdw(const float* x, const float* z, const float* daf_cur,
 #define LAUNCH(DA, HX)                                                        \
   hipLaunchKernelGGL((layer_bwdw_kernel<DA, HX>), grid, block, 0, s, x, z,    \
                      daf_cur, dag_cur, dxin, dx_out, wblock_b, dZ, th, sg,    \
-                     wblock_a, daf_next, dag_next, slabs, B, T, dilation)
+                     wblock_a, daf_next, dag_next, slabs, tile_colsum, B, T, \
+                     dilation)
   if (do_a) { if (dxin) LAUNCH(true, true); else LAUNCH(true, false); }
   else { if (dxin) LAUNCH(false, true); else LAUNCH(false, false); }
 #undef LAUNCH

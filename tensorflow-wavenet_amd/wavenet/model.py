@@ -121,6 +121,7 @@ class _Workspace(object):
         need = max(need, self.nslab_c * 2 * Q * CH)
         alloc('slabs', (need,))
         self.dsum = alloc('dsum', (L, B, 64)) if net.G else None
+        self.tilesum = alloc('tilesum', (L, ntiles, 64)) if net.G else None
         self.dsum_part = alloc(
             'dsum_part', (B * lib.wn_colsum_clip_chunks(T) * 64,)) \
             if net.G else None
@@ -733,10 +734,6 @@ class WaveNetModel(object):
             dxo = ws.dx[xp]
             if fused:
                 # one pass: dx_l, every weight gradient of layer l, da_{l-1}
-                if ws.dsum is not None:
-                    _lib.call('wn_colsum_clip', _lib.ptr(f), _lib.ptr(g), B,
-                              T, _lib.ptr(ws.dsum_part), _lib.ptr(ws.dsum[l]),
-                              st)
                 fn, gn = da(1 - cur) if l > 0 else (None, None)
                 _lib.call('wn_layer_bwdw', _lib.ptr(ws.X[l]),
                           None if dxin is None else _lib.ptr(ws.Z[l]),
@@ -749,6 +746,7 @@ class WaveNetModel(object):
                           _lib.ptr(self._layer_block(P, l - 1)) if l > 0
                           else None,
                           _lib.ptr(fn), _lib.ptr(gn), _lib.ptr(ws.lslabs[l]),
+                          None if ws.dsum is None else _lib.ptr(ws.tilesum[l]),
                           B, T, d, 1 if l > 0 else 0, st)
                 if l > 0:
                     cur = 1 - cur
@@ -788,6 +786,12 @@ class WaveNetModel(object):
                           st)
             dxin = dxo
             xp = 1 - xp
+        if fused and ws.dsum is not None:
+            # per-clip sums of da_l for every layer from the per-tile sums the
+            # fused kernel wrote (fixed order over a clip's tiles)
+            tpc = (T + 31) // 32
+            _lib.call('wn_reduce_slabs', _lib.ptr(ws.tilesum), tpc, 64, L * B,
+                      tpc * 64, 0, 64, _lib.ptr(ws.dsum), 64, 1, 0, st)
         if side is not main:
             main.wait_event(ws.ev_done[0])
         # layer-block gradients: fixed-order sum of the per-workgroup slabs

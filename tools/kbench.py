@@ -249,7 +249,7 @@ def layerpad():
         tb = timeit(lambda: _lib.call('wn_layer_bwdw', x.data_ptr(), z.data_ptr(), f.data_ptr(), g.data_ptr(),
                                       dx.data_ptr(), dxo.data_ptr(), w.data_ptr(), dz.data_ptr(), th.data_ptr(),
                                       sg.data_ptr(), w.data_ptr(), f2.data_ptr(), g2.data_ptr(), slabs2.data_ptr(),
-                                      B, T, d, 1, st()), n=30)
+                                      None, B, T, d, 1, st()), n=30)
         print('pad %7d floats: fwd %5.1f us  bwdw %5.1f us' % (pad, tf * 1e6, tb * 1e6), flush=True)
 
 

@@ -655,8 +655,7 @@ int wn_scalar_causal_wgrad(const float* audio, const float* dx0, float* slabs,
 // (model.py:227-234 under autodiff): dWc[tap][v][:] = sum over rows whose code
 // q[t - (1 - tap)] == v of dx0[t][:].  It is a segmented sum, not a GEMM: 16 MB
 // of dx0 are read once.  Every wave owns a private [2 taps][Q][32] table in
-// LDS and walks a contiguous range of rows IN ORDER (half-wave h = tap h, lane
-// c = channel c, so no two lanes ever touch one address), which keeps the
+// LDS and walks a contiguous range of rows in program order, which keeps the
 // result independent of scheduling; the per-wave tables go out as slabs for
 // wn_reduce_slabs.  Replaces two one-hot MFMA contractions (2 x 110 us at
 // B*T = 128000).
@@ -667,37 +666,60 @@ __global__ __launch_bounds__(128) void causal_wgrad_kernel(
     float* __restrict__ slabs, long rows, long rows_per_slab, int T, int Q) {
   __shared__ float tab[2 * 2 * CWG_QMAX * 32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c = lane & 31, h = lane >> 5;
-  float* mine = tab + (wave * 2 + h) * Q * 32;   // this half-wave's tap table
-  for (int i = c; i < Q * 32; i += 32) mine[i] = 0.f;
+  float* t0 = tab + (size_t)wave * 2 * Q * 32;   // tap 0 (previous sample)
+  float* t1 = t0 + Q * 32;                       // tap 1 (current sample)
+  for (int i = lane; i < 2 * Q * 32; i += 64) t0[i] = 0.f;
   __builtin_amdgcn_wave_barrier();
   const long slab = (long)blockIdx.x * 2 + wave;
   const long r0 = slab * rows_per_slab;
   long r1 = r0 + rows_per_slab;
   if (r1 > rows) r1 = rows;
-  const int shift = 1 - h;                       // tap 0: previous sample
-  for (long r = r0; r < r1; r += 8) {
-    float v[8];
-    int code[8];
+  // One wave-instruction covers 8 rows: lane l -> row l >> 3, channels
+  // 4 (l & 7) .. +3 (16-byte loads, 1 KiB contiguous).  GR groups = 64 rows are
+  // in flight together; the adds go through ds_add_f32 in program order, rows
+  // of one instruction that share a code are resolved by the LDS unit.
+  constexpr int GR = 8;
+  const int lr = lane >> 3, ch = (lane & 7) * 4;
+  // position of this lane's first row inside its clip, advanced by 8 per group
+  // (a 64-bit modulo per row costs more than the loads)
+  int tpos = r0 < r1 ? (int)((r0 + lr) % T) : 0;
+  for (long r = r0; r < r1; r += 8 * GR) {
+    f32x4 v[GR];
+    int c1[GR], c0[GR];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const long rr = r + u;
-      code[u] = -1;
-      v[u] = 0.f;
+    for (int u = 0; u < GR; ++u) {
+      const long rr = r + 8 * u + lr;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      v[u] = z;
+      c1[u] = -1;
+      c0[u] = -1;
       if (rr < r1) {
-        const int t = (int)(rr % T);
-        if (t - shift >= 0) code[u] = q[rr - shift];
-        v[u] = dx0[rr * 32 + c];
+        v[u] = *reinterpret_cast<const f32x4*>(dx0 + rr * 32 + ch);
+        c1[u] = q[rr];
+        if (tpos != 0) c0[u] = q[rr - 1];       // t = 0 has no previous sample
       }
+      tpos += 8;
+      if (tpos >= T) tpos %= T;                 // 32-bit, rarely taken
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (code[u] >= 0 && code[u] < Q) mine[code[u] * 32 + c] += v[u];
+    for (int u = 0; u < GR; ++u) {
+      if (c1[u] >= 0 && c1[u] < Q) {
+        float* p = t1 + c1[u] * 32 + ch;
+        atomicAdd(p, v[u][0]); atomicAdd(p + 1, v[u][1]);
+        atomicAdd(p + 2, v[u][2]); atomicAdd(p + 3, v[u][3]);
+      }
+      if (c0[u] >= 0 && c0[u] < Q) {
+        float* p = t0 + c0[u] * 32 + ch;
+        atomicAdd(p, v[u][0]); atomicAdd(p + 1, v[u][1]);
+        atomicAdd(p + 2, v[u][2]); atomicAdd(p + 3, v[u][3]);
+      }
+    }
   }
   __builtin_amdgcn_wave_barrier();
   // (a slab whose row range is empty still writes its zeros)
-  float* out = slabs + slab * (2L * Q * 32) + (long)h * Q * 32;
-  for (int i = c; i < Q * 32; i += 32) out[i] = mine[i];
+  f32x4* out = reinterpret_cast<f32x4*>(slabs + slab * (2L * Q * 32));
+  const f32x4* src = reinterpret_cast<const f32x4*>(t0);
+  for (int i = lane; i < 2 * Q * 8; i += 64) out[i] = src[i];
 }
 
 int wn_causal_wgrad_slabs(long rows) {

@@ -196,6 +196,53 @@ __global__ __launch_bounds__(256) void xent_kernel(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float lsum = 0.f;
   const long nwaves = (long)gridDim.x * 4;
+  if (Q == 256) {
+    // one 16-byte load per lane holds the whole row: a single pass, each exp
+    // evaluated once, the next row's load in flight under the reductions
+    long row = (long)blockIdx.x * 4 + wave;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row < rows) v = *reinterpret_cast<const f32x4*>(logits + row * ld + lane * 4);
+    for (; row < rows; row += nwaves) {
+      const long nrow = row + nwaves;
+      f32x4 vn = {0.f, 0.f, 0.f, 0.f};
+      if (nrow < rows)
+        vn = *reinterpret_cast<const f32x4*>(logits + nrow * ld + lane * 4);
+      const int t = (int)(row % T);
+      const int label = (t + 1 < T) ? q[row + 1] : -1;
+      const bool has_label = label >= 0 && label < Q;
+      float m = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+      float e[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) e[k] = expf(v[k] - m);
+      float se = (e[0] + e[1]) + (e[2] + e[3]);
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) se += __shfl_xor(se, o);
+      const float lse = m + logf(se);
+      if (has_label) {
+        // the label's logit lives in lane label >> 2
+        const float mine = (label >> 2) == lane ? v[label & 3] : 0.f;
+        float ll = mine;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) ll += __shfl_xor(ll, o);
+        if (lane == 0) lsum += lse - ll;
+      }
+      if (dlogits) {
+        const float inv_se = 1.f / se;
+        const bool back = has_label || tf_quirk;
+        f32x4 g;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float p = back ? e[k] * inv_se : 0.f;
+          if (has_label && lane * 4 + k == label) p -= 1.f;
+          g[k] = p * inv_n;
+        }
+        *reinterpret_cast<f32x4*>(dlogits + row * ld + lane * 4) = g;
+      }
+      v = vn;
+    }
+  } else
   for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += nwaves) {
     const float* lp = logits + row * ld;
     const int t = (int)(row % T);

@@ -574,8 +574,18 @@ __global__ void sum_rows_kernel(const float* __restrict__ in, int rows, int n,
                                 float* __restrict__ out) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n) return;
+  // loads of a batch of rows are issued together (the sum itself stays in row
+  // order): 50 dependent round trips were 20 us for 100 KB
   float s = 0.f;
-  for (int r = 0; r < rows; ++r) s += in[(long)r * n + c];
+  int r = 0;
+  for (; r + 16 <= rows; r += 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = in[(long)(r + u) * n + c];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += v[u];
+  }
+  for (; r < rows; ++r) s += in[(long)r * n + c];
   out[c] = s;
 }
 

@@ -531,25 +531,37 @@ __global__ __launch_bounds__(FGC_THREADS) void fg_chain_kernel(FgStep g) {
           a2 = fmaf(xv[2], q[2], a2); a3 = fmaf(xv[3], q[3], a3);
         }
         const float a = (a0 + a1) + (a2 + a3);
-        const float gate = __shfl(a, nn + 32);
-        const float z = wn_tanh(a) * wn_sigmoid(gate);
+        // lanes 0-31 hold the filter pre-activation, lanes 32-63 the gate's:
+        // one exp + one rcp per lane (tanh(a) = 2 sigmoid(2a) - 1), then the
+        // halves meet through v_permlane32_swap (no LDS round trip)
+        const float s = wn_sigmoid(gsel ? a : 2.f * a);
+        const float act = gsel ? s : fmaf(2.f, s, -1.f);
+        const auto pr = __builtin_amdgcn_permlane32_swap(
+            __float_as_uint(act), __float_as_uint(act), false, false);
+        const float z = __uint_as_float(pr[0]) * __uint_as_float(pr[1]);
         if (lane < 32) {
           g.z_all[l * 32 + lane] = z;
           zv[lane] = z;
         }
         if (l + 1 < L) {
           __builtin_amdgcn_wave_barrier();
+          // dense 32 x 32: each half takes 16 of the 32 inputs
           const float* wd = wl + 4 * 1024 + nn * 32;
-          float d0 = cur_bd, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+          float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
 #pragma unroll
-          for (int c = 0; c < 8; ++c) {
+          for (int cc = 0; cc < 4; ++cc) {
+            const int c = gsel * 4 + cc;
             const int sw = (c ^ (nn & 7)) << 2;
             const f32x4 zz = *reinterpret_cast<const f32x4*>(zv + 4 * c);
             const f32x4 p = *reinterpret_cast<const f32x4*>(wd + sw);
             d0 = fmaf(zz[0], p[0], d0); d1 = fmaf(zz[1], p[1], d1);
             d2 = fmaf(zz[2], p[2], d2); d3 = fmaf(zz[3], p[3], d3);
           }
-          if (lane < 32) x += (d0 + d1) + (d2 + d3);
+          const float dh = (d0 + d1) + (d2 + d3);
+          const auto pd = __builtin_amdgcn_permlane32_swap(
+              __float_as_uint(dh), __float_as_uint(dh), false, false);
+          if (lane < 32)
+            x += cur_bd + (__uint_as_float(pd[0]) + __uint_as_float(pd[1]));
         }
       }
     } else {

@@ -1,7 +1,7 @@
 """Per-kernel roofline table from the committed rocprofv3 summaries:
 profiles/<tag>_bench_kernel_stats.csv (--kernel-trace --stats) and
 profiles/<tag>_pmc_traffic.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes,
-tools/pmc_summary.py).  usage: python tools/roofline_table.py r01_v6 > profiles/r01_v7_roofline_table.md
+tools/pmc_summary.py).  usage: python tools/roofline_table.py r01_v6 > profiles/r01_v8_roofline_table.md
 
 Algorithmic FLOPs per launch at the bench shape (B*T = 128000, default stack):
   gemm_nn3: 620.757 GFLOP per step over 6 launches (skip, post1, post2 and

@@ -723,59 +723,58 @@ __global__ __launch_bounds__(128) void causal_wgrad_kernel(
     float* __restrict__ slabs, long rows, long rows_per_slab, int T, int Q) {
   __shared__ float tab[2 * 2 * CWG_QMAX * 32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float* t0 = tab + (size_t)wave * 2 * Q * 32;   // tap 0 (previous sample)
-  float* t1 = t0 + Q * 32;                       // tap 1 (current sample)
-  for (int i = lane; i < 2 * Q * 32; i += 64) t0[i] = 0.f;
+  const int c = lane & 31, h = lane >> 5;        // channel, tap
+  float* wtab = tab + (size_t)wave * 2 * Q * 32;
+  float* mine = wtab + (size_t)h * Q * 32;       // this half-wave's tap table
+  for (int i = lane; i < 2 * Q * 32; i += 64) wtab[i] = 0.f;
   __builtin_amdgcn_wave_barrier();
   const long slab = (long)blockIdx.x * 2 + wave;
   const long r0 = slab * rows_per_slab;
   long r1 = r0 + rows_per_slab;
   if (r1 > rows) r1 = rows;
-  // One wave-instruction covers 8 rows: lane l -> row l >> 3, channels
-  // 4 (l & 7) .. +3 (16-byte loads, 1 KiB contiguous).  GR groups = 64 rows are
-  // in flight together; the adds go through ds_add_f32 in program order, rows
-  // of one instruction that share a code are resolved by the LDS unit.
-  constexpr int GR = 8;
-  const int lr = lane >> 3, ch = (lane & 7) * 4;
-  // position of this lane's first row inside its clip, advanced by 8 per group
-  // (a 64-bit modulo per row costs more than the loads)
-  int tpos = r0 < r1 ? (int)((r0 + lr) % T) : 0;
-  for (long r = r0; r < r1; r += 8 * GR) {
-    f32x4 v[GR];
-    int c1[GR], c0[GR];
+  // Half-wave h accumulates tap h (tap 0 pairs dx0[t] with the PREVIOUS code),
+  // lane c owns channel c: one row per step, 32 consecutive floats of one
+  // table row, plain read-add-write (a wave's LDS operations execute in
+  // program order, so rows that share a code simply chain).  LDS float
+  // atomics measured ~400 cycles per instruction here, hence none.  Batches of
+  // NB rows are loaded while the previous batch is accumulated.
+  constexpr int NB = 16;
+  const int shift = 1 - h;
+  float v[NB], vn[NB];
+  int code[NB], coden[NB];
+  int tb = r0 < r1 ? (int)(r0 % T) : 0;          // clip position of the batch
+  auto fetch = [&](long r, int t0, float (&vv)[NB], int (&cc)[NB]) {
 #pragma unroll
-    for (int u = 0; u < GR; ++u) {
-      const long rr = r + 8 * u + lr;
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      v[u] = z;
-      c1[u] = -1;
-      c0[u] = -1;
+    for (int u = 0; u < NB; ++u) {
+      const long rr = r + u;
+      cc[u] = -1;
+      vv[u] = 0.f;
       if (rr < r1) {
-        v[u] = *reinterpret_cast<const f32x4*>(dx0 + rr * 32 + ch);
-        c1[u] = q[rr];
-        if (tpos != 0) c0[u] = q[rr - 1];       // t = 0 has no previous sample
+        int t = t0 + u;
+        if (t >= T) t %= T;
+        if (t - shift >= 0) cc[u] = q[rr - shift];
+        vv[u] = dx0[rr * 32 + c];
       }
-      tpos += 8;
-      if (tpos >= T) tpos %= T;                 // 32-bit, rarely taken
     }
+  };
+  if (r0 < r1) fetch(r0, tb, v, code);
+  for (long r = r0; r < r1; r += NB) {
+    tb += NB;
+    if (tb >= T) tb %= T;
+    if (r + NB < r1) fetch(r + NB, tb, vn, coden);
 #pragma unroll
-    for (int u = 0; u < GR; ++u) {
-      if (c1[u] >= 0 && c1[u] < Q) {
-        float* p = t1 + c1[u] * 32 + ch;
-        atomicAdd(p, v[u][0]); atomicAdd(p + 1, v[u][1]);
-        atomicAdd(p + 2, v[u][2]); atomicAdd(p + 3, v[u][3]);
-      }
-      if (c0[u] >= 0 && c0[u] < Q) {
-        float* p = t0 + c0[u] * 32 + ch;
-        atomicAdd(p, v[u][0]); atomicAdd(p + 1, v[u][1]);
-        atomicAdd(p + 2, v[u][2]); atomicAdd(p + 3, v[u][3]);
-      }
+    for (int u = 0; u < NB; ++u)
+      if (code[u] >= 0 && code[u] < Q) mine[code[u] * 32 + c] += v[u];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      v[u] = vn[u];
+      code[u] = coden[u];
     }
   }
   __builtin_amdgcn_wave_barrier();
   // (a slab whose row range is empty still writes its zeros)
   f32x4* out = reinterpret_cast<f32x4*>(slabs + slab * (2L * Q * 32));
-  const f32x4* src = reinterpret_cast<const f32x4*>(t0);
+  const f32x4* src = reinterpret_cast<const f32x4*>(wtab);
   for (int i = lane; i < 2 * Q * 8; i += 64) out[i] = src[i];
 }
 

@@ -70,7 +70,7 @@ def log(msg):
     sys.stderr.flush()
 
 
-def cpu_baseline(params, T, max_seconds=30.0):
+def cpu_baseline(params, T, max_seconds=20.0, max_steps=20):
     """Time the op-for-op CPU restatement of the reference graph (checker /
     baseline only; never part of the measured GPU path)."""
     from oracle import wavenet_oracle as O, torch_graph as TG
@@ -86,7 +86,8 @@ def cpu_baseline(params, T, max_seconds=30.0):
     step(q)                                   # warm-up (allocator, threads)
     log('cpu warm-up step %.1f s' % (time.time() - t0))
     n, t0 = 0, time.time()
-    while n < 3 and (time.time() - t0) < max_seconds:
+    # bounded sample: about 10-20 s of CPU work (0.5-0.8 s per step here)
+    while n < max_steps and (time.time() - t0) < max_seconds - 8.0:
         step(q)
         n += 1
         log('cpu step %d done (%.1f s elapsed)' % (n, time.time() - t0))

@@ -578,118 +578,93 @@ __global__ __launch_bounds__(FGC_THREADS) void fg_chain_kernel(FgStep g) {
   }
 }
 
-// total[s] = sum_{l,k} z[l][k] Ws[l][k][s] + bsum[s]; h1 = relu(total)
+// The three mat-vecs after the chain (skip sum, postprocess1, postprocess2) are
+// latency-bound: a workgroup's time is (weight loads per thread / loads in
+// flight) round trips.  16 outputs x 16 K-slices per 256-thread workgroup (twice
+// the workgroups, half the loads per thread of the first 32 x 8 version) and
+// every thread's loads issued in at most two batches.
+#define FGM_OUTS 16
+#define FGM_PARTS 16
+
+// partial dot product of this thread's K-slice for output column `col`
+// (W is [K][ld], 64-byte coalesced over the 16 output lanes); in_s is in LDS
+template <int BATCH>
+__device__ __forceinline__ float fg_mv_partial(const float* in_s, int K,
+                                               const float* __restrict__ W,
+                                               long ld, int col, int part) {
+  const int per = (K + FGM_PARTS - 1) / FGM_PARTS;
+  const int k0 = part * per, k1 = min(K, k0 + per);
+  const float* w = W + col;
+  float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+  int k = k0;
+  for (; k + BATCH <= k1; k += BATCH) {
+    float wv[BATCH];
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) wv[u] = w[(long)(k + u) * ld];
+#pragma unroll
+    for (int u = 0; u + 3 < BATCH; u += 4) {
+      c0 = fmaf(in_s[k + u], wv[u], c0);
+      c1 = fmaf(in_s[k + u + 1], wv[u + 1], c1);
+      c2 = fmaf(in_s[k + u + 2], wv[u + 2], c2);
+      c3 = fmaf(in_s[k + u + 3], wv[u + 3], c3);
+    }
+#pragma unroll
+    for (int u = BATCH & ~3; u < BATCH; ++u) c0 = fmaf(in_s[k + u], wv[u], c0);
+  }
+  for (; k < k1; ++k) c0 = fmaf(in_s[k], w[(long)k * ld], c0);
+  return (c0 + c1) + (c2 + c3);
+}
+
+__device__ __forceinline__ float fg_mv_reduce(float (*red)[FGM_OUTS], int o) {
+  float t = 0.f;
+#pragma unroll
+  for (int p = 0; p < FGM_PARTS; ++p) t += red[p][o];
+  return t;
+}
+
+// h1[s] = relu(sum_l z_l . Ws_l[:, s] + sum_l bs_l[s])   (model.py:505-509)
 __global__ __launch_bounds__(256) void fg_skip_kernel(FgStep g) {
   __shared__ float zs[FG_MAXL * 32];
-  __shared__ float red[8][32];
-  const int tid = threadIdx.x, o = tid & 31, part = tid >> 5;
-  const int s = blockIdx.x * 32 + o;
+  __shared__ float red[FGM_PARTS][FGM_OUTS];
+  const int tid = threadIdx.x, o = tid & (FGM_OUTS - 1), part = tid / FGM_OUTS;
+  const int s = blockIdx.x * FGM_OUTS + o;
   const int KK = g.L * 32;
   for (int i = tid; i < KK; i += 256) zs[i] = g.z_all[i];
   __syncthreads();
-  const int per = (KK + 7) / 8, k0 = part * per, k1 = min(KK, k0 + per);
-  float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
-  if (s < g.S) {
-    const float* w = g.skip_w + s;
-    int k = k0;
-    for (; k + 40 <= k1; k += 40) {
-      float wv[40];
-#pragma unroll
-      for (int u = 0; u < 40; ++u) wv[u] = w[(long)(k + u) * g.S];
-#pragma unroll
-      for (int u = 0; u < 40; u += 4) {
-        c0 = fmaf(zs[k + u], wv[u], c0);
-        c1 = fmaf(zs[k + u + 1], wv[u + 1], c1);
-        c2 = fmaf(zs[k + u + 2], wv[u + 2], c2);
-        c3 = fmaf(zs[k + u + 3], wv[u + 3], c3);
-      }
-    }
-    for (; k < k1; ++k) c0 = fmaf(zs[k], w[(long)k * g.S], c0);
-  }
-  red[part][o] = (c0 + c1) + (c2 + c3);
+  red[part][o] = s < g.S ? fg_mv_partial<50>(zs, KK, g.skip_w, g.S, s, part) : 0.f;
   __syncthreads();
-  if (part == 0 && s < g.S) {
-    float t = g.skip_bsum ? g.skip_bsum[s] : 0.f;
-#pragma unroll
-    for (int p = 0; p < 8; ++p) t += red[p][o];
-    g.h1[s] = fmaxf(t, 0.f);
-  }
+  if (part == 0 && s < g.S)
+    g.h1[s] = fmaxf((g.skip_bsum ? g.skip_bsum[s] : 0.f) + fg_mv_reduce(red, o), 0.f);
 }
 
 // h2[s] = relu(sum_k h1[k] W1[k][s] + b1[s])
 __global__ __launch_bounds__(256) void fg_post1_kernel(FgStep g) {
   __shared__ float hs[FG_MAXS];
-  __shared__ float red[8][32];
-  const int tid = threadIdx.x, o = tid & 31, part = tid >> 5;
-  const int s = blockIdx.x * 32 + o;
+  __shared__ float red[FGM_PARTS][FGM_OUTS];
+  const int tid = threadIdx.x, o = tid & (FGM_OUTS - 1), part = tid / FGM_OUTS;
+  const int s = blockIdx.x * FGM_OUTS + o;
   const int S = g.S;
   for (int i = tid; i < S; i += 256) hs[i] = g.h1[i];
   __syncthreads();
-  const int per = (S + 7) / 8, k0 = part * per, k1 = min(S, k0 + per);
-  float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
-  if (s < S) {
-    const float* w = g.post1_w + s;
-    int k = k0;
-    for (; k + 32 <= k1; k += 32) {
-      float wv[32];
-#pragma unroll
-      for (int u = 0; u < 32; ++u) wv[u] = w[(long)(k + u) * S];
-#pragma unroll
-      for (int u = 0; u < 32; u += 4) {
-        c0 = fmaf(hs[k + u], wv[u], c0);
-        c1 = fmaf(hs[k + u + 1], wv[u + 1], c1);
-        c2 = fmaf(hs[k + u + 2], wv[u + 2], c2);
-        c3 = fmaf(hs[k + u + 3], wv[u + 3], c3);
-      }
-    }
-    for (; k < k1; ++k) c0 = fmaf(hs[k], w[(long)k * S], c0);
-  }
-  red[part][o] = (c0 + c1) + (c2 + c3);
+  red[part][o] = s < S ? fg_mv_partial<32>(hs, S, g.post1_w, S, s, part) : 0.f;
   __syncthreads();
-  if (part == 0 && s < S) {
-    float t = g.post1_b ? g.post1_b[s] : 0.f;
-#pragma unroll
-    for (int p = 0; p < 8; ++p) t += red[p][o];
-    g.h2[s] = fmaxf(t, 0.f);
-  }
+  if (part == 0 && s < S)
+    g.h2[s] = fmaxf((g.post1_b ? g.post1_b[s] : 0.f) + fg_mv_reduce(red, o), 0.f);
 }
 
-// logits[q] = sum_k h2[k] W2[k][q] + b2[q]   (Q/32 workgroups)
+// logits[q] = sum_k h2[k] W2[k][q] + b2[q]
 __global__ __launch_bounds__(256) void fg_logits_kernel(FgStep g) {
   __shared__ float hs[FG_MAXS];
-  __shared__ float red[8][32];
-  const int tid = threadIdx.x, o = tid & 31, part = tid >> 5;
-  const int q = blockIdx.x * 32 + o;
+  __shared__ float red[FGM_PARTS][FGM_OUTS];
+  const int tid = threadIdx.x, o = tid & (FGM_OUTS - 1), part = tid / FGM_OUTS;
+  const int q = blockIdx.x * FGM_OUTS + o;
   const int S = g.S, Q = g.Q;
   for (int i = tid; i < S; i += 256) hs[i] = g.h2[i];
   __syncthreads();
-  const int per = (S + 7) / 8, k0 = part * per, k1 = min(S, k0 + per);
-  float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
-  if (q < Q) {
-    const float* w = g.post2_w + q;
-    int k = k0;
-    for (; k + 32 <= k1; k += 32) {
-      float wv[32];
-#pragma unroll
-      for (int u = 0; u < 32; ++u) wv[u] = w[(long)(k + u) * Q];
-#pragma unroll
-      for (int u = 0; u < 32; u += 4) {
-        c0 = fmaf(hs[k + u], wv[u], c0);
-        c1 = fmaf(hs[k + u + 1], wv[u + 1], c1);
-        c2 = fmaf(hs[k + u + 2], wv[u + 2], c2);
-        c3 = fmaf(hs[k + u + 3], wv[u + 3], c3);
-      }
-    }
-    for (; k < k1; ++k) c0 = fmaf(hs[k], w[(long)k * Q], c0);
-  }
-  red[part][o] = (c0 + c1) + (c2 + c3);
+  red[part][o] = q < Q ? fg_mv_partial<32>(hs, S, g.post2_w, Q, q, part) : 0.f;
   __syncthreads();
-  if (part == 0 && q < Q) {
-    float t = g.post2_b ? g.post2_b[q] : 0.f;
-#pragma unroll
-    for (int p = 0; p < 8; ++p) t += red[p][o];
-    g.logits[q] = t;
-  }
+  if (part == 0 && q < Q)
+    g.logits[q] = (g.post2_b ? g.post2_b[q] : 0.f) + fg_mv_reduce(red, o);
 }
 
 // float64 softmax, temperature, inverse-CDF draw, cursor update (one wave)
@@ -852,11 +827,11 @@ int wn_fastgen_step(const float* params_causal, const float* layer0,
   g.use_dense_bias = use_biases; g.cw_img = cw_img; g.z_all = z_all;
   g.h1 = h1; g.h2 = h2; g.logits = logits;
   hipStream_t s = (hipStream_t)stream;
-  const int wgs = (S + 31) / 32;
+  const int wgs = (S + FGM_OUTS - 1) / FGM_OUTS;
   hipLaunchKernelGGL(fg_chain_kernel, dim3(1), dim3(FGC_THREADS), 0, s, g);
   hipLaunchKernelGGL(fg_skip_kernel, dim3(wgs), dim3(256), 0, s, g);
   hipLaunchKernelGGL(fg_post1_kernel, dim3(wgs), dim3(256), 0, s, g);
-  hipLaunchKernelGGL(fg_logits_kernel, dim3((Q + 31) / 32), dim3(256), 0, s, g);
+  hipLaunchKernelGGL(fg_logits_kernel, dim3((Q + FGM_OUTS - 1) / FGM_OUTS), dim3(256), 0, s, g);
   hipLaunchKernelGGL(fg_draw_kernel, dim3(1), dim3(64), 0, s, g);
   return wn_check_launch();
 }

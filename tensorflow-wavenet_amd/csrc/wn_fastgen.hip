@@ -301,12 +301,16 @@ __global__ __launch_bounds__(FG_THREADS, 1) void fastgen_kernel(FastGen g) {
       for (int q = lane; q < Q; q += 64) m = fmax(m, pd[q]);
       for (int o = 32; o >= 1; o >>= 1) m = fmax(m, __shfl_xor(m, o));
       double se = 0.0;
-      for (int q = lane; q < Q; q += 64) se += exp(pd[q] - m);
+      for (int q = lane; q < Q; q += 64) {
+        const double e = exp(pd[q] - m);    // evaluated once, kept in LDS
+        pd[q] = e;
+        se += e;
+      }
       for (int o = 32; o >= 1; o >>= 1) se += __shfl_xor(se, o);
       const bool want_p = g.proba_out && (step % g.proba_every == 0);
       float* po = want_p ? g.proba_out + (long)(step / g.proba_every) * Q : nullptr;
       for (int q = lane; q < Q; q += 64) {
-        const float p32 = (float)(exp(pd[q] - m) / se);
+        const float p32 = (float)(pd[q] / se);
         if (po) po[q] = p32;
         pd[q] = (double)p32;  // the float32 probabilities generate.py sees
       }
@@ -316,19 +320,25 @@ __global__ __launch_bounds__(FG_THREADS, 1) void fastgen_kernel(FastGen g) {
       if (wave == 0) {
         // temperature: exp(log(p)/tau - logsumexp) in float64, then inverse
         // CDF with a counter-based uniform (np.random.choice equivalent)
+        // (sampling weights proportional to exp(log(p)/tau); at tau == 1
+        // that is p itself, no transcendental needed)
         const double tau = (double)g.temperature;
-        double mx = -1e300;
-        for (int q = lane; q < Q; q += 64) {
-          const double lp = log(pd[q] > 0.0 ? pd[q] : 1e-300) / tau;
-          pd[q] = lp;
-          mx = fmax(mx, lp);
+        if (g.temperature != 1.0f) {
+          double mx = -1e300;
+          for (int q = lane; q < Q; q += 64) {
+            const double lp = log(pd[q] > 0.0 ? pd[q] : 1e-300) / tau;
+            pd[q] = lp;
+            mx = fmax(mx, lp);
+          }
+          for (int o = 32; o >= 1; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+          for (int q = lane; q < Q; q += 64) pd[q] = exp(pd[q] - mx);
         }
-        for (int o = 32; o >= 1; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+        __builtin_amdgcn_wave_barrier();
         // per-lane contiguous segment [q0, q1): segment sums -> prefix -> pick
         const int per = (Q + 63) / 64;
         const int q0 = lane * per, q1 = min(Q, q0 + per);
         double seg = 0.0;
-        for (int q = q0; q < q1; ++q) seg += exp(pd[q] - mx);
+        for (int q = q0; q < q1; ++q) seg += pd[q];
         double incl = seg;
         for (int o = 1; o < 64; o <<= 1) {
           const double v = __shfl_up(incl, o);
@@ -343,7 +353,7 @@ __global__ __launch_bounds__(FG_THREADS, 1) void fastgen_kernel(FastGen g) {
           double c = excl;
           pick = q1 - 1;
           for (int q = q0; q < q1; ++q) {
-            c += exp(pd[q] - mx);
+            c += pd[q];
             if (u < c) { pick = q; break; }
           }
         }
@@ -681,29 +691,40 @@ __global__ __launch_bounds__(64) void fg_draw_kernel(FgStep g) {
     double m = -1e300;
     for (int q = lane; q < Q; q += 64) m = fmax(m, pd[q]);
     for (int o = 32; o >= 1; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+    // each double-precision exp / log is evaluated once and kept in LDS
     double se = 0.0;
-    for (int q = lane; q < Q; q += 64) se += exp(pd[q] - m);
+    for (int q = lane; q < Q; q += 64) {
+      const double e = exp(pd[q] - m);
+      pd[q] = e;
+      se += e;
+    }
     for (int o = 32; o >= 1; o >>= 1) se += __shfl_xor(se, o);
     const bool want_p = g.proba_out && (local % g.proba_every == 0);
     float* po = want_p ? g.proba_out + (long)(local / g.proba_every) * Q : nullptr;
     for (int q = lane; q < Q; q += 64) {
-      const float p32 = (float)(exp(pd[q] - m) / se);
+      const float p32 = (float)(pd[q] / se);
       if (po) po[q] = p32;
       pd[q] = (double)p32;
     }
     if (local + 1 >= g.n_given) {
+      // sampling weights w_q proportional to exp(log(p_q) / tau)
+      // (generate.py:229-233); at tau == 1 that is p_q itself
       const double tau = (double)g.temperature;
-      double mx = -1e300;
-      for (int q = lane; q < Q; q += 64) {
-        const double lp = log(pd[q] > 0.0 ? pd[q] : 1e-300) / tau;
-        pd[q] = lp;
-        mx = fmax(mx, lp);
+      if (g.temperature != 1.0f) {
+        double mx = -1e300;
+        for (int q = lane; q < Q; q += 64) {
+          const double lp = log(pd[q] > 0.0 ? pd[q] : 1e-300) / tau;
+          pd[q] = lp;
+          mx = fmax(mx, lp);
+        }
+        for (int o = 32; o >= 1; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+        for (int q = lane; q < Q; q += 64) pd[q] = exp(pd[q] - mx);
       }
-      for (int o = 32; o >= 1; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+      __builtin_amdgcn_wave_barrier();
       const int per = (Q + 63) / 64;
       const int q0 = lane * per, q1 = min(Q, q0 + per);
       double seg = 0.0;
-      for (int q = q0; q < q1; ++q) seg += exp(pd[q] - mx);
+      for (int q = q0; q < q1; ++q) seg += pd[q];
       double incl = seg;
       for (int o = 1; o < 64; o <<= 1) {
         const double v = __shfl_up(incl, o);
@@ -718,7 +739,7 @@ __global__ __launch_bounds__(64) void fg_draw_kernel(FgStep g) {
         double c = excl;
         pick = q1 - 1;
         for (int q = q0; q < q1; ++q) {
-          c += exp(pd[q] - mx);
+          c += pd[q];
           if (u < c) { pick = q; break; }
         }
       }

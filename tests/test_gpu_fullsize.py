@@ -213,3 +213,27 @@ def test_global_conditioning_training_and_generation(hip_lib):
         near = [power[np.abs(fr - f).argmin()] for f in freqs]
         others = sum(near) - near[spk]
         assert near[spk] > 10.0 * others, (spk, near)
+
+
+@pytest.mark.parametrize('B,T', [(5, 16000), (8, 16000), (3, 22016)])
+def test_fused_vs_unfused_backward_many_tiles(hip_lib, B, T):
+    """Fused backward kernel (one or two tiles per wave, per-tile column sums
+    for GC) against the un-fused kernel pair at tile counts above the number
+    of resident waves, dilations below, at and above the 32-row tile, incl. a
+    clip length with an odd number of tiles."""
+    from wavenet import WaveNetModel
+    cfg = cfg_with(DEFAULT, batch_size=B, dilations=[1, 32, 64, 512, 2, 256, 16],
+                   skip_channels=64, global_condition_channels=4,
+                   global_condition_cardinality=5)
+    net = WaveNetModel(seed=3, **model_kwargs(cfg))
+    audio = synth_audio(B, T)
+    ids = np.arange(B) % 5
+    net.fused_bwd = True
+    l1 = float(net.loss(audio, ids))
+    g1 = net.grads.clone()
+    net.fused_bwd = False
+    l2 = float(net.loss(audio, ids))
+    g2 = net.grads.clone()
+    assert l1 == l2
+    scale = g2.abs().max().item()
+    assert (g1 - g2).abs().max().item() <= 2e-5 * max(scale, 1.0)

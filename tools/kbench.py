@@ -227,7 +227,7 @@ def layer():
         t = timeit(lambda: _lib.call('wn_layer_bwdw', x.data_ptr(), z.data_ptr(), f.data_ptr(), g.data_ptr(),
                                      dx.data_ptr(), dxo.data_ptr(), w.data_ptr(), dz.data_ptr(), th.data_ptr(),
                                      sg.data_ptr(), w.data_ptr(), f2.data_ptr(), g2.data_ptr(), slabs2.data_ptr(),
-                                     B, T, d, 1, st()), n=20)
+                                     None, B, T, d, 1, st()), n=20)
         print('layer_bwdw d=%3d: %6.1f us' % (d, t * 1e6), flush=True)
 
 

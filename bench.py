@@ -5,8 +5,12 @@ the default wavenet_params.json stack, fp32, synthetic 16 kHz clips resident
 in HBM (BASELINE.json metric; config[1]: B=8 clips x 16000 samples per GPU).
 
     python bench.py --gpus N --steps K --warmup W
-N > 1 is launched by torch.distributed.run, one rank per GPU over RCCL; the
-per-GPU work is fixed (weak scaling), `value` is the whole-job aggregate.
+N > 1: one rank per GPU over RCCL.  Under torch.distributed.run (RANK /
+WORLD_SIZE in the environment) this process IS one rank; run plainly
+(`python bench.py --gpus N`) it starts the N rank processes itself, before
+touching the GPU, and exits with their status.  The per-GPU work is fixed (weak
+scaling), `value` is the whole-job aggregate; `ranks_seen` is an RCCL
+all-reduce of ones.  WORLD_SIZE != --gpus is an error.
 
 Extra objects on the JSON line:
   roofline     - the dominant kernel (gemm_nn3_kernel: the skip-sum /
@@ -25,8 +29,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, 'tensorflow-wavenet_amd'),
-          os.path.join(ROOT, 'tests')):
+for p in (ROOT, os.path.join(ROOT, 'tensorflow-wavenet_amd')):
     if p not in sys.path:
         sys.path.insert(0, p)
 
@@ -101,22 +104,24 @@ def cpu_baseline(params, T, max_seconds=20.0, max_steps=20):
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the newest committed PMC summary
-    (profiles/*_pmc_traffic.json, written by tools/pmc_summary.py from separate
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, with
-    the gfx950 FETCH_SIZE x2 correction).  None when no summary exists."""
+    """(HBM bytes per launch of `kernel`, source file) from the newest
+    committed PMC summary (profiles/*_pmc_traffic.json, written by
+    tools/pmc_summary.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    passes of this same command, with the gfx950 FETCH_SIZE x2 correction).
+    (None, None) when no summary holds the kernel."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')))
-    if not files:
-        return None
-    try:
-        with open(files[-1]) as f:
-            return json.load(f)[kernel]['hbm_bytes_per_launch']
-    except (KeyError, ValueError, OSError):
-        return None
+    for path in reversed(files):
+        try:
+            with open(path) as f:
+                return (json.load(f)[kernel]['hbm_bytes_per_launch'],
+                        os.path.relpath(path, ROOT))
+        except (KeyError, ValueError, OSError):
+            continue
+    return None, None
 
 
-def secondary(net, audio, gc_ids, kw, B, T, gen_samples=4000):
+def secondary(net, audio, gc_ids, kw, B, T, gen_samples=16000):
     """SURVEY 8(d) secondary figures (rank 0, N = 1, after the timed region):
     forward-only samples/s on the same batch, and fast generation
     (BASELINE.json configs[4]: batch 1, seed 128, temperature 1)."""
@@ -148,6 +153,42 @@ def secondary(net, audio, gc_ids, kw, B, T, gen_samples=4000):
             'fastgen_samples': gen_samples}
 
 
+def launch_ranks(n):
+    """Start `n` copies of this script as rank processes (what
+    `python -m torch.distributed.run --nproc-per-node n` would do) and return
+    the worst exit status.  A rank that fails takes the others down."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r),
+                   WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get(
+                       'HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable,
+                                       os.path.abspath(__file__)]
+                                      + sys.argv[1:], env=env))
+    status = 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            rc = p.poll()
+            if rc is None:
+                continue
+            alive.remove(p)
+            if rc != 0:
+                status = status or rc
+                for q in alive:              # our own children, by handle
+                    q.terminate()
+    return status
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -165,10 +206,19 @@ def main():
                     help='skip the forward-only and fast-generation figures')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # run plainly: start the N ranks ourselves.  Nothing in this process
+        # has touched the GPU yet (importing torch does not), the children are
+        # ordinary subprocesses, and the parent only waits for them.
+        sys.exit(launch_ranks(args.gpus))
+
     from wavenet import WaveNetModel, optimizer_factory, parallel
     rank, world, local = parallel.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit('WORLD_SIZE %d != --gpus %d' % (world, args.gpus))
+    if world != args.gpus:
+        raise SystemExit('bench.py: WORLD_SIZE %d != --gpus %d (launch with '
+                         '--nproc-per-node %d, or run `python bench.py --gpus '
+                         '%d` plainly so that it starts the ranks itself)'
+                         % (world, args.gpus, args.gpus, args.gpus))
     # one rank per GPU; WN_SHARE_GPU=1 (rehearsal only) maps every rank to the
     # devices that exist
     ndev = torch.cuda.device_count()
@@ -234,11 +284,21 @@ def main():
     dt = time.perf_counter() - t0
     events = net._gemm_events or []
     net._gemm_events = None
+    ranks_seen = 1
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt[0])
+        ones = torch.ones(1, dtype=torch.float32, device=dev)
+        torch.distributed.all_reduce(ones)          # RCCL: every rank adds 1
+        ranks_seen = int(round(float(ones[0])))
+        if ranks_seen != args.gpus:
+            raise SystemExit('all-reduce saw %d ranks, expected %d'
+                             % (ranks_seen, args.gpus))
     if rank != 0:
+        if world > 1:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
         return
 
     value = world * B * T * args.steps / dt
@@ -249,9 +309,14 @@ def main():
     nlaunch = len(events)
     peak = FP32_MFMA_PEAK_TFLOPS if args.gemm_mode == 'fp32' else \
         2500.0 / int(args.gemm_mode[-1])
+    dom = 'gemm_nn3_kernel' if args.gemm_mode == 'fp32' else \
+        'gemm_nn_split_kernel'
+    traffic, traffic_src = pmc_traffic(dom)
     out = {
         'metric': 'audio samples/sec (train, default wavenet_params.json)',
         'value': value, 'unit': 'audio samples/s', 'n_gpus': world,
+        'ranks_seen': ranks_seen,
+        'dist_backend': torch.distributed.get_backend() if world > 1 else None,
         'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None,
@@ -269,14 +334,13 @@ def main():
                    'parallelism': 'dp%d' % world,
                    'final_loss': float(loss)},
         'roofline': {'bound': 'mfma',
-                     'kernel': 'gemm_nn3_kernel' if args.gemm_mode == 'fp32'
-                     else 'gemm_nn_split_kernel',
+                     'kernel': dom,
                      'achieved': achieved, 'peak': peak,
                      'unit': 'TFLOP/s' if args.gemm_mode == 'fp32' else
                              'TFLOP/s (fp32-equivalent; peak = bf16 dense '
                              '2500 / piece products)',
                      'frac': achieved / peak,
-                     'traffic': pmc_traffic('gemm_nn3_kernel'),
+                     'traffic': traffic, 'traffic_source': traffic_src,
                      'traffic_unit': 'bytes per launch (rocprofv3 PMC pass)',
                      'launches_per_step': nlaunch // max(args.steps, 1),
                      'avg_launch_us': ktime / max(nlaunch, 1) * 1e6,
@@ -288,6 +352,10 @@ def main():
         out['cpu_baseline'] = cpu_baseline(params, T)
         out['gpu_over_cpu'] = value / out['cpu_baseline']['value']
     print(json.dumps(out))
+    sys.stdout.flush()
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == '__main__':

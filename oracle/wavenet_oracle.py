@@ -434,8 +434,20 @@ def loss(cfg, var, audio, gc_ids=None, l2=None, dtype=np.float32,
 
 
 def loss_and_grads(cfg, var, audio, gc_ids=None, l2=None, dtype=np.float32,
-                   tf_xent_zero_label_quirk=True, tf_bias_name_quirk=True):
+                   tf_xent_zero_label_quirk=True, tf_bias_name_quirk=True,
+                   relu_masks=None, return_cache=False):
     """Returns (loss, grads) with grads in the same nested layout as var.
+
+    relu_masks: optional {'total': bool [B,T,S], 'c1': bool [B,T,S]} used as
+    the ReLU derivative of the two post-processing ReLUs (model.py:431,435)
+    instead of this run's own (value > 0).  The gradient is discontinuous in
+    the forward values at the ReLU kink: an implementation whose `total` or
+    `c1` differs by one rounding from this float64 run may legitimately sit on
+    the other side of 0 at a few of the B*T*S positions (float32 numpy vs
+    float64 numpy of THIS file differ by 6e-4 of a variable's gradient at
+    T=5200 for exactly that reason).  A checker passes the implementation's
+    masks here after verifying that they differ from the oracle's only where
+    the oracle's value is within rounding of 0.
 
     tf_xent_zero_label_quirk: TF's fused softmax-xent kernel returns
     backprop = softmax - labels, so the all-zero-label last row of every clip
@@ -463,12 +475,16 @@ def loss_and_grads(cfg, var, audio, gc_ids=None, l2=None, dtype=np.float32,
     dtotal = np.zeros_like(c['total'])
     if cfg.get('residual_postproc', False):
         dtotal = dtotal + dh2
-    dc1 = dh2 * (c['c1'] > 0)
+    m_c1 = (c['c1'] > 0) if relu_masks is None else \
+        np.asarray(relu_masks['c1']).reshape(c['c1'].shape)
+    m_total = (c['total'] > 0) if relu_masks is None else \
+        np.asarray(relu_masks['total']).reshape(c['total'].shape)
+    dc1 = dh2 * m_c1
     g['postprocessing']['postprocess1'][0] = f2(c['h1']).T @ f2(dc1)
     if use_b:
         g['postprocessing']['postprocess1_bias'] = f2(dc1).sum(0)
     dh1 = dc1 @ pp['postprocess1'][0].T
-    dtotal = dtotal + dh1 * (c['total'] > 0)
+    dtotal = dtotal + dh1 * m_total
 
     K = cfg['filter_width']
     dx = None  # gradient wrt the layer's output x'
@@ -533,6 +549,8 @@ def loss_and_grads(cfg, var, audio, gc_ids=None, l2=None, dtype=np.float32,
         for (n, ga), (_, va) in zip(flatten_variables(g),
                                     flatten_variables(var)):
             add_l2(ga, va, n.split('/')[-1])
+    if return_cache:
+        return total_loss, g, c
     return total_loss, g
 
 

@@ -50,6 +50,18 @@ static inline int wn_check_launch() {
   return e == hipSuccess ? WN_OK : WN_ERR_LAUNCH;
 }
 
+// Compute units of the CURRENT device.  Queried on every call (the HIP
+// runtime answers from its own device table; no mutable global here, see the
+// threading contract in include/wavenet_hip.h).
+static inline int wn_device_cus() {
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) !=
+          hipSuccess || n <= 0)
+    n = 256;
+  return n;
+}
+
 static inline bool wn_aligned16(const void* p) {
   return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
 }

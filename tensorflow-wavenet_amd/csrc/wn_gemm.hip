@@ -1278,18 +1278,7 @@ int wn_gemm_nn_split(const float* A, long lda, int a_planes, long a_plane_stride
 // Number of floats one slab needs for wn_gemm_tn.
 long wn_gemm_tn_slab_floats(int Mw, int Nw) { return (long)Mw * Nw + Nw; }
 
-static int tn_device_cus() {
-  static int cus = 0;  // read-only after the first call
-  if (cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) !=
-            hipSuccess || n <= 0)
-      n = 256;
-    cus = n;
-  }
-  return cus;
-}
+static int tn_device_cus() { return wn_device_cus(); }
 
 // Workgroup-tile shape of the LDS-staged TN kernels for an output, or false.
 static bool tn_wg_tile(int Mw, int Nw, int* mf, int* nf) {

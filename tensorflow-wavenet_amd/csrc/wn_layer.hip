@@ -909,15 +909,7 @@ __global__ __launch_bounds__(256) void layer_wgrad_gen_kernel(
 // ---------------------------------------------------------------------------
 // one persistent workgroup per CU (fewer when there is less work)
 static int layer_grid(int B, int T, int waves = LAYER_WAVES) {
-  static int cus = 0;  // read-only after the first call
-  if (cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) !=
-            hipSuccess || n <= 0)
-      n = 256;
-    cus = n;
-  }
+  const int cus = wn_device_cus();
   const long ntiles = (long)B * ((T + 31) / 32);
   long g = (ntiles + waves - 1) / waves;
   if (g > cus) g = cus;

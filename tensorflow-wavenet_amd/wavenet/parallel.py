@@ -45,7 +45,13 @@ def init_from_env(backend=None):
                 'nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        # a rank that dies must not leave the others in a collective for
+        # ever: bounded wait (WN_DIST_TIMEOUT seconds, default 300)
+        import datetime
+        tmo = datetime.timedelta(
+            seconds=float(os.environ.get('WN_DIST_TIMEOUT', '300')))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                timeout=tmo)
     return rank, world, local
 
 
@@ -86,3 +92,22 @@ def allreduce_mean_scalar(value_tensor):
     t = value_tensor.detach().clone()
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t / dist.get_world_size()
+
+
+def agree_step(n_samples, ok=True, device='cpu'):
+    """Make the per-step decisions the SAME on every rank before any compute
+    or collective of that step is issued: returns (T, all_ok) with T = the
+    smallest per-clip sample count any rank holds for this step and all_ok =
+    every rank produced a batch.  Readers cut files into pieces
+    (audio_reader.py:167-174), so ranks routinely see different tail lengths:
+    a rank skipping a step on its own (`if T < 2: continue`) or failing in its
+    reader thread would leave the others inside the gradient all-reduce.  With
+    the common T every rank truncates to, the per-rank B*T are equal and the
+    1/N average of the module docstring is exact."""
+    if not is_distributed():
+        return int(n_samples), bool(ok)
+    t = torch.tensor([int(n_samples), 1 if ok else 0], dtype=torch.int64,
+                     device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    t = t.cpu()
+    return int(t[0]), bool(int(t[1]))

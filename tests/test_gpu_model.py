@@ -9,19 +9,62 @@ import pytest
 import torch
 
 from util import (O, TINY, MID, DEFAULT, cfg_with, build_pair, flat_named,
-                  tree_to_numpy, model_kwargs, synth_audio)
+                  tree_to_numpy, model_kwargs, synth_audio,
+                  oracle_grads_at_device_kinks)
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 TOL = 1e-4
 
 
-def check_grads(net, ref_g, tol=TOL):
+GRAD_REL = 2e-5     # fp32 MFMA path vs float64 oracle, per variable, relative
+                    # to that variable's largest gradient entry
+_ERRLOG = {}
+
+
+def check_grads(net, ref_g, tol=TOL, rel=GRAD_REL, tag=None):
+    """Every variable's gradient against the float64 oracle: <= GRAD_REL of
+    the variable's largest entry (exact-fp32 MFMA accumulation over <= a few
+    10^4 rows observes ~1e-6; a missing small term would be orders above).
+    The observed ratios are logged to gpurun_out/grad_errors.json."""
     got = tree_to_numpy(net.gradients)
+    bad = []
     for (n, a), (_, b) in zip(flat_named(got), flat_named(ref_g)):
         err = np.abs(a - b).max()
-        assert err <= tol * max(1.0, np.abs(b).max()) and \
-            err <= 2e-3 * np.abs(b).max() + 1e-7, (n, err, np.abs(b).max())
+        scale = np.abs(b).max()
+        if tag is not None:
+            _ERRLOG.setdefault(tag, {})[n] = (float(err), float(scale))
+        if not (err <= rel * scale + 1e-9 and err <= tol * max(1.0, scale)):
+            bad.append((n, float(err), float(scale)))
+    assert not bad, bad[:6]
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _dump_errlog():
+    yield
+    if _ERRLOG:
+        import json
+        out = os.path.join(os.path.dirname(GOLD), '..', 'gpurun_out')
+        os.makedirs(out, exist_ok=True)
+        worst = {t: max(((e / (s + 1e-30), n) for n, (e, s) in v.items()
+                         if s > 0), default=(0, ''))
+                 for t, v in _ERRLOG.items()}
+        with open(os.path.join(out, 'grad_errors.json'), 'w') as f:
+            json.dump({'worst_ratio': worst, 'all': _ERRLOG}, f, indent=1)
+
+
+def check_planes(net, cfg, c, B, T, tol=TOL):
+    """Per-layer residual-stream input x_l and gated output z_l against the
+    oracle cache (network_forward(keep=True)), so that a mismatch localises to
+    a layer instead of showing up only in the logits."""
+    ws = [w for w in net._ws.values() if w.T == T][0]
+    R, D = cfg['residual_channels'], cfg['dilation_channels']
+    for l, lc in enumerate(c['layers']):
+        x = ws.X[l].cpu().numpy().reshape(B, T, -1)[:, :, :R]
+        z = ws.Z[l].cpu().numpy().reshape(B, T, -1)[:, :, :D]
+        ex = np.abs(x - lc['x']).max()
+        ez = np.abs(z - lc['z']).max()
+        assert ex < tol and ez < tol, (l, float(ex), float(ez))
 
 
 CASES = [
@@ -57,6 +100,12 @@ CASES = [
     ('default_gc', cfg_with(DEFAULT, batch_size=2,
                             global_condition_channels=32,
                             global_condition_cardinality=377), 700, True, None),
+    # longer than the receptive field (5117) of the default stack
+    ('default_T5200', cfg_with(DEFAULT, batch_size=1), 5200, False, None),
+    ('default_gc_T5200', cfg_with(DEFAULT, batch_size=1,
+                                  global_condition_channels=32,
+                                  global_condition_cardinality=377), 5200, True,
+     None),
 ]
 
 
@@ -68,17 +117,21 @@ def test_loss_and_gradients_vs_oracle(hip_lib, name, cfg, T, gc, l2):
     audio = rng.uniform(-1, 1, (B, T)).astype(np.float32)
     ids = rng.integers(0, cfg['global_condition_cardinality'], B) if gc \
         else None
-    ref_loss, ref_g = O.loss_and_grads(cfg, var, audio, ids, l2=l2,
-                                       dtype=np.float64)
-    _, c = O.loss(cfg, var, audio, ids, l2, np.float64, keep=True)
     loss = net.loss(audio, ids, l2)
     torch.cuda.synchronize()
+    # float64 oracle; at the (measure-zero) ReLU kinks it takes the device's
+    # side after checking that the two differ only within forward rounding
+    ref_loss, ref_g, c, flips = oracle_grads_at_device_kinks(
+        net, cfg, var, audio, ids, l2)
+    _ERRLOG.setdefault('relu_flips', {})[name] = (flips, 0)
     ws = list(net._ws.values())[0]
     # codes: bit exact
     assert np.array_equal(ws.q.cpu().numpy().reshape(B, T),
                           O.mu_law_encode(audio, cfg['quantization_channels']))
     assert abs(float(loss) - ref_loss) < TOL
-    check_grads(net, ref_g)
+    check_grads(net, ref_g, tag=name)
+    if cfg['residual_channels'] <= 32 and cfg['filter_width'] == 2:
+        check_planes(net, cfg, c, B, T)
     # forward-only path gives the same loss and identical logits to the oracle
     loss2 = net.loss(audio, ids, l2, backward=False)
     assert abs(float(loss2) - ref_loss) < TOL
@@ -97,9 +150,9 @@ def test_split_bf16_gemm_mode_parity(hip_lib, mode, case):
     net, var = build_pair(cfg)
     net.gemm_mode = mode
     audio = np.random.default_rng(7).uniform(-1, 1, (B, T)).astype(np.float32)
-    ref_loss, ref_g = O.loss_and_grads(cfg, var, audio, None, l2=l2,
-                                       dtype=np.float64)
     loss = net.loss(audio, None, l2)
+    ref_loss, ref_g, _, _ = oracle_grads_at_device_kinks(net, cfg, var, audio,
+                                                        None, l2)
     assert net._wsplit, 'split path not taken'
     assert abs(float(loss) - ref_loss) < TOL
     check_grads(net, ref_g)

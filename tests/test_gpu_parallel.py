@@ -1,0 +1,98 @@
+"""Data-parallel path with the REAL model on the GPU: N ranks x
+B/N clips through net.loss -> optimizer.minimize must land on the same
+parameters as one process with the whole batch; the RCCL backend initialises
+and reduces the device gradient bucket; bench.py refuses a rank-count
+mismatch and starts its own ranks when run plainly."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from util import ROOT
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_ranks(spec, world, extra_env=None, timeout=600):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r),
+                   WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(HERE, 'dp_worker.py'),
+             json.dumps(spec)], env=env, stdout=subprocess.PIPE,
+            stderr=subprocess.STDOUT))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+        outs.append(o.decode(errors='replace'))
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+
+
+@pytest.mark.parametrize('opt,gc', [('adam', False), ('sgd', True)])
+def test_two_ranks_real_model_equal_single_process(hip_lib, tmp_path, opt, gc):
+    """2 ranks x 2 clips (sharing this box's GPU over gloo) == 1 process x 4
+    clips after 2 full training steps, parameters <= 1e-6."""
+    spec = dict(mode='dp', B=4, T=300, steps=2, opt=opt, lr=1e-3,
+                cfg=dict(global_condition_channels=4,
+                         global_condition_cardinality=5) if gc else {})
+    spec['out'] = str(tmp_path / 'dp2.npz')
+    _run_ranks(spec, 2, dict(WN_SHARE_GPU='1', WN_DIST_BACKEND='gloo'))
+    one = dict(spec, out=str(tmp_path / 'dp1.npz'))
+    _run_ranks(one, 1)
+    a = np.load(spec['out'])
+    b = np.load(one['out'])
+    assert np.abs(a['losses'] - b['losses']).max() < 1e-6
+    assert np.abs(a['params'] - b['params']).max() <= 1e-6
+
+
+def test_rccl_world_one_allreduces_the_gradient_bucket(hip_lib, tmp_path):
+    """backend "nccl" (RCCL) comes up on the device and all-reduces /
+    broadcasts the flat fp32 buckets of the real model."""
+    spec = dict(mode='nccl1', B=2, T=200, steps=1, out=str(tmp_path / 'n.json'))
+    _run_ranks(spec, 1)
+    r = json.load(open(spec['out']))
+    assert r['ok'] and r['backend'] == 'nccl' and r['absmax'] > 0
+
+
+def test_bench_self_launches_two_ranks(hip_lib):
+    """`python bench.py --gpus 2` run plainly starts two rank processes
+    (sharing this box's one GPU over gloo here; RCCL on a multi-GPU node) and
+    reports both in `ranks_seen`."""
+    env = dict(os.environ, WN_SHARE_GPU='1', WN_DIST_BACKEND='gloo')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'),
+                        '--gpus', '2', '--steps', '2', '--warmup', '1',
+                        '--batch', '2', '--samples', '4000',
+                        '--no-secondary', '--no-cpu-baseline'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    line = [l for l in p.stdout.decode().splitlines() if l.startswith('{')][-1]
+    r = json.loads(line)
+    assert r['n_gpus'] == 2 and r['ranks_seen'] == 2
+    assert r['config']['global_batch'] == 4
+    assert r['value'] > 0

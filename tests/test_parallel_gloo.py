@@ -5,6 +5,7 @@ come from the CPU oracle here (tests may use it as a stand-in producer; on the
 GPU the same helpers run on the HIP bucket over RCCL)."""
 import os
 import socket
+import subprocess
 import sys
 
 import numpy as np
@@ -56,6 +57,14 @@ def _worker(rank, world, port, out_dir):
     scale = parallel.allreduce_gradients(bucket)
     avg = bucket.grads * scale
     mloss = parallel.allreduce_mean_scalar(torch.tensor(loss))
+    # per-step agreement (train.py): rank 1 holds a shorter tail piece, and
+    # in the second call its reader "failed"
+    t_common, ok = parallel.agree_step(100 if rank == 0 else 37, True)
+    assert (t_common, ok) == (37, True)
+    t_common, ok = parallel.agree_step(64, rank == 0)
+    assert ok is False
+    t_common, ok = parallel.agree_step(1 if rank == 0 else 500, True)
+    assert t_common == 1            # every rank skips this step together
     np.save(os.path.join(out_dir, 'g%d.npy' % rank), avg.numpy())
     np.save(os.path.join(out_dir, 'l%d.npy' % rank), mloss.numpy())
     dist.destroy_process_group()
@@ -85,3 +94,15 @@ def test_world_size_one_is_identity():
     assert parallel.allreduce_flat_(t) == 1.0
     assert torch.equal(t, torch.arange(5, dtype=torch.float32))
     assert not parallel.is_distributed()
+    assert parallel.agree_step(123, True) == (123, True)
+
+
+def test_bench_rejects_rank_count_mismatch():
+    """`--gpus 8` with WORLD_SIZE=1 must fail loudly, not benchmark 1 GPU."""
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'),
+                        '--gpus', '8', '--steps', '1', '--warmup', '0'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=300)
+    assert p.returncode != 0
+    assert b'WORLD_SIZE 1 != --gpus 8' in p.stderr

@@ -73,3 +73,30 @@ def tree_to_numpy(tree):
     if isinstance(tree, list):
         return [tree_to_numpy(v) for v in tree]
     return tree.detach().cpu().numpy().astype(np.float64)
+
+
+def oracle_grads_at_device_kinks(net, cfg, var, audio, ids=None, l2=None,
+                                 kink_tol=2e-5, **kw):
+    """float64 oracle loss / gradients evaluated with the DEVICE's ReLU
+    decisions (see oracle.loss_and_grads: relu_masks).  First checks that the
+    device's masks differ from the oracle's own only where the oracle's
+    pre-activation is within `kink_tol` of zero (forward rounding), i.e. that
+    passing them changes which subgradient is taken at a kink and nothing
+    else.  Returns (loss, grads, cache, n_flipped)."""
+    B = cfg['batch_size']
+    _, c = O.loss(cfg, var, audio, ids, l2, np.float64, keep=True)
+    T = c['logits'].shape[1]
+    ws = [w for w in net._ws.values() if w.T == T and w.training][0]
+    S = cfg['skip_channels']
+    m_total = (ws.h1 > 0).cpu().numpy().reshape(B, T, S)
+    src = ws.c1 if cfg.get('residual_postproc', False) else ws.h2
+    m_c1 = (src > 0).cpu().numpy().reshape(B, T, S)
+    flips = 0
+    for m, ref in ((m_total, c['total']), (m_c1, c['c1'])):
+        diff = m != (ref > 0)
+        flips += int(diff.sum())
+        assert np.abs(ref[diff]).max(initial=0.0) < kink_tol, \
+            float(np.abs(ref[diff]).max())
+    loss, g = O.loss_and_grads(cfg, var, audio, ids, l2=l2, dtype=np.float64,
+                               relu_masks=dict(total=m_total, c1=m_c1), **kw)
+    return loss, g, c, flips

@@ -273,10 +273,23 @@ def main(argv=None):
     try:
         for step in range(saved_global_step + 1, args.num_steps):
             start_time = time.time()
-            audio = reader.dequeue(args.batch_size)
-            gc = reader.dequeue_gc(args.batch_size) if gc_enabled else None
-            if audio.shape[1] < 2:
+            # every rank takes the same decision for this step (skip / common
+            # clip length / abort) BEFORE any collective of the step is issued
+            err = None
+            try:
+                audio = reader.dequeue(args.batch_size)
+                gc = reader.dequeue_gc(args.batch_size) if gc_enabled else None
+            except Exception as e:        # e.g. a reader-thread failure
+                err, audio, gc = e, None, None
+            n_t, all_ok = parallel.agree_step(
+                audio.shape[1] if err is None else 0, err is None, net.device)
+            if not all_ok:
+                raise RuntimeError('rank %d: a rank failed to produce a batch '
+                                   'at step %d%s' % (rank, step, '' if err is
+                                                     None else ': %r' % err))
+            if n_t < 2:
                 continue
+            audio = audio[:, :n_t]
             trace = args.store_metadata and step % 50 == 0 and rank == 0
             if trace:
                 print('Storing metadata')

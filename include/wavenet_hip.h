@@ -74,6 +74,10 @@ int wn_causal_wgrad(const int32_t* q, const float* dx0, float* slabs,
  * (_create_dilation_layer) incl. both causal_conv calls, ops.py:46-62.
  * wblock = Wf[2][32][32] Wg[2][32][32] Wd[32][32] bf[32] bg[32] bd[32].
  * bias_fg: [B or 1][64] per-clip (bias + global-conditioning) or NULL. */
+/* save_ts: 0 = nothing kept for backward (inference); 1 = tanh and sigmoid
+ * planes (th, sg; wn_layer_bwd / wn_layer_bwdw / the *_k kernels); 2 = the
+ * sigmoid plane only (sg; th may be NULL) for wn_layer_bwd2, which recovers
+ * tanh = z / sigmoid. */
 int wn_layer_fwd(const float* x, float* x_out, float* z, float* th, float* sg,
                  const float* wblock, const float* bias_fg,
                  int bias_clip_stride, int B, int T, int dilation,
@@ -121,6 +125,19 @@ int wn_layer_bwdw(const float* x, const float* z, const float* daf_cur,
                   const float* sg, const float* wblock_a, float* daf_next,
                   float* dag_next, float* slabs, float* tile_colsum, int B,
                   int T, int dilation, int do_a, void* stream);
+
+/* default backward of one block (TF autodiff of model.py:236-330), no
+ * pre-activation-gradient planes in HBM: every tile recomputes da for its
+ * rows t and t+d from dZ_l, dx_{l+1}, z_l and the sigmoid plane, so the only
+ * plane written is dx_l (768 B of HBM traffic per sample and layer instead of
+ * 1408 B).  dxin == NULL for the last layer (its dense output is unused,
+ * model.py:294-300).  slabs: [wn_layer_bwd2_slabs(B, T)][wblock layout] weight
+ * gradients of layer l; tile_colsum as in wn_layer_bwdw. */
+int wn_layer_bwd2_slabs(int B, int T);
+int wn_layer_bwd2(const float* x, const float* z, const float* sg,
+                  const float* dZ, const float* dxin, float* dx_out,
+                  const float* wblock, float* slabs, float* tile_colsum, int B,
+                  int T, int dilation, void* stream);
 
 /* ---- fp32 MFMA GEMMs: the skip sum + post-processing of
  * wavenet/model.py:303-305, 430-440 (_create_network) and their gradients */

@@ -142,6 +142,43 @@ __device__ __forceinline__ RowRegs rows_load(const float* __restrict__ tile0,
   return R;
 }
 
+// address-space-qualified pointers of __builtin_amdgcn_global_load_lds
+typedef const __attribute__((address_space(1))) void* wn_gptr_t;
+typedef __attribute__((address_space(3))) void* wn_lptr_t;
+
+// LDS-DMA of one [32][32] fp32 tile (global rows 128 B apart) into the
+// swizzled LDS tile layout of rows_to_lds, without staging registers: one
+// wave-instruction writes 1 KiB of LDS linearly (lane l -> base + 16 l = row
+// l >> 3, slot l & 7), so the swizzle is applied to the per-lane SOURCE chunk:
+// slot s of row r holds global chunk s ^ (r & 7).  Rows outside [lo, hi) read
+// as zero: the tile is zero-filled by ds_write first and the DMA of those rows
+// is masked off.  `lds_tile` must be wave-uniform.  Completion: vmcnt.
+__device__ __forceinline__ void tile_dma(float* lds_tile,
+                                         const float* __restrict__ tile0,
+                                         int lane, int lo, int hi) {
+  const int rr = lane >> 3;
+  const float* src = tile0 + (long)rr * 32 + (((lane & 7) ^ (rr & 7)) << 2);
+  if (lo <= 0 && hi >= 32) {  // wave-uniform: whole tile real
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      __builtin_amdgcn_global_load_lds((wn_gptr_t)(src + c * 256),
+                                       (wn_lptr_t)(lds_tile + c * 256), 16, 0, 0);
+  } else {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      *reinterpret_cast<f32x4*>(lds_tile + c * 256 + lane * 4) = zero;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int r = 8 * c + rr;
+      if (r >= lo && r < hi)
+        __builtin_amdgcn_global_load_lds((wn_gptr_t)(src + c * 256),
+                                         (wn_lptr_t)(lds_tile + c * 256), 16, 0, 0);
+    }
+  }
+}
+
 __device__ __forceinline__ void rows_store(float* __restrict__ tile0, int lane,
                                            int hi, const RowRegs& R) {
   float* p = tile0 + (long)(lane >> 3) * 32 + (lane & 7) * 4;

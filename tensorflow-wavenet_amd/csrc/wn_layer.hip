@@ -17,6 +17,7 @@
 // order inside each matrix), contiguous in the flat parameter buffer:
 //   Wf[2][32][32]  Wg[2][32][32]  Wd[32][32]  bf[32] bg[32] bd[32]
 #include "wn_common.h"
+#include <cstdlib>
 
 
 // Persistent workgroups: one 1024-thread workgroup (16 waves, 4 per SIMD) per
@@ -25,7 +26,11 @@
 #define LAYER_WG 1024
 #define LAYER_WAVES (LAYER_WG / 64)
 
-template <bool HAS_DENSE, bool SAVE_TS>
+// SAVE: what the backward pass will need besides x and z.  0 = nothing
+// (inference), 1 = tanh and sigmoid planes (un-fused / generic backward
+// kernels), 2 = the sigmoid plane only (layer_bwd2_kernel recovers tanh as
+// z / sigmoid: 512 instead of 640 bytes per sample and layer).
+template <bool HAS_DENSE, int SAVE>
 __global__ __launch_bounds__(LAYER_WG) void layer_fwd_kernel(
     const float* __restrict__ x, float* __restrict__ xo, float* __restrict__ z,
     float* __restrict__ th, float* __restrict__ sg,
@@ -91,16 +96,18 @@ __global__ __launch_bounds__(LAYER_WG) void layer_fwd_kernel(
     // fragments -> LDS -> coalesced stores
     __builtin_amdgcn_wave_barrier();
     frag_to_lds(ta, j, h, zz);
-    if (SAVE_TS) frag_to_lds(tb, j, h, af);
+    if (SAVE == 1) frag_to_lds(tb, j, h, af);
+    if (SAVE == 2) frag_to_lds(tb, j, h, ag);
     __builtin_amdgcn_wave_barrier();
     rows_store(z + off0, lane, hi, rows_from_lds(ta, lane));
-    if (SAVE_TS) {
+    if (SAVE == 1) {
       rows_store(th + off0, lane, hi, rows_from_lds(tb, lane));
       __builtin_amdgcn_wave_barrier();
       frag_to_lds(tb, j, h, ag);
       __builtin_amdgcn_wave_barrier();
       rows_store(sg + off0, lane, hi, rows_from_lds(tb, lane));
     }
+    if (SAVE == 2) rows_store(sg + off0, lane, hi, rows_from_lds(tb, lane));
     if (HAS_DENSE) {
       const f32x16 bd = frag_bcast(wl + LAYER_W_FLOATS + (woff - j - 128 * h), h);
       f32x16 acc;
@@ -598,6 +605,458 @@ __global__ __launch_bounds__(BW_WG) void layer_bwdw_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// Backward of one residual block WITHOUT pre-activation-gradient planes
+// (the default).  layer_bwdw_kernel above passes da_f / da_g of layer l from
+// one launch to the next through HBM (2 planes written, 4 tile reads) because
+// the data gradient needs the anti-causal tap da[t+d].  Here every tile
+// computes da for its own rows t AND for the rows t+d from what the forward
+// pass and the dZ GEMM left behind:
+//     dz[s]   = dZ_l[s] + dx_{l+1}[s] * Wd^T            s in {t, t+d}
+//     tanh    = z / sigmoid                             (z = tanh * sigmoid)
+//     da_f[s] = dz * sigmoid * (1 - tanh^2);  da_g[s] = dz * z * (1 - sigmoid)
+//     dx_l[t] = dx_{l+1}[t] + da[t] * W[1]^T + da[t+d] * W[0]^T
+//     dW[1] += x[t]^T da[t];  dW[0] += x[t-d]^T da[t];  dWd += z[t]^T dx_{l+1}[t]
+// so a launch depends on the previous one only through the dx plane, nothing
+// but dx is written, and the tanh plane is never stored.  Per sample and
+// layer: 5 planes read (dx_{l+1}, dZ, z, sigmoid, x; the shifted second reads
+// of a plane come from L2 / the Infinity Cache) + 1 written = 768 B of HBM
+// traffic instead of 1408 B, for 16 more MFMAs per tile (176 vs 160).
+// Rows outside the clip load as zeros; sigmoid == 0 there, which the guard
+// turns into da == 0.
+// ---------------------------------------------------------------------------
+#define B2_WAVES 8
+
+// (da_f, da_g) fragments from dz, z, sigmoid fragments
+__device__ __forceinline__ void gate_grad(const f32x16& dz, const f32x16& zz,
+                                          const f32x16& ss, f32x16& df,
+                                          f32x16& dg) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float sgm = ss[r];
+    const float th = sgm > 1e-30f ? zz[r] * __builtin_amdgcn_rcpf(sgm) : 0.f;
+    df[r] = dz[r] * (sgm - zz[r] * th);           // dz * sig * (1 - tanh^2)
+    dg[r] = dz[r] * zz[r] * (1.f - sgm);          // dz * tanh * sig * (1 - sig)
+  }
+}
+
+// Register-staged form, kept for A/B (WN_B2_MODE=4p): WAVES = 4 is one wave
+// per SIMD with the whole register file, which is what its software pipeline
+// (PIPE: every load issued one phase ahead, through staging registers) needs;
+// with 8 waves it spills (150 - 300 VGPRs).  Measured at B*T = 128000: 46.6 us
+// vs 44.2 us for the LDS-DMA kernel below and 50.5 us for layer_bwdw_kernel.
+template <bool HAS_DXIN, int WAVES, bool PIPE>
+__global__ __launch_bounds__(WAVES * 64) void layer_bwd2_kernel(
+    const float* __restrict__ x, const float* __restrict__ z,
+    const float* __restrict__ sg, const float* __restrict__ dZ,
+    const float* __restrict__ dxin, float* __restrict__ dx_out,
+    const float* __restrict__ wblock, float* __restrict__ slabs,
+    float* __restrict__ tile_colsum, int B, int T, int d) {
+  constexpr int LDT = 33, MT = 32 * LDT;
+  __shared__ float wl[5 * MT];
+  __shared__ __attribute__((aligned(16))) float tiles[WAVES * 4 * 1024];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 5120; i += WAVES * 64) {
+    const int m = i >> 10, rr = (i >> 5) & 31, cc = i & 31;  // W[m][rr][cc]
+    wl[m * MT + cc * LDT + rr] = wblock[i];                  // m = 4: Wd
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  float* t0 = tiles + wave * 4096;
+  float* t1 = t0 + 1024;
+  float* t2 = t1 + 1024;
+  float* t3 = t2 + 1024;
+  const int tiles_per_clip = (T + 31) >> 5;
+  const int ntiles = tiles_per_clip * B;
+  f32x16 cf0 = frag_zero(), cf1 = frag_zero(), cg0 = frag_zero(),
+         cg1 = frag_zero(), cd = frag_zero();
+  float sf = 0.f, sgs = 0.f, sd = 0.f;
+  // Software pipeline over this wave's tiles: the global loads of a phase are
+  // issued one phase ahead of their use (rows t+d of the NEXT tile during the
+  // weight-gradient products, rows t during the t+d math, the x tiles during
+  // the rows-t math), so that no load latency sits on a tile's critical path.
+  const int tstep = gridDim.x * WAVES;
+  int tile = blockIdx.x * WAVES + wave;
+  RowRegs a0, a1, a2, a3;                  // rows t+d: dx_{l+1}, dZ, z, sigmoid
+  auto load_shifted = [&](int tl) {
+    const int b = tl / tiles_per_clip;
+    const int tt0 = (tl - b * tiles_per_clip) * 32;
+    const int hif = min(min(32, T - tt0), T - d - tt0);
+    const size_t offd = ((size_t)b * T + tt0 + d) * WN_CH;
+    if (hif > 0) {
+      if (HAS_DXIN) a0 = rows_load(dxin + offd, lane, 0, hif);
+      a1 = rows_load(dZ + offd, lane, 0, hif);
+      a2 = rows_load(z + offd, lane, 0, hif);
+      a3 = rows_load(sg + offd, lane, 0, hif);
+    }
+  };
+  if (PIPE && tile < ntiles) load_shifted(tile);
+  for (; tile < ntiles; tile += tstep) {
+    int woff = j + 4 * h * LDT;  // opaque: no hoisting of the weight reads
+    asm volatile("" : "+v"(woff));
+    const float* wlane = wl + woff;
+    const int b = tile / tiles_per_clip;
+    const int tt0 = (tile - b * tiles_per_clip) * 32;
+    const int hi = min(32, T - tt0);
+    const int hi_f = min(hi, T - d - tt0);  // rows whose t+d tap exists
+    const int lo_p = max(0, d - tt0);       // rows whose t-d tap exists
+    const size_t off0 = ((size_t)b * T + tt0) * WN_CH;
+    f32x16 dx = frag_zero();
+    if (!PIPE) load_shifted(tile);
+    if (hi_f > 0) {
+      if (HAS_DXIN) rows_to_lds(t0, lane, a0);
+      rows_to_lds(t1, lane, a1);
+      rows_to_lds(t2, lane, a2);
+      rows_to_lds(t3, lane, a3);
+    }
+    // rows t: in flight during the t+d math (PIPE) or loaded after it
+    RowRegs ri, rz, rzz, rs;
+    auto load_rows_t = [&]() {
+      if (HAS_DXIN) ri = rows_load(dxin + off0, lane, 0, hi);
+      rz = rows_load(dZ + off0, lane, 0, hi);
+      rzz = rows_load(z + off0, lane, 0, hi);
+      rs = rows_load(sg + off0, lane, 0, hi);
+    };
+    if (PIPE) load_rows_t();
+    __builtin_amdgcn_wave_barrier();
+    // ---- rows t+d: da[t+d] * W[0]^T
+    if (hi_f > 0) {
+      f32x16 dz = frag_from_lds(t1, j, h);
+      if (HAS_DXIN) {
+        const f32x16 di = frag_from_lds(t0, j, h);
+        mma32<LDT>(dz, di, wlane + 4 * MT);      // dx_{l+1}[t+d] * Wd^T
+      }
+      f32x16 df, dg;
+      gate_grad(dz, frag_from_lds(t2, j, h), frag_from_lds(t3, j, h), df, dg);
+      mma32<LDT>(dx, df, wlane + 0 * MT);        // da_f[t+d] * Wf[0]^T
+      mma32<LDT>(dx, dg, wlane + 2 * MT);        // da_g[t+d] * Wg[0]^T
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- rows t
+    if (!PIPE) load_rows_t();
+    if (HAS_DXIN) rows_to_lds(t0, lane, ri);     // t0 keeps dx_{l+1}[t]
+    rows_to_lds(t1, lane, rz);
+    rows_to_lds(t2, lane, rzz);                  // t2 keeps z[t]
+    rows_to_lds(t3, lane, rs);
+    // the x tiles: in flight during the rows-t math
+    const RowRegs rxc = rows_load(x + off0, lane, 0, hi);
+    const RowRegs rxp = rows_load(x + off0 - (size_t)d * WN_CH, lane, lo_p, hi);
+    __builtin_amdgcn_wave_barrier();
+    {
+      f32x16 dz = frag_from_lds(t1, j, h);
+      if (HAS_DXIN) {
+        const f32x16 di = frag_from_lds(t0, j, h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dx[r] += di[r];
+        mma32<LDT>(dz, di, wlane + 4 * MT);      // dx_{l+1}[t] * Wd^T
+      }
+      f32x16 df, dg;
+      gate_grad(dz, frag_from_lds(t2, j, h), frag_from_lds(t3, j, h), df, dg);
+      mma32<LDT>(dx, df, wlane + 1 * MT);        // da_f[t] * Wf[1]^T
+      mma32<LDT>(dx, dg, wlane + 3 * MT);        // da_g[t] * Wg[1]^T
+      __builtin_amdgcn_wave_barrier();
+      frag_to_lds(t1, j, h, df);                 // t1 / t3 now hold da[t]
+      frag_to_lds(t3, j, h, dg);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (HAS_DXIN) {                              // dWd += z^T dx_{l+1}
+#pragma unroll 4
+      for (int s = 0; s < 16; ++s) {
+        const int row = 2 * s + h;
+        const float az = tile_elem(t2, row, j), bd = tile_elem(t0, row, j);
+        cd = __builtin_amdgcn_mfma_f32_32x32x2f32(az, bd, cd, 0, 0, 0);
+        sd += bd;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    frag_to_lds(t0, j, h, dx);
+    __builtin_amdgcn_wave_barrier();
+    rows_store(dx_out + off0, lane, hi, rows_from_lds(t0, lane));
+    __builtin_amdgcn_wave_barrier();
+    rows_to_lds(t2, lane, rxc);
+    rows_to_lds(t0, lane, rxp);
+    // next tile's rows t+d: in flight during the weight-gradient products
+    if (PIPE && tile + tstep < ntiles) load_shifted(tile + tstep);
+    __builtin_amdgcn_wave_barrier();
+    float tsf = 0.f, tsg = 0.f;          // this tile's column sums of da[t]
+#pragma unroll 4
+    for (int s = 0; s < 16; ++s) {       // dW[1] += x[t]^T da, dW[0] += x[t-d]^T da
+      const int row = 2 * s + h;
+      const float axc = tile_elem(t2, row, j), axp = tile_elem(t0, row, j);
+      const float bf = tile_elem(t1, row, j), bg = tile_elem(t3, row, j);
+      cf1 = __builtin_amdgcn_mfma_f32_32x32x2f32(axc, bf, cf1, 0, 0, 0);
+      cg1 = __builtin_amdgcn_mfma_f32_32x32x2f32(axc, bg, cg1, 0, 0, 0);
+      cf0 = __builtin_amdgcn_mfma_f32_32x32x2f32(axp, bf, cf0, 0, 0, 0);
+      cg0 = __builtin_amdgcn_mfma_f32_32x32x2f32(axp, bg, cg0, 0, 0, 0);
+      tsf += bf;
+      tsg += bg;
+    }
+    sf += tsf;
+    sgs += tsg;
+    if (tile_colsum) {
+      // per-tile column sums (a tile lies inside one clip): the per-clip sums
+      // the global-conditioning gradients need (model.py:272-284 under
+      // autodiff) without a separate pass over da
+      const float a = tsf + __shfl_xor(tsf, 32), b2 = tsg + __shfl_xor(tsg, 32);
+      if (h == 0) {
+        tile_colsum[(size_t)tile * 64 + j] = a;
+        tile_colsum[(size_t)tile * 64 + 32 + j] = b2;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // ---- weight-gradient slab of this workgroup (fixed-order wave reduction)
+  sf += __shfl_xor(sf, 32);
+  sgs += __shfl_xor(sgs, 32);
+  sd += __shfl_xor(sd, 32);
+  __syncthreads();
+  float* red = tiles;
+  for (int w = 0; w < WAVES; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = 8 * (r >> 2) + 4 * h + (r & 3);
+        const int e = m * 32 + j;
+        if (w == 0) {
+          red[0 * 1024 + e] = cf0[r];
+          red[1 * 1024 + e] = cf1[r];
+          red[2 * 1024 + e] = cg0[r];
+          red[3 * 1024 + e] = cg1[r];
+          red[4 * 1024 + e] = cd[r];
+        } else {
+          red[0 * 1024 + e] += cf0[r];
+          red[1 * 1024 + e] += cf1[r];
+          red[2 * 1024 + e] += cg0[r];
+          red[3 * 1024 + e] += cg1[r];
+          red[4 * 1024 + e] += cd[r];
+        }
+      }
+      if (h == 0) {
+        if (w == 0) {
+          red[LAYER_W_FLOATS + j] = sf;
+          red[LAYER_W_FLOATS + 32 + j] = sgs;
+          red[LAYER_W_FLOATS + 64 + j] = sd;
+        } else {
+          red[LAYER_W_FLOATS + j] += sf;
+          red[LAYER_W_FLOATS + 32 + j] += sgs;
+          red[LAYER_W_FLOATS + 64 + j] += sd;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* out = slabs + (size_t)blockIdx.x * LAYER_BLOCK_FLOATS;
+  for (int e = tid; e < LAYER_BLOCK_FLOATS; e += WAVES * 64) out[e] = red[e];
+}
+
+// ---------------------------------------------------------------------------
+// LDS-DMA form of layer_bwd2_kernel (the default): the same arithmetic, but
+// every input tile goes global -> LDS by global_load_lds (tile_dma) instead of
+// through staging registers.  Without the 4..6 x 16 staging registers two
+// waves per SIMD fit without spills (one wave's gate math / LDS traffic runs
+// under the other's MFMAs), the rows-t tiles are in flight during the rows
+// t+d math and the x tiles during the rows-t math.
+// ---------------------------------------------------------------------------
+#define WN_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define WN_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+template <bool HAS_DXIN>
+__global__ __launch_bounds__(B2_WAVES * 64) void layer_bwd2d_kernel(
+    const float* __restrict__ x, const float* __restrict__ z,
+    const float* __restrict__ sg, const float* __restrict__ dZ,
+    const float* __restrict__ dxin, float* __restrict__ dx_out,
+    const float* __restrict__ wblock, float* __restrict__ slabs,
+    float* __restrict__ tile_colsum, int B, int T, int d) {
+  constexpr int LDT = 33, MT = 32 * LDT;
+  __shared__ float wl[5 * MT];
+  __shared__ __attribute__((aligned(1024))) float tiles[B2_WAVES * 4 * 1024];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 5120; i += B2_WAVES * 64) {
+    const int m = i >> 10, rr = (i >> 5) & 31, cc = i & 31;  // W[m][rr][cc]
+    wl[m * MT + cc * LDT + rr] = wblock[i];                  // m = 4: Wd
+  }
+  __syncthreads();
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  float* t0 = tiles + wave * 4096;
+  float* t1 = t0 + 1024;
+  float* t2 = t1 + 1024;
+  float* t3 = t2 + 1024;
+  const int tiles_per_clip = (T + 31) >> 5;
+  const int ntiles = tiles_per_clip * B;
+  f32x16 cf0 = frag_zero(), cf1 = frag_zero(), cg0 = frag_zero(),
+         cg1 = frag_zero(), cd = frag_zero();
+  float sf = 0.f, sgs = 0.f, sd = 0.f;
+  // The rows t+d of the NEXT tile are fetched into registers during the
+  // weight-gradient products (the only phase with registers to spare and no
+  // free LDS tile), everything else by LDS-DMA one phase ahead of its use.
+  const int tstep = gridDim.x * B2_WAVES;
+  RowRegs a0, a1, a2, a3;
+  // (always assigns a0..a3 -- zeros when there is nothing to load -- so that
+  // their live range ends at the rows_to_lds of the next iteration)
+  auto load_shifted = [&](int tl) {
+    const bool any = tl < ntiles;
+    const int b = any ? tl / tiles_per_clip : 0;
+    const int tt0 = any ? (tl - b * tiles_per_clip) * 32 : 0;
+    const int hif = any ? min(min(32, T - tt0), T - d - tt0) : 0;
+    const size_t offd = ((size_t)b * T + tt0 + d) * WN_CH;
+    if (HAS_DXIN) a0 = rows_load(dxin + offd, lane, 0, hif);
+    a1 = rows_load(dZ + offd, lane, 0, hif);
+    a2 = rows_load(z + offd, lane, 0, hif);
+    a3 = rows_load(sg + offd, lane, 0, hif);
+  };
+  load_shifted(blockIdx.x * B2_WAVES + wave);
+  for (int tile = blockIdx.x * B2_WAVES + wave; tile < ntiles; tile += tstep) {
+    int woff = j + 4 * h * LDT;  // opaque: no hoisting of the weight reads
+    asm volatile("" : "+v"(woff));
+    const float* wlane = wl + woff;
+    const int b = tile / tiles_per_clip;
+    const int tt0 = (tile - b * tiles_per_clip) * 32;
+    const int hi = min(32, T - tt0);
+    const int hi_f = min(hi, T - d - tt0);  // rows whose t+d tap exists
+    const int lo_p = max(0, d - tt0);       // rows whose t-d tap exists
+    const size_t off0 = ((size_t)b * T + tt0) * WN_CH;
+    f32x16 dx = frag_zero();
+    f32x16 dz, di, zz, ss;
+    if (hi_f > 0) {                         // rows t+d -> LDS -> fragments
+      if (HAS_DXIN) rows_to_lds(t0, lane, a0);
+      rows_to_lds(t1, lane, a1);
+      rows_to_lds(t2, lane, a2);
+      rows_to_lds(t3, lane, a3);
+      __builtin_amdgcn_wave_barrier();
+      dz = frag_from_lds(t1, j, h);
+      if (HAS_DXIN) di = frag_from_lds(t0, j, h);
+      zz = frag_from_lds(t2, j, h);
+      ss = frag_from_lds(t3, j, h);
+      WN_WAIT_LGKM0();                      // tiles free again
+    }
+    // rows t: in flight during the rows t+d math
+    if (HAS_DXIN) tile_dma(t0, dxin + off0, lane, 0, hi);
+    tile_dma(t1, dZ + off0, lane, 0, hi);
+    tile_dma(t2, z + off0, lane, 0, hi);
+    tile_dma(t3, sg + off0, lane, 0, hi);
+    if (hi_f > 0) {
+      if (HAS_DXIN) mma32<LDT>(dz, di, wlane + 4 * MT);  // dx_{l+1}[t+d] * Wd^T
+      f32x16 df, dg;
+      gate_grad(dz, zz, ss, df, dg);
+      mma32<LDT>(dx, df, wlane + 0 * MT);        // da_f[t+d] * Wf[0]^T
+      mma32<LDT>(dx, dg, wlane + 2 * MT);        // da_g[t+d] * Wg[0]^T
+    }
+    WN_WAIT_VM0();
+    if (HAS_DXIN) {                              // dWd += z^T dx_{l+1}
+#pragma unroll 4
+      for (int s = 0; s < 16; ++s) {
+        const int row = 2 * s + h;
+        const float az = tile_elem(t2, row, j), bd = tile_elem(t0, row, j);
+        cd = __builtin_amdgcn_mfma_f32_32x32x2f32(az, bd, cd, 0, 0, 0);
+        sd += bd;
+      }
+    }
+    dz = frag_from_lds(t1, j, h);
+    if (HAS_DXIN) di = frag_from_lds(t0, j, h);
+    zz = frag_from_lds(t2, j, h);
+    ss = frag_from_lds(t3, j, h);
+    WN_WAIT_LGKM0();
+    // the x tiles: in flight during the rows-t math
+    tile_dma(t2, x + off0, lane, 0, hi);
+    tile_dma(t0, x + off0 - (size_t)d * WN_CH, lane, lo_p, hi);
+    {
+      if (HAS_DXIN) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dx[r] += di[r];
+        mma32<LDT>(dz, di, wlane + 4 * MT);      // dx_{l+1}[t] * Wd^T
+      }
+      f32x16 df, dg;
+      gate_grad(dz, zz, ss, df, dg);
+      mma32<LDT>(dx, df, wlane + 1 * MT);        // da_f[t] * Wf[1]^T
+      mma32<LDT>(dx, dg, wlane + 3 * MT);        // da_g[t] * Wg[1]^T
+      frag_to_lds(t1, j, h, dx);
+      __builtin_amdgcn_wave_barrier();
+      rows_store(dx_out + off0, lane, hi, rows_from_lds(t1, lane));
+      __builtin_amdgcn_wave_barrier();
+      frag_to_lds(t1, j, h, df);                 // t1 / t3 now hold da[t]
+      frag_to_lds(t3, j, h, dg);
+    }
+    WN_WAIT_VM0();
+    load_shifted(tile + tstep);
+    __builtin_amdgcn_wave_barrier();
+    float tsf = 0.f, tsg = 0.f;          // this tile's column sums of da[t]
+#pragma unroll 4
+    for (int s = 0; s < 16; ++s) {       // dW[1] += x[t]^T da, dW[0] += x[t-d]^T da
+      const int row = 2 * s + h;
+      const float axc = tile_elem(t2, row, j), axp = tile_elem(t0, row, j);
+      const float bf = tile_elem(t1, row, j), bg = tile_elem(t3, row, j);
+      cf1 = __builtin_amdgcn_mfma_f32_32x32x2f32(axc, bf, cf1, 0, 0, 0);
+      cg1 = __builtin_amdgcn_mfma_f32_32x32x2f32(axc, bg, cg1, 0, 0, 0);
+      cf0 = __builtin_amdgcn_mfma_f32_32x32x2f32(axp, bf, cf0, 0, 0, 0);
+      cg0 = __builtin_amdgcn_mfma_f32_32x32x2f32(axp, bg, cg0, 0, 0, 0);
+      tsf += bf;
+      tsg += bg;
+    }
+    sf += tsf;
+    sgs += tsg;
+    if (tile_colsum) {
+      const float a = tsf + __shfl_xor(tsf, 32), b2 = tsg + __shfl_xor(tsg, 32);
+      if (h == 0) {
+        tile_colsum[(size_t)tile * 64 + j] = a;
+        tile_colsum[(size_t)tile * 64 + 32 + j] = b2;
+      }
+    }
+    WN_WAIT_LGKM0();                     // tiles free for the next tile's DMA
+    __builtin_amdgcn_wave_barrier();
+  }
+  // ---- weight-gradient slab of this workgroup.  Fixed-order tree over the
+  // eight waves through LDS: waves 0-3 store, waves 4-7 add into the region of
+  // wave w-4 (the four regions in parallel), then every thread sums the four
+  // regions ((r0+r1)+(r2+r3)) on the way out.
+  sf += __shfl_xor(sf, 32);
+  sgs += __shfl_xor(sgs, 32);
+  sd += __shfl_xor(sd, 32);
+  __syncthreads();
+  constexpr int RS = 5248;               // floats per region (>= block, 128 B multiple)
+  static_assert(4 * RS <= B2_WAVES * 4 * 1024, "reduction regions exceed the tile area");
+  float* red = tiles + (wave & 3) * RS;
+  for (int ph = 0; ph < 2; ++ph) {
+    if ((wave >> 2) == ph) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = 8 * (r >> 2) + 4 * h + (r & 3);
+        const int e = m * 32 + j;
+        if (ph == 0) {
+          red[0 * 1024 + e] = cf0[r];
+          red[1 * 1024 + e] = cf1[r];
+          red[2 * 1024 + e] = cg0[r];
+          red[3 * 1024 + e] = cg1[r];
+          red[4 * 1024 + e] = cd[r];
+        } else {
+          red[0 * 1024 + e] += cf0[r];
+          red[1 * 1024 + e] += cf1[r];
+          red[2 * 1024 + e] += cg0[r];
+          red[3 * 1024 + e] += cg1[r];
+          red[4 * 1024 + e] += cd[r];
+        }
+      }
+      if (h == 0) {
+        if (ph == 0) {
+          red[LAYER_W_FLOATS + j] = sf;
+          red[LAYER_W_FLOATS + 32 + j] = sgs;
+          red[LAYER_W_FLOATS + 64 + j] = sd;
+        } else {
+          red[LAYER_W_FLOATS + j] += sf;
+          red[LAYER_W_FLOATS + 32 + j] += sgs;
+          red[LAYER_W_FLOATS + 64 + j] += sd;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* out = slabs + (size_t)blockIdx.x * LAYER_BLOCK_FLOATS;
+  for (int e = tid; e < LAYER_BLOCK_FLOATS; e += B2_WAVES * 64)
+    out[e] = (tiles[e] + tiles[RS + e]) + (tiles[2 * RS + e] + tiles[3 * RS + e]);
+}
+
+// ---------------------------------------------------------------------------
 // Generic tap count (filter_width K >= 2, runtime): the off-default variant
 // of the three layer kernels.  Layer block = Wf[K][32][32] Wg[K][32][32]
 // Wd[32][32] bf bg bd.  Tap k reads x[t - s_k], s_k = (K-1-k + (K-1)/2) * d
@@ -925,7 +1384,8 @@ int wn_layer_fwd(const float* x, float* x_out, float* z, float* th, float* sg,
   if (!x || !z || !wblock) return WN_ERR_NULL;
   if (B <= 0 || T <= 0 || dilation <= 0) return WN_ERR_BAD_SHAPE;
   if (has_dense && !x_out) return WN_ERR_NULL;
-  if (save_ts && (!th || !sg)) return WN_ERR_NULL;
+  if (save_ts < 0 || save_ts > 2) return WN_ERR_BAD_SHAPE;
+  if ((save_ts == 1 && !th) || (save_ts && !sg)) return WN_ERR_NULL;
   if (!wn_aligned16(x) || !wn_aligned16(z) || !wn_aligned16(wblock) ||
       (x_out && !wn_aligned16(x_out)) || (th && !wn_aligned16(th)) ||
       (sg && !wn_aligned16(sg)))
@@ -936,10 +1396,11 @@ int wn_layer_fwd(const float* x, float* x_out, float* z, float* th, float* sg,
   hipLaunchKernelGGL((layer_fwd_kernel<HD, TS>), grid, block, 0, s, x,      \
                      x_out, z, th, sg, wblock, bias_fg, bias_clip_stride, B, \
                      T, dilation)
-  if (has_dense && save_ts) LAUNCH(true, true);
-  else if (has_dense) LAUNCH(true, false);
-  else if (save_ts) LAUNCH(false, true);
-  else LAUNCH(false, false);
+  if (has_dense) {
+    if (save_ts == 2) LAUNCH(true, 2); else if (save_ts) LAUNCH(true, 1); else LAUNCH(true, 0);
+  } else {
+    if (save_ts == 2) LAUNCH(false, 2); else if (save_ts) LAUNCH(false, 1); else LAUNCH(false, 0);
+  }
 #undef LAUNCH
   return wn_check_launch();
 }
@@ -1083,6 +1544,41 @@ int wn_layer_bwdw(const float* x, const float* z, const float* daf_cur,
                      dilation)
   if (do_a) { if (dxin) LAUNCH(true, true); else LAUNCH(true, false); }
   else { if (dxin) LAUNCH(false, true); else LAUNCH(false, false); }
+#undef LAUNCH
+  return wn_check_launch();
+}
+
+// number of slabs (workgroups) wn_layer_bwd2 writes for this shape (an upper
+// bound over the kernel variants: slabs past the launched grid stay unused)
+static int b2_waves() {
+  const char* e = getenv("WN_B2_MODE");   // A/B knob: "d" (default) or "4p"
+  return (e && e[0] == '4') ? 4 : B2_WAVES;
+}
+int wn_layer_bwd2_slabs(int B, int T) { return layer_grid(B, T, b2_waves()); }
+
+int wn_layer_bwd2(const float* x, const float* z, const float* sg,
+                  const float* dZ, const float* dxin, float* dx_out,
+                  const float* wblock, float* slabs, float* tile_colsum, int B,
+                  int T, int dilation, void* stream) {
+  if (B <= 0 || T <= 0 || dilation <= 0) return WN_ERR_BAD_SHAPE;
+  if (!x || !z || !sg || !dZ || !dx_out || !wblock || !slabs)
+    return WN_ERR_NULL;
+  const void* ptrs[] = {x, z, sg, dZ, dxin, dx_out, wblock};
+  for (const void* p : ptrs)
+    if (p && !wn_aligned16(p)) return WN_ERR_MISALIGNED;
+  const int waves = b2_waves();
+  dim3 grid(layer_grid(B, T, waves)), block(waves * 64);
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(KERNEL)                                                        \
+  hipLaunchKernelGGL(KERNEL, grid, block, 0, s, x, z, sg, dZ, dxin, dx_out,   \
+                     wblock, slabs, tile_colsum, B, T, dilation)
+  if (waves == 4) {  // register-staged, one wave per SIMD (A/B)
+    if (dxin) LAUNCH((layer_bwd2_kernel<true, 4, true>));
+    else LAUNCH((layer_bwd2_kernel<false, 4, true>));
+  } else {           // default: LDS-DMA kernel, two waves per SIMD
+    if (dxin) LAUNCH((layer_bwd2d_kernel<true>));
+    else LAUNCH((layer_bwd2d_kernel<false>));
+  }
 #undef LAUNCH
   return wn_check_launch();
 }

@@ -44,6 +44,9 @@ SIGNATURES = {
     'wn_layer_bwdw_slabs': (c_int, [c_int, c_int]),
     'wn_layer_bwdw': (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
                               c_int, c_int, c_int, c_int, P]),
+    'wn_layer_bwd2_slabs': (c_int, [c_int, c_int]),
+    'wn_layer_bwd2': (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int,
+                              P]),
     'wn_gemm_nn': (c_int, [P, c_long, c_int, c_long, P, c_int, P, P, c_long,
                            P, c_long, P, c_long, c_int, c_long, P, c_long,
                            c_int, c_int, c_int, P]),

@@ -93,14 +93,18 @@ class _Workspace(object):
         alloc('proba', (Q,))
         if not training:
             return
-        alloc('TH', (L, N, CH))
+        # legacy backward kernels (un-fused pair, wn_layer_bwdw, generic
+        # filter widths) also need the tanh plane and two ping-pong pairs of
+        # pre-activation-gradient planes; the default wn_layer_bwd2 does not
+        self.legacy = net._legacy_bwd()
+        self.TH = alloc('TH', (L, N, CH)) if self.legacy else None
         alloc('SG', (L, N, CH))
         alloc('dZ', (L, N, CH))
         alloc('dc1', (N, S))
         alloc('dtotal', (N, S))
         self.dh2 = alloc('dh2', (N, S)) if net.residual_postproc else None
         self.c1 = alloc('c1', (N, S)) if net.residual_postproc else None
-        alloc('da', (2, 2, N, CH))    # [pingpong][f|g]
+        self.da = alloc('da', (2, 2, N, CH)) if self.legacy else None
         alloc('dx', (2, N, CH))
         alloc('w2t', (Q, S))
         alloc('w1t', (S, S))
@@ -108,7 +112,9 @@ class _Workspace(object):
         ntiles = B * ((T + 31) // 32)
         self.nslab = max(1, min(512, ntiles // 4))
         self.nslab_f = lib.wn_layer_bwdw_slabs(B, T)      # fused kernel
-        alloc('lslabs', (L, max(self.nslab, self.nslab_f), net.LAYER_BLOCK))
+        self.nslab_2 = lib.wn_layer_bwd2_slabs(B, T)
+        alloc('lslabs', (L, max(self.nslab, self.nslab_f, self.nslab_2),
+                         net.LAYER_BLOCK))
         need = 0
         self.splits = {}
         for key, (mw, nw) in dict(post2=(S, Q), post1=(S, S), skip=(L * CH, S),
@@ -187,7 +193,12 @@ class WaveNetModel(object):
         # 12.80 ms/step: 100 cross-stream event edges per step cost more than
         # the overlap recovers), so it is off by default.
         self.overlap_wgrad = False
-        # fused backward kernel (data + weight gradients in one pass)
+        # backward of a residual block: 'bwd2' (default: one kernel per layer,
+        # pre-activation gradients recomputed per tile, only dx goes through
+        # HBM, tanh recovered as z / sigmoid); 'bwdw' (round-1 fused kernel:
+        # da planes through HBM, tanh + sigmoid planes); fused_bwd=False: the
+        # un-fused data / weight kernel pair.  Kept for A/B and tests.
+        self.layer_bwd = 'bwd2'
         self.fused_bwd = True
         # generate(): four kernels per sample over many CUs, replayed from a
         # hipGraph, instead of the single-workgroup persistent kernel
@@ -443,6 +454,10 @@ class WaveNetModel(object):
             self._side = torch.cuda.Stream(device=self.device)
         return self._side
 
+    def _legacy_bwd(self):
+        return (self.layer_bwd != 'bwd2' or not self.fused_bwd
+                or self.generic_layers or self.overlap_wgrad)
+
     def _check_supported(self):
         if self._unsupported:
             raise NotImplementedError(self._unsupported)
@@ -454,6 +469,10 @@ class WaveNetModel(object):
     def _workspace(self, B, T, training):
         key = (B, T, bool(training))
         ws = self._ws.get(key)
+        if ws is not None and training and self._legacy_bwd() and \
+                not ws.legacy:
+            self._ws = {}          # switched to a legacy backward: re-allocate
+            ws = None
         if ws is not None:
             return ws
         # carve out of a resident larger workspace of the same batch size
@@ -531,7 +550,7 @@ class WaveNetModel(object):
     # ------------------------------------------------------------ launch plans
     def _plan_key(self, tag, ws, ids, extra):
         return (tag, extra, ids is not None, self.generic_layers,
-                self.fused_bwd, self.gemm_mode, self.causal_wgrad_segsum, self.tf_xent_zero_label_quirk,
+                self.fused_bwd, self.layer_bwd, self.gemm_mode, self.causal_wgrad_segsum, self.tf_xent_zero_label_quirk,
                 _lib.stream(), self.params.data_ptr(), self.grads.data_ptr())
 
     def _stage_ids(self, ws, ids):
@@ -596,7 +615,7 @@ class WaveNetModel(object):
             fargs = (_lib.ptr(ws.X[l]),
                      None if last else _lib.ptr(ws.X[l + 1]),
                      _lib.ptr(ws.Z[l]),
-                     _lib.ptr(ws.TH[l]) if save_ts else None,
+                     _lib.ptr(ws.TH[l]) if save_ts == 1 else None,
                      _lib.ptr(ws.SG[l]) if save_ts else None,
                      _lib.ptr(self._layer_block(P, l)),
                      None if bias is None else _lib.ptr(bias[l]), bstride,
@@ -606,7 +625,7 @@ class WaveNetModel(object):
                           0 if last else 1, 1 if save_ts else 0, st)
             else:
                 _lib.call('wn_layer_fwd', *fargs, 0 if last else 1,
-                          1 if save_ts else 0, st)
+                          int(save_ts), st)
         bsum = None
         if self.use_biases:
             _lib.call('wn_sum_rows', _lib.ptr(self._seg(P, 'skip_b')), L, S,
@@ -695,6 +714,23 @@ class WaveNetModel(object):
                   N * CH, None, N, L * CH, S, 0, st)
 
         # residual stack, last layer first
+        if not self._legacy_bwd():
+            # one launch per layer; the launches are chained through dx only
+            dxin, xp = None, 0
+            tsum = None if ws.dsum is None else ws.tilesum
+            for l in range(L - 1, -1, -1):
+                dxo = ws.dx[xp]
+                _lib.call('wn_layer_bwd2', _lib.ptr(ws.X[l]), _lib.ptr(ws.Z[l]),
+                          _lib.ptr(ws.SG[l]), _lib.ptr(ws.dZ[l]),
+                          _lib.ptr(dxin), _lib.ptr(dxo),
+                          _lib.ptr(self._layer_block(P, l)),
+                          _lib.ptr(ws.lslabs[l]),
+                          None if tsum is None else _lib.ptr(tsum[l]),
+                          B, T, int(self.dilations[l]), st)
+                dxin, xp = dxo, 1 - xp
+            self._backward_tail(ws, ids, dxin, ws.nslab_2, True)
+            return
+
         def da(p):
             return ws.da[p][0], ws.da[p][1]
         gen = self.generic_layers
@@ -786,14 +822,24 @@ class WaveNetModel(object):
                           st)
             dxin = dxo
             xp = 1 - xp
+        if side is not main:
+            main.wait_event(ws.ev_done[0])
+        self._backward_tail(ws, ids, dxin, nslab, fused)
+
+    def _backward_tail(self, ws, ids, dxin, nslab, fused):
+        """After the residual stack: slab reductions of the layer-block
+        gradients, causal-layer and global-conditioning gradients."""
+        st = _lib.stream()
+        B, T, N, L, S, Q = ws.B, ws.T, ws.N, self.L, self.S, self.Q
+        P, Gr = self.params, self.grads
+        ub = 1 if self.use_biases else 0
+        lib = _lib.load()
         if fused and ws.dsum is not None:
             # per-clip sums of da_l for every layer from the per-tile sums the
             # fused kernel wrote (fixed order over a clip's tiles)
             tpc = (T + 31) // 32
             _lib.call('wn_reduce_slabs', _lib.ptr(ws.tilesum), tpc, 64, L * B,
                       tpc * 64, 0, 64, _lib.ptr(ws.dsum), 64, 1, 0, st)
-        if side is not main:
-            main.wait_event(ws.ev_done[0])
         # layer-block gradients: fixed-order sum of the per-workgroup slabs
         lo, _ = self.segments['layers']
         _lib.call('wn_reduce_slabs', _lib.ptr(ws.lslabs), nslab,
@@ -886,7 +932,10 @@ class WaveNetModel(object):
             ws.audio.copy_(audio.reshape(-1))
         ids = self._gc_ids(global_condition_batch, B)
         st = _lib.stream()
-        self._forward(ws, ids, save_ts=backward)
+        # 0: inference; 1: tanh + sigmoid planes (legacy backward kernels);
+        # 2: sigmoid plane only (wn_layer_bwd2)
+        self._forward(ws, ids, save_ts=0 if not backward else
+                      (1 if self._legacy_bwd() else 2))
         _lib.call('wn_xent', _lib.ptr(ws.logits), self.Q, _lib.ptr(ws.q),
                   _lib.ptr(ws.logits) if backward else None,
                   _lib.ptr(ws.loss_parts), B, T, self.Q,
@@ -949,7 +998,7 @@ class WaveNetModel(object):
             # decode the codes back to floats in [-1, 1] (model.py:570-576)
             ws.audio.copy_(mu_law_decode(w, self.Q).reshape(-1))
         ids = self._gc_ids(global_condition, B)
-        self._forward(ws, ids, save_ts=False)
+        self._forward(ws, ids, save_ts=0)
         out = torch.empty(self.Q, dtype=torch.float32, device=self.device)
         _lib.call('wn_softmax64_row', _lib.ptr(ws.logits[B * T - 1]), self.Q,
                   _lib.ptr(out), _lib.stream())
@@ -1149,7 +1198,7 @@ class WaveNetModel(object):
         ws = self._workspace(1, n0, False)
         ws.q.copy_(w)
         ids = self._gc_ids(global_condition, 1)
-        self._forward(ws, ids, save_ts=False)
+        self._forward(ws, ids, save_ts=0)
         src, dst, roff = [], [], 0
         for l, d in enumerate(self.dilations):
             t = np.arange(max(0, n0 - d), n0, dtype=np.int64)

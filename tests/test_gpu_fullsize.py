@@ -228,12 +228,14 @@ def test_fused_vs_unfused_backward_many_tiles(hip_lib, B, T):
     net = WaveNetModel(seed=3, **model_kwargs(cfg))
     audio = synth_audio(B, T)
     ids = np.arange(B) % 5
-    net.fused_bwd = True
-    l1 = float(net.loss(audio, ids))
-    g1 = net.grads.clone()
-    net.fused_bwd = False
-    l2 = float(net.loss(audio, ids))
-    g2 = net.grads.clone()
-    assert l1 == l2
+    res = []
+    for kind, fused in (('bwd2', True), ('bwdw', True), ('bwdw', False)):
+        # default (da recomputed per tile, tanh = z / sigmoid), round-1 fused
+        # kernel (da planes, tanh plane), un-fused kernel pair
+        net.layer_bwd, net.fused_bwd = kind, fused
+        res.append((float(net.loss(audio, ids)), net.grads.clone()))
+    (l0, g0), (l1, g1), (l2, g2) = res
+    assert l0 == l1 == l2
     scale = g2.abs().max().item()
     assert (g1 - g2).abs().max().item() <= 2e-5 * max(scale, 1.0)
+    assert (g0 - g2).abs().max().item() <= 2e-5 * max(scale, 1.0)

@@ -231,6 +231,38 @@ def layer():
         print('layer_bwdw d=%3d: %6.1f us' % (d, t * 1e6), flush=True)
 
 
+def bwd2():
+    """wn_layer_bwd2 variants (WN_B2_MODE) next to wn_layer_bwdw, several batch
+    sizes: per-tile latency vs throughput"""
+    T = 16000
+    modes = os.environ.get('KB_B2', 'd,4p').split(',')
+    for B in (1, 2, 4, 8, 16):
+        N = B * T
+        mk = lambda: torch.randn(N * 32, device=dev)
+        x, z, dZ, dxin, dxo, f, g, th, fn, gn = [mk() for _ in range(10)]
+        sg = torch.rand(N * 32, device=dev) * 0.9 + 0.05
+        w = torch.randn(5216, device=dev) * 0.1
+        for d in (4, 512):
+            line = 'B=%2d d=%3d:' % (B, d)
+            for m in modes:
+                os.environ['WN_B2_MODE'] = m
+                nsl = lib.wn_layer_bwd2_slabs(B, T)
+                slabs = torch.empty(nsl * 5216, device=dev)
+                t = timeit(lambda: _lib.call('wn_layer_bwd2', x.data_ptr(), z.data_ptr(), sg.data_ptr(), dZ.data_ptr(),
+                                             dxin.data_ptr(), dxo.data_ptr(), w.data_ptr(), slabs.data_ptr(), None,
+                                             B, T, d, st()), n=20, warm=3)
+                line += '  bwd2[%s] %6.1f us' % (m, t * 1e6)
+            nsl = lib.wn_layer_bwdw_slabs(B, T)
+            slabs = torch.empty(nsl * 5216, device=dev)
+            t = timeit(lambda: _lib.call('wn_layer_bwdw', x.data_ptr(), z.data_ptr(), f.data_ptr(), g.data_ptr(),
+                                         dxin.data_ptr(), dxo.data_ptr(), w.data_ptr(), dZ.data_ptr(), th.data_ptr(),
+                                         sg.data_ptr(), w.data_ptr(), fn.data_ptr(), gn.data_ptr(), slabs.data_ptr(),
+                                         None, B, T, d, 1, st()), n=20, warm=3)
+            line += '  bwdw %6.1f us' % (t * 1e6)
+            print(line, flush=True)
+    os.environ.pop('WN_B2_MODE', None)
+
+
 def layerpad():
     """are the layer kernels sensitive to the relative alignment of their
     planes?  (12 planes carved from one buffer at stride N*32 + pad floats)"""

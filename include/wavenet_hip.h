@@ -260,10 +260,15 @@ int wn_fastgen_run(const float* params_causal, const float* layer0,
                    int push, void* stream);
 
 /* Multi-CU variant: enqueues ONE generation step as five kernels (chain on
- * one CU; skip sum, conv1 and conv2 on S/32 / Q/32 CUs; float64 softmax +
- * draw).
- * Everything step-dependent lives in device memory (cursors), so the host
- * captures a few hundred calls into a hipGraph and replays it. */
+ * one CU, current tap only; skip sum + the NEXT step's past-tap
+ * pre-activations, conv1 and conv2 on S/16 / Q/16 CUs; float64 softmax +
+ * draw).  Everything step- or call-dependent lives in device memory
+ * (cursors, ctl), so the host captures a few hundred calls into a hipGraph
+ * ONCE and replays it for every generate() call.
+ * ctl: int32[8] = {base (cursors[0] when the call started), n_given,
+ * proba_every, temperature (float bits), seed lo, seed hi, 0, 0}.
+ * pre: float[L][64], maintained by the step kernels; wn_fastgen_pre fills it
+ * for the step the queues are at (call once before a sequence of steps). */
 int wn_fastgen_step(const float* params_causal, const float* layer0,
                     long layer_stride, const float* skip_w,
                     const float* skip_bsum, const float* post1_w,
@@ -271,11 +276,15 @@ int wn_fastgen_step(const float* params_causal, const float* layer0,
                     const float* post2_b, const float* gc_bias_fg,
                     const int32_t* dilations_dev, int L, int S, int Q,
                     float* state, int32_t* cursors, int32_t* samples_io,
-                    int base, int n_given, float temperature, uint64_t seed,
-                    float* proba_out, int proba_every, int use_biases,
-                    const float* cw_img, float* z_all, float* h1, float* h2,
-                    float* logits, void* stream);
-/* cw_img [L][5120]: the chain weights transposed + swizzled for the LDS ring */
+                    const int32_t* ctl, float* proba_out, int use_biases,
+                    const float* cw_img, float* pre, float* z_all, float* h1,
+                    float* h2, float* logits, void* stream);
+int wn_fastgen_pre(const float* layer0, long layer_stride,
+                   const float* gc_bias_fg, const int32_t* dilations_dev,
+                   int L, const float* state, const int32_t* cursors,
+                   float* pre, void* stream);
+/* cw_img [L][3072]: Wf[1] | Wg[1] | Wd of every layer, transposed + swizzled
+ * for the chain's LDS ring */
 int wn_fastgen_pack(const float* layer0, long layer_stride, float* img, int L,
                     void* stream);
 

@@ -382,18 +382,37 @@ __global__ __launch_bounds__(FG_THREADS, 1) void fastgen_kernel(FastGen g) {
 // Multi-CU fast generation: one generated sample = five small kernels on the
 // stream (captured into a hipGraph by the host, hundreds of samples per
 // replay):
-//   A fg_chain_kernel   1 workgroup : the serial residual chain; four loader
-//                        waves stream the 20 KB/layer chain weights through a
-//                        4-slot LDS ring three layers ahead of the chain wave
-//   B fg_skip_kernel    S/32 WGs    : total = sum_l z_l Ws_l (+bias), ReLU
-//   C fg_post1_kernel   S/32 WGs    : conv1 (+bias), ReLU
-//   D fg_logits_kernel  Q/32 WGs    : conv2 logits
+//   A fg_chain_kernel   1 workgroup : the serial residual chain, CURRENT tap
+//                        only.  The past-tap half of every layer's dilated
+//                        conv, pre_l = x_l[t - d_l] (Wf[0] | Wg[0]) + bias_l,
+//                        reads a queue entry that is at least one step old,
+//                        so it is computed for ALL layers in parallel by the
+//                        previous step's kernel B and the chain starts from
+//                        a 12.8 KB table in LDS: no global load, half the
+//                        mat-vec work and 12 KB instead of 20 KB of weights
+//                        per layer on the critical path.  Four loader waves
+//                        stream Wf[1] | Wg[1] | Wd through a 4-slot LDS ring
+//                        three layers ahead of the chain wave.
+//   B fg_skip_kernel    S/16 WGs    : total = sum_l z_l Ws_l (+bias), ReLU;
+//                        + L more workgroups: pre_l of the NEXT step
+//   C fg_post1_kernel   S/16 WGs    : conv1 (+bias), ReLU
+//   D fg_logits_kernel  Q/16 WGs    : conv2 logits
 //   E fg_draw_kernel    1 wave      : float64 softmax, temperature,
 //                        inverse-CDF draw, cursor update
 // Kernel boundaries are the grid-wide synchronisation (about 1.5 us each):
 // no in-launch flags, nothing that can hang.  The 3.3 MB skip and 1 MB conv1
-// weights are read by S/32 CUs in parallel instead of one CU's load path.
+// weights are read by S/16 CUs in parallel instead of one CU's load path.
+// Everything that differs between two generate() calls (first step, seed,
+// temperature, number of given samples) is read from a device control block,
+// so one captured graph serves every call.
 // ===========================================================================
+#define FGCTL_BASE 0         // cursors[0] when the call started
+#define FGCTL_NGIVEN 1
+#define FGCTL_PEVERY 2
+#define FGCTL_TEMP 3         // float bits
+#define FGCTL_SEED 4         // 4, 5: uint64 seed (lo, hi)
+#define FGCTL_WORDS 8
+
 struct FgStep {
   const float* causal;
   const float* layer0;
@@ -409,15 +428,12 @@ struct FgStep {
   int L, S, Q;
   float* state;
   int32_t* cursors;      // [0] steps done, [1] previous code
-  int32_t* samples;      // indexed by (cursors[0] - base)
-  int base;              // cursors[0] at the start of this generate() call
-  int n_given;
-  float temperature;
-  uint64_t seed;
+  int32_t* samples;      // indexed by (cursors[0] - ctl[BASE])
+  const int32_t* ctl;    // per-call control block (device)
   float* proba_out;
-  int proba_every;
   int use_dense_bias;
-  const float* cw_img;   // [L][5120] chain weights, transposed + swizzled
+  const float* cw_img;   // [L][3072] Wf[1] | Wg[1] | Wd, transposed + swizzled
+  float* pre;            // [L][64] past-tap pre-activations of the next step
   float* z_all;          // [L][32]
   float* h1;             // [S]
   float* h2;             // [S]
@@ -426,32 +442,68 @@ struct FgStep {
 
 #define FGC_THREADS 320
 #define FGC_SLOTS 4
+#define FGC_CW 3072            // ring slot: Wf[1] | Wg[1] | Wd   (floats)
 
-// Ring-slot image: the five 32x32 matrices TRANSPOSED ([out n][in k], k
+// Ring-slot image: the three 32x32 matrices TRANSPOSED ([out n][in k], k
 // contiguous) with the 16-byte chunk c of row n stored at chunk c ^ (n & 7).
 // The chain lane that owns output n then reads its whole weight row with
-// eight ds_read_b128 per matrix (2-way conflicts at worst), and the 64 input
-// values are broadcast from LDS with 16 ds_read_b128 instead of 64
-// v_readlane: ~170 instructions per layer instead of ~350.
+// eight ds_read_b128 per matrix (2-way conflicts at worst), and the input
+// values are broadcast from LDS with ds_read_b128 instead of v_readlane.
 __device__ __forceinline__ int fgc_widx(int m, int n, int k) {
   return m * 1024 + n * 32 + ((((k >> 2) ^ (n & 7)) << 2) | (k & 3));
 }
 
 // one-off: layer blocks -> ring-slot images (weights are constant while
-// generating)
+// generating).  Source matrices 1 (Wf[1]), 3 (Wg[1]), 4 (Wd) -> slots 0, 1, 2.
 __global__ void fg_pack_kernel(const float* __restrict__ layer0, long layer_stride,
                                float* __restrict__ img, int L) {
   const int l = blockIdx.x;
   const float* blk = layer0 + (long)l * layer_stride;
-  for (int i = threadIdx.x; i < FG_CW; i += blockDim.x) {
-    const int m = i >> 10, k = (i >> 5) & 31, n = i & 31;   // W[m][k][n]
-    img[(long)l * FG_CW + fgc_widx(m, n, k)] = blk[i];
+  for (int i = threadIdx.x; i < FGC_CW; i += blockDim.x) {
+    const int m = i >> 10, k = (i >> 5) & 31, n = i & 31;   // slot m: W[k][n]
+    const int src = m == 0 ? 1 : (m == 1 ? 3 : 4);
+    img[(long)l * FGC_CW + fgc_widx(m, n, k)] = blk[src * 1024 + k * 32 + n];
   }
 }
 
+// pre[l][0:32 | 32:64] = x_l[t' - d_l] (Wf[0] | Wg[0]) + bias_fg[l]  for the
+// step t' = cursors[0] + ahead: the entry the queue of layer l hands out at
+// that step (model.py:335-338 `state`), which is at least one step old.
+__device__ __forceinline__ void fg_pre_layer(const FgStep& g, int l, int ahead,
+                                             float* lds /* >= 32 + 256 floats */) {
+  const int tid = threadIdx.x;                 // 256 threads
+  const int tpos = g.cursors[0] + ahead;
+  int roff = 0;
+  for (int i = 0; i < l; ++i) roff += g.dil[i];
+  const int d = g.dil[l];
+  float* sv = lds;
+  float* red = lds + 32;
+  if (tid < 32) sv[tid] = g.state[((long)roff + tpos % d) * 32 + tid];
+  __syncthreads();
+  // thread -> output n = tid & 63 (filter | gate), K-slice tid >> 6 (8 inputs)
+  const int n = tid & 63, ks = tid >> 6;
+  const float* W = g.layer0 + (long)l * g.layer_stride +
+                   (n < 32 ? 0 : 2 * 1024) + (n & 31);      // Wf[0] / Wg[0]
+  float a = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a = fmaf(sv[ks * 8 + k], W[(ks * 8 + k) * 32], a);
+  red[tid] = a;
+  __syncthreads();
+  if (tid < 64)
+    g.pre[l * 64 + tid] = (g.bias_fg ? g.bias_fg[l * 64 + tid] : 0.f) +
+                          ((red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]));
+}
+
+__global__ __launch_bounds__(256) void fg_pre_kernel(FgStep g, int ahead) {
+  __shared__ float lds[32 + 256];
+  fg_pre_layer(g, blockIdx.x, ahead, lds);
+}
+
 __global__ __launch_bounds__(FGC_THREADS) void fg_chain_kernel(FgStep g) {
-  __shared__ __attribute__((aligned(16))) float wring[FGC_SLOTS][FG_CW];
-  __shared__ __attribute__((aligned(16))) float inv[64];   // [state | x]
+  __shared__ __attribute__((aligned(16))) float wring[FGC_SLOTS][FGC_CW];
+  __shared__ __attribute__((aligned(16))) float pre_s[FG_MAXL * 64];
+  __shared__ __attribute__((aligned(16))) float bd_s[FG_MAXL * 32];
+  __shared__ __attribute__((aligned(16))) float inv[32];   // x, broadcast
   __shared__ __attribute__((aligned(16))) float zv[32];
   __shared__ int pos[FG_MAXL], roff[FG_MAXL], sdil[FG_MAXL];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -459,49 +511,44 @@ __global__ __launch_bounds__(FGC_THREADS) void fg_chain_kernel(FgStep g) {
   const int lt = tid - 64;                       // loader thread 0..255
   const int steps_done = g.cursors[0];
   const int prev_code = g.cursors[1];
-  const int code = g.samples[steps_done - g.base];
-  for (int l = tid; l < L; l += FGC_THREADS) {
-    sdil[l] = g.dil[l];
-    pos[l] = steps_done % g.dil[l];
-  }
-  __syncthreads();
-  if (tid == 0) {
-    int off = 0;
-    for (int l = 0; l < L; ++l) { roff[l] = off; off += sdil[l]; }
-  }
-  // loaders: 256 threads x 5 float4 = one layer of the pre-packed image
-  f32x4 s0[5], s1[5], s2[5];
-  auto ld = [&](f32x4 (&r)[5], int l) {
+  const int code = g.samples[steps_done - g.ctl[FGCTL_BASE]];
+  // loaders: 256 threads x 3 float4 = one layer of the pre-packed image
+  f32x4 s0[3], s1[3], s2[3];
+  auto ld = [&](f32x4 (&r)[3], int l) {
     if (l < L) {
-      const f32x4* src = reinterpret_cast<const f32x4*>(g.cw_img + (long)l * FG_CW);
+      const f32x4* src = reinterpret_cast<const f32x4*>(g.cw_img + (long)l * FGC_CW);
 #pragma unroll
-      for (int k = 0; k < 5; ++k) r[k] = src[lt + 256 * k];
+      for (int k = 0; k < 3; ++k) r[k] = src[lt + 256 * k];
     }
   };
-  auto stl = [&](const f32x4 (&r)[5], int l) {   // straight 16-byte copies
+  auto stl = [&](const f32x4 (&r)[3], int l) {   // straight 16-byte copies
     if (l < L) {
       f32x4* dst = reinterpret_cast<f32x4*>(wring[l % FGC_SLOTS]);
 #pragma unroll
-      for (int k = 0; k < 5; ++k) dst[lt + 256 * k] = r[k];
+      for (int k = 0; k < 3; ++k) dst[lt + 256 * k] = r[k];
     }
   };
-  float x = 0.f, stv = 0.f, bias = 0.f, bdv = 0.f;
-  auto chain_prefetch = [&](int l) {
-    bias = g.bias_fg ? g.bias_fg[l * 64 + lane] : 0.f;
-    bdv = g.use_dense_bias
-              ? g.layer0[(long)l * g.layer_stride + LAYER_OFF_BD + (lane & 31)]
-              : 0.f;
-    stv = lane < 32 ? g.state[((long)roff[l] + pos[l]) * 32 + lane] : 0.f;
-  };
-  __syncthreads();
+  // nothing in the prologue depends on the new sample except the causal
+  // gather: every global load is issued before the first barrier
+  float x = 0.f;
   if (wave >= 1) {
     ld(s0, 0);
     ld(s1, 1);
     ld(s2, 2);
-    stl(s0, 0);
-    ld(s0, 3);
   } else {
-    chain_prefetch(0);
+    // ring offsets = exclusive prefix sum of the dilations (wave scan, L <= 64)
+    const int dl = lane < L ? g.dil[lane] : 0;
+    int incl = dl;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o);
+      if (lane >= o) incl += v;
+    }
+    if (lane < L) {
+      sdil[lane] = dl;
+      roff[lane] = incl - dl;
+      pos[lane] = steps_done % dl;
+    }
     if (lane < 32) {
       float v = 0.f;
       if (prev_code >= 0 && prev_code < Q) v = g.causal[(long)prev_code * 32 + lane];
@@ -509,34 +556,35 @@ __global__ __launch_bounds__(FGC_THREADS) void fg_chain_kernel(FgStep g) {
       x = v;
     }
   }
+  for (int i = tid; i < L * 64; i += FGC_THREADS) pre_s[i] = g.pre[i];
+  for (int i = tid; i < L * 32; i += FGC_THREADS)
+    bd_s[i] = g.use_dense_bias
+                  ? g.layer0[(long)(i >> 5) * g.layer_stride + LAYER_OFF_BD + (i & 31)]
+                  : 0.f;
+  if (wave >= 1) {
+    stl(s0, 0);
+    ld(s0, 3);
+  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   const int nn = lane & 31, gsel = lane >> 5;     // output row, 0 filter / 1 gate
-  auto body = [&](int l, f32x4 (&set)[5]) {
+  auto body = [&](int l, f32x4 (&set)[3]) {
     if (wave == 0) {
       if (l < L) {
         const float* wl = wring[l % FGC_SLOTS];
-        const float cur_bias = bias, cur_bd = bdv;
         if (lane < 32) {
           g.state[((long)roff[l] + pos[l]) * 32 + lane] = x;  // enqueue x_l[t]
-          inv[lane] = stv;                                    // x_l[t - d]
-          inv[32 + lane] = x;
+          inv[lane] = x;
         }
-        if (l + 1 < L) chain_prefetch(l + 1);
         __builtin_amdgcn_wave_barrier();
-        // conv: lane -> output nn of filter (gsel 0) or gate (gsel 1)
-        const float* w0 = wl + (gsel * 2) * 1024 + nn * 32;       // past tap
-        const float* w1 = w0 + 1024;                              // current tap
-        float a0 = cur_bias, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        // current tap: lane -> output nn of filter (gsel 0) or gate (gsel 1)
+        const float* w1 = wl + gsel * 1024 + nn * 32;
+        float a0 = pre_s[l * 64 + lane], a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
           const int sw = (c ^ (nn & 7)) << 2;
-          const f32x4 sv = *reinterpret_cast<const f32x4*>(inv + 4 * c);
-          const f32x4 xv = *reinterpret_cast<const f32x4*>(inv + 32 + 4 * c);
-          const f32x4 p = *reinterpret_cast<const f32x4*>(w0 + sw);
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(inv + 4 * c);
           const f32x4 q = *reinterpret_cast<const f32x4*>(w1 + sw);
-          a0 = fmaf(sv[0], p[0], a0); a1 = fmaf(sv[1], p[1], a1);
-          a2 = fmaf(sv[2], p[2], a2); a3 = fmaf(sv[3], p[3], a3);
           a0 = fmaf(xv[0], q[0], a0); a1 = fmaf(xv[1], q[1], a1);
           a2 = fmaf(xv[2], q[2], a2); a3 = fmaf(xv[3], q[3], a3);
         }
@@ -556,7 +604,7 @@ __global__ __launch_bounds__(FGC_THREADS) void fg_chain_kernel(FgStep g) {
         if (l + 1 < L) {
           __builtin_amdgcn_wave_barrier();
           // dense 32 x 32: each half takes 16 of the 32 inputs
-          const float* wd = wl + 4 * 1024 + nn * 32;
+          const float* wd = wl + 2 * 1024 + nn * 32;
           float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
 #pragma unroll
           for (int cc = 0; cc < 4; ++cc) {
@@ -571,7 +619,7 @@ __global__ __launch_bounds__(FGC_THREADS) void fg_chain_kernel(FgStep g) {
           const auto pd = __builtin_amdgcn_permlane32_swap(
               __float_as_uint(dh), __float_as_uint(dh), false, false);
           if (lane < 32)
-            x += cur_bd + (__uint_as_float(pd[0]) + __uint_as_float(pd[1]));
+            x += bd_s[l * 32 + lane] + (__uint_as_float(pd[0]) + __uint_as_float(pd[1]));
         }
       }
     } else {
@@ -633,9 +681,15 @@ __device__ __forceinline__ float fg_mv_reduce(float (*red)[FGM_OUTS], int o) {
 }
 
 // h1[s] = relu(sum_l z_l . Ws_l[:, s] + sum_l bs_l[s])   (model.py:505-509)
+// (+ g.L more workgroups: the past-tap pre-activations of the NEXT step)
 __global__ __launch_bounds__(256) void fg_skip_kernel(FgStep g) {
   __shared__ float zs[FG_MAXL * 32];
   __shared__ float red[FGM_PARTS][FGM_OUTS];
+  const int nskip = (g.S + FGM_OUTS - 1) / FGM_OUTS;
+  if ((int)blockIdx.x >= nskip) {        // workgroup-uniform
+    fg_pre_layer(g, blockIdx.x - nskip, 1, zs);
+    return;
+  }
   const int tid = threadIdx.x, o = tid & (FGM_OUTS - 1), part = tid / FGM_OUTS;
   const int s = blockIdx.x * FGM_OUTS + o;
   const int KK = g.L * 32;
@@ -677,16 +731,24 @@ __global__ __launch_bounds__(256) void fg_logits_kernel(FgStep g) {
     g.logits[q] = (g.post2_b ? g.post2_b[q] : 0.f) + fg_mv_reduce(red, o);
 }
 
-// float64 softmax, temperature, inverse-CDF draw, cursor update (one wave)
+// float64 softmax, temperature, inverse-CDF draw, cursor update (one wave).
+// (Folding this into fg_logits_kernel -- the last workgroup to arrive, by an
+// agent-scope ticket, does the draw -- was measured: 47.1 vs 46.8 us per
+// sample; the release / acquire fences cost what the saved boundary returns.)
 __global__ __launch_bounds__(64) void fg_draw_kernel(FgStep g) {
   __shared__ double pd[FG_MAXQ];
   const int lane = threadIdx.x, wave = 0;
   const int Q = g.Q;
   const int steps_done = g.cursors[0];
-  const int local = steps_done - g.base;
+  const int local = steps_done - g.ctl[FGCTL_BASE];
   const int code = g.samples[local];
+  const int n_given = g.ctl[FGCTL_NGIVEN];
+  const int proba_every = g.ctl[FGCTL_PEVERY] > 0 ? g.ctl[FGCTL_PEVERY] : 1;
+  const float temperature = __int_as_float(g.ctl[FGCTL_TEMP]);
+  const uint64_t seed = (uint64_t)(uint32_t)g.ctl[FGCTL_SEED] |
+                        ((uint64_t)(uint32_t)g.ctl[FGCTL_SEED + 1] << 32);
   for (int q = lane; q < Q; q += 64) pd[q] = (double)g.logits[q];
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();
   if (wave == 0) {
     double m = -1e300;
     for (int q = lane; q < Q; q += 64) m = fmax(m, pd[q]);
@@ -699,18 +761,18 @@ __global__ __launch_bounds__(64) void fg_draw_kernel(FgStep g) {
       se += e;
     }
     for (int o = 32; o >= 1; o >>= 1) se += __shfl_xor(se, o);
-    const bool want_p = g.proba_out && (local % g.proba_every == 0);
-    float* po = want_p ? g.proba_out + (long)(local / g.proba_every) * Q : nullptr;
+    const bool want_p = g.proba_out && (local % proba_every == 0);
+    float* po = want_p ? g.proba_out + (long)(local / proba_every) * Q : nullptr;
     for (int q = lane; q < Q; q += 64) {
       const float p32 = (float)(pd[q] / se);
       if (po) po[q] = p32;
       pd[q] = (double)p32;
     }
-    if (local + 1 >= g.n_given) {
+    if (local + 1 >= n_given) {
       // sampling weights w_q proportional to exp(log(p_q) / tau)
       // (generate.py:229-233); at tau == 1 that is p_q itself
-      const double tau = (double)g.temperature;
-      if (g.temperature != 1.0f) {
+      const double tau = (double)temperature;
+      if (temperature != 1.0f) {
         double mx = -1e300;
         for (int q = lane; q < Q; q += 64) {
           const double lp = log(pd[q] > 0.0 ? pd[q] : 1e-300) / tau;
@@ -731,7 +793,7 @@ __global__ __launch_bounds__(64) void fg_draw_kernel(FgStep g) {
         if (lane >= o) incl += v;
       }
       const double total = __shfl(incl, 63);
-      const uint64_t r = splitmix64(g.seed ^ splitmix64((uint64_t)steps_done));
+      const uint64_t r = splitmix64(seed ^ splitmix64((uint64_t)steps_done));
       const double u = (double)(r >> 11) * (1.0 / 9007199254740992.0) * total;
       const double excl = incl - seg;
       int pick = -1;
@@ -814,10 +876,12 @@ int wn_fastgen_run(const float* params_causal, const float* layer0,
 }
 
 
-// Enqueue ONE generation step (4 kernels) on `stream`.  `base` = value of
-// cursors[0] when this generate() call started (samples_io / proba_out are
-// indexed relative to it); everything step-dependent is read from device
-// memory, so the call can be captured into a hipGraph and replayed.
+// Enqueue ONE generation step (five kernels) on `stream`.  Everything
+// step- or call-dependent is read from device memory (cursors, ctl), so the
+// call can be captured into a hipGraph once and replayed for every call.
+// `pre` must hold the past-tap pre-activations of the step about to run
+// (wn_fastgen_pre before the first step of a sequence; afterwards every step
+// leaves the next step's behind).
 int wn_fastgen_step(const float* params_causal, const float* layer0,
                     long layer_stride, const float* skip_w,
                     const float* skip_bsum, const float* post1_w,
@@ -825,39 +889,55 @@ int wn_fastgen_step(const float* params_causal, const float* layer0,
                     const float* post2_b, const float* gc_bias_fg,
                     const int32_t* dilations_dev, int L, int S, int Q,
                     float* state, int32_t* cursors, int32_t* samples_io,
-                    int base, int n_given, float temperature, uint64_t seed,
-                    float* proba_out, int proba_every, int use_biases,
-                    const float* cw_img, float* z_all, float* h1, float* h2,
-                    float* logits, void* stream) {
-  if (!cw_img || !logits) return WN_ERR_NULL;
+                    const int32_t* ctl, float* proba_out, int use_biases,
+                    const float* cw_img, float* pre, float* z_all, float* h1,
+                    float* h2, float* logits, void* stream) {
+  if (!cw_img || !logits || !ctl || !pre) return WN_ERR_NULL;
   if (!params_causal || !layer0 || !skip_w || !post1_w || !post2_w ||
       !dilations_dev || !state || !cursors || !samples_io || !z_all || !h1 ||
       !h2)
     return WN_ERR_NULL;
-  if (L <= 0 || S <= 0 || Q <= 0 || n_given < 1) return WN_ERR_BAD_SHAPE;
+  if (L <= 0 || S <= 0 || Q <= 0) return WN_ERR_BAD_SHAPE;
   if (S > FG_MAXS || Q > FG_MAXQ || L > FG_MAXL) return WN_ERR_UNSUPPORTED;
-  if (!(temperature > 0.f)) return WN_ERR_BAD_SHAPE;
   FgStep g;
   g.causal = params_causal; g.layer0 = layer0; g.layer_stride = layer_stride;
   g.skip_w = skip_w; g.skip_bsum = skip_bsum; g.post1_w = post1_w;
   g.post1_b = post1_b; g.post2_w = post2_w; g.post2_b = post2_b;
   g.bias_fg = gc_bias_fg; g.dil = dilations_dev; g.L = L; g.S = S; g.Q = Q;
-  g.state = state; g.cursors = cursors; g.samples = samples_io; g.base = base;
-  g.n_given = n_given; g.temperature = temperature; g.seed = seed;
-  g.proba_out = proba_out; g.proba_every = proba_every > 0 ? proba_every : 1;
-  g.use_dense_bias = use_biases; g.cw_img = cw_img; g.z_all = z_all;
-  g.h1 = h1; g.h2 = h2; g.logits = logits;
+  g.state = state; g.cursors = cursors; g.samples = samples_io; g.ctl = ctl;
+  g.proba_out = proba_out;
+  g.use_dense_bias = use_biases; g.cw_img = cw_img; g.pre = pre;
+  g.z_all = z_all; g.h1 = h1; g.h2 = h2; g.logits = logits;
   hipStream_t s = (hipStream_t)stream;
   const int wgs = (S + FGM_OUTS - 1) / FGM_OUTS;
   hipLaunchKernelGGL(fg_chain_kernel, dim3(1), dim3(FGC_THREADS), 0, s, g);
-  hipLaunchKernelGGL(fg_skip_kernel, dim3(wgs), dim3(256), 0, s, g);
+  hipLaunchKernelGGL(fg_skip_kernel, dim3(wgs + L), dim3(256), 0, s, g);
   hipLaunchKernelGGL(fg_post1_kernel, dim3(wgs), dim3(256), 0, s, g);
   hipLaunchKernelGGL(fg_logits_kernel, dim3((Q + FGM_OUTS - 1) / FGM_OUTS), dim3(256), 0, s, g);
   hipLaunchKernelGGL(fg_draw_kernel, dim3(1), dim3(64), 0, s, g);
   return wn_check_launch();
 }
 
-// Build the chain-weight image wn_fastgen_step streams: img [L][5120].
+// Past-tap pre-activations pre[L][64] of the step the queues are at
+// (cursors[0]); needed once before the first wn_fastgen_step of a sequence.
+int wn_fastgen_pre(const float* layer0, long layer_stride,
+                   const float* gc_bias_fg, const int32_t* dilations_dev,
+                   int L, const float* state, const int32_t* cursors,
+                   float* pre, void* stream) {
+  if (!layer0 || !dilations_dev || !state || !cursors || !pre) return WN_ERR_NULL;
+  if (L <= 0) return WN_ERR_BAD_SHAPE;
+  if (L > FG_MAXL) return WN_ERR_UNSUPPORTED;
+  FgStep g = {};
+  g.layer0 = layer0; g.layer_stride = layer_stride; g.bias_fg = gc_bias_fg;
+  g.dil = dilations_dev; g.L = L; g.state = const_cast<float*>(state);
+  g.cursors = const_cast<int32_t*>(cursors); g.pre = pre;
+  hipLaunchKernelGGL(fg_pre_kernel, dim3(L), dim3(256), 0, (hipStream_t)stream,
+                     g, 0);
+  return wn_check_launch();
+}
+
+// Build the chain-weight image wn_fastgen_step streams: img [L][3072]
+// (Wf[1] | Wg[1] | Wd of every layer, transposed + swizzled).
 int wn_fastgen_pack(const float* layer0, long layer_stride, float* img, int L,
                     void* stream) {
   if (!layer0 || !img) return WN_ERR_NULL;

@@ -94,8 +94,9 @@ SIGNATURES = {
                                c_int, c_int, P, P, P, c_int, c_int, c_float,
                                c_u64, P, c_int, c_int, c_int, P]),
     'wn_fastgen_step': (c_int, [P, P, c_long, P, P, P, P, P, P, P, P, c_int,
-                                c_int, c_int, P, P, P, c_int, c_int, c_float,
-                                c_u64, P, c_int, c_int, P, P, P, P, P, P]),
+                                c_int, c_int, P, P, P, P, P, c_int, P, P, P,
+                                P, P, P, P]),
+    'wn_fastgen_pre': (c_int, [P, c_long, P, P, c_int, P, P, P, P]),
     'wn_fastgen_pack': (c_int, [P, c_long, P, c_int, P]),
 }
 

@@ -1024,8 +1024,12 @@ class WaveNetModel(object):
                                   device=self.device),
                 z_all=torch.zeros(self.L * CH, dtype=torch.float32,
                                   device=self.device),
-                cw_img=torch.zeros(self.L * 5120, dtype=torch.float32,
+                cw_img=torch.zeros(self.L * 3072, dtype=torch.float32,
                                    device=self.device),
+                pre=torch.zeros(self.L * 64, dtype=torch.float32,
+                                device=self.device),
+                ctl=torch.zeros(8, dtype=torch.int32, device=self.device),
+                graphs={}, warm=False,
                 h1=torch.zeros(self.S, dtype=torch.float32,
                                device=self.device),
                 h2=torch.zeros(self.S, dtype=torch.float32,
@@ -1082,32 +1086,81 @@ class WaveNetModel(object):
                 g['steps'] += int(n_steps)
             return
         base = g['steps']
-        # weights are constant while generating: pack the chain blocks once
+        st = _lib.stream()
+        # weights are constant while generating: pack the chain blocks once,
+        # and compute the past-tap pre-activations of the first step (every
+        # step then leaves the next step's behind)
         _lib.call('wn_fastgen_pack', _lib.ptr(self._layer_block(P, 0)),
-                  self.layer_stride, _lib.ptr(g['cw_img']), self.L,
-                  _lib.stream())
-        tail = (base, int(n_given), float(temperature), sd,
-                _lib.ptr(proba_out), int(proba_every), 1 if ub else 0,
-                _lib.ptr(g['cw_img']), _lib.ptr(g['z_all']), _lib.ptr(g['h1']),
-                _lib.ptr(g['h2']), _lib.ptr(g['logits']))
+                  self.layer_stride, _lib.ptr(g['cw_img']), self.L, st)
+        _lib.call('wn_fastgen_pre', _lib.ptr(self._layer_block(P, 0)),
+                  self.layer_stride, None if bias is None else _lib.ptr(bias),
+                  _lib.ptr(g['dil']), self.L, _lib.ptr(g['state']),
+                  _lib.ptr(g['cursors']), _lib.ptr(g['pre']), st)
+        # per-call values live in device memory (ctl) and in two persistent
+        # buffers (codes, probabilities), so a captured graph holds nothing
+        # that changes between calls and is reused
+        n_io = int(n_steps) + 1
+        pe = max(1, int(proba_every))
+        io = self._gen_buf('io_buf', n_io, torch.int32)
+        io[:n_io].copy_(samples_io[:n_io])
+        pb = None
+        if proba_out is not None:
+            rows = (int(n_steps) + pe - 1) // pe
+            pb = self._gen_buf('proba_buf', rows * self.Q, torch.float32)
+        ctl = np.zeros(8, np.uint32)
+        ctl[0], ctl[1], ctl[2] = base, int(n_given), pe
+        ctl[3] = np.float32(temperature).view(np.uint32)
+        ctl[4], ctl[5] = sd & 0xffffffff, sd >> 32
+        g['ctl'].copy_(torch.from_numpy(ctl.view(np.int32)))
+        common = common[:-1] + (_lib.ptr(io),)
+        tail = (_lib.ptr(g['ctl']), _lib.ptr(pb), 1 if ub else 0,
+                _lib.ptr(g['cw_img']), _lib.ptr(g['pre']), _lib.ptr(g['z_all']),
+                _lib.ptr(g['h1']), _lib.ptr(g['h2']), _lib.ptr(g['logits']))
 
         def one():
             _lib.call('wn_fastgen_step', *common, *tail, _lib.stream())
-        per = self.fastgen_graph_steps
+
+        def graph_of(nsteps):
+            key = (common, tail, nsteps)
+            gr = g['graphs'].get(key)
+            if gr is None:
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr):
+                    for _ in range(nsteps):
+                        one()
+                if len(g['graphs']) > 8:
+                    g['graphs'].clear()
+                g['graphs'][key] = gr
+            return gr
         done = 0
-        if n_steps >= 2 * per:
-            one()                      # warm-up outside the capture
-            done = 1
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                for _ in range(per):
-                    one()
-            while n_steps - done >= per:
-                graph.replay()
-                done += per
+        if not g['warm']:
+            one()                      # module load etc. outside any capture
+            done, g['warm'] = 1, True
+        for per in (int(self.fastgen_graph_steps),
+                    max(1, int(self.fastgen_graph_steps) // 10)):
+            if per > 1 and n_steps - done >= per:
+                gr = graph_of(per)
+                while n_steps - done >= per:
+                    gr.replay()
+                    done += per
         for _ in range(n_steps - done):
             one()
         g['steps'] += int(n_steps)
+        samples_io[:n_io].copy_(io[:n_io])
+        if proba_out is not None:
+            proba_out.view(-1).copy_(pb[:proba_out.numel()])
+
+    def _gen_buf(self, name, n, dtype):
+        """Persistent per-generator buffer of at least n elements (grown
+        geometrically; growing drops the captured graphs, which hold its
+        address)."""
+        g = self._gen
+        buf = g.get(name)
+        if buf is None or buf.numel() < n:
+            cap = max(int(n), 2 * (buf.numel() if buf is not None else 0), 4096)
+            g[name] = buf = torch.zeros(cap, dtype=dtype, device=self.device)
+            g['graphs'].clear()
+        return buf
 
     def predict_proba_incremental(self, waveform, global_condition=None,
                                   name='wavenet', push=True):

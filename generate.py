@@ -159,6 +159,9 @@ def main(argv=None):
                 dump(waveform)
     else:
         rng = np.random.default_rng(args.seed)
+        # one workspace for the whole window: the growing inputs of the first
+        # `window` steps are views of it
+        net.reserve(1, min(args.window, len(waveform) + args.samples))
         for step in range(args.samples):
             window = waveform[-args.window:] if len(waveform) > args.window \
                 else waveform

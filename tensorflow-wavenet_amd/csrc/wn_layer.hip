@@ -53,8 +53,12 @@ __global__ __launch_bounds__(LAYER_WG) void layer_fwd_kernel(
   float* tb = ta + 1024;
   const int tiles_per_clip = (T + 31) >> 5;
   const int ntiles = tiles_per_clip * B;
-  for (int tile = blockIdx.x * LAYER_WAVES + wave; tile < ntiles;
-       tile += gridDim.x * LAYER_WAVES) {
+  // few tiles (small batches): one tile per wave, spread over ALL CUs wave by
+  // wave (layer_grid sizes the grid for it), so a SIMD runs one tile, not four
+  const bool sparse = ntiles < (int)gridDim.x * LAYER_WAVES;
+  for (int tile = sparse ? wave * (int)gridDim.x + (int)blockIdx.x
+                         : (int)blockIdx.x * LAYER_WAVES + wave;
+       tile < ntiles; tile += gridDim.x * LAYER_WAVES) {
     // opaque per-iteration LDS offset: keeps the 80 weight reads next to their
     // MFMAs instead of being hoisted into (and spilling from) registers
     int woff = j + 4 * h * 32;  // n0 = 0, i = j
@@ -906,8 +910,11 @@ __global__ __launch_bounds__(B2_WAVES * 64) void layer_bwd2d_kernel(
     a2 = rows_load(z + offd, lane, 0, hif);
     a3 = rows_load(sg + offd, lane, 0, hif);
   };
-  load_shifted(blockIdx.x * B2_WAVES + wave);
-  for (int tile = blockIdx.x * B2_WAVES + wave; tile < ntiles; tile += tstep) {
+  // few tiles (small batches): one tile per wave, spread over all CUs
+  const int tile0 = ntiles < tstep ? wave * (int)gridDim.x + (int)blockIdx.x
+                                   : (int)blockIdx.x * B2_WAVES + wave;
+  load_shifted(tile0);
+  for (int tile = tile0; tile < ntiles; tile += tstep) {
     int woff = j + 4 * h * LDT;  // opaque: no hoisting of the weight reads
     asm volatile("" : "+v"(woff));
     const float* wlane = wl + woff;
@@ -1367,10 +1374,13 @@ __global__ __launch_bounds__(256) void layer_wgrad_gen_kernel(
 // C ABI
 // ---------------------------------------------------------------------------
 // one persistent workgroup per CU (fewer when there is less work)
-static int layer_grid(int B, int T, int waves = LAYER_WAVES) {
+// (`spread`: kernels with the sparse tile mapping get one workgroup per CU as
+// soon as there are that many tiles, each running ceil(ntiles / cus) waves)
+static int layer_grid(int B, int T, int waves = LAYER_WAVES, bool spread = false) {
   const int cus = wn_device_cus();
   const long ntiles = (long)B * ((T + 31) / 32);
   long g = (ntiles + waves - 1) / waves;
+  if (spread && ntiles < (long)cus * waves) g = ntiles;
   if (g > cus) g = cus;
   return (int)(g < 1 ? 1 : g);
 }
@@ -1390,7 +1400,7 @@ int wn_layer_fwd(const float* x, float* x_out, float* z, float* th, float* sg,
       (x_out && !wn_aligned16(x_out)) || (th && !wn_aligned16(th)) ||
       (sg && !wn_aligned16(sg)))
     return WN_ERR_MISALIGNED;
-  dim3 grid(layer_grid(B, T)), block(LAYER_WG);
+  dim3 grid(layer_grid(B, T, LAYER_WAVES, true)), block(LAYER_WG);
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(HD, TS)                                                      \
   hipLaunchKernelGGL((layer_fwd_kernel<HD, TS>), grid, block, 0, s, x,      \
@@ -1554,7 +1564,9 @@ static int b2_waves() {
   const char* e = getenv("WN_B2_MODE");   // A/B knob: "d" (default) or "4p"
   return (e && e[0] == '4') ? 4 : B2_WAVES;
 }
-int wn_layer_bwd2_slabs(int B, int T) { return layer_grid(B, T, b2_waves()); }
+int wn_layer_bwd2_slabs(int B, int T) {
+  return layer_grid(B, T, b2_waves(), b2_waves() == B2_WAVES);
+}
 
 int wn_layer_bwd2(const float* x, const float* z, const float* sg,
                   const float* dZ, const float* dxin, float* dx_out,
@@ -1567,7 +1579,7 @@ int wn_layer_bwd2(const float* x, const float* z, const float* sg,
   for (const void* p : ptrs)
     if (p && !wn_aligned16(p)) return WN_ERR_MISALIGNED;
   const int waves = b2_waves();
-  dim3 grid(layer_grid(B, T, waves)), block(waves * 64);
+  dim3 grid(layer_grid(B, T, waves, waves == B2_WAVES)), block(waves * 64);
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(KERNEL)                                                        \
   hipLaunchKernelGGL(KERNEL, grid, block, 0, s, x, z, sg, dZ, dxin, dx_out,   \

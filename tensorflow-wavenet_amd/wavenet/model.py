@@ -349,13 +349,17 @@ class WaveNetModel(object):
         return var
 
     def _init_variables(self, seed):
+        """Xavier / identity / zero initialisation (model.py:7-28) drawn on the
+        host into a flat staging buffer of the same layout and uploaded ONCE
+        (not one small copy per variable)."""
         gen = torch.Generator().manual_seed(int(seed))
-        v = self.variables
+        host = torch.zeros(self.params.numel(), dtype=torch.float32)
+        v = self._views(host)
         with torch.no_grad():
             if self.card is not None:
                 e = v['embeddings']['gc_embedding']
                 if self.card == self.G:                      # model.py:16-19
-                    e.copy_(torch.eye(self.card, device=self.device))
+                    e.copy_(torch.eye(self.card))
                 else:
                     _xavier_(e, gen)
             _xavier_(v['causal_layer']['filter'], gen)
@@ -367,6 +371,7 @@ class WaveNetModel(object):
             _xavier_(v['postprocessing']['postprocess1'], gen)
             _xavier_(v['postprocessing']['postprocess2'], gen)
             # biases: zeros (model.py:27)
+            self.params.copy_(host)
 
     def histogram_summaries(self, bins=30):
         """Counterpart of the `histograms=True` summaries of
@@ -482,8 +487,21 @@ class WaveNetModel(object):
                 ws = _Workspace(self, B, T, training, parent=cand)
                 break
         if ws is None:
-            ws = _Workspace(self, B, T, training)
-            self._ws = {}             # keep one owning allocation resident
+            # grow geometrically (the naive generation path asks for T, T+1,
+            # ... up to its window) and keep ONE owner per kind resident: a
+            # training step and forward-only calls of another length do not
+            # evict each other's buffers and launch plans
+            prev = [w for (b, t, tr), w in self._ws.items()
+                    if w.capacity == w.N and tr == bool(training) and b == B]
+            t_alloc = T
+            if prev and not training:
+                t_alloc = max(T, min(2 * max(w.T for w in prev), 1 << 20))
+            self._ws = {k: w for k, w in self._ws.items()
+                        if self._owner_kind(w) != bool(training)}
+            owner = _Workspace(self, B, t_alloc, training)
+            self._ws[(B, t_alloc, bool(training))] = owner
+            ws = owner if t_alloc == T else \
+                _Workspace(self, B, T, training, parent=owner)
         self._ws[key] = ws
         if len(self._ws) > 64:        # views are cheap but unbounded otherwise
             owners = {k: v for k, v in self._ws.items()
@@ -491,6 +509,17 @@ class WaveNetModel(object):
             self._ws = owners
             self._ws[key] = ws
         return ws
+
+    @staticmethod
+    def _owner_kind(ws):
+        return bool(ws.training)
+
+    def reserve(self, batch_size, max_samples, training=False):
+        """Allocate the workspace for up to `max_samples` samples per clip now
+        (generate.py's window, train.py's sample_size), so that later calls
+        with shorter inputs carve views out of it instead of allocating."""
+        self._check_supported()
+        return self._workspace(int(batch_size), int(max_samples), training)
 
     def _gc_ids(self, global_condition, B):
         if self.card is None or global_condition is None:
@@ -534,7 +563,9 @@ class WaveNetModel(object):
             nprod = {'bf16x3': 3, 'bf16x6': 6, 'bf16x9': 9}[self.gemm_mode]
             M, N, K = args[-5], args[-4], args[-3]
             if K % 16 == 0:
-                key = (K, N)
+                # one scratch buffer per WEIGHT (its address), not per shape:
+                # equal-shaped GEMMs never share pieces
+                key = (args[4], K, N)
                 buf = self._wsplit.get(key)
                 if buf is None:
                     nb = _lib.load().wn_gemm_split_w_bytes(K, N)

@@ -457,3 +457,39 @@ def test_unsupported_configs_raise(hip_lib):
         net.loss(np.zeros((2, 16), np.float32), np.array([1, 2, 3]))
     with pytest.raises(ValueError):
         net.loss(np.zeros((2, 16), np.float32))
+
+
+def test_workspace_reserve_and_owner_per_kind(hip_lib):
+    """net.reserve(): growing forward-only inputs are views of one allocation
+    (same plane address, no new owner); without a reservation the capacity
+    grows geometrically; a training workspace and a forward-only one of
+    another length do not evict each other (the recorded launch plans of the
+    training workspace survive)."""
+    cfg = cfg_with(MID, batch_size=1)
+    net, var = build_pair(cfg)
+    rng = np.random.default_rng(0)
+    data = rng.integers(0, 256, 400)
+    owner = net.reserve(1, 300)
+    base = owner.X.data_ptr()
+    for T in (7, 120, 300):
+        p = net.predict_proba(data[:T]).cpu().numpy()
+        ws = net._ws[(1, T, False)]
+        assert ws.X.data_ptr() == base
+        assert np.abs(p - O.predict_proba(cfg, var, data[:T],
+                                          dtype=np.float64)).max() < 1e-5
+    owners = lambda: [w for w in net._ws.values() if w.capacity == w.N]
+    assert len(owners()) == 1
+    net.predict_proba(data[:301])           # past the reservation: grows x2
+    assert max(w.T for w in owners()) >= 600 and len(owners()) == 1
+    # training owner next to the eval owner
+    audio = rng.uniform(-1, 1, (1, 150)).astype(np.float32)
+    for _ in range(3):
+        net.loss(audio)
+    tr = net._ws[(1, 150, True)]
+    assert any(isinstance(pl, list) for pl in tr.plans.values())
+    net.predict_proba(data[:350])
+    net.predict_proba(data[:800])           # new eval owner
+    assert net._ws[(1, 150, True)] is tr    # training buffers + plans kept
+    l1 = float(net.loss(audio))
+    ref, _ = O.loss_and_grads(cfg, var, audio, dtype=np.float64)
+    assert abs(l1 - ref) < TOL

@@ -263,6 +263,26 @@ def bwd2():
     os.environ.pop('WN_B2_MODE', None)
 
 
+def lk():
+    """the two default layer kernels at the bench shape (B=8, T=16000):
+    wn_layer_fwd (sigmoid plane only) and wn_layer_bwd2; median of 5 x 40"""
+    B, T = int(os.environ.get('KB_B', 8)), 16000
+    N = B * T
+    mk = lambda: torch.randn(N * 32, device=dev)
+    x, xo, z, dZ, dxin, dxo = [mk() for _ in range(6)]
+    sg = torch.rand(N * 32, device=dev) * 0.9 + 0.05
+    w = torch.randn(5216, device=dev) * 0.1
+    slabs = torch.empty(lib.wn_layer_bwd2_slabs(B, T) * 5216, device=dev)
+    for d in (4, 512):
+        f = lambda: _lib.call('wn_layer_fwd', x.data_ptr(), xo.data_ptr(), z.data_ptr(), None, sg.data_ptr(),
+                              w.data_ptr(), None, 0, B, T, d, 1, 2, st())
+        b = lambda: _lib.call('wn_layer_bwd2', x.data_ptr(), z.data_ptr(), sg.data_ptr(), dZ.data_ptr(),
+                              dxin.data_ptr(), dxo.data_ptr(), w.data_ptr(), slabs.data_ptr(), None, B, T, d, st())
+        tf = sorted(timeit(f, n=40, warm=3) for _ in range(5))[2]
+        tb = sorted(timeit(b, n=40, warm=3) for _ in range(5))[2]
+        print('B=%d d=%3d: fwd %6.2f us   bwd2 %6.2f us' % (B, d, tf * 1e6, tb * 1e6), flush=True)
+
+
 def layerpad():
     """are the layer kernels sensitive to the relative alignment of their
     planes?  (12 planes carved from one buffer at stride N*32 + pad floats)"""

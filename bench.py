@@ -253,6 +253,8 @@ def main():
         net.use_launch_plans = os.environ['WN_LAUNCH_PLANS'] == '1'
     if os.environ.get('WN_FUSED_BWD') is not None:       # A/B knob
         net.fused_bwd = os.environ['WN_FUSED_BWD'] == '1'
+    if os.environ.get('WN_OVERLAP_TN') is not None:      # A/B knob
+        net.overlap_tn = os.environ['WN_OVERLAP_TN'] == '1'
     if os.environ.get('WN_OVERLAP_WGRAD') is not None:   # A/B knob
         net.overlap_wgrad = os.environ['WN_OVERLAP_WGRAD'] == '1'
     parallel.broadcast_parameters(net)

@@ -170,6 +170,18 @@ def call(name, *args):
         check(code, name)
 
 
+def call_py(fn):
+    """Run a host-side action that belongs INTO the launch sequence (a
+    cross-stream event record / wait) and, while recording, append it to the
+    plan so that a replay repeats it at the same position."""
+    def wrapped():
+        fn()
+        return 0
+    if _rec is not None:
+        _rec.append((wrapped, (), 'py', None))
+    wrapped()
+
+
 def call_timed(name, args, flops, events):
     """`call` for the GEMMs; with `events` (a list) the launch is bracketed by
     HIP events on torch's current stream and (start, end, flops) is appended

@@ -122,10 +122,14 @@ class _Workspace(object):
             sp = lib.wn_gemm_tn_splits(N, mw, nw, 1 if key == 'causal' else 0)
             self.splits[key] = sp
             need = max(need, sp * lib.wn_gemm_tn_slab_floats(mw, nw))
+        need_tn = need
         need = max(need, 256 * 32 * CH)          # scalar-input causal wgrad
         self.nslab_c = lib.wn_causal_wgrad_slabs(N)
         need = max(need, self.nslab_c * 2 * Q * CH)
         alloc('slabs', (need,))
+        alloc('slabs_tn', (need_tn,))     # TN GEMMs on the side stream
+        self.ev_fork = torch.cuda.Event() if dev.type == 'cuda' else None
+        self.ev_join = torch.cuda.Event() if dev.type == 'cuda' else None
         self.dsum = alloc('dsum', (L, B, 64)) if net.G else None
         self.tilesum = alloc('tilesum', (L, ntiles, 64)) if net.G else None
         self.dsum_part = alloc(
@@ -193,6 +197,12 @@ class WaveNetModel(object):
         # 12.80 ms/step: 100 cross-stream event edges per step cost more than
         # the overlap recovers), so it is off by default.
         self.overlap_wgrad = False
+        # Run the three weight-gradient (TN) GEMMs of the skip / post-processing
+        # convs on a second, lower-priority HIP stream next to the dZ GEMM and
+        # the residual-stack backward (one fork after the dtotal GEMM, one join
+        # before the slab reductions): the layer kernels keep the matrix pipes
+        # about a third busy, the TN GEMMs are MFMA-bound.
+        self.overlap_tn = False
         # backward of a residual block: 'bwd2' (default: one kernel per layer,
         # pre-activation gradients recomputed per tile, only dx goes through
         # HBM, tanh recovered as z / sigmoid); 'bwdw' (round-1 fused kernel:
@@ -456,7 +466,9 @@ class WaveNetModel(object):
     # ------------------------------------------------------------------ helpers
     def _side_stream(self):
         if getattr(self, '_side', None) is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            # lower priority than the default stream: the residual-stack
+            # kernels on the main stream are the critical path
+            self._side = torch.cuda.Stream(device=self.device, priority=0)
         return self._side
 
     def _legacy_bwd(self):
@@ -581,7 +593,7 @@ class WaveNetModel(object):
     # ------------------------------------------------------------ launch plans
     def _plan_key(self, tag, ws, ids, extra):
         return (tag, extra, ids is not None, self.generic_layers,
-                self.fused_bwd, self.layer_bwd, self.gemm_mode, self.causal_wgrad_segsum, self.tf_xent_zero_label_quirk,
+                self.fused_bwd, self.layer_bwd, self.overlap_tn, self.gemm_mode, self.causal_wgrad_segsum, self.tf_xent_zero_label_quirk,
                 _lib.stream(), self.params.data_ptr(), self.grads.data_ptr())
 
     def _stage_ids(self, ws, ids):
@@ -692,24 +704,33 @@ class WaveNetModel(object):
         dlog = ws.logits
         lib = _lib.load()
 
-        def tn(A, lda, a_planes, a_pstride, codes, shift, Gm, ldg, key, mw, nw,
-               dst, dst_bias, replicate=1, rep_stride=0):
+        deferred = []          # TN GEMMs postponed to the side stream
+        ovl = self.overlap_tn and not self.overlap_wgrad
+
+        def tn(*a, **kw):
+            if ovl:
+                deferred.append((a, kw))
+            else:
+                tn_now(st, ws.slabs, *a, **kw)
+
+        def tn_now(st, slabs, A, lda, a_planes, a_pstride, codes, shift, Gm,
+                   ldg, key, mw, nw, dst, dst_bias, replicate=1, rep_stride=0):
             sp = ws.splits[key]
             sl = lib.wn_gemm_tn_slab_floats(mw, nw)
             if self.gemm_mode != 'fp32' and codes is None and N % 16 == 0:
                 # opt-in split-bf16 products (fewer, larger splits)
                 sp = min(sp, lib.wn_gemm_tn_splits(N, mw, nw, 2))
                 _lib.call('wn_gemm_tn_split', A, lda, a_planes, a_pstride, Gm,
-                          ldg, _lib.ptr(ws.slabs), sp, N, mw, nw, ub,
+                          ldg, _lib.ptr(slabs), sp, N, mw, nw, ub,
                           int(self.gemm_mode[-1]), st)
             else:
                 _lib.call('wn_gemm_tn', A, lda, a_planes, a_pstride, codes,
-                          shift, T, Gm, ldg, _lib.ptr(ws.slabs), sp, N, mw, nw,
+                          shift, T, Gm, ldg, _lib.ptr(slabs), sp, N, mw, nw,
                           ub, st)
-            _lib.call('wn_reduce_slabs', _lib.ptr(ws.slabs), sp, sl, 1, 0, 0,
+            _lib.call('wn_reduce_slabs', _lib.ptr(slabs), sp, sl, 1, 0, 0,
                       mw * nw, dst, 0, 1, 0, st)
             if ub and dst_bias is not None:
-                _lib.call('wn_reduce_slabs', _lib.ptr(ws.slabs), sp, sl, 1, 0,
+                _lib.call('wn_reduce_slabs', _lib.ptr(slabs), sp, sl, 1, 0,
                           mw * nw, nw, dst_bias, 0, replicate, rep_stride, st)
 
         # postprocess2:  dW2 = h2^T dlogits ; dh2 = dlogits W2^T
@@ -737,6 +758,15 @@ class WaveNetModel(object):
         tn(_lib.ptr(ws.Z), 0, L, N * CH, None, 0, _lib.ptr(ws.dtotal), S,
            'skip', L * CH, S, _lib.ptr(self._seg(Gr, 'skip_w')),
            _lib.ptr(self._seg(Gr, 'skip_b')), replicate=L, rep_stride=S)
+        if ovl:
+            # fork: everything the three TN GEMMs read exists now
+            main_s = torch.cuda.current_stream()
+            side_s = self._side_stream()
+            _lib.call_py(lambda: (ws.ev_fork.record(main_s),
+                                  side_s.wait_event(ws.ev_fork)))
+            for a, kw in deferred:
+                tn_now(side_s.cuda_stream, ws.slabs_tn, *a, **kw)
+            _lib.call_py(lambda: ws.ev_join.record(side_s))
         # dZ planes = dtotal Ws_all^T
         _lib.call('wn_transpose', _lib.ptr(self._seg(P, 'skip_w')), L * CH, S,
                   S, _lib.ptr(ws.wst), L * CH, st)
@@ -860,6 +890,9 @@ class WaveNetModel(object):
     def _backward_tail(self, ws, ids, dxin, nslab, fused):
         """After the residual stack: slab reductions of the layer-block
         gradients, causal-layer and global-conditioning gradients."""
+        if self.overlap_tn and not self.overlap_wgrad:
+            main_s = torch.cuda.current_stream()
+            _lib.call_py(lambda: main_s.wait_event(ws.ev_join))     # join
         st = _lib.stream()
         B, T, N, L, S, Q = ws.B, ws.T, ws.N, self.L, self.S, self.Q
         P, Gr = self.params, self.grads

@@ -239,3 +239,10 @@ def test_fused_vs_unfused_backward_many_tiles(hip_lib, B, T):
     scale = g2.abs().max().item()
     assert (g1 - g2).abs().max().item() <= 2e-5 * max(scale, 1.0)
     assert (g0 - g2).abs().max().item() <= 2e-5 * max(scale, 1.0)
+    # the TN GEMMs on a second stream: same kernels, same slab order -> same bits
+    net.layer_bwd, net.fused_bwd = 'bwd2', True
+    for ovl in (True, False, True):
+        net.overlap_tn = ovl
+        for _ in range(3):                 # eager, recorded, replayed plan
+            l3 = float(net.loss(audio, ids))
+            assert l3 == l0 and torch.equal(net.grads, g0)

@@ -121,7 +121,7 @@ def pmc_traffic(kernel):
     return None, None
 
 
-def secondary(net, audio, gc_ids, kw, B, T, gen_samples=16000):
+def secondary(net, audio, gc_ids, kw, B, T, gen_samples=16000, opt=None):
     """SURVEY 8(d) secondary figures (rank 0, N = 1, after the timed region):
     forward-only samples/s on the same batch, and fast generation
     (BASELINE.json configs[4]: batch 1, seed 128, temperature 1)."""
@@ -135,6 +135,22 @@ def secondary(net, audio, gc_ids, kw, B, T, gen_samples=16000):
     torch.cuda.synchronize()
     fwd = B * T * 10 / (time.perf_counter() - t0)
     log('forward only: %.0f samples/s' % fwd)
+    # opt-in split-bf16 GEMM mode on the same batch (NOT the headline: fp32
+    # operands rebuilt from 6 bf16 piece products, same error vs float64 as the
+    # fp32 MFMA kernels)
+    optin = None
+    if net.gemm_mode == 'fp32' and opt is not None:
+        net.gemm_mode = 'bf16x6'
+        for _ in range(3):
+            opt.minimize(net.loss(audio, gc_ids))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            opt.minimize(net.loss(audio, gc_ids))
+        torch.cuda.synchronize()
+        optin = (time.perf_counter() - t0) / 10 * 1e3
+        net.gemm_mode = 'fp32'
+        log('opt-in bf16x6 GEMM mode: %.2f ms/step' % optin)
     kw1 = dict(kw)
     kw1['batch_size'] = 1
     gen = WaveNetModel(seed=0, **kw1)
@@ -150,7 +166,8 @@ def secondary(net, audio, gc_ids, kw, B, T, gen_samples=16000):
     return {'forward_only_samples_per_s': fwd,
             'fastgen_samples_per_s': gen_samples / dt,
             'fastgen_us_per_sample': dt / gen_samples * 1e6,
-            'fastgen_samples': gen_samples}
+            'fastgen_samples': gen_samples,
+            'optin_bf16x6_ms_per_step': optin}
 
 
 def launch_ranks(n):
@@ -349,7 +366,7 @@ def main():
                      'flops_per_step': flops / max(args.steps, 1)},
     }
     if world == 1 and not args.no_secondary:
-        out['secondary'] = secondary(net, audio, gc_ids, kw, B, T)
+        out['secondary'] = secondary(net, audio, gc_ids, kw, B, T, opt=opt)
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(params, T)
         out['gpu_over_cpu'] = value / out['cpu_baseline']['value']

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Collect the per-round evidence on the GPU box (run through gpurun from the
+# repo root):  tools/collect_profiles.sh <tag>   -> gpurun_out/<tag>_*
+# Counters are collected in their own passes (never with --sys-trace); the
+# program directly follows `--` (no env / shell wrapper).
+set -e -o pipefail
+TAG=${1:-rXX}
+R=${GRAFT_REPO_ROOT:-$PWD}
+O=$R/gpurun_out
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+ARGS="--steps 5 --warmup 3 --no-cpu-baseline --no-secondary"
+python3 $R/bench.py > $O/${TAG}_bench.log 2> $O/${TAG}_bench.err
+tail -1 $O/${TAG}_bench.log | cut -c1-300
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -- python3 $R/bench.py $ARGS > /dev/null 2>&1
+cp $O/${TAG}_stats/*/*kernel_stats.csv $O/${TAG}_bench_kernel_stats.csv
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_fetch -- python3 $R/bench.py --steps 2 --warmup 3 --no-cpu-baseline --no-secondary > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_write -- python3 $R/bench.py --steps 2 --warmup 3 --no-cpu-baseline --no-secondary > /dev/null 2>&1
+python3 $R/tools/pmc_summary.py $O/${TAG}_fetch/*/*_counter_collection.csv $O/${TAG}_write/*/*_counter_collection.csv $O/${TAG}_pmc_traffic.json
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/${TAG}_mfma -- python3 $R/bench.py --steps 2 --warmup 3 --no-cpu-baseline --no-secondary > /dev/null 2>&1
+python3 $R/tools/pmc_mfma.py $O/${TAG}_mfma/*/*_counter_collection.csv $O/${TAG}_mfma_util.json
+# raw traces are large: keep the summaries only
+rm -rf $O/${TAG}_stats $O/${TAG}_fetch $O/${TAG}_write $O/${TAG}_mfma

@@ -51,10 +51,12 @@ int wn_mu_law_decode(const int32_t* codes, float* audio, long n,
                      const float* lut_dev, int Q, void* stream);
 
 /* ---- causal layer on one-hot input as a gather: wavenet/model.py:227-234
- * (_create_causal_layer) + :518-531 (_one_hot).  Wc is [K][Q][32],
- * K = filter_width taps at shifts (K-1-k) + (K-1)/2. */
+ * (_create_causal_layer) + :518-531 (_one_hot).  Wc is [K][Q][ldw] (the
+ * 32 channels of one block start at Wc; ldw = padded channel count, 32 for
+ * <= 32 residual channels), K = filter_width taps at shifts (K-1-k) + (K-1)/2;
+ * x0 is the [B*T][32] plane of that block. */
 int wn_causal_gather(const int32_t* q, const float* Wc, float* x0, int B,
-                     int T, int Q, int K, void* stream);
+                     int T, int Q, int K, int ldw, void* stream);
 
 /* ---- causal layer on scalar input (scalar_input=True): wavenet/model.py:
  * 143-153, 227-234, 646-648; W is [K0][32], K0 = initial_filter_width <= 32.
@@ -113,6 +115,26 @@ int wn_layer_wgrad_k(const float* x, const float* daf, const float* dag,
                      const float* z, const float* dxin, float* slabs,
                      int num_slabs, int B, int T, int dilation, int K,
                      void* stream);
+
+/* more than 32 residual / dilation channels: channels are cut into 32-wide
+ * blocks, each block of an activation is its own [B*T][32] plane, and one
+ * launch computes ONE output block from all input blocks (weights in the
+ * reference's [K][Cin][Cout] layout, row stride ldw = padded channel count).
+ * fwd: z / tanh / sigmoid planes of dilation block jb; wf / wg point at column
+ * 32 jb of Wf / Wg; x is input block 0, block i at x + i * in_plane_stride.
+ * bwd: dx plane of residual block rb from the da planes of all dilation
+ * blocks; wf / wg point at row 32 rb; tap_stride = floats between taps.
+ * K * blocks <= 8.  The 1x1 convs of such a layer are wn_gemm_nn calls in
+ * plane mode; its weight gradients come from wn_layer_wgrad_k per block pair. */
+int wn_layer_fwd_blk(const float* x, long in_plane_stride, int in_blocks,
+                     float* z, float* th, float* sg, const float* wf,
+                     const float* wg, int ldw, const float* bias_f,
+                     const float* bias_g, int bias_clip_stride, int B, int T,
+                     int dilation, int K, int save_ts, void* stream);
+int wn_layer_bwd_blk(const float* daf, const float* dag, long da_plane_stride,
+                     int da_blocks, const float* dxin, float* dx_out,
+                     const float* wf, const float* wg, int ldw, long tap_stride,
+                     int B, int T, int dilation, int K, void* stream);
 
 /* fused backward of one block: phase B + all weight gradients of layer l and
  * phase A of layer l-1 in one pass (reads da_l / dx_{l+1} once).
@@ -205,17 +227,20 @@ int wn_l2_partials_count(void);
 int wn_l2_partials(const float* p, long n, const float* mask, float* partials,
                    void* stream);
 
-/* ---- global conditioning: wavenet/model.py:272-284, 533-562 */
+/* ---- global conditioning: wavenet/model.py:272-284, 533-562.  ch = padded
+ * dilation channel count (32, or 64 with two channel blocks): out is
+ * [L][B][2 ch] = filter | gate bias (+ embedding * Wgc), dsum likewise. */
 int wn_gc_bias(const float* layer0, long layer_stride, long off_bias,
                long off_gc, int G, const float* emb, int card,
-               const int32_t* ids, float* out, int L, int B, void* stream);
+               const int32_t* ids, float* out, int L, int B, int ch,
+               void* stream);
 int wn_colsum_clip_chunks(int T);
 int wn_colsum_clip(const float* plane0, const float* plane1, int B, int T,
                    float* part, float* out, void* stream);
 int wn_gc_grad(const float* layer0, long layer_stride, long off_gc, int G,
                const float* emb, int card, const int32_t* ids,
                const float* dsum, int L, int B, float* glayer0, float* gemb,
-               void* stream);
+               int ch, void* stream);
 
 /* ---- thin exported ops of wavenet/__init__.py:1-4 (arbitrary shapes):
  * causal_conv ops.py:46-62, time_to_batch :27-34, batch_to_time :37-43 */

@@ -1271,6 +1271,162 @@ __global__ __launch_bounds__(GEN_WG) void layer_bwd_gen_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// More than 32 residual / dilation channels (the reference constructor has no
+// limit, model.py:46-60): channels are cut into 32-wide BLOCKS, every block of
+// an activation is its own [rows][32] plane (so the skip / dZ / dWs GEMMs see
+// L * blocks planes and need no change), and a (tap k, input block i) pair is
+// one "virtual tap" of the generic kernels above: output block jb of
+//     a_f = sum_{k,i} x_i[t - s_k] * Wf[k][32 i .. 32 i + 31][32 jb .. 32 jb + 31]
+// One launch per OUTPUT block; the weights stay in the reference's
+// [K][Cin][Cout] layout (row stride ldw = padded channel count) and are read
+// block-wise.  The 1x1 dense conv and dz = dZ + dx' Wd^T are plane-mode GEMMs
+// (wn_gemm_nn) on the host side.  Correctness-first, like the generic-tap
+// kernels (off-default configurations).
+// ---------------------------------------------------------------------------
+template <bool SAVE_TS>
+__global__ __launch_bounds__(GEN_WG) void layer_fwd_blk_kernel(
+    const float* __restrict__ x, long in_plane_stride, int in_blocks,
+    float* __restrict__ z, float* __restrict__ th, float* __restrict__ sg,
+    const float* __restrict__ wf, const float* __restrict__ wg, int ldw,
+    const float* __restrict__ bias_f, const float* __restrict__ bias_g,
+    int bias_clip_stride, int B, int T, int d, int K) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int NV = K * in_blocks;               // virtual taps (k, i)
+  float* wl = smem;                           // [2 NV][32][32]: filter, gate
+  float* tiles = smem + 2 * NV * 1024;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < NV * 1024; i += GEN_WG) {
+    const int v = i >> 10, r = (i >> 5) & 31, c = i & 31;
+    const long src = (long)(v * 32 + r) * ldw + c;   // row (k*in_blocks + i)*32 + r
+    wl[i] = wf[src];
+    wl[NV * 1024 + i] = wg[src];
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  float* ta = tiles + wave * 1024;
+  const int tiles_per_clip = (T + 31) >> 5;
+  const int ntiles = tiles_per_clip * B;
+  for (int tile = blockIdx.x * GEN_WAVES + wave; tile < ntiles;
+       tile += gridDim.x * GEN_WAVES) {
+    int woff = j + 4 * h * 32;
+    asm volatile("" : "+v"(woff));
+    const float* wlane = wl + woff;
+    const int b = tile / tiles_per_clip;
+    const int t0 = (tile - b * tiles_per_clip) * 32;
+    const int hi = min(32, T - t0);
+    const size_t off0 = ((size_t)b * T + t0) * WN_CH;
+    f32x16 af = bias_f ? frag_bcast(bias_f + (size_t)b * bias_clip_stride, h) : frag_zero();
+    f32x16 ag = bias_g ? frag_bcast(bias_g + (size_t)b * bias_clip_stride, h) : frag_zero();
+    for (int v = 0; v < NV; ++v) {
+      const int k = v / in_blocks, i = v - k * in_blocks;
+      const int sh = tap_shift(K, k, d);
+      const RowRegs r = rows_load(x + (size_t)i * in_plane_stride + off0 - (size_t)sh * WN_CH,
+                                  lane, max(0, sh - t0), hi);
+      __builtin_amdgcn_wave_barrier();
+      rows_to_lds(ta, lane, r);
+      __builtin_amdgcn_wave_barrier();
+      const f32x16 xk = frag_from_lds(ta, j, h);
+      mma32<32>(af, xk, wlane + v * 1024);
+      mma32<32>(ag, xk, wlane + (NV + v) * 1024);
+    }
+    f32x16 zz;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      af[r] = wn_tanh(af[r]);
+      ag[r] = wn_sigmoid(ag[r]);
+      zz[r] = af[r] * ag[r];
+    }
+    __builtin_amdgcn_wave_barrier();
+    frag_to_lds(ta, j, h, zz);
+    __builtin_amdgcn_wave_barrier();
+    rows_store(z + off0, lane, hi, rows_from_lds(ta, lane));
+    if (SAVE_TS) {
+      __builtin_amdgcn_wave_barrier();
+      frag_to_lds(ta, j, h, af);
+      __builtin_amdgcn_wave_barrier();
+      rows_store(th + off0, lane, hi, rows_from_lds(ta, lane));
+      __builtin_amdgcn_wave_barrier();
+      frag_to_lds(ta, j, h, ag);
+      __builtin_amdgcn_wave_barrier();
+      rows_store(sg + off0, lane, hi, rows_from_lds(ta, lane));
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// data gradient of output (residual-channel) block rb:
+//   dx[t] = dxin[t] + sum_{k,jb} da_f[jb][t + s_k] Wf[k][rb rows][jb cols]^T + (gate)
+template <bool HAS_DXIN>
+__global__ __launch_bounds__(GEN_WG) void layer_bwd_blk_kernel(
+    const float* __restrict__ daf, const float* __restrict__ dag,
+    long da_plane_stride, int da_blocks, const float* __restrict__ dxin,
+    float* __restrict__ dx_out, const float* __restrict__ wf,
+    const float* __restrict__ wg, int ldw, long tap_stride, int B, int T, int d,
+    int K) {
+  constexpr int LDT = 33, MT = 32 * LDT;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int NV = K * da_blocks;               // virtual taps (k, jb)
+  float* wl = smem;                           // [2 NV] transposed blocks
+  float* tiles = smem + (2 * NV * MT + 3) / 4 * 4;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < NV * 1024; i += GEN_WG) {
+    const int v = i >> 10, rr = (i >> 5) & 31, cc = i & 31;
+    const int k = v / da_blocks, jb = v - k * da_blocks;
+    const long src = (long)k * tap_stride + (long)rr * ldw + jb * 32 + cc;
+    wl[v * MT + cc * LDT + rr] = wf[src];
+    wl[(NV + v) * MT + cc * LDT + rr] = wg[src];
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  float* ta = tiles + wave * 2048;
+  float* tb = ta + 1024;
+  const int tiles_per_clip = (T + 31) >> 5;
+  const int ntiles = tiles_per_clip * B;
+  for (int tile = blockIdx.x * GEN_WAVES + wave; tile < ntiles;
+       tile += gridDim.x * GEN_WAVES) {
+    int woff = j + 4 * h * LDT;
+    asm volatile("" : "+v"(woff));
+    const float* wlane = wl + woff;
+    const int b = tile / tiles_per_clip;
+    const int t0 = (tile - b * tiles_per_clip) * 32;
+    const int hi = min(32, T - t0);
+    const size_t off0 = ((size_t)b * T + t0) * WN_CH;
+    f32x16 dx;
+    if (HAS_DXIN) {
+      rows_to_lds(ta, lane, rows_load(dxin + off0, lane, 0, hi));
+      __builtin_amdgcn_wave_barrier();
+      dx = frag_from_lds(ta, j, h);
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      dx = frag_zero();
+    }
+    for (int v = 0; v < NV; ++v) {
+      const int k = v / da_blocks, jb = v - k * da_blocks;
+      const int sh = tap_shift(K, k, d);
+      const int hi_f = min(hi, T - sh - t0);
+      const size_t o = (size_t)jb * da_plane_stride + off0 + (size_t)sh * WN_CH;
+      const RowRegs rf = rows_load(daf + o, lane, 0, hi_f);
+      const RowRegs rg = rows_load(dag + o, lane, 0, hi_f);
+      __builtin_amdgcn_wave_barrier();
+      rows_to_lds(ta, lane, rf);
+      rows_to_lds(tb, lane, rg);
+      __builtin_amdgcn_wave_barrier();
+      const f32x16 fk = frag_from_lds(ta, j, h);
+      const f32x16 gk = frag_from_lds(tb, j, h);
+      mma32<LDT>(dx, fk, wlane + v * MT);
+      mma32<LDT>(dx, gk, wlane + (NV + v) * MT);
+    }
+    __builtin_amdgcn_wave_barrier();
+    frag_to_lds(ta, j, h, dx);
+    __builtin_amdgcn_wave_barrier();
+    rows_store(dx_out + off0, lane, hi, rows_from_lds(ta, lane));
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // weight gradients, one tap per pass; slab layout == layer block layout
 template <bool HAS_DENSE>
 __global__ __launch_bounds__(256) void layer_wgrad_gen_kernel(
@@ -1502,6 +1658,66 @@ int wn_layer_bwd_k(const float* daf_cur, const float* dag_cur,
   if (do_b && do_a) { if (hx) { LAUNCH(true, true, true); } else { LAUNCH(true, true, false); } }
   else if (do_b) { if (hx) { LAUNCH(true, false, true); } else { LAUNCH(true, false, false); } }
   else { if (hx) { LAUNCH(false, true, true); } else { LAUNCH(false, true, false); } }
+#undef LAUNCH
+  return wn_check_launch();
+}
+
+// ---- more than 32 channels: one launch per 32-wide OUTPUT block
+int wn_layer_fwd_blk(const float* x, long in_plane_stride, int in_blocks,
+                     float* z, float* th, float* sg, const float* wf,
+                     const float* wg, int ldw, const float* bias_f,
+                     const float* bias_g, int bias_clip_stride, int B, int T,
+                     int dilation, int K, int save_ts, void* stream) {
+  if (!x || !z || !wf || !wg) return WN_ERR_NULL;
+  if (B <= 0 || T <= 0 || dilation <= 0 || K < 2 || in_blocks < 1 || ldw < 32)
+    return WN_ERR_BAD_SHAPE;
+  if (K * in_blocks > 8) return WN_ERR_UNSUPPORTED;
+  if (save_ts && (!th || !sg)) return WN_ERR_NULL;
+  const void* ptrs[] = {x, z, th, sg};
+  for (const void* p : ptrs)
+    if (p && !wn_aligned16(p)) return WN_ERR_MISALIGNED;
+  if ((in_plane_stride & 3) != 0) return WN_ERR_MISALIGNED;
+  dim3 grid(layer_grid(B, T, GEN_WAVES)), block(GEN_WG);
+  const size_t lds = ((size_t)2 * K * in_blocks * 1024 + GEN_WAVES * 1024) * 4;
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(TS)                                                            \
+  if (hipFuncSetAttribute((const void*)layer_fwd_blk_kernel<TS>,              \
+                          hipFuncAttributeMaxDynamicSharedMemorySize,         \
+                          (int)lds) != hipSuccess)                            \
+    return WN_ERR_LAUNCH;                                                     \
+  hipLaunchKernelGGL((layer_fwd_blk_kernel<TS>), grid, block, lds, s, x,      \
+                     in_plane_stride, in_blocks, z, th, sg, wf, wg, ldw,      \
+                     bias_f, bias_g, bias_clip_stride, B, T, dilation, K)
+  if (save_ts) { LAUNCH(true); } else { LAUNCH(false); }
+#undef LAUNCH
+  return wn_check_launch();
+}
+
+int wn_layer_bwd_blk(const float* daf, const float* dag, long da_plane_stride,
+                     int da_blocks, const float* dxin, float* dx_out,
+                     const float* wf, const float* wg, int ldw, long tap_stride,
+                     int B, int T, int dilation, int K, void* stream) {
+  if (!daf || !dag || !dx_out || !wf || !wg) return WN_ERR_NULL;
+  if (B <= 0 || T <= 0 || dilation <= 0 || K < 2 || da_blocks < 1 || ldw < 32)
+    return WN_ERR_BAD_SHAPE;
+  if (K * da_blocks > 8) return WN_ERR_UNSUPPORTED;
+  const void* ptrs[] = {daf, dag, dxin, dx_out};
+  for (const void* p : ptrs)
+    if (p && !wn_aligned16(p)) return WN_ERR_MISALIGNED;
+  if ((da_plane_stride & 3) != 0) return WN_ERR_MISALIGNED;
+  dim3 grid(layer_grid(B, T, GEN_WAVES)), block(GEN_WG);
+  const size_t lds = (((size_t)2 * K * da_blocks * 33 * 32 + 3) / 4 * 4 +
+                      GEN_WAVES * 2048) * 4;
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(HX)                                                            \
+  if (hipFuncSetAttribute((const void*)layer_bwd_blk_kernel<HX>,              \
+                          hipFuncAttributeMaxDynamicSharedMemorySize,         \
+                          (int)lds) != hipSuccess)                            \
+    return WN_ERR_LAUNCH;                                                     \
+  hipLaunchKernelGGL((layer_bwd_blk_kernel<HX>), grid, block, lds, s, daf,    \
+                     dag, da_plane_stride, da_blocks, dxin, dx_out, wf, wg,   \
+                     ldw, tap_stride, B, T, dilation, K)
+  if (dxin) { LAUNCH(true); } else { LAUNCH(false); }
 #undef LAUNCH
   return wn_check_launch();
 }

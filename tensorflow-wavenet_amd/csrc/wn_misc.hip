@@ -115,7 +115,7 @@ __global__ void mu_law_decode_kernel(const int32_t* __restrict__ codes,
 __global__ void causal_gather_kernel(const int32_t* __restrict__ q,
                                      const float* __restrict__ Wc,
                                      float* __restrict__ x0, long rows, int T,
-                                     int Q, int K) {
+                                     int Q, int K, int ldw) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long row = idx >> 3;
   const int c4 = (idx & 7) * 4;
@@ -128,7 +128,7 @@ __global__ void causal_gather_kernel(const int32_t* __restrict__ q,
     if (t < s) continue;
     const int code = q[row - s];
     if (code >= 0 && code < Q)
-      v += *reinterpret_cast<const f32x4*>(Wc + ((long)k * Q + code) * 32 + c4);
+      v += *reinterpret_cast<const f32x4*>(Wc + ((long)k * Q + code) * ldw + c4);
   }
   *reinterpret_cast<f32x4*>(x0 + row * 32 + c4) = v;
 }
@@ -401,26 +401,22 @@ __global__ void gc_bias_kernel(const float* __restrict__ layer0, long layer_stri
                                long off_bias, long off_gc, int G,
                                const float* __restrict__ emb, int card,
                                const int32_t* __restrict__ ids,
-                               float* __restrict__ out, int B) {
-  const int l = blockIdx.x, b = blockIdx.y, c = threadIdx.x;  // c < 64
+                               float* __restrict__ out, int B, int ch) {
+  const int l = blockIdx.x, b = blockIdx.y, c = threadIdx.x;  // c < 2 ch
   const float* blk = layer0 + (long)l * layer_stride;
-  float v = blk[off_bias + c];  // bf (0..31) then bg (32..63)
+  float v = blk[off_bias + c];  // bf (0..ch-1) then bg (ch..2ch-1)
   if (emb) {
     const int id = ids[b];
     if (id >= 0 && id < card) {
-      // Wgcf [G][32] at off_gc, Wgcg [G][32] at off_gc + G*32
-      const float* w = blk + off_gc + (c >= 32 ? (long)G * 32 : 0) + (c & 31);
+      // Wgcf [G][ch] at off_gc, Wgcg [G][ch] at off_gc + G*ch
+      const float* w = blk + off_gc + (c >= ch ? (long)G * ch : 0) + (c % ch);
       const float* e = emb + (long)id * G;
-      for (int g = 0; g < G; ++g) v += e[g] * w[(long)g * 32];
+      for (int g = 0; g < G; ++g) v += e[g] * w[(long)g * ch];
     }
   }
-  out[((long)l * B + b) * 64 + c] = v;
+  out[((long)l * B + b) * 2 * ch + c] = v;
 }
 
-// per-clip column sums of TWO planes (da_f, da_g), stage 1 of 2:
-//   part[b][chunk][0:32]  = sum over the chunk's rows of P0[b][t][:]
-//   part[b][chunk][32:64] = same for P1
-// grid (chunks, B); wn_reduce_slabs sums the chunks in a fixed order.
 __global__ __launch_bounds__(256) void colsum_clip_kernel(
     const float* __restrict__ P0, const float* __restrict__ P1, int T,
     int rows_per_chunk, float* __restrict__ part) {
@@ -454,18 +450,18 @@ __global__ void gc_grad_kernel(const float* __restrict__ layer0, long layer_stri
                                int card, const int32_t* __restrict__ ids,
                                const float* __restrict__ dsum, int L, int B,
                                float* __restrict__ glayer0,
-                               float* __restrict__ gemb) {
+                               float* __restrict__ gemb, int ch) {
   const int tid = threadIdx.x;
   if ((int)blockIdx.x < L) {
     const int l = blockIdx.x;
     float* gw = glayer0 + (long)l * layer_stride + off_gc;
-    for (int e = tid; e < 2 * G * 32; e += blockDim.x) {
-      const int which = e / (G * 32), g = (e / 32) % G, c = e & 31;
+    for (int e = tid; e < 2 * G * ch; e += blockDim.x) {
+      const int which = e / (G * ch), g = (e / ch) % G, c = e % ch;
       float s = 0.f;
       for (int b = 0; b < B; ++b) {
         const int id = ids[b];
         if (id < 0 || id >= card) continue;
-        s += emb[(long)id * G + g] * dsum[((long)l * B + b) * 64 + which * 32 + c];
+        s += emb[(long)id * G + g] * dsum[((long)l * B + b) * 2 * ch + which * ch + c];
       }
       gw[e] = s;
     }
@@ -480,10 +476,10 @@ __global__ void gc_grad_kernel(const float* __restrict__ layer0, long layer_stri
       float s = 0.f;
       for (int l = 0; l < L; ++l) {
         const float* w = layer0 + (long)l * layer_stride + off_gc;
-        const float* ds = dsum + ((long)l * B + b) * 64;
-        for (int c = 0; c < 32; ++c)
-          s += ds[c] * w[(long)gi * 32 + c] +
-               ds[32 + c] * w[(long)(G + gi) * 32 + c];
+        const float* ds = dsum + ((long)l * B + b) * 2 * ch;
+        for (int c = 0; c < ch; ++c)
+          s += ds[c] * w[(long)gi * ch + c] +
+               ds[ch + c] * w[(long)(G + gi) * ch + c];
       }
       tmp[e] = s;
     }
@@ -498,9 +494,6 @@ __global__ void gc_grad_kernel(const float* __restrict__ layer0, long layer_stri
   }
 }
 
-// ---------------------------------------------------------------------------
-// thin exported ops (wavenet/__init__.py:1-4), arbitrary shapes, not hot
-// ---------------------------------------------------------------------------
 __global__ void causal_conv_kernel(const float* __restrict__ x,
                                    const float* __restrict__ w,
                                    float* __restrict__ y, int B, int T, int Cin,
@@ -671,15 +664,16 @@ int wn_mu_law_decode(const int32_t* codes, float* audio, long n,
 }
 
 int wn_causal_gather(const int32_t* q, const float* Wc, float* x0, int B,
-                     int T, int Q, int K, void* stream) {
+                     int T, int Q, int K, int ldw, void* stream) {
   if (!q || !Wc || !x0) return WN_ERR_NULL;
-  if (B <= 0 || T <= 0 || Q <= 0 || K <= 0) return WN_ERR_BAD_SHAPE;
+  if (B <= 0 || T <= 0 || Q <= 0 || K <= 0 || ldw < 32 || (ldw & 3))
+    return WN_ERR_BAD_SHAPE;
   if (!wn_aligned16(Wc) || !wn_aligned16(x0)) return WN_ERR_MISALIGNED;
   const long rows = (long)B * T;
   const long threads = rows * 8;
   hipLaunchKernelGGL(causal_gather_kernel, dim3((unsigned)((threads + 255) / 256)),
                      dim3(256), 0, (hipStream_t)stream, q, Wc, x0, rows, T, Q,
-                     K);
+                     K, ldw);
   return wn_check_launch();
 }
 
@@ -876,13 +870,14 @@ int wn_l2_partials(const float* p, long n, const float* mask, float* partials,
 
 int wn_gc_bias(const float* layer0, long layer_stride, long off_bias,
                long off_gc, int G, const float* emb, int card,
-               const int32_t* ids, float* out, int L, int B, void* stream) {
+               const int32_t* ids, float* out, int L, int B, int ch,
+               void* stream) {
   if (!layer0 || !out) return WN_ERR_NULL;
   if (emb && !ids) return WN_ERR_NULL;
-  if (L <= 0 || B <= 0) return WN_ERR_BAD_SHAPE;
-  hipLaunchKernelGGL(gc_bias_kernel, dim3(L, B), dim3(64), 0,
+  if (L <= 0 || B <= 0 || ch < 32 || ch > 512) return WN_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(gc_bias_kernel, dim3(L, B), dim3(2 * ch), 0,
                      (hipStream_t)stream, layer0, layer_stride, off_bias,
-                     off_gc, G, emb, card, ids, out, B);
+                     off_gc, G, emb, card, ids, out, B, ch);
   return wn_check_launch();
 }
 
@@ -911,13 +906,13 @@ int wn_colsum_clip(const float* plane0, const float* plane1, int B, int T,
 int wn_gc_grad(const float* layer0, long layer_stride, long off_gc, int G,
                const float* emb, int card, const int32_t* ids,
                const float* dsum, int L, int B, float* glayer0, float* gemb,
-               void* stream) {
+               int ch, void* stream) {
   if (!layer0 || !emb || !ids || !dsum || !glayer0 || !gemb) return WN_ERR_NULL;
-  if (L <= 0 || B <= 0 || G <= 0 || card <= 0) return WN_ERR_BAD_SHAPE;
+  if (L <= 0 || B <= 0 || G <= 0 || card <= 0 || ch < 32) return WN_ERR_BAD_SHAPE;
   if ((size_t)B * G * sizeof(float) > 48 * 1024) return WN_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(gc_grad_kernel, dim3(L + 1), dim3(256),
                      (size_t)B * G * sizeof(float), (hipStream_t)stream, layer0, layer_stride, off_gc, G, emb,
-                     card, ids, dsum, L, B, glayer0, gemb);
+                     card, ids, dsum, L, B, glayer0, gemb, ch);
   return wn_check_launch();
 }
 

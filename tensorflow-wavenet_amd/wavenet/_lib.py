@@ -22,7 +22,8 @@ SIGNATURES = {
     'wn_mu_law_decode_table_host': (c_int, [c_int, P]),
     'wn_mu_law_encode': (c_int, [P, P, c_long, P, c_int, P]),
     'wn_mu_law_decode': (c_int, [P, P, c_long, P, c_int, P]),
-    'wn_causal_gather': (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
+    'wn_causal_gather': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int,
+                                 P]),
     'wn_scalar_causal_fwd': (c_int, [P, P, P, c_int, c_int, c_int, P]),
     'wn_scalar_causal_wgrad': (c_int, [P, P, P, c_int, c_int, c_int, c_int,
                                        P]),
@@ -41,6 +42,10 @@ SIGNATURES = {
                                c_int, c_int, c_int, c_int, P]),
     'wn_layer_wgrad_k': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int,
                                  c_int, P]),
+    'wn_layer_fwd_blk': (c_int, [P, c_long, c_int, P, P, P, P, P, c_int, P, P,
+                                 c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    'wn_layer_bwd_blk': (c_int, [P, P, c_long, c_int, P, P, P, P, c_int,
+                                 c_long, c_int, c_int, c_int, c_int, P]),
     'wn_layer_bwdw_slabs': (c_int, [c_int, c_int]),
     'wn_layer_bwdw': (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
                               c_int, c_int, c_int, c_int, P]),
@@ -75,11 +80,11 @@ SIGNATURES = {
     'wn_l2_partials_count': (c_int, []),
     'wn_l2_partials': (c_int, [P, c_long, P, P, P]),
     'wn_gc_bias': (c_int, [P, c_long, c_long, c_long, c_int, P, c_int, P, P,
-                           c_int, c_int, P]),
+                           c_int, c_int, c_int, P]),
     'wn_colsum_clip_chunks': (c_int, [c_int]),
     'wn_colsum_clip': (c_int, [P, P, c_int, c_int, P, P, P]),
     'wn_gc_grad': (c_int, [P, c_long, c_long, c_int, P, c_int, P, P, c_int,
-                           c_int, P, P, P]),
+                           c_int, P, P, c_int, P]),
     'wn_causal_conv': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int,
                                c_int, P]),
     'wn_time_to_batch': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),

@@ -1,0 +1,167 @@
+"""Residual stack with more than 32 residual / dilation channels
+(_create_dilation_layer, wavenet/model.py:236-330, whose constructor puts no
+limit on the channel counts, model.py:46-60).
+
+Channels are cut into 32-wide blocks; block cb of layer l's activation is the
+[B*T][32] plane l * CB + cb of X / Z / TH / SG / dZ, so the skip-sum, dZ and
+dWs GEMMs of model.py see L * CB planes and run unchanged.  Per layer:
+
+  forward   one wn_layer_fwd_blk per dilation-channel block (all taps and all
+            input blocks contracted inside the kernel), then the 1x1 residual
+            conv as a plane-mode wn_gemm_nn per residual-channel block;
+  backward  dz = dZ + dx' Wd^T (plane-mode wn_gemm_nn per block), the gate
+            gradients (phase A of wn_layer_bwd_k), the weight gradients from
+            wn_layer_wgrad_k per (input block, output block) pair -- their
+            32 x 32 results are copied into the [K][C][C] gradient matrices --
+            and dx per residual block (wn_layer_bwd_blk).
+
+Weights stay in the reference's [K][Cin][Cout] layout (C = 32 * CB padded
+channels), so `net.variables` are plain views exactly as for <= 32 channels.
+Correctness-first: this is an off-default configuration (the default
+wavenet_params.json has 32 / 32 channels and runs the fused kernels).
+"""
+import torch
+
+from . import _lib
+
+CH = 32
+
+
+def _blk(net, flat, l):
+    K, C = net.KW, net.CHn
+    b = net._layer_block(flat, l)
+    M = C * C
+    return dict(wf=b[0:K * M], wg=b[K * M:2 * K * M], wd=b[2 * K * M:(2 * K + 1) * M],
+                bf=b[net.OFF_BF:net.OFF_BF + C], bg=b[net.OFF_BG:net.OFF_BG + C],
+                bd=b[net.OFF_BD:net.OFF_BD + C], all=b)
+
+
+def forward_layers(net, ws, bias, bstride, save_ts, st):
+    """Layers 0..L-1 on ws.X[0:CB] (the causal layer's output planes)."""
+    L, CB, K, C = net.L, net.CB, net.KW, net.CHn
+    B, T, N = ws.B, ws.T, ws.N
+    P = net.params
+    pstride = N * CH
+    for l, d in enumerate(net.dilations):
+        w = _blk(net, P, l)
+        x0 = ws.X[l * CB]
+        for jb in range(CB):
+            bf = bg = None
+            if bias is not None:
+                row = bias[l].reshape(-1)
+                bf, bg = row[jb * CH:], row[C + jb * CH:]
+            _lib.call('wn_layer_fwd_blk', _lib.ptr(x0), pstride, CB,
+                      _lib.ptr(ws.Z[l * CB + jb]),
+                      _lib.ptr(ws.TH[l * CB + jb]) if save_ts else None,
+                      _lib.ptr(ws.SG[l * CB + jb]) if save_ts else None,
+                      _lib.ptr(w['wf'][jb * CH:]), _lib.ptr(w['wg'][jb * CH:]),
+                      C, _lib.ptr(bf), _lib.ptr(bg), bstride, B, T, int(d), K,
+                      1 if save_ts else 0, st)
+        if l == L - 1:
+            break
+        # x_{l+1}[rb] = x_l[rb] + z_l Wd[:, rb] (+ bd[rb])   model.py:294-300,330
+        for rb in range(CB):
+            _lib.call('wn_gemm_nn', _lib.ptr(ws.Z[l * CB]), 0, CB, pstride,
+                      _lib.ptr(w['wd'][rb * CH:]), C,
+                      _lib.ptr(w['bd'][rb * CH:]) if net.use_biases else None,
+                      None, 0, _lib.ptr(ws.X[l * CB + rb]), CH,
+                      _lib.ptr(ws.X[(l + 1) * CB + rb]), CH, 0, 0, None,
+                      N, CH, C, 0, st)
+
+
+def backward_layers(net, ws, ids, st):
+    """Residual stack (last layer first), causal layer and global-conditioning
+    gradients; ws.dZ holds dtotal * Ws^T (model.py's dZ GEMM ran before)."""
+    L, CB, K, C, Q = net.L, net.CB, net.KW, net.CHn, net.Q
+    B, T, N = ws.B, ws.T, ws.N
+    P, Gr = net.params, net.grads
+    ub = net.use_biases
+    pstride = N * CH
+    lib = _lib.load()
+    WF = (2 * K + 1) * 1024
+    nslab = ws.nslab
+    # every layer-block gradient entry is rewritten below except the padding
+    # and the last layer's (gradient-free) dense conv: start from zero
+    lo, ln = net.segments['layers']
+    Gr[lo:lo + ln].zero_()
+    daf, dag = ws.da[0][:CB], ws.da[0][CB:]
+    dxin, xp = None, 0
+    for l in range(L - 1, -1, -1):
+        d = int(net.dilations[l])
+        w, g = _blk(net, P, l), _blk(net, Gr, l)
+        M = C * C
+        gf = g['wf'].view(K, C, C)
+        gg = g['wg'].view(K, C, C)
+        gd = g['wd'].view(C, C)
+        if dxin is not None:
+            _lib.call('wn_transpose', _lib.ptr(w['wd']), C, C, C,
+                      _lib.ptr(ws.wdT), C, st)
+        # ---- gate gradients of every dilation-channel block
+        for jb in range(CB):
+            dz = ws.dZ[l * CB + jb]
+            if dxin is not None:
+                # dz = dZ + dx' Wd^T   (Wd^T as [res][dil], columns of block jb)
+                _lib.call('wn_gemm_nn', _lib.ptr(dxin[0]), 0, CB, pstride,
+                          _lib.ptr(ws.wdT.view(-1)[jb * CH:]), C, None, None, 0,
+                          _lib.ptr(dz), CH, _lib.ptr(ws.dzb[jb]), CH, 0, 0,
+                          None, N, CH, C, 0, st)
+                dz = ws.dzb[jb]
+            _lib.call('wn_layer_bwd_k', None, None, None, None, None,
+                      _lib.ptr(dz), _lib.ptr(ws.TH[l * CB + jb]),
+                      _lib.ptr(ws.SG[l * CB + jb]), _lib.ptr(w['all']),
+                      _lib.ptr(daf[jb]), _lib.ptr(dag[jb]), B, T, d, K, 0, 1, st)
+            if ws.dsum is not None:
+                _lib.call('wn_colsum_clip', _lib.ptr(daf[jb]), _lib.ptr(dag[jb]),
+                          B, T, _lib.ptr(ws.dsum_part), _lib.ptr(ws.cs_tmp), st)
+                dv = ws.dsum[l].view(B, 2, CB, CH)
+                dv[:, 0, jb].copy_(ws.cs_tmp[:, :CH])
+                dv[:, 1, jb].copy_(ws.cs_tmp[:, CH:])
+        # ---- weight gradients per (input block a, output block b) pair
+        for a in range(CB):
+            for b in range(CB):
+                _lib.call('wn_layer_wgrad_k', _lib.ptr(ws.X[l * CB + a]),
+                          _lib.ptr(daf[b]), _lib.ptr(dag[b]),
+                          None if dxin is None else _lib.ptr(ws.Z[l * CB + a]),
+                          None if dxin is None else _lib.ptr(dxin[b]),
+                          _lib.ptr(ws.lslabs), nslab, B, T, d, K, st)
+                tmp = ws.blk_tmp
+                _lib.call('wn_reduce_slabs', _lib.ptr(ws.lslabs), nslab,
+                          WF + 96, 1, 0, 0, WF + 96, _lib.ptr(tmp), 0, 1, 0, st)
+                ra, rb_ = slice(a * CH, (a + 1) * CH), slice(b * CH, (b + 1) * CH)
+                gf[:, ra, rb_].copy_(tmp[0:K * 1024].view(K, CH, CH))
+                gg[:, ra, rb_].copy_(tmp[K * 1024:2 * K * 1024].view(K, CH, CH))
+                if dxin is not None:
+                    gd[ra, rb_].copy_(tmp[2 * K * 1024:WF].view(CH, CH))
+                if a == 0 and ub:
+                    g['bf'][rb_].copy_(tmp[WF:WF + CH])
+                    g['bg'][rb_].copy_(tmp[WF + CH:WF + 2 * CH])
+                    if dxin is not None:
+                        g['bd'][rb_].copy_(tmp[WF + 2 * CH:WF + 3 * CH])
+        # ---- dx of every residual-channel block
+        dxo = ws.dx[xp]
+        for rb in range(CB):
+            _lib.call('wn_layer_bwd_blk', _lib.ptr(daf[0]), _lib.ptr(dag[0]),
+                      pstride, CB, None if dxin is None else _lib.ptr(dxin[rb]),
+                      _lib.ptr(dxo[rb]), _lib.ptr(w['wf'][rb * CH * C:]),
+                      _lib.ptr(w['wg'][rb * CH * C:]), C, M, B, T, d, K, st)
+        dxin, xp = dxo, 1 - xp
+    # ---- causal layer (model.py:227-234): one-hot contraction per tap / block
+    gc_ = net._seg(Gr, 'causal').view(K, Q, C)
+    sp = ws.splits['causal']
+    sl = lib.wn_gemm_tn_slab_floats(Q, CH)
+    for tap in range(K):
+        shift = (K - 1 - tap) + (K - 1) // 2
+        for cb in range(CB):
+            _lib.call('wn_gemm_tn', None, 0, 0, 0, _lib.ptr(ws.q), shift, T,
+                      _lib.ptr(dxin[cb]), CH, _lib.ptr(ws.slabs), sp, N, Q, CH,
+                      0, st)
+            _lib.call('wn_reduce_slabs', _lib.ptr(ws.slabs), sp, sl, 1, 0, 0,
+                      Q * CH, _lib.ptr(ws.blk_tmp), 0, 1, 0, st)
+            gc_[tap, :, cb * CH:(cb + 1) * CH].copy_(
+                ws.blk_tmp[:Q * CH].view(Q, CH))
+    if ws.dsum is not None:
+        _lib.call('wn_gc_grad', _lib.ptr(net._layer_block(P, 0)),
+                  net.layer_stride, net.OFF_GC, net.G,
+                  _lib.ptr(net._seg(P, 'emb')), net.card, _lib.ptr(ids),
+                  _lib.ptr(ws.dsum), L, B, _lib.ptr(net._layer_block(Gr, 0)),
+                  _lib.ptr(net._seg(Gr, 'emb')), C, st)

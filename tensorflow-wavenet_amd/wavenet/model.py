@@ -24,13 +24,13 @@ import torch
 from . import _lib
 from .ops import mu_law_encode, mu_law_decode, mu_law_tables
 
-CH = 32                      # padded residual / dilation channels per plane
-# layer block (floats) for filter width K:
-#   Wf[K][32][32] Wg[K][32][32] Wd[32][32] bf[32] bg[32] bd[32] (+ gc weights)
+CH = 32                      # channels per activation plane (one block)
+# layer block (floats) for filter width K and C = 32 * blocks padded channels:
+#   Wf[K][C][C] Wg[K][C][C] Wd[C][C] bf[C] bg[C] bd[C] (+ gc weights [G][C] x 2)
 
 
-def layer_w(K):
-    return (2 * K + 1) * 1024
+def layer_w(K, C=CH):
+    return (2 * K + 1) * C * C
 
 
 def _align(n, a=32):
@@ -57,6 +57,8 @@ class _Workspace(object):
     def __init__(self, net, B, T, training, parent=None):
         dev = net.device
         L, S, Q = net.L, net.S, net.Q
+        CB, CHn = net.CB, net.CHn       # channel blocks, padded channels
+        LP = L * CB                     # activation planes per tensor
         N = B * T
         f32 = dict(dtype=torch.float32, device=dev)
         self.B, self.T, self.N, self.training = B, T, N, training
@@ -79,12 +81,12 @@ class _Workspace(object):
         self.gc_ids = alloc('gc_ids', (B,), torch.int32) \
             if net.card is not None else None
         self.audio = alloc('audio', (N,)) if net.scalar_input else None
-        alloc('X', (L, N, CH))
-        alloc('Z', (L, N, CH))
+        alloc('X', (LP, N, CH))
+        alloc('Z', (LP, N, CH))
         alloc('h1', (N, S))
         alloc('h2', (N, S))
         alloc('logits', (N, Q))
-        alloc('bias_fg', (L, B, 64))
+        alloc('bias_fg', (L, B, 2 * CHn))
         alloc('bsum', (S,))
         self.total = alloc('total', (N, S)) if net.residual_postproc else None
         self.nparts = lib.wn_xent_partials(N)
@@ -97,18 +99,23 @@ class _Workspace(object):
         # filter widths) also need the tanh plane and two ping-pong pairs of
         # pre-activation-gradient planes; the default wn_layer_bwd2 does not
         self.legacy = net._legacy_bwd()
-        self.TH = alloc('TH', (L, N, CH)) if self.legacy else None
-        alloc('SG', (L, N, CH))
-        alloc('dZ', (L, N, CH))
+        self.TH = alloc('TH', (LP, N, CH)) if self.legacy else None
+        alloc('SG', (LP, N, CH))
+        alloc('dZ', (LP, N, CH))
         alloc('dc1', (N, S))
         alloc('dtotal', (N, S))
         self.dh2 = alloc('dh2', (N, S)) if net.residual_postproc else None
         self.c1 = alloc('c1', (N, S)) if net.residual_postproc else None
-        self.da = alloc('da', (2, 2, N, CH)) if self.legacy else None
-        alloc('dx', (2, N, CH))
+        self.da = alloc('da', (2, 2 * CB, N, CH)) if self.legacy else None
+        alloc('dx', (2, CB, N, CH))
+        if CB > 1:                       # channel-block path scratch
+            alloc('dzb', (CB, N, CH))
+            alloc('wdT', (CHn, CHn))
+            alloc('blk_tmp', (max((2 * net.KW + 1) * 1024 + 96, Q * CH),))
+            alloc('cs_tmp', (B, 64))
         alloc('w2t', (Q, S))
         alloc('w1t', (S, S))
-        alloc('wst', (S, L * CH))
+        alloc('wst', (S, L * CHn))
         ntiles = B * ((T + 31) // 32)
         self.nslab = max(1, min(512, ntiles // 4))
         self.nslab_f = lib.wn_layer_bwdw_slabs(B, T)      # fused kernel
@@ -117,7 +124,7 @@ class _Workspace(object):
                          net.LAYER_BLOCK))
         need = 0
         self.splits = {}
-        for key, (mw, nw) in dict(post2=(S, Q), post1=(S, S), skip=(L * CH, S),
+        for key, (mw, nw) in dict(post2=(S, Q), post1=(S, S), skip=(L * CHn, S),
                                   causal=(Q, CH)).items():
             sp = lib.wn_gemm_tn_splits(N, mw, nw, 1 if key == 'causal' else 0)
             self.splits[key] = sp
@@ -130,7 +137,7 @@ class _Workspace(object):
         alloc('slabs_tn', (need_tn,))     # TN GEMMs on the side stream
         self.ev_fork = torch.cuda.Event() if dev.type == 'cuda' else None
         self.ev_join = torch.cuda.Event() if dev.type == 'cuda' else None
-        self.dsum = alloc('dsum', (L, B, 64)) if net.G else None
+        self.dsum = alloc('dsum', (L, B, 2 * CHn)) if net.G else None
         self.tilesum = alloc('tilesum', (L, ntiles, 64)) if net.G else None
         self.dsum_part = alloc(
             'dsum_part', (B * lib.wn_colsum_clip_chunks(T) * 64,)) \
@@ -247,22 +254,29 @@ class WaveNetModel(object):
             self._unsupported = 'filter_width must be in [2, 8] on the HIP path'
         elif scalar_input and initial_filter_width > 32:
             self._unsupported = 'initial_filter_width > 32 not supported yet'
-        elif self.R > CH or self.D > CH:
-            self._unsupported = 'residual/dilation channels > 32 not supported yet'
+        elif self.R > 2 * CH or self.D > 2 * CH:
+            self._unsupported = 'residual/dilation channels > 64 not supported yet'
+        elif max(self.R, self.D) > CH and (filter_width > 4 or scalar_input):
+            self._unsupported = ('more than 32 residual/dilation channels needs '
+                                 'filter_width <= 4 and one-hot input')
         elif self.S % 4 or self.Q % 4:
             self._unsupported = 'skip/quantization channels must be multiples of 4'
         elif self.G is not None and self.card is None:
             self._unsupported = ('dense-vector global conditioning cannot run in '
                                  'the reference either (model.py:547,553)')
         self.KW = K = int(filter_width)
+        # more than 32 residual / dilation channels: 32-wide channel blocks,
+        # one activation plane per block (wavenet/blocked.py)
+        self.CB = max(1, (max(self.R, self.D) + CH - 1) // CH)
+        self.CHn = C = CH * self.CB
         # K = 2 runs the tuned kernels; other widths (or forcing it, for
         # tests) the generic-tap kernels
         self.generic_layers = K != 2
-        self.LAYER_W = layer_w(K)
+        self.LAYER_W = layer_w(K, C)
         self.OFF_BF = self.LAYER_W
-        self.OFF_BG = self.LAYER_W + 32
-        self.OFF_BD = self.LAYER_W + 64
-        self.LAYER_BLOCK = self.LAYER_W + 96
+        self.OFF_BG = self.LAYER_W + C
+        self.OFF_BD = self.LAYER_W + 2 * C
+        self.LAYER_BLOCK = self.LAYER_W + 3 * C
         self.OFF_GC = self.LAYER_BLOCK
         self._ws = {}
         self._gen = None
@@ -280,7 +294,8 @@ class WaveNetModel(object):
             self.params = torch.zeros(4, device=self.device)
             self.grads = torch.zeros(4, device=self.device)
             return {}
-        self.layer_stride = self.LAYER_BLOCK + (2 * G * CH if G else 0)
+        C = self.CHn
+        self.layer_stride = self.LAYER_BLOCK + (2 * G * C if G else 0)
         seg, off = {}, 0
         def add(name, n):
             nonlocal off
@@ -289,9 +304,9 @@ class WaveNetModel(object):
         if card is not None:
             add('emb', card * G)
         add('causal', (self.initial_filter_width if self.scalar_input
-                       else self.KW * Q) * CH)
+                       else self.KW * Q) * C)
         add('layers', L * self.layer_stride)
-        add('skip_w', L * CH * S)
+        add('skip_w', L * C * S)
         add('skip_b', L * S)
         add('post1_w', S * S)
         add('post2_w', S * Q)
@@ -313,6 +328,7 @@ class WaveNetModel(object):
         L, S, Q, R, D, G, card = (self.L, self.S, self.Q, self.R, self.D,
                                   self.G, self.card)
         var = dict()
+        CH = self.CHn              # padded channel count of every weight
         if card is not None:
             var['embeddings'] = {
                 'gc_embedding': self._seg(flat, 'emb').view(card, G)}
@@ -333,9 +349,10 @@ class WaveNetModel(object):
             K = self.KW
             OFF_GC, OFF_BF, OFF_BG, OFF_BD = (self.OFF_GC, self.OFF_BF,
                                               self.OFF_BG, self.OFF_BD)
-            cur['filter'] = blk[0:K * 1024].view(K, CH, CH)[:, :R, :D]
-            cur['gate'] = blk[K * 1024:2 * K * 1024].view(K, CH, CH)[:, :R, :D]
-            cur['dense'] = blk[2 * K * 1024:(2 * K + 1) * 1024].view(
+            M = CH * CH
+            cur['filter'] = blk[0:K * M].view(K, CH, CH)[:, :R, :D]
+            cur['gate'] = blk[K * M:2 * K * M].view(K, CH, CH)[:, :R, :D]
+            cur['dense'] = blk[2 * K * M:(2 * K + 1) * M].view(
                 1, CH, CH)[:, :D, :R]
             cur['skip'] = skw[i][:, :D, :]
             if G is not None:
@@ -473,7 +490,7 @@ class WaveNetModel(object):
 
     def _legacy_bwd(self):
         return (self.layer_bwd != 'bwd2' or not self.fused_bwd
-                or self.generic_layers or self.overlap_wgrad)
+                or self.generic_layers or self.overlap_wgrad or self.CB > 1)
 
     def _check_supported(self):
         if self._unsupported:
@@ -558,13 +575,14 @@ class WaveNetModel(object):
         if not self.use_biases and ids is None:
             return None, 0
         nb = B if ids is not None else 1
-        out = ws_bias.view(-1)[:self.L * nb * 64].view(self.L, nb, 64)
+        W2 = 2 * self.CHn                  # filter | gate, padded channels
+        out = ws_bias.view(-1)[:self.L * nb * W2].view(self.L, nb, W2)
         emb = self._seg(self.params, 'emb') if ids is not None else None
         _lib.call('wn_gc_bias', _lib.ptr(self._layer_block(self.params, 0)),
                   self.layer_stride, self.OFF_BF, self.OFF_GC, self.G or 0,
                   _lib.ptr(emb), self.card or 0, _lib.ptr(ids), _lib.ptr(out),
-                  self.L, nb, _lib.stream())
-        return out, (64 if ids is not None else 0)
+                  self.L, nb, self.CHn, _lib.stream())
+        return out, (W2 if ids is not None else 0)
 
     def _nn(self, *args):
         """wn_gemm_nn (or, when `gemm_mode` asks for it, wn_gemm_nn_split),
@@ -624,8 +642,10 @@ class WaveNetModel(object):
 
     def _backward(self, ws, ids):
         ids = self._stage_ids(ws, ids)
-        if not self.use_launch_plans or self.overlap_wgrad:
-            return self._backward_eager(ws, ids)   # side stream: torch events
+        if not self.use_launch_plans or self.overlap_wgrad or self.CB > 1:
+            # (side stream with torch events / the channel-block path, whose
+            # gradient-block copies are torch ops a launch plan cannot replay)
+            return self._backward_eager(ws, ids)
         key = self._plan_key('bwd', ws, ids, None)
         plan = ws.plans.get(key, 0)
         if plan == 0:
@@ -649,11 +669,16 @@ class WaveNetModel(object):
                       _lib.ptr(self._seg(P, 'causal')), _lib.ptr(ws.X[0]), B,
                       T, self.initial_filter_width, st)
         else:
-            _lib.call('wn_causal_gather', _lib.ptr(ws.q),
-                      _lib.ptr(self._seg(P, 'causal')), _lib.ptr(ws.X[0]), B,
-                      T, Q, self.KW, st)
+            wc = self._seg(P, 'causal')
+            for cb in range(self.CB):          # one plane per channel block
+                _lib.call('wn_causal_gather', _lib.ptr(ws.q),
+                          _lib.ptr(wc[cb * CH:]), _lib.ptr(ws.X[cb]), B, T, Q,
+                          self.KW, self.CHn, st)
         bias, bstride = self._bias_fg(ws.bias_fg, ids, B)
-        for l, d in enumerate(self.dilations):
+        if self.CB > 1:
+            from . import blocked
+            blocked.forward_layers(self, ws, bias, bstride, bool(save_ts), st)
+        for l, d in enumerate(self.dilations if self.CB == 1 else []):
             last = l == L - 1
             fargs = (_lib.ptr(ws.X[l]),
                      None if last else _lib.ptr(ws.X[l + 1]),
@@ -675,11 +700,12 @@ class WaveNetModel(object):
                       _lib.ptr(ws.bsum), st)
             bsum = ws.bsum
         # total = sum_l z_l * Ws_l (+ sum_l bs_l); h1 = relu(total)
-        self._nn(_lib.ptr(ws.Z), 0, L, N * CH,
+        LP, C = L * self.CB, self.CHn      # planes, padded channels
+        self._nn(_lib.ptr(ws.Z), 0, LP, N * CH,
                   _lib.ptr(self._seg(P, 'skip_w')), S, _lib.ptr(bsum), None, 0,
                   None, 0, _lib.ptr(ws.h1), S, 0, 0,
                   _lib.ptr(ws.total) if self.residual_postproc else None,
-                  N, S, L * CH, 1, st)
+                  N, S, L * C, 1, st)
         b1 = self._seg(P, 'post1_b') if self.use_biases else None
         b2 = self._seg(P, 'post2_b') if self.use_biases else None
         rp = self.residual_postproc
@@ -755,8 +781,9 @@ class WaveNetModel(object):
                   None, _lib.ptr(ws.h1), S, _lib.ptr(ws.dh2) if rp else None,
                   S, _lib.ptr(ws.dtotal), S, 0, 0, None, N, S, S, 0, st)
         # skip convs: dWs_all = Z^T dtotal ; dbs_l = colsum(dtotal) for every l
-        tn(_lib.ptr(ws.Z), 0, L, N * CH, None, 0, _lib.ptr(ws.dtotal), S,
-           'skip', L * CH, S, _lib.ptr(self._seg(Gr, 'skip_w')),
+        LP, C = L * self.CB, self.CHn      # planes, padded channels
+        tn(_lib.ptr(ws.Z), 0, LP, N * CH, None, 0, _lib.ptr(ws.dtotal), S,
+           'skip', L * C, S, _lib.ptr(self._seg(Gr, 'skip_w')),
            _lib.ptr(self._seg(Gr, 'skip_b')), replicate=L, rep_stride=S)
         if ovl:
             # fork: everything the three TN GEMMs read exists now
@@ -768,11 +795,20 @@ class WaveNetModel(object):
                 tn_now(side_s.cuda_stream, ws.slabs_tn, *a, **kw)
             _lib.call_py(lambda: ws.ev_join.record(side_s))
         # dZ planes = dtotal Ws_all^T
-        _lib.call('wn_transpose', _lib.ptr(self._seg(P, 'skip_w')), L * CH, S,
-                  S, _lib.ptr(ws.wst), L * CH, st)
+        _lib.call('wn_transpose', _lib.ptr(self._seg(P, 'skip_w')), L * C, S,
+                  S, _lib.ptr(ws.wst), L * C, st)
         self._nn(_lib.ptr(ws.dtotal), S, 0, 0, _lib.ptr(ws.wst),
-                  L * CH, None, None, 0, None, 0, _lib.ptr(ws.dZ), 0, L,
-                  N * CH, None, N, L * CH, S, 0, st)
+                  L * C, None, None, 0, None, 0, _lib.ptr(ws.dZ), 0, LP,
+                  N * CH, None, N, L * C, S, 0, st)
+        if self.CB > 1:
+            # channel-block path: residual stack, causal layer and global
+            # conditioning gradients (wavenet/blocked.py)
+            from . import blocked
+            if ovl:
+                main_s = torch.cuda.current_stream()
+                _lib.call_py(lambda: main_s.wait_event(ws.ev_join))
+            blocked.backward_layers(self, ws, ids, st)
+            return
 
         # residual stack, last layer first
         if not self._legacy_bwd():
@@ -945,7 +981,7 @@ class WaveNetModel(object):
                       _lib.ptr(self._seg(P, 'emb')), self.card, _lib.ptr(ids),
                       _lib.ptr(ws.dsum), L, B,
                       _lib.ptr(self._layer_block(Gr, 0)),
-                      _lib.ptr(self._seg(Gr, 'emb')), st)
+                      _lib.ptr(self._seg(Gr, 'emb')), self.CHn, st)
 
     # ------------------------------------------------------------------ API
     def encode(self, input_batch, B=None):
@@ -1236,6 +1272,9 @@ class WaveNetModel(object):
         if self.filter_width > 2:
             raise NotImplementedError("Incremental generation does not "
                                       "support filter_width > 2.")
+        if self.CB > 1:
+            raise NotImplementedError("Fast generation supports at most 32 "
+                                      "residual / dilation channels.")
         if self.scalar_input:
             raise NotImplementedError("Scalar input is not supported by "
                                       "fast generation.")
@@ -1263,9 +1302,10 @@ class WaveNetModel(object):
         Returns int32 codes [len(seed) + num_samples] (and the probabilities
         of every `return_proba_every`-th step when requested)."""
         self._check_supported()
-        if self.filter_width > 2 or self.scalar_input:
-            raise NotImplementedError('fast generation needs filter_width 2 '
-                                      'and one-hot input')
+        if self.filter_width > 2 or self.scalar_input or self.CB > 1:
+            raise NotImplementedError('fast generation needs filter_width 2, '
+                                      'one-hot input and at most 32 residual / '
+                                      'dilation channels')
         if seed_samples is None:
             seed_samples = [self.Q // 2]
         s = torch.as_tensor(np.asarray(seed_samples), dtype=torch.int32).reshape(-1)
@@ -1301,9 +1341,10 @@ class WaveNetModel(object):
         ONE batch forward pass: layer l's queue (capacity d_l) holds the last
         d_l inputs x_l[t] of that layer (model.py:473-484), which are rows of
         the forward pass's per-layer activation planes."""
-        if self.filter_width > 2 or self.scalar_input:
-            raise NotImplementedError('fast generation needs filter_width 2 '
-                                      'and one-hot input')
+        if self.filter_width > 2 or self.scalar_input or self.CB > 1:
+            raise NotImplementedError('fast generation needs filter_width 2, '
+                                      'one-hot input and at most 32 residual / '
+                                      'dilation channels')
         self._check_supported()
         g = self._generator(global_condition)
         self._gen_reset()

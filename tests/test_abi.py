@@ -41,7 +41,7 @@ def test_argument_validation_without_gpu(hip_lib):
     # all of these return before any launch
     assert hip_lib.wn_layer_fwd(None, None, None, None, None, None, None, 0,
                                 1, 8, 1, 1, 1, None) == -5       # NULL
-    assert hip_lib.wn_causal_gather(None, None, None, 1, 1, 1, 2, None) == -5
+    assert hip_lib.wn_causal_gather(None, None, None, 1, 1, 1, 2, 32, None) == -5
     buf = (ctypes.c_float * 64)()
     a = ctypes.addressof(buf)
     assert hip_lib.wn_gemm_nn(a, 8, 0, 0, a, 8, None, None, 0, None, 0, a, 8,

@@ -90,6 +90,16 @@ CASES = [
                             initial_filter_width=32), 150, False, None),
     ('scalar_T_lt_k', cfg_with(TINY, batch_size=1, scalar_input=True,
                                initial_filter_width=32), 9, False, None),
+    # more than 32 channels: two 32-wide channel blocks (wavenet/blocked.py)
+    ('r64', cfg_with(MID, batch_size=2, residual_channels=64,
+                     dilation_channels=64, skip_channels=32), 150, False, None),
+    ('r48_d40_gc', cfg_with(MID, batch_size=2, residual_channels=48,
+                            dilation_channels=40, skip_channels=32,
+                            global_condition_channels=4,
+                            global_condition_cardinality=5), 130, True, None),
+    ('r40_k3_nobias', cfg_with(TINY, batch_size=1, residual_channels=40,
+                               dilation_channels=24, filter_width=3,
+                               use_biases=False), 70, False, None),
     ('k3', cfg_with(TINY, batch_size=2, filter_width=3), 90, False, None),
     ('k3_mid_gc', cfg_with(MID, batch_size=2, filter_width=3,
                            global_condition_channels=4,
@@ -130,7 +140,8 @@ def test_loss_and_gradients_vs_oracle(hip_lib, name, cfg, T, gc, l2):
                           O.mu_law_encode(audio, cfg['quantization_channels']))
     assert abs(float(loss) - ref_loss) < TOL
     check_grads(net, ref_g, tag=name)
-    if cfg['residual_channels'] <= 32 and cfg['filter_width'] == 2:
+    if max(cfg['residual_channels'], cfg['dilation_channels']) <= 32 and \
+            cfg['filter_width'] == 2:
         check_planes(net, cfg, c, B, T)
     # forward-only path gives the same loss and identical logits to the oracle
     loss2 = net.loss(audio, ids, l2, backward=False)
@@ -444,7 +455,8 @@ def test_prime_generator_with_global_condition(hip_lib):
 
 def test_unsupported_configs_raise(hip_lib):
     from wavenet import WaveNetModel
-    for kw in (dict(filter_width=9), dict(residual_channels=64),
+    for kw in (dict(filter_width=9), dict(residual_channels=65),
+               dict(residual_channels=64, filter_width=5),
                dict(scalar_input=True, initial_filter_width=64)):
         cfg = cfg_with(TINY, batch_size=1, **kw)
         net = WaveNetModel(**model_kwargs(cfg))

@@ -96,3 +96,54 @@ def test_bench_self_launches_two_ranks(hip_lib):
     assert r['n_gpus'] == 2 and r['ranks_seen'] == 2
     assert r['config']['global_batch'] == 4
     assert r['value'] > 0
+
+
+def test_train_py_two_ranks_on_wav_data(hip_lib, tmp_path):
+    """train.py itself under two ranks (one GPU, gloo) on a wav corpus whose
+    files are sharded over the ranks: the ranks see different piece lengths
+    (tail pieces), so every step goes through parallel.agree_step; the run
+    must finish on both ranks (no collective left hanging), log a mean loss
+    per step and leave one checkpoint."""
+    from scipy.io import wavfile
+    data = tmp_path / 'corpus'
+    rate = 16000
+    for spk, n in ((225, 3), (226, 2)):
+        os.makedirs(str(data / ('p%d' % spk)))
+        for rec in range(n):
+            t = np.arange(int(rate * (0.55 + 0.17 * rec + 0.05 * spk % 3))) / rate
+            sig = 0.5 * np.sin(2 * np.pi * (200 + 40 * rec) * t)
+            wavfile.write(str(data / ('p%d' % spk) / ('p%d_%03d.wav' % (spk, rec))),
+                          rate, (sig * 32767).astype(np.int16))
+    params = dict(filter_width=2, sample_rate=16000,
+                  dilations=[1, 2, 4, 8, 16, 32] * 2, residual_channels=32,
+                  dilation_channels=32, quantization_channels=256,
+                  skip_channels=64, use_biases=True, scalar_input=False,
+                  initial_filter_width=32)
+    pj = str(tmp_path / 'params.json')
+    json.dump(params, open(pj, 'w'))
+    logdir = str(tmp_path / 'run')
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2',
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   WN_DIST_BACKEND='gloo', WN_DIST_TIMEOUT='120')
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(ROOT, 'train.py'), '--data_dir',
+             str(data), '--sample_size', '3000', '--batch_size', '1',
+             '--wavenet_params', pj, '--logdir', logdir, '--num_steps', '8',
+             '--silence_threshold', '0', '--learning_rate', '0.002'],
+            env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+        outs.append(o.decode(errors='replace'))
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    ev = [json.loads(l) for l in open(os.path.join(logdir, 'events.jsonl'))]
+    assert len(ev) >= 5 and all(np.isfinite(e['loss']) for e in ev)
+    assert any(f.startswith('model.ckpt-') for f in os.listdir(logdir))

@@ -156,10 +156,18 @@ int wn_layer_bwdw(const float* x, const float* z, const float* daf_cur,
  * model.py:294-300).  slabs: [wn_layer_bwd2_slabs(B, T)][wblock layout] weight
  * gradients of layer l; tile_colsum as in wn_layer_bwdw. */
 int wn_layer_bwd2_slabs(int B, int T);
+/* wimg: this layer's image out of wn_layer_bwd2_pack (the five matrices
+ * transposed with row stride 33, wn_layer_bwd2_wimg_floats() floats per layer,
+ * L images back to back; rebuilt once per step), which the kernel pulls into
+ * LDS by LDS-DMA; wblock is the plain layer block (A/B kernel variants). */
+int wn_layer_bwd2_wimg_floats(void);
+int wn_layer_bwd2_pack(const float* layer0, long layer_stride, float* wimg,
+                       int L, void* stream);
 int wn_layer_bwd2(const float* x, const float* z, const float* sg,
                   const float* dZ, const float* dxin, float* dx_out,
-                  const float* wblock, float* slabs, float* tile_colsum, int B,
-                  int T, int dilation, void* stream);
+                  const float* wblock, const float* wimg, float* slabs,
+                  float* tile_colsum, int B, int T, int dilation,
+                  void* stream);
 
 /* ---- fp32 MFMA GEMMs: the skip sum + post-processing of
  * wavenet/model.py:303-305, 430-440 (_create_network) and their gradients */

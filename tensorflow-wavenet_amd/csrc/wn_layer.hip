@@ -37,18 +37,19 @@ __global__ __launch_bounds__(LAYER_WG) void layer_fwd_kernel(
     const float* __restrict__ wblock,      // LAYER_BLOCK_FLOATS
     const float* __restrict__ bias_fg,     // [B or 1][64] (bias + gc), or null
     int bias_clip_stride, int B, int T, int d) {
-  __shared__ __attribute__((aligned(16))) float wl[LAYER_W_FLOATS + 32];
+  __shared__ __attribute__((aligned(1024))) float wl[LAYER_W_FLOATS + 32];
   __shared__ __attribute__((aligned(16))) float tiles[LAYER_WAVES * 2 * 1024];
   const int tid = threadIdx.x;
-  {
-    const f32x4* src = reinterpret_cast<const f32x4*>(wblock);
-    f32x4* dst = reinterpret_cast<f32x4*>(wl);
-    for (int i = tid; i < LAYER_W_FLOATS / 4; i += LAYER_WG) dst[i] = src[i];
-    if (tid < 32) wl[LAYER_W_FLOATS + tid] = wblock[LAYER_OFF_BD + tid];
-  }
-  __syncthreads();
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, h = lane >> 5;
+  // weights: 20 pieces of 1 KiB straight into LDS by LDS-DMA (asynchronous, no
+  // staging registers), issued BEFORE the first tile's loads and waited for
+  // together with them: the two latencies overlap
+  for (int p = wave; p < LAYER_W_FLOATS / 256; p += LAYER_WAVES)
+    __builtin_amdgcn_global_load_lds((wn_gptr_t)(wblock + p * 256 + lane * 4),
+                                     (wn_lptr_t)(wl + p * 256), 16, 0, 0);
+  if (tid < 32) wl[LAYER_W_FLOATS + tid] = wblock[LAYER_OFF_BD + tid];
   float* ta = tiles + wave * 2048;
   float* tb = ta + 1024;
   const int tiles_per_clip = (T + 31) >> 5;
@@ -56,9 +57,25 @@ __global__ __launch_bounds__(LAYER_WG) void layer_fwd_kernel(
   // few tiles (small batches): one tile per wave, spread over ALL CUs wave by
   // wave (layer_grid sizes the grid for it), so a SIMD runs one tile, not four
   const bool sparse = ntiles < (int)gridDim.x * LAYER_WAVES;
-  for (int tile = sparse ? wave * (int)gridDim.x + (int)blockIdx.x
-                         : (int)blockIdx.x * LAYER_WAVES + wave;
-       tile < ntiles; tile += gridDim.x * LAYER_WAVES) {
+  int tile = sparse ? wave * (int)gridDim.x + (int)blockIdx.x
+                    : (int)blockIdx.x * LAYER_WAVES + wave;
+  // coalesced loads (8 full rows per instruction); always assigns rc / rp
+  // (zeros for a wave without a tile)
+  RowRegs rc, rp;
+  auto load_tile = [&](int tl) {
+    const bool any = tl < ntiles;
+    const int b = any ? tl / tiles_per_clip : 0;
+    const int t0 = any ? (tl - b * tiles_per_clip) * 32 : 0;
+    const int hi = any ? min(32, T - t0) : 0;
+    const size_t off0 = ((size_t)b * T + t0) * WN_CH;
+    rc = rows_load(x + off0, lane, 0, hi);
+    rp = rows_load(x + off0 - (size_t)d * WN_CH, lane, max(0, d - t0), hi);
+  };
+  load_tile(tile);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                 // every wave's weight pieces have landed
+  for (bool first = true; tile < ntiles;
+       tile += gridDim.x * LAYER_WAVES, first = false) {
     // opaque per-iteration LDS offset: keeps the 80 weight reads next to their
     // MFMAs instead of being hoisted into (and spilling from) registers
     int woff = j + 4 * h * 32;  // n0 = 0, i = j
@@ -67,11 +84,9 @@ __global__ __launch_bounds__(LAYER_WG) void layer_fwd_kernel(
     const int b = tile / tiles_per_clip;
     const int t0 = (tile - b * tiles_per_clip) * 32;
     const int hi = min(32, T - t0);          // real rows of this tile
-    const int lo_p = max(0, d - t0);         // rows whose past tap exists
     const size_t off0 = ((size_t)b * T + t0) * WN_CH;
-    // coalesced loads (8 full rows per instruction), then LDS -> fragments
-    const RowRegs rc = rows_load(x + off0, lane, 0, hi);
-    const RowRegs rp = rows_load(x + off0 - (size_t)d * WN_CH, lane, lo_p, hi);
+    if (!first) load_tile(tile);
+    // global rows -> LDS -> fragments
     rows_to_lds(ta, lane, rc);
     rows_to_lds(tb, lane, rp);
     __builtin_amdgcn_wave_barrier();
@@ -629,6 +644,7 @@ __global__ __launch_bounds__(BW_WG) void layer_bwdw_kernel(
 // turns into da == 0.
 // ---------------------------------------------------------------------------
 #define B2_WAVES 8
+#define B2_WIMG 5376   // 5 x 33 x 32 transposed weights, padded to 21 KiB
 
 // (da_f, da_g) fragments from dz, z, sigmoid fragments
 __device__ __forceinline__ void gate_grad(const f32x16& dz, const f32x16& zz,
@@ -853,6 +869,21 @@ __global__ __launch_bounds__(WAVES * 64) void layer_bwd2_kernel(
   for (int e = tid; e < LAYER_BLOCK_FLOATS; e += WAVES * 64) out[e] = red[e];
 }
 
+// Weight image of layer_bwd2d_kernel: the five 32 x 32 matrices of a layer
+// block transposed with row stride 33 ([m][cout cc][cin rr] at m*1056 + cc*33 +
+// rr; the layout the kernel's LDS reads are conflict-free on), one 21 KiB
+// image per layer, rebuilt once per step for all layers.
+__global__ void bwd2_pack_kernel(const float* __restrict__ layer0, long layer_stride,
+                                 float* __restrict__ img) {
+  const float* blk = layer0 + (long)blockIdx.x * layer_stride;
+  float* out = img + (long)blockIdx.x * B2_WIMG;
+  for (int i = threadIdx.x; i < 5120; i += blockDim.x) {
+    const int m = i >> 10, rr = (i >> 5) & 31, cc = i & 31;  // W[m][rr][cc]
+    out[m * 1056 + cc * 33 + rr] = blk[i];
+  }
+  for (int i = 5280 + threadIdx.x; i < B2_WIMG; i += blockDim.x) out[i] = 0.f;
+}
+
 // ---------------------------------------------------------------------------
 // LDS-DMA form of layer_bwd2_kernel (the default): the same arithmetic, but
 // every input tile goes global -> LDS by global_load_lds (tile_dma) instead of
@@ -869,19 +900,33 @@ __global__ __launch_bounds__(B2_WAVES * 64) void layer_bwd2d_kernel(
     const float* __restrict__ x, const float* __restrict__ z,
     const float* __restrict__ sg, const float* __restrict__ dZ,
     const float* __restrict__ dxin, float* __restrict__ dx_out,
-    const float* __restrict__ wblock, float* __restrict__ slabs,
+    const float* __restrict__ wimg, float* __restrict__ slabs,
     float* __restrict__ tile_colsum, int B, int T, int d) {
+#ifdef B2_STAMPS
+  unsigned long long* dbg = reinterpret_cast<unsigned long long*>(tile_colsum);
+  tile_colsum = nullptr;
+  int tix = 0;
+#define STAMP(i)                                                          \
+  if ((threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == 7)) \
+    dbg[((size_t)blockIdx.x * 2 + ((threadIdx.x >> 6) == 7)) * 64 + (i)] = __builtin_amdgcn_s_memtime()
+  STAMP(0);
+  if ((threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == 7))
+    dbg[((size_t)blockIdx.x * 2 + ((threadIdx.x >> 6) == 7)) * 64 + 40] = __builtin_amdgcn_s_memrealtime();
+#else
+#define STAMP(i)
+#endif
   constexpr int LDT = 33, MT = 32 * LDT;
-  __shared__ float wl[5 * MT];
+  __shared__ __attribute__((aligned(1024))) float wl[B2_WIMG];
   __shared__ __attribute__((aligned(1024))) float tiles[B2_WAVES * 4 * 1024];
   const int tid = threadIdx.x;
-  for (int i = tid; i < 5120; i += B2_WAVES * 64) {
-    const int m = i >> 10, rr = (i >> 5) & 31, cc = i & 31;  // W[m][rr][cc]
-    wl[m * MT + cc * LDT + rr] = wblock[i];                  // m = 4: Wd
-  }
-  __syncthreads();
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // the layer's transposed weights (wn_layer_bwd2_pack) go straight into LDS
+  // by LDS-DMA, 21 pieces of 1 KiB, issued before the first tile's loads and
+  // waited for together with them
+  for (int p = wave; p < B2_WIMG / 256; p += B2_WAVES)
+    __builtin_amdgcn_global_load_lds((wn_gptr_t)(wimg + p * 256 + lane * 4),
+                                     (wn_lptr_t)(wl + p * 256), 16, 0, 0);
   const int j = lane & 31, h = lane >> 5;
   float* t0 = tiles + wave * 4096;
   float* t1 = t0 + 1024;
@@ -914,7 +959,12 @@ __global__ __launch_bounds__(B2_WAVES * 64) void layer_bwd2d_kernel(
   const int tile0 = ntiles < tstep ? wave * (int)gridDim.x + (int)blockIdx.x
                                    : (int)blockIdx.x * B2_WAVES + wave;
   load_shifted(tile0);
+  STAMP(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();               // every wave's weight pieces have landed
+  STAMP(2);
   for (int tile = tile0; tile < ntiles; tile += tstep) {
+    STAMP(3 + 10 * tix + 0);
     int woff = j + 4 * h * LDT;  // opaque: no hoisting of the weight reads
     asm volatile("" : "+v"(woff));
     const float* wlane = wl + woff;
@@ -938,11 +988,13 @@ __global__ __launch_bounds__(B2_WAVES * 64) void layer_bwd2d_kernel(
       ss = frag_from_lds(t3, j, h);
       WN_WAIT_LGKM0();                      // tiles free again
     }
+    STAMP(3 + 10 * tix + 1);
     // rows t: in flight during the rows t+d math
     if (HAS_DXIN) tile_dma(t0, dxin + off0, lane, 0, hi);
     tile_dma(t1, dZ + off0, lane, 0, hi);
     tile_dma(t2, z + off0, lane, 0, hi);
     tile_dma(t3, sg + off0, lane, 0, hi);
+    STAMP(3 + 10 * tix + 2);
     if (hi_f > 0) {
       if (HAS_DXIN) mma32<LDT>(dz, di, wlane + 4 * MT);  // dx_{l+1}[t+d] * Wd^T
       f32x16 df, dg;
@@ -950,7 +1002,9 @@ __global__ __launch_bounds__(B2_WAVES * 64) void layer_bwd2d_kernel(
       mma32<LDT>(dx, df, wlane + 0 * MT);        // da_f[t+d] * Wf[0]^T
       mma32<LDT>(dx, dg, wlane + 2 * MT);        // da_g[t+d] * Wg[0]^T
     }
+    STAMP(3 + 10 * tix + 3);
     WN_WAIT_VM0();
+    STAMP(3 + 10 * tix + 4);
     if (HAS_DXIN) {                              // dWd += z^T dx_{l+1}
 #pragma unroll 4
       for (int s = 0; s < 16; ++s) {
@@ -968,6 +1022,7 @@ __global__ __launch_bounds__(B2_WAVES * 64) void layer_bwd2d_kernel(
     // the x tiles: in flight during the rows-t math
     tile_dma(t2, x + off0, lane, 0, hi);
     tile_dma(t0, x + off0 - (size_t)d * WN_CH, lane, lo_p, hi);
+    STAMP(3 + 10 * tix + 5);
     {
       if (HAS_DXIN) {
 #pragma unroll
@@ -985,7 +1040,9 @@ __global__ __launch_bounds__(B2_WAVES * 64) void layer_bwd2d_kernel(
       frag_to_lds(t1, j, h, df);                 // t1 / t3 now hold da[t]
       frag_to_lds(t3, j, h, dg);
     }
+    STAMP(3 + 10 * tix + 6);
     WN_WAIT_VM0();
+    STAMP(3 + 10 * tix + 7);
     load_shifted(tile + tstep);
     __builtin_amdgcn_wave_barrier();
     float tsf = 0.f, tsg = 0.f;          // this tile's column sums of da[t]
@@ -1003,6 +1060,7 @@ __global__ __launch_bounds__(B2_WAVES * 64) void layer_bwd2d_kernel(
     }
     sf += tsf;
     sgs += tsg;
+    STAMP(3 + 10 * tix + 8);
     if (tile_colsum) {
       const float a = tsf + __shfl_xor(tsf, 32), b2 = tsg + __shfl_xor(tsg, 32);
       if (h == 0) {
@@ -1012,6 +1070,10 @@ __global__ __launch_bounds__(B2_WAVES * 64) void layer_bwd2d_kernel(
     }
     WN_WAIT_LGKM0();                     // tiles free for the next tile's DMA
     __builtin_amdgcn_wave_barrier();
+    STAMP(3 + 10 * tix + 9);
+#ifdef B2_STAMPS
+    ++tix;
+#endif
   }
   // ---- weight-gradient slab of this workgroup.  Fixed-order tree over the
   // eight waves through LDS: waves 0-3 store, waves 4-7 add into the region of
@@ -1020,7 +1082,9 @@ __global__ __launch_bounds__(B2_WAVES * 64) void layer_bwd2d_kernel(
   sf += __shfl_xor(sf, 32);
   sgs += __shfl_xor(sgs, 32);
   sd += __shfl_xor(sd, 32);
+  STAMP(30);
   __syncthreads();
+  STAMP(31);
   constexpr int RS = 5248;               // floats per region (>= block, 128 B multiple)
   static_assert(4 * RS <= B2_WAVES * 4 * 1024, "reduction regions exceed the tile area");
   float* red = tiles + (wave & 3) * RS;
@@ -1058,9 +1122,16 @@ __global__ __launch_bounds__(B2_WAVES * 64) void layer_bwd2d_kernel(
     }
     __syncthreads();
   }
+  STAMP(32);
   float* out = slabs + (size_t)blockIdx.x * LAYER_BLOCK_FLOATS;
   for (int e = tid; e < LAYER_BLOCK_FLOATS; e += B2_WAVES * 64)
     out[e] = (tiles[e] + tiles[RS + e]) + (tiles[2 * RS + e] + tiles[3 * RS + e]);
+  STAMP(33);
+#ifdef B2_STAMPS
+  if ((threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == 7))
+    dbg[((size_t)blockIdx.x * 2 + ((threadIdx.x >> 6) == 7)) * 64 + 41] = __builtin_amdgcn_s_memrealtime();
+#endif
+#undef STAMP
 }
 
 // ---------------------------------------------------------------------------
@@ -1784,28 +1855,41 @@ int wn_layer_bwd2_slabs(int B, int T) {
   return layer_grid(B, T, b2_waves(), b2_waves() == B2_WAVES);
 }
 
+int wn_layer_bwd2_wimg_floats(void) { return B2_WIMG; }
+
+int wn_layer_bwd2_pack(const float* layer0, long layer_stride, float* wimg,
+                       int L, void* stream) {
+  if (!layer0 || !wimg) return WN_ERR_NULL;
+  if (L <= 0) return WN_ERR_BAD_SHAPE;
+  if (!wn_aligned16(wimg)) return WN_ERR_MISALIGNED;
+  hipLaunchKernelGGL(bwd2_pack_kernel, dim3(L), dim3(256), 0,
+                     (hipStream_t)stream, layer0, layer_stride, wimg);
+  return wn_check_launch();
+}
+
 int wn_layer_bwd2(const float* x, const float* z, const float* sg,
                   const float* dZ, const float* dxin, float* dx_out,
-                  const float* wblock, float* slabs, float* tile_colsum, int B,
-                  int T, int dilation, void* stream) {
+                  const float* wblock, const float* wimg, float* slabs,
+                  float* tile_colsum, int B, int T, int dilation,
+                  void* stream) {
   if (B <= 0 || T <= 0 || dilation <= 0) return WN_ERR_BAD_SHAPE;
-  if (!x || !z || !sg || !dZ || !dx_out || !wblock || !slabs)
+  if (!x || !z || !sg || !dZ || !dx_out || !wblock || !wimg || !slabs)
     return WN_ERR_NULL;
-  const void* ptrs[] = {x, z, sg, dZ, dxin, dx_out, wblock};
+  const void* ptrs[] = {x, z, sg, dZ, dxin, dx_out, wblock, wimg};
   for (const void* p : ptrs)
     if (p && !wn_aligned16(p)) return WN_ERR_MISALIGNED;
   const int waves = b2_waves();
   dim3 grid(layer_grid(B, T, waves, waves == B2_WAVES)), block(waves * 64);
   hipStream_t s = (hipStream_t)stream;
-#define LAUNCH(KERNEL)                                                        \
+#define LAUNCH(KERNEL, W)                                                     \
   hipLaunchKernelGGL(KERNEL, grid, block, 0, s, x, z, sg, dZ, dxin, dx_out,   \
-                     wblock, slabs, tile_colsum, B, T, dilation)
+                     W, slabs, tile_colsum, B, T, dilation)
   if (waves == 4) {  // register-staged, one wave per SIMD (A/B)
-    if (dxin) LAUNCH((layer_bwd2_kernel<true, 4, true>));
-    else LAUNCH((layer_bwd2_kernel<false, 4, true>));
+    if (dxin) LAUNCH((layer_bwd2_kernel<true, 4, true>), wblock);
+    else LAUNCH((layer_bwd2_kernel<false, 4, true>), wblock);
   } else {           // default: LDS-DMA kernel, two waves per SIMD
-    if (dxin) LAUNCH((layer_bwd2d_kernel<true>));
-    else LAUNCH((layer_bwd2d_kernel<false>));
+    if (dxin) LAUNCH((layer_bwd2d_kernel<true>), wimg);
+    else LAUNCH((layer_bwd2d_kernel<false>), wimg);
   }
 #undef LAUNCH
   return wn_check_launch();

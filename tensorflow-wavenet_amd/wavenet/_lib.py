@@ -50,8 +50,10 @@ SIGNATURES = {
     'wn_layer_bwdw': (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
                               c_int, c_int, c_int, c_int, P]),
     'wn_layer_bwd2_slabs': (c_int, [c_int, c_int]),
-    'wn_layer_bwd2': (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int,
-                              P]),
+    'wn_layer_bwd2_wimg_floats': (c_int, []),
+    'wn_layer_bwd2_pack': (c_int, [P, c_long, P, c_int, P]),
+    'wn_layer_bwd2': (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int,
+                              c_int, P]),
     'wn_gemm_nn': (c_int, [P, c_long, c_int, c_long, P, c_int, P, P, c_long,
                            P, c_long, P, c_long, c_int, c_long, P, c_long,
                            c_int, c_int, c_int, P]),

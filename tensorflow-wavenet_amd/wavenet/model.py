@@ -120,6 +120,7 @@ class _Workspace(object):
         self.nslab = max(1, min(512, ntiles // 4))
         self.nslab_f = lib.wn_layer_bwdw_slabs(B, T)      # fused kernel
         self.nslab_2 = lib.wn_layer_bwd2_slabs(B, T)
+        alloc('wimg', (L, lib.wn_layer_bwd2_wimg_floats()))
         alloc('lslabs', (L, max(self.nslab, self.nslab_f, self.nslab_2),
                          net.LAYER_BLOCK))
         need = 0
@@ -815,13 +816,17 @@ class WaveNetModel(object):
             # one launch per layer; the launches are chained through dx only
             dxin, xp = None, 0
             tsum = None if ws.dsum is None else ws.tilesum
+            # transposed weight images of all layers (the kernels DMA them
+            # into LDS): one small launch per step
+            _lib.call('wn_layer_bwd2_pack', _lib.ptr(self._layer_block(P, 0)),
+                      self.layer_stride, _lib.ptr(ws.wimg), L, st)
             for l in range(L - 1, -1, -1):
                 dxo = ws.dx[xp]
                 _lib.call('wn_layer_bwd2', _lib.ptr(ws.X[l]), _lib.ptr(ws.Z[l]),
                           _lib.ptr(ws.SG[l]), _lib.ptr(ws.dZ[l]),
                           _lib.ptr(dxin), _lib.ptr(dxo),
                           _lib.ptr(self._layer_block(P, l)),
-                          _lib.ptr(ws.lslabs[l]),
+                          _lib.ptr(ws.wimg[l]), _lib.ptr(ws.lslabs[l]),
                           None if tsum is None else _lib.ptr(tsum[l]),
                           B, T, int(self.dilations[l]), st)
                 dxin, xp = dxo, 1 - xp

@@ -215,6 +215,7 @@ def layer():
     mk = lambda: torch.randn(N * 32, device=dev)
     x, xo, z, th, sg, dz, f, g, f2, g2, dx, dxo = [mk() for _ in range(12)]
     w = torch.randn(5216, device=dev) * 0.1
+    wimg = torch.randn(5376, device=dev) * 0.1
     nslab = 512
     slabs = torch.empty(nslab * 5216, device=dev)
     for d in (1, 64, 512):
@@ -242,6 +243,7 @@ def bwd2():
         x, z, dZ, dxin, dxo, f, g, th, fn, gn = [mk() for _ in range(10)]
         sg = torch.rand(N * 32, device=dev) * 0.9 + 0.05
         w = torch.randn(5216, device=dev) * 0.1
+        wimg = torch.randn(5376, device=dev) * 0.1
         for d in (4, 512):
             line = 'B=%2d d=%3d:' % (B, d)
             for m in modes:
@@ -249,7 +251,7 @@ def bwd2():
                 nsl = lib.wn_layer_bwd2_slabs(B, T)
                 slabs = torch.empty(nsl * 5216, device=dev)
                 t = timeit(lambda: _lib.call('wn_layer_bwd2', x.data_ptr(), z.data_ptr(), sg.data_ptr(), dZ.data_ptr(),
-                                             dxin.data_ptr(), dxo.data_ptr(), w.data_ptr(), slabs.data_ptr(), None,
+                                             dxin.data_ptr(), dxo.data_ptr(), w.data_ptr(), wimg.data_ptr(), slabs.data_ptr(), None,
                                              B, T, d, st()), n=20, warm=3)
                 line += '  bwd2[%s] %6.1f us' % (m, t * 1e6)
             nsl = lib.wn_layer_bwdw_slabs(B, T)
@@ -272,14 +274,16 @@ def lk():
     x, xo, z, dZ, dxin, dxo = [mk() for _ in range(6)]
     sg = torch.rand(N * 32, device=dev) * 0.9 + 0.05
     w = torch.randn(5216, device=dev) * 0.1
+    wimg = torch.randn(5376, device=dev) * 0.1
     slabs = torch.empty(lib.wn_layer_bwd2_slabs(B, T) * 5216, device=dev)
     for d in (4, 512):
         f = lambda: _lib.call('wn_layer_fwd', x.data_ptr(), xo.data_ptr(), z.data_ptr(), None, sg.data_ptr(),
                               w.data_ptr(), None, 0, B, T, d, 1, 2, st())
         b = lambda: _lib.call('wn_layer_bwd2', x.data_ptr(), z.data_ptr(), sg.data_ptr(), dZ.data_ptr(),
-                              dxin.data_ptr(), dxo.data_ptr(), w.data_ptr(), slabs.data_ptr(), None, B, T, d, st())
-        tf = sorted(timeit(f, n=40, warm=3) for _ in range(5))[2]
-        tb = sorted(timeit(b, n=40, warm=3) for _ in range(5))[2]
+                              dxin.data_ptr(), dxo.data_ptr(), w.data_ptr(), wimg.data_ptr(), slabs.data_ptr(), None, B, T, d, st())
+        only = os.environ.get('KB_LK', '')          # 'fwd' / 'bwd': one kernel only
+        tf = sorted(timeit(f, n=40, warm=3) for _ in range(5))[2] if only != 'bwd' else 0.0
+        tb = sorted(timeit(b, n=40, warm=3) for _ in range(5))[2] if only != 'fwd' else 0.0
         print('B=%d d=%3d: fwd %6.2f us   bwd2 %6.2f us' % (B, d, tf * 1e6, tb * 1e6), flush=True)
 
 
@@ -289,6 +293,7 @@ def layerpad():
     B, T = 8, 16000
     N = B * T
     w = torch.randn(5216, device=dev) * 0.1
+    wimg = torch.randn(5376, device=dev) * 0.1
     nsl = lib.wn_layer_bwdw_slabs(B, T)
     slabs2 = torch.empty(max(nsl, 1) * 5216, device=dev)
     for pad in (0, 64, 1088, 8256, 65600, 524352):

@@ -53,6 +53,7 @@ struct GemmNN {
   int tiles_n;
   int nwg;
   int tiles_m;
+  int tile_rows;        // rows a tile OWNS (<= 128; 128 = all it computes)
 };
 
 // address-space-qualified pointers of __builtin_amdgcn_global_load_lds
@@ -80,7 +81,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 #define EP_LD 68
 __device__ __forceinline__ void gemm_epilogue(const GemmNN& g, f32x16 (&acc)[2][2],
                                               float* lds, long m0, int n0,
-                                              int wm, int wn, int wave, int lane) {
+                                              int wm, int wn, int wave, int lane,
+                                              long m_end = -1) {
+  if (m_end < 0) m_end = g.M;
   const int j = lane & 31, h = lane >> 5;
   float* tile = lds + wave * (32 * EP_LD);
   const int rr = lane >> 4, cc = (lane & 15) * 4;   // row-in-group, column
@@ -105,7 +108,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmNN& g, f32x16 (&acc)[2][
       const int row = it * 4 + rr;
       const long m = mbase + row;
       f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * EP_LD + cc);
-      if (m >= g.M || n >= g.N) continue;
+      if (m >= m_end || n >= g.N) continue;
       v += bias4;
       if (g.Cpre) *reinterpret_cast<f32x4*>(g.Cpre + m * g.ldc + n) = v;
       if (g.relu) {
@@ -334,6 +337,15 @@ __device__ __forceinline__ void mma_split(f32x16& acc, const Split3& a, const Sp
 }
 
 __global__ __launch_bounds__(256, 4) void gemm_nn3_kernel(GemmNN g) {
+#ifdef NN3_STAMPS   // diagnostic build: g.Cpre carries a stamp buffer [nwg][8]
+  unsigned long long* dbg = reinterpret_cast<unsigned long long*>(g.Cpre) + (size_t)blockIdx.x * 8;
+  g.Cpre = nullptr;
+#define NSTAMP(i) if (threadIdx.x == 0) dbg[i] = __builtin_amdgcn_s_memtime()
+  NSTAMP(0);
+  if (threadIdx.x == 0) dbg[6] = __builtin_amdgcn_s_memrealtime();
+#else
+#define NSTAMP(i)
+#endif
   constexpr int NS = 2;  // LDS stages (3 with a counted vmcnt: measured equal or slower)
   constexpr int LDSF = NS * N3_STAGE > 4 * 32 * EP_LD ? NS * N3_STAGE : 4 * 32 * EP_LD;
   __shared__ __attribute__((aligned(1024))) float smem[LDSF];
@@ -343,7 +355,8 @@ __global__ __launch_bounds__(256, 4) void gemm_nn3_kernel(GemmNN g) {
   const int wm = wave & 1, wn = wave >> 1;
   const int logical = xcd_remap(blockIdx.x, g.nwg);
   const int tile_n = logical % g.tiles_n;
-  const long m0 = (long)(logical / g.tiles_n) * NN_TM;
+  const long m0 = (long)(logical / g.tiles_n) * g.tile_rows;
+  const long m_end = m0 + g.tile_rows < g.M ? m0 + g.tile_rows : g.M;
   const int n0 = tile_n * NN_TN;
   const int nk = g.K / N3_KC;
 
@@ -387,6 +400,9 @@ __global__ __launch_bounds__(256, 4) void gemm_nn3_kernel(GemmNN g) {
     // chunk kc landed (this wave's pieces), then everybody's; the barrier
     // also retires every wave's reads of the stage that is refilled next
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef NN3_STAMPS
+    if (kc == 0) { NSTAMP(1); }
+#endif
     if (kc + 1 < nk) stage(kc + 1, st ^ 1);
     const float* As = smem + st * N3_STAGE;
     const float* Bs = As + NN_TM * N3_KC;
@@ -418,8 +434,15 @@ __global__ __launch_bounds__(256, 4) void gemm_nn3_kernel(GemmNN g) {
   }
   // every wave is done with the operand stages before they become the
   // epilogue's staging tiles
+  NSTAMP(2);
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  gemm_epilogue(g, acc, smem, m0, n0, wm, wn, wave, lane);
+  NSTAMP(3);
+  gemm_epilogue(g, acc, smem, m0, n0, wm, wn, wave, lane, m_end);
+  NSTAMP(4);
+#ifdef NN3_STAMPS
+  if (threadIdx.x == 0) dbg[7] = __builtin_amdgcn_s_memrealtime();
+#endif
+#undef NSTAMP
 }
 
 // ---------------------------------------------------------------------------
@@ -1213,8 +1236,9 @@ static int gemm_nn_launch(const float* A, long lda, int a_planes, long a_plane_s
   g.addend = addend; g.ld_add = ld_add; g.C = C; g.ldc = ldc;
   g.c_plane_stride = c_plane_stride; g.c_planes = c_planes; g.Cpre = Cpre;
   g.M = M; g.N = N; g.K = K; g.relu = relu;
-  const long tiles_m = (M + NN_TM - 1) / NN_TM;
+  long tiles_m = (M + NN_TM - 1) / NN_TM;
   g.tiles_n = (N + NN_TN - 1) / NN_TN;
+  g.tile_rows = NN_TM;
   const long nwg = tiles_m * g.tiles_n;
   if (nwg > 0x7fffffffL) return WN_ERR_BAD_SHAPE;
   g.nwg = (int)nwg;

@@ -255,11 +255,14 @@ class WaveNetModel(object):
             self._unsupported = 'filter_width must be in [2, 8] on the HIP path'
         elif scalar_input and initial_filter_width > 32:
             self._unsupported = 'initial_filter_width > 32 not supported yet'
-        elif self.R > 2 * CH or self.D > 2 * CH:
-            self._unsupported = 'residual/dilation channels > 64 not supported yet'
-        elif max(self.R, self.D) > CH and (filter_width > 4 or scalar_input):
+        elif max(self.R, self.D) > CH and (
+                filter_width * ((max(self.R, self.D) + CH - 1) // CH) > 8
+                or scalar_input):
+            # channel-block kernels: filter_width x blocks <= 8 "virtual taps"
+            # (128 channels at filter width 2, 64 at widths 3 and 4)
             self._unsupported = ('more than 32 residual/dilation channels needs '
-                                 'filter_width <= 4 and one-hot input')
+                                 'filter_width * ceil(channels / 32) <= 8 and '
+                                 'one-hot input')
         elif self.S % 4 or self.Q % 4:
             self._unsupported = 'skip/quantization channels must be multiples of 4'
         elif self.G is not None and self.card is None:

@@ -97,6 +97,9 @@ CASES = [
                             dilation_channels=40, skip_channels=32,
                             global_condition_channels=4,
                             global_condition_cardinality=5), 130, True, None),
+    ('r96_d128', cfg_with(TINY, batch_size=1, residual_channels=96,
+                          dilation_channels=128, skip_channels=32,
+                          quantization_channels=32), 60, False, None),
     ('r40_k3_nobias', cfg_with(TINY, batch_size=1, residual_channels=40,
                                dilation_channels=24, filter_width=3,
                                use_biases=False), 70, False, None),
@@ -455,7 +458,7 @@ def test_prime_generator_with_global_condition(hip_lib):
 
 def test_unsupported_configs_raise(hip_lib):
     from wavenet import WaveNetModel
-    for kw in (dict(filter_width=9), dict(residual_channels=65),
+    for kw in (dict(filter_width=9), dict(residual_channels=129),
                dict(residual_channels=64, filter_width=5),
                dict(scalar_input=True, initial_filter_width=64)):
         cfg = cfg_with(TINY, batch_size=1, **kw)

@@ -274,7 +274,7 @@ int wn_sum_rows(const float* in, int rows, int n, float* out, void* stream);
  * device and on-device sampling. */
 long wn_fastgen_state_floats(const int32_t* dilations_host, int L);
 int wn_fastgen_init(float* state, long state_floats, int32_t* cursors, int L,
-                    void* stream);
+                    void* stream);   /* cursors: int32[>= 3] */
 /* samples_io holds n_steps + 1 codes; the first n_given are inputs (seed /
  * priming, generate.py:195-210), the rest are drawn on the device.  Step i
  * consumes samples_io[i]; proba_out (optional) receives the next-sample
@@ -292,10 +292,10 @@ int wn_fastgen_run(const float* params_causal, const float* layer0,
                    float* proba_out, int proba_every, int use_biases,
                    int push, void* stream);
 
-/* Multi-CU variant: enqueues ONE generation step as five kernels (chain on
- * one CU, current tap only; skip sum + the NEXT step's past-tap
- * pre-activations, conv1 and conv2 on S/16 / Q/16 CUs; float64 softmax +
- * draw).  Everything step- or call-dependent lives in device memory
+/* Multi-CU variant: enqueues ONE generation step as four kernels (chain on
+ * one CU, current tap only, preceded by the previous step's float64 softmax +
+ * draw; skip sum + the NEXT step's past-tap pre-activations, conv1 and conv2
+ * on S/16 / Q/16 CUs).  Everything step- or call-dependent lives in device memory
  * (cursors, ctl), so the host captures a few hundred calls into a hipGraph
  * ONCE and replays it for every generate() call.
  * ctl: int32[8] = {base (cursors[0] when the call started), n_given,
@@ -312,6 +312,13 @@ int wn_fastgen_step(const float* params_causal, const float* layer0,
                     const int32_t* ctl, float* proba_out, int use_biases,
                     const float* cw_img, float* pre, float* z_all, float* h1,
                     float* h2, float* logits, void* stream);
+/* cursors is int32[4] for the step path: {steps done, previous code, draw
+ * pending, 0}.  A step's softmax / draw / cursor update runs at the start of
+ * the NEXT step's chain kernel; wn_fastgen_finish does it for the last step
+ * of a sequence (no-op when nothing is pending). */
+int wn_fastgen_finish(int Q, int32_t* cursors, int32_t* samples_io,
+                      const int32_t* ctl, float* proba_out, const float* logits,
+                      void* stream);
 int wn_fastgen_pre(const float* layer0, long layer_stride,
                    const float* gc_bias_fg, const int32_t* dilations_dev,
                    int L, const float* state, const int32_t* cursors,

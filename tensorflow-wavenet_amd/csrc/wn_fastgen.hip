@@ -379,7 +379,7 @@ __global__ __launch_bounds__(FG_THREADS, 1) void fastgen_kernel(FastGen g) {
 }
 
 // ===========================================================================
-// Multi-CU fast generation: one generated sample = five small kernels on the
+// Multi-CU fast generation: one generated sample = four small kernels on the
 // stream (captured into a hipGraph by the host, hundreds of samples per
 // replay):
 //   A fg_chain_kernel   1 workgroup : the serial residual chain, CURRENT tap
@@ -396,9 +396,11 @@ __global__ __launch_bounds__(FG_THREADS, 1) void fastgen_kernel(FastGen g) {
 //   B fg_skip_kernel    S/16 WGs    : total = sum_l z_l Ws_l (+bias), ReLU;
 //                        + L more workgroups: pre_l of the NEXT step
 //   C fg_post1_kernel   S/16 WGs    : conv1 (+bias), ReLU
-//   D fg_logits_kernel  Q/16 WGs    : conv2 logits
-//   E fg_draw_kernel    1 wave      : float64 softmax, temperature,
-//                        inverse-CDF draw, cursor update
+//   D fg_logits_kernel  Q/16 WGs    : conv2 logits (marks a draw pending)
+//   (the float64 softmax, temperature, inverse-CDF draw and cursor update of
+//    step t run at the START of step t+1's kernel A, on its chain wave, while
+//    the loader waves run their prologue; wn_fastgen_finish draws for the
+//    last step of a run)
 // Kernel boundaries are the grid-wide synchronisation (about 1.5 us each):
 // no in-launch flags, nothing that can hang.  The 3.3 MB skip and 1 MB conv1
 // weights are read by S/16 CUs in parallel instead of one CU's load path.
@@ -427,7 +429,7 @@ struct FgStep {
   const int32_t* dil;
   int L, S, Q;
   float* state;
-  int32_t* cursors;      // [0] steps done, [1] previous code
+  int32_t* cursors;      // [0] steps done, [1] previous code, [2] draw pending
   int32_t* samples;      // indexed by (cursors[0] - ctl[BASE])
   const int32_t* ctl;    // per-call control block (device)
   float* proba_out;
@@ -499,33 +501,60 @@ __global__ __launch_bounds__(256) void fg_pre_kernel(FgStep g, int ahead) {
   fg_pre_layer(g, blockIdx.x, ahead, lds);
 }
 
+__device__ __forceinline__ int fg_draw_wave(const FgStep& g, double* pd, int lane,
+                                            int steps_done);
+
 __global__ __launch_bounds__(FGC_THREADS) void fg_chain_kernel(FgStep g) {
-  __shared__ __attribute__((aligned(16))) float wring[FGC_SLOTS][FGC_CW];
-  __shared__ __attribute__((aligned(16))) float pre_s[FG_MAXL * 64];
-  __shared__ __attribute__((aligned(16))) float bd_s[FG_MAXL * 32];
+  // ring slot: Wf[1] | Wg[1] | Wd image, then this step's pre[l][64] and the
+  // dense bias bd[l][32] (fetched by the loaders with the weights, so the
+  // chain needs no table of its own and the prologue no bulk load)
+  __shared__ __attribute__((aligned(16))) float wring[FGC_SLOTS][FGC_CW + 128];
   __shared__ __attribute__((aligned(16))) float inv[32];   // x, broadcast
   __shared__ __attribute__((aligned(16))) float zv[32];
   __shared__ int pos[FG_MAXL], roff[FG_MAXL], sdil[FG_MAXL];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int L = g.L, Q = g.Q;
   const int lt = tid - 64;                       // loader thread 0..255
-  const int steps_done = g.cursors[0];
-  const int prev_code = g.cursors[1];
-  const int code = g.samples[steps_done - g.ctl[FGCTL_BASE]];
+  __shared__ double pd[FG_MAXQ];
+  // the previous step's logits are still to be drawn from (cursors[2]): wave 0
+  // does that first, while the loader waves run their prologue.  The values
+  // it leaves in cursors[] are carried in registers here (this CU's L1 may
+  // still hold the old ones).
+  int steps_done = g.cursors[0];
+  int prev_code = g.cursors[1];
+  int code = 0;
+  if (wave == 0) {
+    if (g.cursors[2]) {
+      prev_code = g.samples[steps_done - g.ctl[FGCTL_BASE]];
+      code = fg_draw_wave(g, pd, lane, steps_done);
+      steps_done += 1;
+    } else {
+      code = g.samples[steps_done - g.ctl[FGCTL_BASE]];
+    }
+  }
   // loaders: 256 threads x 3 float4 = one layer of the pre-packed image
-  f32x4 s0[3], s1[3], s2[3];
-  auto ld = [&](f32x4 (&r)[3], int l) {
+  // (+ one float4 of pre[l] for loader threads 0..15, of bd[l] for 16..23)
+  f32x4 s0[4], s1[4], s2[4];
+  auto ld = [&](f32x4 (&r)[4], int l) {
     if (l < L) {
       const f32x4* src = reinterpret_cast<const f32x4*>(g.cw_img + (long)l * FGC_CW);
 #pragma unroll
       for (int k = 0; k < 3; ++k) r[k] = src[lt + 256 * k];
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      r[3] = zero;
+      if (lt < 16)
+        r[3] = reinterpret_cast<const f32x4*>(g.pre + (long)l * 64)[lt];
+      else if (lt < 24 && g.use_dense_bias)
+        r[3] = reinterpret_cast<const f32x4*>(
+            g.layer0 + (long)l * g.layer_stride + LAYER_OFF_BD)[lt - 16];
     }
   };
-  auto stl = [&](const f32x4 (&r)[3], int l) {   // straight 16-byte copies
+  auto stl = [&](const f32x4 (&r)[4], int l) {   // straight 16-byte copies
     if (l < L) {
       f32x4* dst = reinterpret_cast<f32x4*>(wring[l % FGC_SLOTS]);
 #pragma unroll
       for (int k = 0; k < 3; ++k) dst[lt + 256 * k] = r[k];
+      if (lt < 24) dst[FGC_CW / 4 + lt] = r[3];
     }
   };
   // nothing in the prologue depends on the new sample except the causal
@@ -556,11 +585,6 @@ __global__ __launch_bounds__(FGC_THREADS) void fg_chain_kernel(FgStep g) {
       x = v;
     }
   }
-  for (int i = tid; i < L * 64; i += FGC_THREADS) pre_s[i] = g.pre[i];
-  for (int i = tid; i < L * 32; i += FGC_THREADS)
-    bd_s[i] = g.use_dense_bias
-                  ? g.layer0[(long)(i >> 5) * g.layer_stride + LAYER_OFF_BD + (i & 31)]
-                  : 0.f;
   if (wave >= 1) {
     stl(s0, 0);
     ld(s0, 3);
@@ -568,7 +592,7 @@ __global__ __launch_bounds__(FGC_THREADS) void fg_chain_kernel(FgStep g) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   const int nn = lane & 31, gsel = lane >> 5;     // output row, 0 filter / 1 gate
-  auto body = [&](int l, f32x4 (&set)[3]) {
+  auto body = [&](int l, f32x4 (&set)[4]) {
     if (wave == 0) {
       if (l < L) {
         const float* wl = wring[l % FGC_SLOTS];
@@ -579,7 +603,7 @@ __global__ __launch_bounds__(FGC_THREADS) void fg_chain_kernel(FgStep g) {
         __builtin_amdgcn_wave_barrier();
         // current tap: lane -> output nn of filter (gsel 0) or gate (gsel 1)
         const float* w1 = wl + gsel * 1024 + nn * 32;
-        float a0 = pre_s[l * 64 + lane], a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        float a0 = wl[FGC_CW + lane], a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
           const int sw = (c ^ (nn & 7)) << 2;
@@ -619,7 +643,7 @@ __global__ __launch_bounds__(FGC_THREADS) void fg_chain_kernel(FgStep g) {
           const auto pd = __builtin_amdgcn_permlane32_swap(
               __float_as_uint(dh), __float_as_uint(dh), false, false);
           if (lane < 32)
-            x += bd_s[l * 32 + lane] + (__uint_as_float(pd[0]) + __uint_as_float(pd[1]));
+            x += wl[FGC_CW + 64 + lane] + (__uint_as_float(pd[0]) + __uint_as_float(pd[1]));
         }
       }
     } else {
@@ -729,17 +753,21 @@ __global__ __launch_bounds__(256) void fg_logits_kernel(FgStep g) {
   __syncthreads();
   if (part == 0 && q < Q)
     g.logits[q] = (g.post2_b ? g.post2_b[q] : 0.f) + fg_mv_reduce(red, o);
+  if (blockIdx.x == 0 && tid == 0) g.cursors[2] = 1;   // a draw is pending
 }
 
-// float64 softmax, temperature, inverse-CDF draw, cursor update (one wave).
+// float64 softmax of the pending logits, temperature, inverse-CDF draw, cursor
+// update; executed by ONE wave (pd: FG_MAXQ doubles of LDS owned by it).
+// Returns the code the NEXT step consumes (the drawn sample, or the given one)
+// and leaves cursors = {steps_done + 1, code, 0 (nothing pending)}.
 // (Folding this into fg_logits_kernel -- the last workgroup to arrive, by an
 // agent-scope ticket, does the draw -- was measured: 47.1 vs 46.8 us per
-// sample; the release / acquire fences cost what the saved boundary returns.)
-__global__ __launch_bounds__(64) void fg_draw_kernel(FgStep g) {
-  __shared__ double pd[FG_MAXQ];
-  const int lane = threadIdx.x, wave = 0;
+// sample; the release / acquire fences cost what the saved boundary returns.
+// It runs at the START of the next step's chain kernel instead, next to that
+// kernel's weight / table prologue.)
+__device__ __forceinline__ int fg_draw_wave(const FgStep& g, double* pd, int lane,
+                                            int steps_done) {
   const int Q = g.Q;
-  const int steps_done = g.cursors[0];
   const int local = steps_done - g.ctl[FGCTL_BASE];
   const int code = g.samples[local];
   const int n_given = g.ctl[FGCTL_NGIVEN];
@@ -749,72 +777,82 @@ __global__ __launch_bounds__(64) void fg_draw_kernel(FgStep g) {
                         ((uint64_t)(uint32_t)g.ctl[FGCTL_SEED + 1] << 32);
   for (int q = lane; q < Q; q += 64) pd[q] = (double)g.logits[q];
   __builtin_amdgcn_wave_barrier();
-  if (wave == 0) {
-    double m = -1e300;
-    for (int q = lane; q < Q; q += 64) m = fmax(m, pd[q]);
-    for (int o = 32; o >= 1; o >>= 1) m = fmax(m, __shfl_xor(m, o));
-    // each double-precision exp / log is evaluated once and kept in LDS
-    double se = 0.0;
-    for (int q = lane; q < Q; q += 64) {
-      const double e = exp(pd[q] - m);
-      pd[q] = e;
-      se += e;
-    }
-    for (int o = 32; o >= 1; o >>= 1) se += __shfl_xor(se, o);
-    const bool want_p = g.proba_out && (local % proba_every == 0);
-    float* po = want_p ? g.proba_out + (long)(local / proba_every) * Q : nullptr;
-    for (int q = lane; q < Q; q += 64) {
-      const float p32 = (float)(pd[q] / se);
-      if (po) po[q] = p32;
-      pd[q] = (double)p32;
-    }
-    if (local + 1 >= n_given) {
-      // sampling weights w_q proportional to exp(log(p_q) / tau)
-      // (generate.py:229-233); at tau == 1 that is p_q itself
-      const double tau = (double)temperature;
-      if (temperature != 1.0f) {
-        double mx = -1e300;
-        for (int q = lane; q < Q; q += 64) {
-          const double lp = log(pd[q] > 0.0 ? pd[q] : 1e-300) / tau;
-          pd[q] = lp;
-          mx = fmax(mx, lp);
-        }
-        for (int o = 32; o >= 1; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
-        for (int q = lane; q < Q; q += 64) pd[q] = exp(pd[q] - mx);
-      }
-      __builtin_amdgcn_wave_barrier();
-      const int per = (Q + 63) / 64;
-      const int q0 = lane * per, q1 = min(Q, q0 + per);
-      double seg = 0.0;
-      for (int q = q0; q < q1; ++q) seg += pd[q];
-      double incl = seg;
-      for (int o = 1; o < 64; o <<= 1) {
-        const double v = __shfl_up(incl, o);
-        if (lane >= o) incl += v;
-      }
-      const double total = __shfl(incl, 63);
-      const uint64_t r = splitmix64(seed ^ splitmix64((uint64_t)steps_done));
-      const double u = (double)(r >> 11) * (1.0 / 9007199254740992.0) * total;
-      const double excl = incl - seg;
-      int pick = -1;
-      if (u >= excl && u < incl) {
-        double c = excl;
-        pick = q1 - 1;
-        for (int q = q0; q < q1; ++q) {
-          c += pd[q];
-          if (u < c) { pick = q; break; }
-        }
-      }
-      int best = pick;
-      for (int o = 32; o >= 1; o >>= 1) best = max(best, __shfl_xor(best, o));
-      if (best < 0) best = Q - 1;
-      if (lane == 0) g.samples[local + 1] = best;
-    }
-    if (lane == 0) {
-      g.cursors[0] = steps_done + 1;
-      g.cursors[1] = code;
-    }
+  double m = -1e300;
+  for (int q = lane; q < Q; q += 64) m = fmax(m, pd[q]);
+  for (int o = 32; o >= 1; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+  // each double-precision exp / log is evaluated once and kept in LDS
+  double se = 0.0;
+  for (int q = lane; q < Q; q += 64) {
+    const double e = exp(pd[q] - m);
+    pd[q] = e;
+    se += e;
   }
+  for (int o = 32; o >= 1; o >>= 1) se += __shfl_xor(se, o);
+  const bool want_p = g.proba_out && (local % proba_every == 0);
+  float* po = want_p ? g.proba_out + (long)(local / proba_every) * Q : nullptr;
+  for (int q = lane; q < Q; q += 64) {
+    const float p32 = (float)(pd[q] / se);
+    if (po) po[q] = p32;
+    pd[q] = (double)p32;
+  }
+  int next = 0;
+  if (local + 1 >= n_given) {
+    // sampling weights w_q proportional to exp(log(p_q) / tau)
+    // (generate.py:229-233); at tau == 1 that is p_q itself
+    const double tau = (double)temperature;
+    if (temperature != 1.0f) {
+      double mx = -1e300;
+      for (int q = lane; q < Q; q += 64) {
+        const double lp = log(pd[q] > 0.0 ? pd[q] : 1e-300) / tau;
+        pd[q] = lp;
+        mx = fmax(mx, lp);
+      }
+      for (int o = 32; o >= 1; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+      for (int q = lane; q < Q; q += 64) pd[q] = exp(pd[q] - mx);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int per = (Q + 63) / 64;
+    const int q0 = lane * per, q1 = min(Q, q0 + per);
+    double seg = 0.0;
+    for (int q = q0; q < q1; ++q) seg += pd[q];
+    double incl = seg;
+    for (int o = 1; o < 64; o <<= 1) {
+      const double v = __shfl_up(incl, o);
+      if (lane >= o) incl += v;
+    }
+    const double total = __shfl(incl, 63);
+    const uint64_t r = splitmix64(seed ^ splitmix64((uint64_t)steps_done));
+    const double u = (double)(r >> 11) * (1.0 / 9007199254740992.0) * total;
+    const double excl = incl - seg;
+    int pick = -1;
+    if (u >= excl && u < incl) {
+      double c = excl;
+      pick = q1 - 1;
+      for (int q = q0; q < q1; ++q) {
+        c += pd[q];
+        if (u < c) { pick = q; break; }
+      }
+    }
+    int best = pick;
+    for (int o = 32; o >= 1; o >>= 1) best = max(best, __shfl_xor(best, o));
+    if (best < 0) best = Q - 1;
+    if (lane == 0) g.samples[local + 1] = best;
+    next = best;
+  } else {
+    next = g.samples[local + 1];           // still inside the given samples
+  }
+  if (lane == 0) {
+    g.cursors[0] = steps_done + 1;
+    g.cursors[1] = code;
+    g.cursors[2] = 0;
+  }
+  return next;
+}
+
+// the draw of the LAST step of a run (nothing follows it)
+__global__ __launch_bounds__(64) void fg_draw_kernel(FgStep g) {
+  __shared__ double pd[FG_MAXQ];
+  if (g.cursors[2]) fg_draw_wave(g, pd, threadIdx.x, g.cursors[0]);
 }
 
 extern "C" {
@@ -838,6 +876,8 @@ int wn_fastgen_init(float* state, long state_floats, int32_t* cursors, int L,
   if (hipMemsetD32Async((hipDeviceptr_t)cursors, (int)init[0], 1, s) != hipSuccess)
     return WN_ERR_LAUNCH;
   if (hipMemsetD32Async((hipDeviceptr_t)(cursors + 1), (int)init[1], 1, s) != hipSuccess)
+    return WN_ERR_LAUNCH;
+  if (hipMemsetD32Async((hipDeviceptr_t)(cursors + 2), 0, 1, s) != hipSuccess)
     return WN_ERR_LAUNCH;
   return WN_OK;
 }
@@ -876,7 +916,7 @@ int wn_fastgen_run(const float* params_causal, const float* layer0,
 }
 
 
-// Enqueue ONE generation step (five kernels) on `stream`.  Everything
+// Enqueue ONE generation step (four kernels) on `stream`.  Everything
 // step- or call-dependent is read from device memory (cursors, ctl), so the
 // call can be captured into a hipGraph once and replayed for every call.
 // `pre` must hold the past-tap pre-activations of the step about to run
@@ -914,7 +954,22 @@ int wn_fastgen_step(const float* params_causal, const float* layer0,
   hipLaunchKernelGGL(fg_skip_kernel, dim3(wgs + L), dim3(256), 0, s, g);
   hipLaunchKernelGGL(fg_post1_kernel, dim3(wgs), dim3(256), 0, s, g);
   hipLaunchKernelGGL(fg_logits_kernel, dim3((Q + FGM_OUTS - 1) / FGM_OUTS), dim3(256), 0, s, g);
-  hipLaunchKernelGGL(fg_draw_kernel, dim3(1), dim3(64), 0, s, g);
+  return wn_check_launch();
+}
+
+// Draw from the logits the last wn_fastgen_step left pending (every step's
+// draw otherwise happens at the start of the NEXT step's chain kernel).  Call
+// once after a sequence of steps; a no-op when nothing is pending.
+int wn_fastgen_finish(int Q, int32_t* cursors, int32_t* samples_io,
+                      const int32_t* ctl, float* proba_out, const float* logits,
+                      void* stream) {
+  if (!cursors || !samples_io || !ctl || !logits) return WN_ERR_NULL;
+  if (Q <= 0) return WN_ERR_BAD_SHAPE;
+  if (Q > FG_MAXQ) return WN_ERR_UNSUPPORTED;
+  FgStep g = {};
+  g.Q = Q; g.cursors = cursors; g.samples = samples_io; g.ctl = ctl;
+  g.proba_out = proba_out; g.logits = const_cast<float*>(logits);
+  hipLaunchKernelGGL(fg_draw_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, g);
   return wn_check_launch();
 }
 

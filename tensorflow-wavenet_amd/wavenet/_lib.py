@@ -104,6 +104,7 @@ SIGNATURES = {
                                 c_int, c_int, P, P, P, P, P, c_int, P, P, P,
                                 P, P, P, P]),
     'wn_fastgen_pre': (c_int, [P, c_long, P, P, c_int, P, P, P, P]),
+    'wn_fastgen_finish': (c_int, [c_int, P, P, P, P, P, P]),
     'wn_fastgen_pack': (c_int, [P, c_long, P, c_int, P]),
 }
 

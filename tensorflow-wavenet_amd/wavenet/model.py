@@ -1122,7 +1122,8 @@ class WaveNetModel(object):
             nfl = lib.wn_fastgen_state_floats(dil.ctypes.data, self.L)
             g = dict(
                 state=torch.zeros(nfl, dtype=torch.float32, device=self.device),
-                cursors=torch.zeros(2, dtype=torch.int32, device=self.device),
+                # [0] steps done, [1] previous code, [2] draw pending
+                cursors=torch.zeros(4, dtype=torch.int32, device=self.device),
                 dil=torch.from_numpy(dil).to(self.device),
                 bias=torch.zeros((self.L, 1, 64), dtype=torch.float32,
                                  device=self.device),
@@ -1253,6 +1254,10 @@ class WaveNetModel(object):
                     done += per
         for _ in range(n_steps - done):
             one()
+        # the last step's draw (every other one ran inside the next step)
+        _lib.call('wn_fastgen_finish', self.Q, _lib.ptr(g['cursors']),
+                  _lib.ptr(io), _lib.ptr(g['ctl']), _lib.ptr(pb),
+                  _lib.ptr(g['logits']), _lib.stream())
         g['steps'] += int(n_steps)
         samples_io[:n_io].copy_(io[:n_io])
         if proba_out is not None:

@@ -504,7 +504,14 @@ __global__ __launch_bounds__(256) void fg_pre_kernel(FgStep g, int ahead) {
 __device__ __forceinline__ int fg_draw_wave(const FgStep& g, double* pd, int lane,
                                             int steps_done);
 
+#ifdef FG_STAMPS   // diagnostic build: per-layer phase stamps of the chain wave
+__device__ unsigned long long fg_dbg[8 + FG_MAXL * 8];
+#define FSTAMP(i) if (threadIdx.x == 0) fg_dbg[i] = __builtin_amdgcn_s_memtime()
+#else
+#define FSTAMP(i)
+#endif
 __global__ __launch_bounds__(FGC_THREADS) void fg_chain_kernel(FgStep g) {
+  FSTAMP(0);
   // ring slot: Wf[1] | Wg[1] | Wd image, then this step's pre[l][64] and the
   // dense bias bd[l][32] (fetched by the loaders with the weights, so the
   // chain needs no table of its own and the prologue no bulk load)
@@ -523,6 +530,7 @@ __global__ __launch_bounds__(FGC_THREADS) void fg_chain_kernel(FgStep g) {
   int steps_done = g.cursors[0];
   int prev_code = g.cursors[1];
   int code = 0;
+  FSTAMP(1);
   if (wave == 0) {
     if (g.cursors[2]) {
       prev_code = g.samples[steps_done - g.ctl[FGCTL_BASE]];
@@ -532,6 +540,7 @@ __global__ __launch_bounds__(FGC_THREADS) void fg_chain_kernel(FgStep g) {
       code = g.samples[steps_done - g.ctl[FGCTL_BASE]];
     }
   }
+  FSTAMP(2);
   // loaders: 256 threads x 3 float4 = one layer of the pre-packed image
   // (+ one float4 of pre[l] for loader threads 0..15, of bd[l] for 16..23)
   f32x4 s0[4], s1[4], s2[4];
@@ -591,11 +600,13 @@ __global__ __launch_bounds__(FGC_THREADS) void fg_chain_kernel(FgStep g) {
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  FSTAMP(3);
   const int nn = lane & 31, gsel = lane >> 5;     // output row, 0 filter / 1 gate
   auto body = [&](int l, f32x4 (&set)[4]) {
     if (wave == 0) {
       if (l < L) {
         const float* wl = wring[l % FGC_SLOTS];
+        FSTAMP(8 + l * 8 + 0);
         if (lane < 32) {
           g.state[((long)roff[l] + pos[l]) * 32 + lane] = x;  // enqueue x_l[t]
           inv[lane] = x;
@@ -613,6 +624,7 @@ __global__ __launch_bounds__(FGC_THREADS) void fg_chain_kernel(FgStep g) {
           a2 = fmaf(xv[2], q[2], a2); a3 = fmaf(xv[3], q[3], a3);
         }
         const float a = (a0 + a1) + (a2 + a3);
+        FSTAMP(8 + l * 8 + 1);
         // lanes 0-31 hold the filter pre-activation, lanes 32-63 the gate's:
         // one exp + one rcp per lane (tanh(a) = 2 sigmoid(2a) - 1), then the
         // halves meet through v_permlane32_swap (no LDS round trip)
@@ -621,6 +633,7 @@ __global__ __launch_bounds__(FGC_THREADS) void fg_chain_kernel(FgStep g) {
         const auto pr = __builtin_amdgcn_permlane32_swap(
             __float_as_uint(act), __float_as_uint(act), false, false);
         const float z = __uint_as_float(pr[0]) * __uint_as_float(pr[1]);
+        FSTAMP(8 + l * 8 + 2);
         if (lane < 32) {
           g.z_all[l * 32 + lane] = z;
           zv[lane] = z;
@@ -645,6 +658,7 @@ __global__ __launch_bounds__(FGC_THREADS) void fg_chain_kernel(FgStep g) {
           if (lane < 32)
             x += wl[FGC_CW + 64 + lane] + (__uint_as_float(pd[0]) + __uint_as_float(pd[1]));
         }
+        FSTAMP(8 + l * 8 + 3);
       }
     } else {
       stl(set, l + 1);
@@ -652,6 +666,9 @@ __global__ __launch_bounds__(FGC_THREADS) void fg_chain_kernel(FgStep g) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+#ifdef FG_STAMPS
+    if (l < L) { FSTAMP(8 + l * 8 + 4); }
+#endif
   };
   for (int l = 0; l < L; l += 3) {
     body(l, s1);          // stores layer l+1 (set (l+1)%3 == 1 when l%3 == 0)
@@ -1001,5 +1018,11 @@ int wn_fastgen_pack(const float* layer0, long layer_stride, float* img, int L,
                      (hipStream_t)stream, layer0, layer_stride, img, L);
   return wn_check_launch();
 }
+
+#ifdef FG_STAMPS
+int wn_diag_fg_stamps(unsigned long long* out_host) {
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(fg_dbg), sizeof(fg_dbg)) == hipSuccess ? 0 : WN_ERR_LAUNCH;
+}
+#endif
 
 }  // extern "C"

@@ -248,7 +248,7 @@ int wn_colsum_clip(const float* plane0, const float* plane1, int B, int T,
 int wn_gc_grad(const float* layer0, long layer_stride, long off_gc, int G,
                const float* emb, int card, const int32_t* ids,
                const float* dsum, int L, int B, float* glayer0, float* gemb,
-               int ch, void* stream);
+               float* scratch /* L * B * G floats */, int ch, void* stream);
 
 /* ---- thin exported ops of wavenet/__init__.py:1-4 (arbitrary shapes):
  * causal_conv ops.py:46-62, time_to_batch :27-34, batch_to_time :37-43 */

@@ -450,7 +450,7 @@ __global__ void gc_grad_kernel(const float* __restrict__ layer0, long layer_stri
                                int card, const int32_t* __restrict__ ids,
                                const float* __restrict__ dsum, int L, int B,
                                float* __restrict__ glayer0,
-                               float* __restrict__ gemb, int ch) {
+                               float* __restrict__ part, int ch) {
   const int tid = threadIdx.x;
   if ((int)blockIdx.x < L) {
     const int l = blockIdx.x;
@@ -466,30 +466,42 @@ __global__ void gc_grad_kernel(const float* __restrict__ layer0, long layer_stri
       gw[e] = s;
     }
   } else {
-    // embedding rows.  Phase 1 (parallel): tmp[b][g] = sum_l dsum_l[b] Wgc_l[g]^T
-    // Phase 2: rows are added clip by clip in a fixed order (deterministic
-    // when several clips share an id).
-    extern __shared__ float tmp[];      // [B][G]
-    for (int e = tid; e < card * G; e += blockDim.x) gemb[e] = 0.f;
+    // embedding rows, stage 1 (one workgroup per layer): the layer's share
+    // part[l][b][g] = dsum_l[b] . Wgc_l[g] of every clip's embedding gradient
+    const int l = blockIdx.x - L;
+    const float* w = layer0 + (long)l * layer_stride + off_gc;
     for (int e = tid; e < B * G; e += blockDim.x) {
       const int b = e / G, gi = e - b * G;
+      const float* ds = dsum + ((long)l * B + b) * 2 * ch;
       float s = 0.f;
-      for (int l = 0; l < L; ++l) {
-        const float* w = layer0 + (long)l * layer_stride + off_gc;
-        const float* ds = dsum + ((long)l * B + b) * 2 * ch;
-        for (int c = 0; c < ch; ++c)
-          s += ds[c] * w[(long)gi * ch + c] +
-               ds[ch + c] * w[(long)(G + gi) * ch + c];
-      }
-      tmp[e] = s;
+      for (int c = 0; c < ch; ++c)
+        s += ds[c] * w[(long)gi * ch + c] + ds[ch + c] * w[(long)(G + gi) * ch + c];
+      part[((long)l * B + b) * G + gi] = s;
     }
-    __syncthreads();
-    for (int gi = tid; gi < G; gi += blockDim.x) {
-      for (int b = 0; b < B; ++b) {
-        const int id = ids[b];
-        if (id < 0 || id >= card) continue;
-        gemb[(long)id * G + gi] += tmp[b * G + gi];
-      }
+  }
+}
+
+// embedding rows, stage 2 (one workgroup): tmp[b][g] = sum_l part[l][b][g] in
+// layer order, then the rows are added clip by clip in a fixed order
+// (deterministic when several clips share an id).
+__global__ void gc_grad_emb_kernel(const float* __restrict__ part, int L, int B,
+                                   int G, int card,
+                                   const int32_t* __restrict__ ids,
+                                   float* __restrict__ gemb) {
+  extern __shared__ float tmp[];      // [B][G]
+  const int tid = threadIdx.x;
+  for (int e = tid; e < card * G; e += blockDim.x) gemb[e] = 0.f;
+  for (int e = tid; e < B * G; e += blockDim.x) {
+    float s = 0.f;
+    for (int l = 0; l < L; ++l) s += part[(long)l * B * G + e];
+    tmp[e] = s;
+  }
+  __syncthreads();
+  for (int gi = tid; gi < G; gi += blockDim.x) {
+    for (int b = 0; b < B; ++b) {
+      const int id = ids[b];
+      if (id < 0 || id >= card) continue;
+      gemb[(long)id * G + gi] += tmp[b * G + gi];
     }
   }
 }
@@ -903,16 +915,22 @@ int wn_colsum_clip(const float* plane0, const float* plane1, int B, int T,
                          1, 0, stream);
 }
 
+// scratch: L * B * G floats (the per-layer shares of the embedding gradient)
 int wn_gc_grad(const float* layer0, long layer_stride, long off_gc, int G,
                const float* emb, int card, const int32_t* ids,
                const float* dsum, int L, int B, float* glayer0, float* gemb,
-               int ch, void* stream) {
-  if (!layer0 || !emb || !ids || !dsum || !glayer0 || !gemb) return WN_ERR_NULL;
+               float* scratch, int ch, void* stream) {
+  if (!layer0 || !emb || !ids || !dsum || !glayer0 || !gemb || !scratch)
+    return WN_ERR_NULL;
   if (L <= 0 || B <= 0 || G <= 0 || card <= 0 || ch < 32) return WN_ERR_BAD_SHAPE;
   if ((size_t)B * G * sizeof(float) > 48 * 1024) return WN_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(gc_grad_kernel, dim3(L + 1), dim3(256),
-                     (size_t)B * G * sizeof(float), (hipStream_t)stream, layer0, layer_stride, off_gc, G, emb,
-                     card, ids, dsum, L, B, glayer0, gemb, ch);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gc_grad_kernel, dim3(2 * L), dim3(256), 0, s, layer0,
+                     layer_stride, off_gc, G, emb, card, ids, dsum, L, B,
+                     glayer0, scratch, ch);
+  hipLaunchKernelGGL(gc_grad_emb_kernel, dim3(1), dim3(256),
+                     (size_t)B * G * sizeof(float), s, scratch, L, B, G, card,
+                     ids, gemb);
   return wn_check_launch();
 }
 

@@ -86,7 +86,7 @@ SIGNATURES = {
     'wn_colsum_clip_chunks': (c_int, [c_int]),
     'wn_colsum_clip': (c_int, [P, P, c_int, c_int, P, P, P]),
     'wn_gc_grad': (c_int, [P, c_long, c_long, c_int, P, c_int, P, P, c_int,
-                           c_int, P, P, c_int, P]),
+                           c_int, P, P, P, c_int, P]),
     'wn_causal_conv': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int,
                                c_int, P]),
     'wn_time_to_batch': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),

@@ -164,4 +164,4 @@ def backward_layers(net, ws, ids, st):
                   net.layer_stride, net.OFF_GC, net.G,
                   _lib.ptr(net._seg(P, 'emb')), net.card, _lib.ptr(ids),
                   _lib.ptr(ws.dsum), L, B, _lib.ptr(net._layer_block(Gr, 0)),
-                  _lib.ptr(net._seg(Gr, 'emb')), C, st)
+                  _lib.ptr(net._seg(Gr, 'emb')), _lib.ptr(ws.gc_part), C, st)

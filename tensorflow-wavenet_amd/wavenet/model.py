@@ -139,6 +139,7 @@ class _Workspace(object):
         self.ev_fork = torch.cuda.Event() if dev.type == 'cuda' else None
         self.ev_join = torch.cuda.Event() if dev.type == 'cuda' else None
         self.dsum = alloc('dsum', (L, B, 2 * CHn)) if net.G else None
+        self.gc_part = alloc('gc_part', (L, B, net.G)) if net.G else None
         self.tilesum = alloc('tilesum', (L, ntiles, 64)) if net.G else None
         self.dsum_part = alloc(
             'dsum_part', (B * lib.wn_colsum_clip_chunks(T) * 64,)) \
@@ -989,7 +990,8 @@ class WaveNetModel(object):
                       _lib.ptr(self._seg(P, 'emb')), self.card, _lib.ptr(ids),
                       _lib.ptr(ws.dsum), L, B,
                       _lib.ptr(self._layer_block(Gr, 0)),
-                      _lib.ptr(self._seg(Gr, 'emb')), self.CHn, st)
+                      _lib.ptr(self._seg(Gr, 'emb')), _lib.ptr(ws.gc_part),
+                      self.CHn, st)
 
     # ------------------------------------------------------------------ API
     def encode(self, input_batch, B=None):

@@ -37,6 +37,17 @@ __global__ __launch_bounds__(LAYER_WG) void layer_fwd_kernel(
     const float* __restrict__ wblock,      // LAYER_BLOCK_FLOATS
     const float* __restrict__ bias_fg,     // [B or 1][64] (bias + gc), or null
     int bias_clip_stride, int B, int T, int d) {
+#ifdef FWD_STAMPS   // diagnostic build: th carries a stamp buffer [grid][2][16]
+  unsigned long long* dbg = reinterpret_cast<unsigned long long*>(th);
+#define FWSTAMP(i)                                                          \
+  if ((threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == 15)) \
+    dbg[((size_t)blockIdx.x * 2 + ((threadIdx.x >> 6) == 15)) * 16 + (i)] = __builtin_amdgcn_s_memtime()
+  FWSTAMP(0);
+  if ((threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == 15))
+    dbg[((size_t)blockIdx.x * 2 + ((threadIdx.x >> 6) == 15)) * 16 + 14] = __builtin_amdgcn_s_memrealtime();
+#else
+#define FWSTAMP(i)
+#endif
   __shared__ __attribute__((aligned(1024))) float wl[LAYER_W_FLOATS + 32];
   __shared__ __attribute__((aligned(16))) float tiles[LAYER_WAVES * 2 * 1024];
   const int tid = threadIdx.x;
@@ -72,8 +83,11 @@ __global__ __launch_bounds__(LAYER_WG) void layer_fwd_kernel(
     rp = rows_load(x + off0 - (size_t)d * WN_CH, lane, max(0, d - t0), hi);
   };
   load_tile(tile);
+  FWSTAMP(1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  FWSTAMP(2);
   __syncthreads();                 // every wave's weight pieces have landed
+  FWSTAMP(3);
   for (bool first = true; tile < ntiles;
        tile += gridDim.x * LAYER_WAVES, first = false) {
     // opaque per-iteration LDS offset: keeps the 80 weight reads next to their
@@ -92,6 +106,7 @@ __global__ __launch_bounds__(LAYER_WG) void layer_fwd_kernel(
     __builtin_amdgcn_wave_barrier();
     f32x16 xc = frag_from_lds(ta, j, h);
     f32x16 xp = frag_from_lds(tb, j, h);
+    FWSTAMP(4);
     f32x16 af, ag;
     if (bias_fg) {
       const float* bp = bias_fg + (size_t)b * bias_clip_stride;
@@ -105,6 +120,7 @@ __global__ __launch_bounds__(LAYER_WG) void layer_fwd_kernel(
     mma32<32>(af, xc, wlane + 1 * 1024);  // Wf[1]: current tap
     mma32<32>(ag, xp, wlane + 2 * 1024);  // Wg[0]
     mma32<32>(ag, xc, wlane + 3 * 1024);  // Wg[1]
+    FWSTAMP(5);
     f32x16 zz;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -112,6 +128,7 @@ __global__ __launch_bounds__(LAYER_WG) void layer_fwd_kernel(
       ag[r] = wn_sigmoid(ag[r]);
       zz[r] = af[r] * ag[r];
     }
+    FWSTAMP(6);
     // fragments -> LDS -> coalesced stores
     __builtin_amdgcn_wave_barrier();
     frag_to_lds(ta, j, h, zz);
@@ -127,19 +144,31 @@ __global__ __launch_bounds__(LAYER_WG) void layer_fwd_kernel(
       rows_store(sg + off0, lane, hi, rows_from_lds(tb, lane));
     }
     if (SAVE == 2) rows_store(sg + off0, lane, hi, rows_from_lds(tb, lane));
+    FWSTAMP(7);
     if (HAS_DENSE) {
       const f32x16 bd = frag_bcast(wl + LAYER_W_FLOATS + (woff - j - 128 * h), h);
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = xc[r] + bd[r];
       mma32<32>(acc, zz, wlane + 4 * 1024);  // Wd
+      FWSTAMP(8);
       __builtin_amdgcn_wave_barrier();
       frag_to_lds(ta, j, h, acc);
       __builtin_amdgcn_wave_barrier();
       rows_store(xo + off0, lane, hi, rows_from_lds(ta, lane));
     }
+    FWSTAMP(9);
+#ifdef FWD_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores drained (diagnostic only)
+#endif
+    FWSTAMP(10);
     __builtin_amdgcn_wave_barrier();
   }
+#ifdef FWD_STAMPS
+  if ((threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == 15))
+    dbg[((size_t)blockIdx.x * 2 + ((threadIdx.x >> 6) == 15)) * 16 + 15] = __builtin_amdgcn_s_memrealtime();
+#endif
+#undef FWSTAMP
 }
 
 // Backward-data.  Phase B of layer l then phase A of layer l-1 on the same

@@ -106,3 +106,23 @@ def test_bench_rejects_rank_count_mismatch():
                        timeout=300)
     assert p.returncode != 0
     assert b'WORLD_SIZE 1 != --gpus 8' in p.stderr
+
+
+def test_bench_self_launch_reports_rank_failure():
+    """`python bench.py --gpus 2` run plainly (no WORLD_SIZE) starts the rank
+    processes itself; without GPUs every rank must fail loudly and the
+    launcher must hand that failure on (non-zero exit), not hang or print a
+    one-GPU number."""
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'WN_SHARE_GPU'):
+        env.pop(k, None)
+    import torch as _t
+    if _t.cuda.is_available():
+        pytest.skip('needs a box without GPUs')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'),
+                        '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=600)
+    assert p.returncode != 0
+    assert b'has no GPU' in p.stderr
+    assert b'"metric"' not in p.stdout

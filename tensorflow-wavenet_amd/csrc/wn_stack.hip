@@ -1,0 +1,332 @@
+// The whole residual stack in ONE launch: a persistent, dependency-driven
+// version of layer_fwd_kernel (wn_layer.hip) for
+// WaveNetModel._create_dilation_layer x L (wavenet/model.py:236-330, the loop
+// at model.py:417-428).
+//
+// A per-layer launch pays a fixed start and end (launch, weight staging, first
+// loads, the slowest wave's tail: ~5 us of the forward kernel's 21 us at
+// B*T = 128000) fifty times, and reloads from HBM the tile it has just written.
+// Here a workgroup keeps a GROUP of 16 consecutive 32-row tiles (one per wave)
+// and walks it through all L layers:
+//   * the tile's own rows x_l[t] never leave the wave's registers: the dense
+//     1x1 accumulator of layer l IS the B operand of layer l+1;
+//   * the dilated tap x_l[t-d] belongs to another wave (another workgroup,
+//     usually another XCD): x_{l+1} is written through to memory (sc1 stores),
+//     the producer publishes flag[l+1][tile] = epoch after `s_waitcnt vmcnt(0)`,
+//     the consumer polls the flag(s) of the one or two tiles its rows come from
+//     and reads them with sc1 loads (the per-XCD L2s are not coherent with
+//     each other; sc1 accesses are performed at device scope);
+//   * the next layer's 20 KB of weights are fetched by LDS-DMA into the other
+//     half of a double buffer while the current layer computes.
+// No grid-wide barrier anywhere: a wave waits only for the tiles it reads.
+//
+// Deadlock freedom does not depend on how many workgroups are resident: groups
+// are handed out by an atomic ticket in increasing order, a group's rows depend
+// only on rows of the same or LOWER groups (the taps are causal), and a
+// workgroup finishes all layers of its group before it takes another ticket --
+// so the lowest unfinished group can always run to completion.  Every poll is
+// additionally bounded (2 s of s_memrealtime): on expiry the wave records
+// ctl[3] = 1 and carries on without waiting, so the grid always drains.
+#include "wn_common.h"
+
+#define STACK_WG 1024
+#define STACK_WAVES (STACK_WG / 64)
+#define STACK_WBUF (LAYER_W_FLOATS + 256)   // 21 KiB: keeps both halves 1 KiB aligned
+
+struct StackFwd {
+  float* X;            // [L][N][32]  X[l] = input of layer l (X[0]: causal layer)
+  float* Z;            // [L][N][32]
+  float* SG;           // [L][N][32] sigmoid planes (SAVE == 2) or null
+  const float* params; // layer 0's parameter block
+  long layer_stride;   // floats between layer blocks
+  const float* bias;   // [L][B or 1][64] filter|gate bias (+ gc), or null
+  long bias_layer_stride;
+  int bias_clip_stride;
+  const int* dil;      // [L] dilations (device)
+  unsigned* flags;     // [L][ntiles]
+  unsigned* ctl;       // [0] group ticket [1] workgroups done [2] epoch [3] error
+  int L, B, T;
+  long plane;          // N * 32 floats
+#ifdef STACK_STAMPS
+  unsigned long long* dbg;   // diagnostic build: [grid][2][L][8] s_memtime stamps
+#endif
+};
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// device-scope (sc1) row-contiguous tile access: same lane <-> row mapping as
+// rows_load / rows_store of wn_common.h
+__device__ __forceinline__ RowRegs rows_load_dev(const float* tile0, int lane,
+                                                 int lo, int hi) {
+  RowRegs R;
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)tile0, 0, 0x7fffffff, 0x00020000);
+  const int vo = ((lane >> 3) * 32 + (lane & 7) * 4) * 4;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int r = 8 * c + (lane >> 3);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r >= lo && r < hi)
+      v = __builtin_bit_cast(
+          f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo + c * 1024, 0, 16));
+    R.v[c] = v;
+  }
+  return R;
+}
+
+__device__ __forceinline__ void rows_store_dev(float* tile0, int lane, int hi,
+                                               const RowRegs& R) {
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)tile0, 0, 0x7fffffff, 0x00020000);
+  const int vo = ((lane >> 3) * 32 + (lane & 7) * 4) * 4;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int r = 8 * c + (lane >> 3);
+    if (r < hi)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, R.v[c]),
+                                             rs, vo + c * 1024, 0, 16);
+  }
+}
+
+// poll until flag[idx] == epoch on every lane that has an idx >= 0
+__device__ __forceinline__ void wait_flags(const unsigned* fl, int idx,
+                                           unsigned epoch, unsigned* ctl,
+                                           bool& dead, int lane) {
+  if (dead) return;
+  unsigned spins = 0;
+  unsigned long long t_start = 0;
+  for (;;) {
+    bool pending = false;
+    if (idx >= 0)
+      pending = __hip_atomic_load(fl + idx, __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_AGENT) != epoch;
+    if (__builtin_amdgcn_ballot_w64(pending) == 0) break;
+    if ((++spins & 63u) == 0) {
+      const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+      if (t_start == 0) t_start = now;
+      if (now - t_start > 200000000ull) {   // 2 s at 100 MHz
+        if (lane == 0)
+          __hip_atomic_store(ctl + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        dead = true;
+        break;
+      }
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  asm volatile("" ::: "memory");
+}
+
+template <int SAVE>
+__global__ __launch_bounds__(STACK_WG) void stack_fwd_kernel(StackFwd a) {
+  __shared__ __attribute__((aligned(1024))) float wl[2 * STACK_WBUF];
+  __shared__ __attribute__((aligned(16))) float tiles[STACK_WAVES * 1024];
+  __shared__ int s_group;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int T = a.T, L = a.L;
+  const int tiles_per_clip = (T + 31) >> 5;
+  const int ntiles = tiles_per_clip * a.B;
+  const int ngroups = (ntiles + STACK_WAVES - 1) / STACK_WAVES;
+  const unsigned epoch =
+      __hip_atomic_load(a.ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  float* ta = tiles + wave * 1024;
+  bool dead = false;
+#ifdef STACK_STAMPS
+#define SSTAMP(l, i)                                                         \
+  if (lane == 0 && (wave == 0 || wave == STACK_WAVES - 1))                   \
+    a.dbg[(((size_t)blockIdx.x * 2 + (wave != 0)) * L + (l)) * 8 + (i)] =    \
+        __builtin_amdgcn_s_memtime()
+  // clock calibration per workgroup: {realtime, memtime} at entry and exit
+  unsigned long long* cal = a.dbg + (size_t)gridDim.x * 2 * L * 8 + (size_t)blockIdx.x * 4;
+  if (tid == 0) { cal[0] = __builtin_amdgcn_s_memrealtime(); cal[1] = __builtin_amdgcn_s_memtime(); }
+#else
+#define SSTAMP(l, i)
+#endif
+
+  auto issue_weights = [&](int l, int buf) {
+    const float* wb = a.params + (long)l * a.layer_stride;
+    float* dst = wl + buf * STACK_WBUF;
+    for (int p = wave; p < LAYER_W_FLOATS / 256; p += STACK_WAVES)
+      __builtin_amdgcn_global_load_lds((wn_gptr_t)(wb + p * 256 + lane * 4),
+                                       (wn_lptr_t)(dst + p * 256), 16, 0, 0);
+    if (tid < 32) dst[LAYER_W_FLOATS + tid] = wb[LAYER_OFF_BD + tid];
+  };
+
+  for (;;) {
+    if (tid == 0) s_group = (int)atomicAdd(a.ctl, 1u);
+    __syncthreads();
+    const int g = __builtin_amdgcn_readfirstlane(s_group);
+    __syncthreads();
+    if (g >= ngroups) break;
+    const int tile = g * STACK_WAVES + wave;
+    const bool any = tile < ntiles;
+    const int b = any ? tile / tiles_per_clip : 0;
+    const int tt = any ? tile - b * tiles_per_clip : 0;   // tile index inside the clip
+    const int t0 = tt * 32;
+    const int hi = any ? min(32, T - t0) : 0;
+    const size_t off0 = ((size_t)b * T + t0) * WN_CH;
+
+    issue_weights(0, 0);
+    f32x16 xc;
+    {
+      const RowRegs rc = rows_load_dev(a.X + off0, lane, 0, hi);
+      rows_to_lds(ta, lane, rc);
+      __builtin_amdgcn_wave_barrier();
+      xc = frag_from_lds(ta, j, h);
+    }
+
+    for (int l = 0; l < L; ++l) {
+      const int d = a.dil[l];
+      SSTAMP(l, 0);
+      // layer l's weights have landed for every wave, and every wave is
+      // through layer l-1 (the other buffer is free)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (l + 1 < L) issue_weights(l + 1, (l + 1) & 1);
+      if (!any) continue;
+      SSTAMP(l, 1);
+      const float* xl = a.X + (size_t)l * a.plane;
+      // ---- the dilated tap: rows t0-d .. t0-d+31 of x_l, written by the
+      // owners of (at most) two tiles of this clip
+      const int lo_row = t0 - d;
+      if (l > 0 && lo_row + 31 >= 0) {
+        const int first = max(lo_row, 0) >> 5, last = (lo_row + 31) >> 5;
+        int idx = -1;
+        if (lane == 0 && first != tt) idx = b * tiles_per_clip + first;
+        if (lane == 1 && last != first && last != tt) idx = b * tiles_per_clip + last;
+        wait_flags(a.flags + (size_t)l * ntiles, idx, epoch, a.ctl, dead, lane);
+      }
+      SSTAMP(l, 2);
+      f32x16 xp;
+      {
+        const RowRegs rp = rows_load_dev(xl + off0 - (size_t)d * WN_CH, lane,
+                                         max(0, d - t0), hi);
+        __builtin_amdgcn_wave_barrier();
+        rows_to_lds(ta, lane, rp);
+        __builtin_amdgcn_wave_barrier();
+        xp = frag_from_lds(ta, j, h);
+      }
+#ifdef STACK_STAMPS
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+      SSTAMP(l, 3);
+      int woff = j + 4 * h * 32 + (l & 1) * STACK_WBUF;
+      asm volatile("" : "+v"(woff));
+      const float* wlane = wl + woff;
+      f32x16 af, ag;
+      if (a.bias) {
+        const float* bp = a.bias + (size_t)l * a.bias_layer_stride +
+                          (size_t)b * a.bias_clip_stride;
+        af = frag_bcast(bp, h);
+        ag = frag_bcast(bp + 32, h);
+      } else {
+        af = frag_zero();
+        ag = frag_zero();
+      }
+      mma32<32>(af, xp, wlane + 0 * 1024);  // Wf[0]: past tap
+      mma32<32>(af, xc, wlane + 1 * 1024);  // Wf[1]: current tap
+      mma32<32>(ag, xp, wlane + 2 * 1024);  // Wg[0]
+      mma32<32>(ag, xc, wlane + 3 * 1024);  // Wg[1]
+      SSTAMP(l, 4);
+      f32x16 zz;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        af[r] = wn_tanh(af[r]);
+        ag[r] = wn_sigmoid(ag[r]);
+        zz[r] = af[r] * ag[r];
+      }
+      __builtin_amdgcn_wave_barrier();
+      frag_to_lds(ta, j, h, zz);
+      __builtin_amdgcn_wave_barrier();
+      rows_store(a.Z + (size_t)l * a.plane + off0, lane, hi, rows_from_lds(ta, lane));
+      if (SAVE == 2) {
+        __builtin_amdgcn_wave_barrier();
+        frag_to_lds(ta, j, h, ag);
+        __builtin_amdgcn_wave_barrier();
+        rows_store(a.SG + (size_t)l * a.plane + off0, lane, hi, rows_from_lds(ta, lane));
+      }
+      SSTAMP(l, 5);
+      if (l + 1 < L) {
+        const f32x16 bd = frag_bcast(wl + (l & 1) * STACK_WBUF + LAYER_W_FLOATS, h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xc[r] += bd[r];
+        mma32<32>(xc, zz, wlane + 4 * 1024);  // Wd
+        SSTAMP(l, 6);
+        __builtin_amdgcn_wave_barrier();
+        frag_to_lds(ta, j, h, xc);
+        __builtin_amdgcn_wave_barrier();
+        rows_store_dev(a.X + (size_t)(l + 1) * a.plane + off0, lane, hi,
+                       rows_from_lds(ta, lane));
+        // x_{l+1} of this tile is in memory: publish it
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0)
+          __hip_atomic_store(a.flags + (size_t)(l + 1) * ntiles + tile, epoch,
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        SSTAMP(l, 7);
+      }
+    }
+    __syncthreads();   // every wave is through the last layer: wl is free again
+  }
+#ifdef STACK_STAMPS
+  if (tid == 0) { cal[2] = __builtin_amdgcn_s_memrealtime(); cal[3] = __builtin_amdgcn_s_memtime(); }
+#endif
+  // the last workgroup to leave re-arms the control block for the next launch
+  if (tid == 0) {
+    const unsigned done = atomicAdd(a.ctl + 1, 1u);
+    if (done == gridDim.x - 1) {
+      __hip_atomic_store(a.ctl + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.ctl + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.ctl + 2, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+#ifdef STACK_STAMPS
+static unsigned long long* g_stack_dbg = nullptr;
+extern "C" int wn_diag_stack_dbg(unsigned long long* p) { g_stack_dbg = p; return WN_OK; }
+#endif
+
+extern "C" {
+
+// unsigned ints of `flags` for a (B, T, L) problem
+long wn_stack_flag_count(int B, int T, int L) {
+  if (B <= 0 || T <= 0 || L <= 0) return 0;
+  return (long)L * B * ((T + 31) / 32);
+}
+
+int wn_stack_fwd(float* X, float* Z, float* SG, const float* params,
+                 long layer_stride, const float* bias, long bias_layer_stride,
+                 int bias_clip_stride, const int* dilations, unsigned* flags,
+                 unsigned* ctl, int L, int B, int T, int save_sg, void* stream) {
+  if (!X || !Z || !params || !dilations || !flags || !ctl) return WN_ERR_NULL;
+  if (save_sg && !SG) return WN_ERR_NULL;
+  if (L <= 0 || B <= 0 || T <= 0 || layer_stride < LAYER_BLOCK_FLOATS)
+    return WN_ERR_BAD_SHAPE;
+  if (!wn_aligned16(X) || !wn_aligned16(Z) || (SG && !wn_aligned16(SG)) ||
+      !wn_aligned16(params) || (layer_stride & 3))
+    return WN_ERR_MISALIGNED;
+  StackFwd a;
+  a.X = X; a.Z = Z; a.SG = SG; a.params = params; a.layer_stride = layer_stride;
+  a.bias = bias; a.bias_layer_stride = bias_layer_stride;
+  a.bias_clip_stride = bias_clip_stride; a.dil = dilations; a.flags = flags;
+  a.ctl = ctl; a.L = L; a.B = B; a.T = T; a.plane = (long)B * T * WN_CH;
+#ifdef STACK_STAMPS
+  if (!g_stack_dbg) return WN_ERR_NULL;
+  a.dbg = g_stack_dbg;
+#endif
+  const long ntiles = (long)B * ((T + 31) / 32);
+  long g = (ntiles + STACK_WAVES - 1) / STACK_WAVES;
+  const int cus = wn_device_cus();
+  if (g > cus) g = cus;
+  dim3 grid((unsigned)g), block(STACK_WG);
+  hipStream_t s = (hipStream_t)stream;
+  if (save_sg)
+    hipLaunchKernelGGL((stack_fwd_kernel<2>), grid, block, 0, s, a);
+  else
+    hipLaunchKernelGGL((stack_fwd_kernel<0>), grid, block, 0, s, a);
+  return wn_check_launch();
+}
+
+}  // extern "C"

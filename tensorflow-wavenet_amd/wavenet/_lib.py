@@ -31,6 +31,9 @@ SIGNATURES = {
     'wn_causal_wgrad': (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     'wn_layer_fwd': (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int,
                              c_int, c_int, P]),
+    'wn_stack_flag_count': (c_long, [c_int, c_int, c_int]),
+    'wn_stack_fwd': (c_int, [P, P, P, P, c_long, P, c_long, c_int, P, P, P,
+                             c_int, c_int, c_int, c_int, P]),
     'wn_layer_bwd': (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int,
                              c_int, c_int, c_int, P]),
     'wn_layer_wgrad_slab_floats': (c_int, []),

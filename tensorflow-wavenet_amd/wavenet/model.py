@@ -17,6 +17,7 @@ There is no CPU / PyTorch compute fallback: without the HIP library or a GPU
 every entry point raises.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -87,6 +88,14 @@ class _Workspace(object):
         alloc('h2', (N, S))
         alloc('logits', (N, Q))
         alloc('bias_fg', (L, B, 2 * CHn))
+        # persistent residual-stack kernels (wn_stack_fwd): one "rows are in
+        # memory" flag per (layer, 32-row tile) and a 4-word control block
+        # {group ticket, workgroups done, epoch, error}; epochs start at 1
+        alloc('stack_flags', (lib.wn_stack_flag_count(B, T, L),), torch.int32,
+              fill=0)
+        alloc('stack_ctl', (4,), torch.int32, fill=0)
+        if parent is None:
+            self.stack_ctl[2] = 1
         alloc('bsum', (S,))
         self.total = alloc('total', (N, S)) if net.residual_postproc else None
         self.nparts = lib.wn_xent_partials(N)
@@ -219,6 +228,11 @@ class WaveNetModel(object):
         # un-fused data / weight kernel pair.  Kept for A/B and tests.
         self.layer_bwd = 'bwd2'
         self.fused_bwd = True
+        # forward of the residual stack as ONE persistent launch
+        # (wn_stack_fwd: tiles stay in registers from layer to layer, the
+        # dilated taps are handed over through per-tile flags) instead of one
+        # wn_layer_fwd launch per layer.  WN_STACK_FWD=0 selects the latter.
+        self.stack_fwd = os.environ.get('WN_STACK_FWD', '1') != '0'
         # generate(): four kernels per sample over many CUs, replayed from a
         # hipGraph, instead of the single-workgroup persistent kernel
         self.fastgen_multi_cu = True
@@ -284,6 +298,8 @@ class WaveNetModel(object):
         self.LAYER_BLOCK = self.LAYER_W + 3 * C
         self.OFF_GC = self.LAYER_BLOCK
         self._ws = {}
+        self._dil_dev = torch.tensor(self.dilations, dtype=torch.int32,
+                                     device=self.device)
         self._gen = None
         self.init_ops = []
         self.push_ops = []
@@ -616,7 +632,7 @@ class WaveNetModel(object):
     # ------------------------------------------------------------ launch plans
     def _plan_key(self, tag, ws, ids, extra):
         return (tag, extra, ids is not None, self.generic_layers,
-                self.fused_bwd, self.layer_bwd, self.overlap_tn, self.gemm_mode, self.causal_wgrad_segsum, self.tf_xent_zero_label_quirk,
+                self.fused_bwd, self.layer_bwd, self.overlap_tn, self.stack_fwd, self.gemm_mode, self.causal_wgrad_segsum, self.tf_xent_zero_label_quirk,
                 _lib.stream(), self.params.data_ptr(), self.grads.data_ptr())
 
     def _stage_ids(self, ws, ids):
@@ -683,7 +699,20 @@ class WaveNetModel(object):
         if self.CB > 1:
             from . import blocked
             blocked.forward_layers(self, ws, bias, bstride, bool(save_ts), st)
-        for l, d in enumerate(self.dilations if self.CB == 1 else []):
+        stack = (self.stack_fwd and self.CB == 1 and not self.generic_layers
+                 and save_ts in (0, 2) and B * ((T + 31) // 32) >= 1024)
+        if stack:
+            # all L layers in one persistent launch (csrc/wn_stack.hip)
+            _lib.call('wn_stack_fwd', _lib.ptr(ws.X), _lib.ptr(ws.Z),
+                      _lib.ptr(ws.SG) if save_ts else None,
+                      _lib.ptr(self._layer_block(P, 0)), self.layer_stride,
+                      None if bias is None else _lib.ptr(bias),
+                      0 if bias is None else bias.shape[1] * bias.shape[2],
+                      bstride, _lib.ptr(self._dil_dev),
+                      _lib.ptr(ws.stack_flags), _lib.ptr(ws.stack_ctl),
+                      L, B, T, 1 if save_ts else 0, st)
+        for l, d in enumerate(self.dilations if self.CB == 1 and not stack
+                              else []):
             last = l == L - 1
             fargs = (_lib.ptr(ws.X[l]),
                      None if last else _lib.ptr(ws.X[l + 1]),

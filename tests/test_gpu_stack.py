@@ -1,0 +1,89 @@
+"""The persistent residual-stack launch (csrc/wn_stack.hip, `net.stack_fwd`)
+against the one-launch-per-layer kernels it replaces: same arithmetic in the
+same order, so every activation plane, the logits, the loss and every gradient
+must be BITWISE equal (model.py:236-330 x L, model.py:417-428).  The
+per-layer path is itself checked against the oracle in test_gpu_model.py."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from util import ROOT, TINY, build_pair, cfg_with, synth_audio
+
+pytestmark = pytest.mark.gpu
+
+
+def default_cfg(B, **kw):
+    p = json.load(open(os.path.join(ROOT, 'wavenet_params.json')))
+    c = {k: p[k] for k in p if k != 'sample_rate'}
+    c['batch_size'] = B
+    c.update(kw)
+    return c
+
+
+def _pair(cfg):
+    """two models with identical weights (biases N(0, 0.1)): persistent stack
+    launch vs one launch per layer"""
+    a, _ = build_pair(cfg)
+    b, _ = build_pair(cfg)
+    assert torch.equal(a.params, b.params)
+    a.stack_fwd, b.stack_fwd = True, False
+    return a, b
+
+
+def _ctl(net):
+    ws = list(net._ws.values())
+    return [w.stack_ctl.cpu().tolist() for w in ws]
+
+
+CASES = [
+    ('default_B8_T16000', lambda: default_cfg(8), 8, 16000, None),
+    ('default_B1_T16000', lambda: default_cfg(1), 1, 16000, None),
+    ('default_B3_T5211', lambda: default_cfg(3), 3, 5211, None),       # ragged last tile
+    ('default_B20_T16000', lambda: default_cfg(20), 20, 16000, None),  # more groups than CUs
+    ('default_gc_B4_T7000', lambda: default_cfg(
+        4, global_condition_channels=32, global_condition_cardinality=377), 4, 7000, 'gc'),
+    ('tiny_B2_T100', lambda: cfg_with(TINY, batch_size=2), 2, 100, None),
+    ('default_nobias_B2_T4000', lambda: default_cfg(2, use_biases=False), 2, 4000, None),
+]
+
+
+@pytest.mark.parametrize('name,mk,B,T,kind', CASES, ids=[c[0] for c in CASES])
+def test_stack_forward_bitwise_equals_per_layer(hip_lib, name, mk, B, T, kind):
+    cfg = mk()
+    a, b = _pair(cfg)
+    audio = synth_audio(B, T)
+    gc = None
+    if kind == 'gc':
+        gc = np.array([(37 * i) % 377 for i in range(B)], np.int32)
+    for rep in range(3):        # epochs 1, 2, 3 on the same workspace (and the launch plan)
+        la = a.loss(audio, global_condition_batch=gc) if gc is not None else a.loss(audio)
+        lb = b.loss(audio, global_condition_batch=gc) if gc is not None else b.loss(audio)
+        torch.cuda.synchronize()
+        wa, wb = list(a._ws.values())[0], list(b._ws.values())[0]
+        for pl in ('X', 'Z', 'SG'):
+            pa, pb = getattr(wa, pl), getattr(wb, pl)
+            if not torch.equal(pa, pb):
+                bad = [l for l in range(pa.shape[0]) if not torch.equal(pa[l], pb[l])]
+                raise AssertionError('%s planes differ at layers %s (rep %d)' % (pl, bad[:8], rep))
+        assert float(la) == float(lb)
+        assert torch.equal(a.grads, b.grads)
+        ctl = wa.stack_ctl.cpu().tolist()
+        assert ctl[0] == 0 and ctl[1] == 0 and ctl[3] == 0, ctl
+        assert ctl[2] == 2 + rep, ctl
+
+
+def test_stack_inference_forward(hip_lib):
+    """predict_proba / loss(backward=False): no sigmoid planes."""
+    a, b = _pair(default_cfg(1))
+    audio = synth_audio(1, 6000)
+    a.loss(audio, backward=False)
+    b.loss(audio, backward=False)
+    wa, wb = list(a._ws.values())[0], list(b._ws.values())[0]
+    assert torch.equal(wa.logits, wb.logits)
+    q = np.random.default_rng(2).integers(0, 256, 3000).astype(np.int32)
+    assert torch.equal(a.predict_proba(q), b.predict_proba(q))
+    for ws in a._ws.values():
+        assert ws.stack_ctl.cpu().tolist()[3] == 0

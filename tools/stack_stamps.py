@@ -1,0 +1,66 @@
+"""In-kernel phase stamps of stack_fwd_kernel (diagnostic build -DSTACK_STAMPS,
+loaded through WN_LIB_PATH): per layer, for the first and the last wave of
+every workgroup."""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, 'tensorflow-wavenet_amd')
+if 'WN_LIB_PATH' not in os.environ:
+    out = os.path.join(PKG, 'build', 'ab', 'lib_stack_stamps.so')
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    srcs = [os.path.join(PKG, 'csrc', f) for f in
+            ('wn_layer.hip', 'wn_stack.hip', 'wn_gemm.hip', 'wn_misc.hip', 'wn_fastgen.hip')]
+    subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
+                           '-DSTACK_STAMPS', '-shared', '-o', out] + srcs)
+    os.environ['WN_LIB_PATH'] = out
+    if len(sys.argv) > 1 and sys.argv[1] == 'build':
+        sys.exit(0)
+sys.path.insert(0, PKG)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import ctypes
+import json
+import numpy as np
+import torch
+from wavenet import _lib, WaveNetModel
+from util import model_kwargs, synth_audio
+lib = _lib.load()
+B, T = int(os.environ.get('KB_B', 8)), 16000
+p = json.load(open(os.path.join(ROOT, 'wavenet_params.json')))
+cfg = {k: p[k] for k in p if k != 'sample_rate'}
+cfg['batch_size'] = B
+net = WaveNetModel(seed=0, **model_kwargs(cfg))
+net.use_launch_plans = False
+L = net.L
+grid = min(256, (B * (T // 32) + 15) // 16)
+dbg = torch.zeros(grid * 2 * L * 8 + grid * 4, dtype=torch.int64, device='cuda')
+lib.wn_diag_stack_dbg.argtypes = [ctypes.c_void_p]
+lib.wn_diag_stack_dbg(dbg.data_ptr())
+audio = synth_audio(B, T)
+for it in range(4):
+    dbg.zero_()
+    net.loss(audio)
+torch.cuda.synchronize()
+raw = dbg.cpu().numpy()
+s = raw[:grid * 2 * L * 8].reshape(grid, 2, L, 8).astype(np.float64)
+cal = raw[grid * 2 * L * 8:].reshape(grid, 4).astype(np.float64)
+clk = np.median((cal[:, 3] - cal[:, 1]) / ((cal[:, 2] - cal[:, 0]) * 10.0))    # GHz
+print('clock %.2f GHz; kernel (entry -> exit of a workgroup) median %.1f us, max %.1f us' % (
+    clk, np.median(cal[:, 2] - cal[:, 0]) / 100.0, (cal[:, 2].max() - cal[:, 0].min()) / 100.0))
+names = ['top of layer', 'weights barrier', 'flags seen', "x[t-d] in fragments", '64 conv MFMAs',
+         'tanh/sigmoid, z + sigmoid stores issued', 'dense MFMAs', "x' stored, drained, flag posted"]
+for wv in (0, 1):
+    print('--- wave %d of the workgroup: median over workgroups and layers 1..L-2, us per phase' % (0 if wv == 0 else 15))
+    tot = 0
+    for i in range(1, 8):
+        dt = (s[:, wv, 1:L - 1, i] - s[:, wv, 1:L - 1, i - 1]) / clk / 1e3
+        print('%-42s %6.2f   (p90 %6.2f)' % (names[i], np.median(dt), np.percentile(dt, 90)))
+        tot += np.median(dt)
+    per = (s[:, wv, 2:L - 1, 0] - s[:, wv, 1:L - 2, 0]) / clk / 1e3
+    print('%-42s %6.2f   (sum of medians %.2f)' % ('layer period', np.median(per), tot))
+# by dilation
+dil = net.dilations
+print('--- layer period by dilation (wave 0, median over workgroups)')
+per = (s[:, 0, 1:, 0] - s[:, 0, :-1, 0]) / clk / 1e3
+for l in range(0, L - 1):
+    if l < 12 or l % 10 == 0:
+        wf = (s[:, 0, l, 2] - s[:, 0, l, 1]) / clk / 1e3
+        print('layer %2d d=%3d: period %6.2f us, flag wait %5.2f us' % (l, dil[l], np.median(per[:, l]), np.median(wf)))

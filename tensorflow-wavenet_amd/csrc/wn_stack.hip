@@ -6,8 +6,8 @@
 // A per-layer launch pays a fixed start and end (launch, weight staging, first
 // loads, the slowest wave's tail: ~5 us of the forward kernel's 21 us at
 // B*T = 128000) fifty times, and reloads from HBM the tile it has just written.
-// Here a workgroup keeps a GROUP of 16 consecutive 32-row tiles (one per wave)
-// and walks it through all L layers:
+// Here a workgroup keeps a GROUP of consecutive 32-row tiles (one per wave, 16
+// waves unless the batch is small) and walks it through all L layers:
 //   * the tile's own rows x_l[t] never leave the wave's registers: the dense
 //     1x1 accumulator of layer l IS the B operand of layer l+1;
 //   * the dilated tap x_l[t-d] belongs to another wave (another workgroup,
@@ -16,8 +16,11 @@
 //     the consumer polls the flag(s) of the one or two tiles its rows come from
 //     and reads them with sc1 loads (the per-XCD L2s are not coherent with
 //     each other; sc1 accesses are performed at device scope);
-//   * the next layer's 20 KB of weights are fetched by LDS-DMA into the other
-//     half of a double buffer while the current layer computes.
+//   * weights sit in a two-layer LDS ring: the wave that is LAST to finish
+//     layer l refills that layer's half with layer l+2 by LDS-DMA and marks it
+//     ready one layer later; the waves of a workgroup are never held at a
+//     barrier inside the stack and drift up to a layer apart, so one wave's
+//     flag / load latency hides under the MFMAs of the others on its SIMD.
 // No grid-wide barrier anywhere: a wave waits only for the tiles it reads.
 //
 // Deadlock freedom does not depend on how many workgroups are resident: groups
@@ -29,8 +32,7 @@
 // ctl[3] = 1 and carries on without waiting, so the grid always drains.
 #include "wn_common.h"
 
-#define STACK_WG 1024
-#define STACK_WAVES (STACK_WG / 64)
+#define STACK_MAXL 256   // layers (LDS bookkeeping words per layer)
 #define STACK_WBUF (LAYER_W_FLOATS + 256)   // 21 KiB: keeps both halves 1 KiB aligned
 
 struct StackFwd {
@@ -48,7 +50,7 @@ struct StackFwd {
   int L, B, T;
   long plane;          // N * 32 floats
 #ifdef STACK_STAMPS
-  unsigned long long* dbg;   // diagnostic build: [grid][2][L][8] s_memtime stamps
+  unsigned long long* dbg;   // diagnostic build: [grid][16][L][12] s_memtime stamps
 #endif
 };
 
@@ -116,11 +118,23 @@ __device__ __forceinline__ void wait_flags(const unsigned* fl, int idx,
   asm volatile("" ::: "memory");
 }
 
-template <int SAVE>
-__global__ __launch_bounds__(STACK_WG) void stack_fwd_kernel(StackFwd a) {
+// bounded spin on a workgroup-local LDS word
+__device__ __forceinline__ void wait_lds(const int* p, bool& dead) {
+  unsigned spins = 0;
+  while (!dead && __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > (1u << 24)) dead = true;
+  }
+  asm volatile("" ::: "memory");
+}
+
+template <int SAVE, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void stack_fwd_kernel(StackFwd a) {
   __shared__ __attribute__((aligned(1024))) float wl[2 * STACK_WBUF];
-  __shared__ __attribute__((aligned(16))) float tiles[STACK_WAVES * 1024];
+  __shared__ __attribute__((aligned(16))) float tiles[WAVES * 1024];
   __shared__ int s_group;
+  // per layer: waves that no longer read its weights / its weights are in LDS
+  __shared__ int s_done[STACK_MAXL], s_ready[STACK_MAXL];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -128,30 +142,36 @@ __global__ __launch_bounds__(STACK_WG) void stack_fwd_kernel(StackFwd a) {
   const int T = a.T, L = a.L;
   const int tiles_per_clip = (T + 31) >> 5;
   const int ntiles = tiles_per_clip * a.B;
-  const int ngroups = (ntiles + STACK_WAVES - 1) / STACK_WAVES;
+  const int ngroups = (ntiles + WAVES - 1) / WAVES;
   const unsigned epoch =
       __hip_atomic_load(a.ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   float* ta = tiles + wave * 1024;
   bool dead = false;
 #ifdef STACK_STAMPS
 #define SSTAMP(l, i)                                                         \
-  if (lane == 0 && (wave == 0 || wave == STACK_WAVES - 1))                   \
-    a.dbg[(((size_t)blockIdx.x * 2 + (wave != 0)) * L + (l)) * 8 + (i)] =    \
+  if (lane == 0)                                                             \
+    a.dbg[(((size_t)blockIdx.x * 16 + wave) * L + (l)) * 12 + (i)] =         \
         __builtin_amdgcn_s_memtime()
   // clock calibration per workgroup: {realtime, memtime} at entry and exit
-  unsigned long long* cal = a.dbg + (size_t)gridDim.x * 2 * L * 8 + (size_t)blockIdx.x * 4;
+  unsigned long long* cal = a.dbg + (size_t)gridDim.x * 16 * L * 12 + (size_t)blockIdx.x * 4;
   if (tid == 0) { cal[0] = __builtin_amdgcn_s_memrealtime(); cal[1] = __builtin_amdgcn_s_memtime(); }
 #else
 #define SSTAMP(l, i)
 #endif
 
-  auto issue_weights = [&](int l, int buf) {
+  // pieces [p0, p0 + step, ...) of layer l's 20 KiB of weights by LDS-DMA, and
+  // (from the wave that takes piece 0) its dense bias as one 4-byte-per-lane
+  // piece: floats LAYER_OFF_BD .. +63 of the block (the second half belongs to
+  // the next layer's block and is never read; the last layer has no dense conv)
+  auto issue_weights = [&](int l, int p0, int step) {
     const float* wb = a.params + (long)l * a.layer_stride;
-    float* dst = wl + buf * STACK_WBUF;
-    for (int p = wave; p < LAYER_W_FLOATS / 256; p += STACK_WAVES)
+    float* dst = wl + (l & 1) * STACK_WBUF;
+    for (int p = p0; p < LAYER_W_FLOATS / 256; p += step)
       __builtin_amdgcn_global_load_lds((wn_gptr_t)(wb + p * 256 + lane * 4),
                                        (wn_lptr_t)(dst + p * 256), 16, 0, 0);
-    if (tid < 32) dst[LAYER_W_FLOATS + tid] = wb[LAYER_OFF_BD + tid];
+    if (p0 == 0 && l + 1 < L)
+      __builtin_amdgcn_global_load_lds((wn_gptr_t)(wb + LAYER_OFF_BD + lane),
+                                       (wn_lptr_t)(dst + LAYER_W_FLOATS), 4, 0, 0);
   };
 
   for (;;) {
@@ -160,7 +180,8 @@ __global__ __launch_bounds__(STACK_WG) void stack_fwd_kernel(StackFwd a) {
     const int g = __builtin_amdgcn_readfirstlane(s_group);
     __syncthreads();
     if (g >= ngroups) break;
-    const int tile = g * STACK_WAVES + wave;
+    const int tile = g * WAVES + wave;
+    const int nactive = min(WAVES, ntiles - g * WAVES);
     const bool any = tile < ntiles;
     const int b = any ? tile / tiles_per_clip : 0;
     const int tt = any ? tile - b * tiles_per_clip : 0;   // tile index inside the clip
@@ -168,7 +189,12 @@ __global__ __launch_bounds__(STACK_WG) void stack_fwd_kernel(StackFwd a) {
     const int hi = any ? min(32, T - t0) : 0;
     const size_t off0 = ((size_t)b * T + t0) * WN_CH;
 
-    issue_weights(0, 0);
+    for (int i = tid; i < L; i += WAVES * 64) {
+      s_done[i] = 0;
+      s_ready[i] = i < 2;
+    }
+    issue_weights(0, wave, WAVES);
+    if (L > 1) issue_weights(1, wave, WAVES);
     f32x16 xc;
     {
       const RowRegs rc = rows_load_dev(a.X + off0, lane, 0, hi);
@@ -176,16 +202,14 @@ __global__ __launch_bounds__(STACK_WG) void stack_fwd_kernel(StackFwd a) {
       __builtin_amdgcn_wave_barrier();
       xc = frag_from_lds(ta, j, h);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();        // weights of layers 0 and 1 are in LDS
+    int publish = 0;        // layer whose weights this wave has in flight
 
-    for (int l = 0; l < L; ++l) {
+    for (int l = 0; any && l < L; ++l) {
       const int d = a.dil[l];
       SSTAMP(l, 0);
-      // layer l's weights have landed for every wave, and every wave is
-      // through layer l-1 (the other buffer is free)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (l + 1 < L) issue_weights(l + 1, (l + 1) & 1);
-      if (!any) continue;
+      wait_lds(s_ready + l, dead);
       SSTAMP(l, 1);
       const float* xl = a.X + (size_t)l * a.plane;
       // ---- the dilated tap: rows t0-d .. t0-d+31 of x_l, written by the
@@ -208,6 +232,14 @@ __global__ __launch_bounds__(STACK_WG) void stack_fwd_kernel(StackFwd a) {
         __builtin_amdgcn_wave_barrier();
         xp = frag_from_lds(ta, j, h);
       }
+      if (publish) {
+        // the weight pieces issued at the end of the previous layer are older
+        // than the loads just consumed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0)
+          __hip_atomic_store(s_ready + publish, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        publish = 0;
+      }
 #ifdef STACK_STAMPS
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
@@ -225,34 +257,37 @@ __global__ __launch_bounds__(STACK_WG) void stack_fwd_kernel(StackFwd a) {
         af = frag_zero();
         ag = frag_zero();
       }
+#ifndef STACK_NOMMA
       mma32<32>(af, xp, wlane + 0 * 1024);  // Wf[0]: past tap
       mma32<32>(af, xc, wlane + 1 * 1024);  // Wf[1]: current tap
       mma32<32>(ag, xp, wlane + 2 * 1024);  // Wg[0]
       mma32<32>(ag, xc, wlane + 3 * 1024);  // Wg[1]
+#else
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { af[r] += xp[r] * wlane[0]; ag[r] += xc[r] * wlane[1024]; }
+#endif
       SSTAMP(l, 4);
       f32x16 zz;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
+#ifndef STACK_NOACT
         af[r] = wn_tanh(af[r]);
         ag[r] = wn_sigmoid(ag[r]);
+#endif
         zz[r] = af[r] * ag[r];
       }
-      __builtin_amdgcn_wave_barrier();
-      frag_to_lds(ta, j, h, zz);
-      __builtin_amdgcn_wave_barrier();
-      rows_store(a.Z + (size_t)l * a.plane + off0, lane, hi, rows_from_lds(ta, lane));
-      if (SAVE == 2) {
-        __builtin_amdgcn_wave_barrier();
-        frag_to_lds(ta, j, h, ag);
-        __builtin_amdgcn_wave_barrier();
-        rows_store(a.SG + (size_t)l * a.plane + off0, lane, hi, rows_from_lds(ta, lane));
-      }
       SSTAMP(l, 5);
+      // x' first: it is what other waves wait for
       if (l + 1 < L) {
         const f32x16 bd = frag_bcast(wl + (l & 1) * STACK_WBUF + LAYER_W_FLOATS, h);
 #pragma unroll
         for (int r = 0; r < 16; ++r) xc[r] += bd[r];
+#ifndef STACK_NOMMA
         mma32<32>(xc, zz, wlane + 4 * 1024);  // Wd
+#else
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xc[r] += zz[r] * wlane[4096];
+#endif
         SSTAMP(l, 6);
         __builtin_amdgcn_wave_barrier();
         frag_to_lds(ta, j, h, xc);
@@ -266,6 +301,29 @@ __global__ __launch_bounds__(STACK_WG) void stack_fwd_kernel(StackFwd a) {
                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         SSTAMP(l, 7);
       }
+      __builtin_amdgcn_wave_barrier();
+      frag_to_lds(ta, j, h, zz);
+      __builtin_amdgcn_wave_barrier();
+      rows_store(a.Z + (size_t)l * a.plane + off0, lane, hi, rows_from_lds(ta, lane));
+      if (SAVE == 2) {
+        __builtin_amdgcn_wave_barrier();
+        frag_to_lds(ta, j, h, ag);
+        __builtin_amdgcn_wave_barrier();
+        rows_store(a.SG + (size_t)l * a.plane + off0, lane, hi, rows_from_lds(ta, lane));
+      }
+      // this wave no longer reads layer l's weights; the last one to say so
+      // refills their buffer with layer l + 2
+      {
+        int old = 0;
+        if (lane == 0)
+          old = __hip_atomic_fetch_add(s_done + l, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old == nactive - 1 && l + 2 < L) {
+          issue_weights(l + 2, 0, 1);
+          publish = l + 2;
+        }
+      }
+      SSTAMP(l, 8);
     }
     __syncthreads();   // every wave is through the last layer: wl is free again
   }
@@ -316,16 +374,41 @@ int wn_stack_fwd(float* X, float* Z, float* SG, const float* params,
   if (!g_stack_dbg) return WN_ERR_NULL;
   a.dbg = g_stack_dbg;
 #endif
+  if (L > STACK_MAXL) return WN_ERR_UNSUPPORTED;
+  // waves (= tiles) per workgroup: 16 when that fills every CU, fewer for
+  // small batches so that the tiles still spread over the whole chip
   const long ntiles = (long)B * ((T + 31) / 32);
-  long g = (ntiles + STACK_WAVES - 1) / STACK_WAVES;
   const int cus = wn_device_cus();
+  // (a layer costs a workgroup about max(7 us of dependent latency, 2.2 us of
+  // matrix-pipe time per wave of a SIMD); groups beyond one per CU run in passes)
+  int waves = 16;
+  long best = -1;
+  for (int w = 16; w >= 1; w >>= 1) {
+    const long groups = (ntiles + w - 1) / w;
+    const long passes = (groups + cus - 1) / cus;
+    const long per_layer = w * 22 / 4 > 70 ? w * 22 / 4 : 70;   // 0.1 us
+    const long cost = passes * per_layer;
+    if (best < 0 || cost <= best) { best = cost; waves = w; }   // ties: fewer waves per CU
+  }
+  long g = (ntiles + waves - 1) / waves;
   if (g > cus) g = cus;
-  dim3 grid((unsigned)g), block(STACK_WG);
+  dim3 grid((unsigned)g), block(waves * 64);
   hipStream_t s = (hipStream_t)stream;
-  if (save_sg)
-    hipLaunchKernelGGL((stack_fwd_kernel<2>), grid, block, 0, s, a);
-  else
-    hipLaunchKernelGGL((stack_fwd_kernel<0>), grid, block, 0, s, a);
+#define LAUNCH(W)                                                             \
+  do {                                                                        \
+    if (save_sg)                                                              \
+      hipLaunchKernelGGL((stack_fwd_kernel<2, W>), grid, block, 0, s, a);     \
+    else                                                                      \
+      hipLaunchKernelGGL((stack_fwd_kernel<0, W>), grid, block, 0, s, a);     \
+  } while (0)
+  switch (waves) {
+    case 16: LAUNCH(16); break;
+    case 8: LAUNCH(8); break;
+    case 4: LAUNCH(4); break;
+    case 2: LAUNCH(2); break;
+    default: LAUNCH(1); break;
+  }
+#undef LAUNCH
   return wn_check_launch();
 }
 

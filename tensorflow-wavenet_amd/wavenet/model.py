@@ -700,7 +700,7 @@ class WaveNetModel(object):
             from . import blocked
             blocked.forward_layers(self, ws, bias, bstride, bool(save_ts), st)
         stack = (self.stack_fwd and self.CB == 1 and not self.generic_layers
-                 and save_ts in (0, 2) and B * ((T + 31) // 32) >= 1024)
+                 and save_ts in (0, 2) and L <= 256)
         if stack:
             # all L layers in one persistent launch (csrc/wn_stack.hip)
             _lib.call('wn_stack_fwd', _lib.ptr(ws.X), _lib.ptr(ws.Z),

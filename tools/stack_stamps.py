@@ -10,7 +10,7 @@ if 'WN_LIB_PATH' not in os.environ:
     srcs = [os.path.join(PKG, 'csrc', f) for f in
             ('wn_layer.hip', 'wn_stack.hip', 'wn_gemm.hip', 'wn_misc.hip', 'wn_fastgen.hip')]
     subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
-                           '-DSTACK_STAMPS', '-shared', '-o', out] + srcs)
+                           '-DSTACK_STAMPS', '-shared', '-o', out] + os.environ.get('KB_DEFS', '').split() + srcs)
     os.environ['WN_LIB_PATH'] = out
     if len(sys.argv) > 1 and sys.argv[1] == 'build':
         sys.exit(0)
@@ -31,31 +31,41 @@ net = WaveNetModel(seed=0, **model_kwargs(cfg))
 net.use_launch_plans = False
 L = net.L
 grid = min(256, (B * (T // 32) + 15) // 16)
-dbg = torch.zeros(grid * 2 * L * 8 + grid * 4, dtype=torch.int64, device='cuda')
+dbg = torch.zeros(grid * 16 * L * 12 + grid * 4, dtype=torch.int64, device='cuda')
 lib.wn_diag_stack_dbg.argtypes = [ctypes.c_void_p]
 lib.wn_diag_stack_dbg(dbg.data_ptr())
 audio = synth_audio(B, T)
+fwd_only = os.environ.get('KB_FWDONLY', '0') == '1'     # no sigmoid planes (SAVE = 0)
 for it in range(4):
     dbg.zero_()
-    net.loss(audio)
+    net.loss(audio, backward=not fwd_only)
 torch.cuda.synchronize()
 raw = dbg.cpu().numpy()
-s = raw[:grid * 2 * L * 8].reshape(grid, 2, L, 8).astype(np.float64)
-cal = raw[grid * 2 * L * 8:].reshape(grid, 4).astype(np.float64)
+s = raw[:grid * 16 * L * 12].reshape(grid, 16, L, 12).astype(np.float64)
+cal = raw[grid * 16 * L * 12:].reshape(grid, 4).astype(np.float64)
 clk = np.median((cal[:, 3] - cal[:, 1]) / ((cal[:, 2] - cal[:, 0]) * 10.0))    # GHz
 print('clock %.2f GHz; kernel (entry -> exit of a workgroup) median %.1f us, max %.1f us' % (
     clk, np.median(cal[:, 2] - cal[:, 0]) / 100.0, (cal[:, 2].max() - cal[:, 0].min()) / 100.0))
 names = ['top of layer', 'weights barrier', 'flags seen', "x[t-d] in fragments", '64 conv MFMAs',
-         'tanh/sigmoid, z + sigmoid stores issued', 'dense MFMAs', "x' stored, drained, flag posted"]
-for wv in (0, 1):
-    print('--- wave %d of the workgroup: median over workgroups and layers 1..L-2, us per phase' % (0 if wv == 0 else 15))
+         'tanh/sigmoid, z + sigmoid stores issued', 'dense MFMAs', "x' stored, drained, flag posted",
+         'weight ring bookkeeping (+ refill by the last wave)', 'z store issued', 'sigmoid store issued']
+for wv in (0, 15):
+    print('--- wave %d of the workgroup: median over workgroups and layers 1..L-2, us per phase' % wv)
     tot = 0
-    for i in range(1, 8):
+    for i in range(1, 11):
         dt = (s[:, wv, 1:L - 1, i] - s[:, wv, 1:L - 1, i - 1]) / clk / 1e3
         print('%-42s %6.2f   (p90 %6.2f)' % (names[i], np.median(dt), np.percentile(dt, 90)))
         tot += np.median(dt)
     per = (s[:, wv, 2:L - 1, 0] - s[:, wv, 1:L - 2, 0]) / clk / 1e3
     print('%-42s %6.2f   (sum of medians %.2f)' % ('layer period', np.median(per), tot))
+print('--- per wave: median us of flag wait / conv / dense / whole layer minus flag wait')
+for wv in range(16):
+    f = (s[:, wv, 1:L - 1, 2] - s[:, wv, 1:L - 1, 1]) / clk / 1e3
+    c = (s[:, wv, 1:L - 1, 4] - s[:, wv, 1:L - 1, 3]) / clk / 1e3
+    dn = (s[:, wv, 1:L - 1, 6] - s[:, wv, 1:L - 1, 5]) / clk / 1e3
+    per = (s[:, wv, 2:L - 1, 0] - s[:, wv, 1:L - 2, 0]) / clk / 1e3
+    print('wave %2d (SIMD %d): flags %5.2f  conv %5.2f  dense %5.2f  busy %5.2f  period %5.2f' % (
+        wv, wv & 3, np.median(f), np.median(c), np.median(dn), np.median(per) - np.median(f), np.median(per)))
 # by dilation
 dil = net.dilations
 print('--- layer period by dilation (wave 0, median over workgroups)')

@@ -153,6 +153,8 @@ typedef __attribute__((address_space(3))) void* wn_lptr_t;
 // slot s of row r holds global chunk s ^ (r & 7).  Rows outside [lo, hi) read
 // as zero: the tile is zero-filled by ds_write first and the DMA of those rows
 // is masked off.  `lds_tile` must be wave-uniform.  Completion: vmcnt.
+// AUX: cache policy of the loads (16 = sc1, device scope: see wn_stack.hip).
+template <int AUX = 0>
 __device__ __forceinline__ void tile_dma(float* lds_tile,
                                          const float* __restrict__ tile0,
                                          int lane, int lo, int hi) {
@@ -162,7 +164,7 @@ __device__ __forceinline__ void tile_dma(float* lds_tile,
 #pragma unroll
     for (int c = 0; c < 4; ++c)
       __builtin_amdgcn_global_load_lds((wn_gptr_t)(src + c * 256),
-                                       (wn_lptr_t)(lds_tile + c * 256), 16, 0, 0);
+                                       (wn_lptr_t)(lds_tile + c * 256), 16, 0, AUX);
   } else {
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -174,7 +176,7 @@ __device__ __forceinline__ void tile_dma(float* lds_tile,
       const int r = 8 * c + rr;
       if (r >= lo && r < hi)
         __builtin_amdgcn_global_load_lds((wn_gptr_t)(src + c * 256),
-                                         (wn_lptr_t)(lds_tile + c * 256), 16, 0, 0);
+                                         (wn_lptr_t)(lds_tile + c * 256), 16, 0, AUX);
     }
   }
 }
@@ -277,6 +279,24 @@ __device__ __forceinline__ float wn_sigmoid(float x) {
 __device__ __forceinline__ float wn_tanh(float x) {
   // 1 - 2/(e^{2x}+1); saturates correctly at +-inf of the exp.
   return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x));
+}
+
+// Backward of a residual block without pre-activation-gradient planes
+// (layer_bwd2d_kernel in wn_layer.hip, stack_bwd_kernel in wn_stack.hip):
+// transposed weight image per layer, 5 x [cout][33] + padding = 21 KiB
+#define B2_WIMG 5376
+
+// (da_f, da_g) fragments from dz, z, sigmoid fragments; tanh = z / sigmoid
+__device__ __forceinline__ void gate_grad(const f32x16& dz, const f32x16& zz,
+                                          const f32x16& ss, f32x16& df,
+                                          f32x16& dg) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float sgm = ss[r];
+    const float th = sgm > 1e-30f ? zz[r] * __builtin_amdgcn_rcpf(sgm) : 0.f;
+    df[r] = dz[r] * (sgm - zz[r] * th);           // dz * sig * (1 - tanh^2)
+    dg[r] = dz[r] * zz[r] * (1.f - sgm);          // dz * tanh * sig * (1 - sig)
+  }
 }
 
 #endif  // __HIPCC__

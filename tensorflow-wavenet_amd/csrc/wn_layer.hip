@@ -673,20 +673,7 @@ __global__ __launch_bounds__(BW_WG) void layer_bwdw_kernel(
 // turns into da == 0.
 // ---------------------------------------------------------------------------
 #define B2_WAVES 8
-#define B2_WIMG 5376   // 5 x 33 x 32 transposed weights, padded to 21 KiB
-
-// (da_f, da_g) fragments from dz, z, sigmoid fragments
-__device__ __forceinline__ void gate_grad(const f32x16& dz, const f32x16& zz,
-                                          const f32x16& ss, f32x16& df,
-                                          f32x16& dg) {
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const float sgm = ss[r];
-    const float th = sgm > 1e-30f ? zz[r] * __builtin_amdgcn_rcpf(sgm) : 0.f;
-    df[r] = dz[r] * (sgm - zz[r] * th);           // dz * sig * (1 - tanh^2)
-    dg[r] = dz[r] * zz[r] * (1.f - sgm);          // dz * tanh * sig * (1 - sig)
-  }
-}
+// (B2_WIMG and gate_grad live in wn_common.h: wn_stack.hip shares them)
 
 // Register-staged form, kept for A/B (WN_B2_MODE=4p): WAVES = 4 is one wave
 // per SIMD with the whole register file, which is what its software pipeline

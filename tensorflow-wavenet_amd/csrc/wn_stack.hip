@@ -32,6 +32,9 @@
 // ctl[3] = 1 and carries on without waiting, so the grid always drains.
 #include "wn_common.h"
 
+#define WN_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define WN_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
 #define STACK_MAXL 256   // layers (LDS bookkeeping words per layer)
 #define STACK_WBUF (LAYER_W_FLOATS + 256)   // 21 KiB: keeps both halves 1 KiB aligned
 
@@ -341,6 +344,296 @@ __global__ __launch_bounds__(WAVES * 64) void stack_fwd_kernel(StackFwd a) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// Backward of the whole residual stack in one launch: layer_bwd2d_kernel
+// (wn_layer.hip; the hand-written gradient of model.py:236-330) wrapped in a
+// layer loop l = L-1 .. 0 with the same hand-over scheme as the forward:
+// DX[l] = dL/dx_l goes to memory with sc1 stores, flag[l][tile] = epoch
+// publishes it, the rows t+d of DX[l+1] (the anti-causal tap) are read with sc1
+// loads after their owners' flags.  A workgroup keeps a GROUP of WAVES x tpw
+// consecutive tiles for all layers; groups are handed out in DECREASING order
+// (a group depends on rows of the same or HIGHER groups), so the highest
+// unfinished group can always finish whatever the residency.
+// The weight gradients are reduced over the workgroup's waves once per layer
+// (fixed-order tree through LDS, as in layer_bwd2d_kernel) into one slab per
+// (layer, group): bitwise reproducible whichever workgroup ran the group.
+// The layer's transposed weight image is fetched by LDS-DMA during the
+// previous layer's reduction.
+// ---------------------------------------------------------------------------
+struct StackBwd {
+  const float* X;      // [L][N][32]
+  const float* Z;
+  const float* SG;
+  const float* dZ;
+  float* DX;           // [L][N][32]  DX[l] = dL/dx_l
+  const float* wimg;   // [L][B2_WIMG] (wn_layer_bwd2_pack)
+  float* slabs;        // [L][>= groups][LAYER_BLOCK_FLOATS]
+  long slab_layer_stride;
+  float* tilesum;      // [L][ntiles][64] per-tile column sums of da, or null
+  const int* dil;
+  unsigned* flags;     // [L][ntiles]
+  unsigned* ctl;       // as StackFwd
+  int L, B, T, tpw;    // tpw: tiles per wave and layer
+  long plane;
+};
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
+  constexpr int LDT = 33, MT = 32 * LDT;
+  constexpr int RS = 5248;                       // floats per reduction region
+  constexpr int REG = WAVES >= 4 ? 4 : WAVES;    // reduction regions
+  constexpr int TILE_FLOATS = WAVES * 4096 > REG * RS ? WAVES * 4096 : REG * RS;
+  __shared__ __attribute__((aligned(1024))) float wl[B2_WIMG];
+  __shared__ __attribute__((aligned(1024))) float tiles[TILE_FLOATS];
+  __shared__ int s_group;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  float* t0 = tiles + wave * 4096;
+  float* t1 = t0 + 1024;
+  float* t2 = t1 + 1024;
+  float* t3 = t2 + 1024;
+  const int T = a.T, L = a.L;
+  const int tiles_per_clip = (T + 31) >> 5;
+  const int ntiles = tiles_per_clip * a.B;
+  const int GS = WAVES * a.tpw;
+  const int ngroups = (ntiles + GS - 1) / GS;
+  const unsigned epoch =
+      __hip_atomic_load(a.ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  bool dead = false;
+
+  auto issue_wimg = [&](int l) {
+    const float* src = a.wimg + (size_t)l * B2_WIMG;
+    for (int p = wave; p < B2_WIMG / 256; p += WAVES)
+      __builtin_amdgcn_global_load_lds((wn_gptr_t)(src + p * 256 + lane * 4),
+                                       (wn_lptr_t)(wl + p * 256), 16, 0, 0);
+  };
+
+  for (;;) {
+    if (tid == 0) s_group = (int)atomicAdd(a.ctl, 1u);
+    __syncthreads();
+    const int ticket = __builtin_amdgcn_readfirstlane(s_group);
+    __syncthreads();
+    if (ticket >= ngroups) break;
+    const int g = ngroups - 1 - ticket;
+    const int tbase = g * GS, tend = min(ntiles, tbase + GS);
+    issue_wimg(L - 1);
+
+    for (int l = L - 1; l >= 0; --l) {
+      const int d = a.dil[l];
+      const bool hx = l + 1 < L;              // a gradient flows into x_{l+1}
+      const float* x = a.X + (size_t)l * a.plane;
+      const float* z = a.Z + (size_t)l * a.plane;
+      const float* sg = a.SG + (size_t)l * a.plane;
+      const float* dZ = a.dZ + (size_t)l * a.plane;
+      const float* dxin = a.DX + (size_t)(hx ? l + 1 : l) * a.plane;
+      float* dx_out = a.DX + (size_t)l * a.plane;
+      const unsigned* fl_in = a.flags + (size_t)(hx ? l + 1 : l) * ntiles;
+      unsigned* fl_out = a.flags + (size_t)l * ntiles;
+      float* tile_colsum = a.tilesum ? a.tilesum + (size_t)l * ntiles * 64 : nullptr;
+      // this layer's weight image has landed for every wave; the reduction of
+      // the layer above no longer reads the tile area
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      f32x16 cf0 = frag_zero(), cf1 = frag_zero(), cg0 = frag_zero(),
+             cg1 = frag_zero(), cd = frag_zero();
+      float sf = 0.f, sgs = 0.f, sd = 0.f;
+      RowRegs a0, a1, a2, a3;
+      // rows t+d of a tile (always assigns a0..a3); the dx_{l+1} rows wait for
+      // their owners' flags
+      auto load_shifted = [&](int tl) {
+        const bool any = tl < tend;
+        const int b = any ? tl / tiles_per_clip : 0;
+        const int tt = any ? tl - b * tiles_per_clip : 0;
+        const int tt0 = tt * 32;
+        const int hif = any ? min(min(32, T - tt0), T - d - tt0) : 0;
+        const size_t offd = ((size_t)b * T + tt0 + d) * WN_CH;
+        if (hx) {
+          if (hif > 0) {
+            const int first = (tt0 + d) >> 5, last = (tt0 + d + hif - 1) >> 5;
+            int idx = -1;
+            if (lane == 0 && first != tt) idx = b * tiles_per_clip + first;
+            if (lane == 1 && last != first && last != tt) idx = b * tiles_per_clip + last;
+            wait_flags(fl_in, idx, epoch, a.ctl, dead, lane);
+          }
+          a0 = rows_load_dev(dxin + offd, lane, 0, hif);
+        } else {
+          const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) a0.v[c] = zero;
+        }
+        a1 = rows_load(dZ + offd, lane, 0, hif);
+        a2 = rows_load(z + offd, lane, 0, hif);
+        a3 = rows_load(sg + offd, lane, 0, hif);
+      };
+      load_shifted(tbase + wave);
+      for (int tile = tbase + wave; tile < tend; tile += WAVES) {
+        int woff = j + 4 * h * LDT;  // opaque: no hoisting of the weight reads
+        asm volatile("" : "+v"(woff));
+        const float* wlane = wl + woff;
+        const int b = tile / tiles_per_clip;
+        const int tt0 = (tile - b * tiles_per_clip) * 32;
+        const int hi = min(32, T - tt0);
+        const int hi_f = min(hi, T - d - tt0);  // rows whose t+d tap exists
+        const int lo_p = max(0, d - tt0);       // rows whose t-d tap exists
+        const size_t off0 = ((size_t)b * T + tt0) * WN_CH;
+        f32x16 dx = frag_zero();
+        f32x16 dz, di, zz, ss;
+        if (hi_f > 0) {                         // rows t+d -> LDS -> fragments
+          if (hx) rows_to_lds(t0, lane, a0);
+          rows_to_lds(t1, lane, a1);
+          rows_to_lds(t2, lane, a2);
+          rows_to_lds(t3, lane, a3);
+          __builtin_amdgcn_wave_barrier();
+          dz = frag_from_lds(t1, j, h);
+          if (hx) di = frag_from_lds(t0, j, h);
+          zz = frag_from_lds(t2, j, h);
+          ss = frag_from_lds(t3, j, h);
+          WN_WAIT_LGKM0();                      // tiles free again
+        }
+        // rows t: in flight during the rows t+d math (dx_{l+1}[t] is this
+        // wave's own store of the layer above)
+        if (hx) tile_dma<16>(t0, dxin + off0, lane, 0, hi);
+        tile_dma(t1, dZ + off0, lane, 0, hi);
+        tile_dma(t2, z + off0, lane, 0, hi);
+        tile_dma(t3, sg + off0, lane, 0, hi);
+        if (hi_f > 0) {
+          if (hx) mma32<LDT>(dz, di, wlane + 4 * MT);  // dx_{l+1}[t+d] * Wd^T
+          f32x16 df, dg;
+          gate_grad(dz, zz, ss, df, dg);
+          mma32<LDT>(dx, df, wlane + 0 * MT);        // da_f[t+d] * Wf[0]^T
+          mma32<LDT>(dx, dg, wlane + 2 * MT);        // da_g[t+d] * Wg[0]^T
+        }
+        WN_WAIT_VM0();
+        if (hx) {                                    // dWd += z^T dx_{l+1}
+#pragma unroll 4
+          for (int s2 = 0; s2 < 16; ++s2) {
+            const int row = 2 * s2 + h;
+            const float az = tile_elem(t2, row, j), bd = tile_elem(t0, row, j);
+            cd = __builtin_amdgcn_mfma_f32_32x32x2f32(az, bd, cd, 0, 0, 0);
+            sd += bd;
+          }
+        }
+        dz = frag_from_lds(t1, j, h);
+        if (hx) di = frag_from_lds(t0, j, h);
+        zz = frag_from_lds(t2, j, h);
+        ss = frag_from_lds(t3, j, h);
+        WN_WAIT_LGKM0();
+        // the x tiles: in flight during the rows-t math
+        tile_dma(t2, x + off0, lane, 0, hi);
+        tile_dma(t0, x + off0 - (size_t)d * WN_CH, lane, lo_p, hi);
+        {
+          if (hx) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dx[r] += di[r];
+            mma32<LDT>(dz, di, wlane + 4 * MT);      // dx_{l+1}[t] * Wd^T
+          }
+          f32x16 df, dg;
+          gate_grad(dz, zz, ss, df, dg);
+          mma32<LDT>(dx, df, wlane + 1 * MT);        // da_f[t] * Wf[1]^T
+          mma32<LDT>(dx, dg, wlane + 3 * MT);        // da_g[t] * Wg[1]^T
+          frag_to_lds(t1, j, h, dx);
+          __builtin_amdgcn_wave_barrier();
+          rows_store_dev(dx_out + off0, lane, hi, rows_from_lds(t1, lane));
+          __builtin_amdgcn_wave_barrier();
+          frag_to_lds(t1, j, h, df);                 // t1 / t3 now hold da[t]
+          frag_to_lds(t3, j, h, dg);
+        }
+        WN_WAIT_VM0();                               // x tiles in, dx_l out
+        if (lane == 0)
+          __hip_atomic_store(fl_out + tile, epoch, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+        load_shifted(tile + WAVES);
+        __builtin_amdgcn_wave_barrier();
+        float tsf = 0.f, tsg = 0.f;          // this tile's column sums of da[t]
+#pragma unroll 4
+        for (int s2 = 0; s2 < 16; ++s2) {    // dW[1] += x[t]^T da, dW[0] += x[t-d]^T da
+          const int row = 2 * s2 + h;
+          const float axc = tile_elem(t2, row, j), axp = tile_elem(t0, row, j);
+          const float bf = tile_elem(t1, row, j), bg = tile_elem(t3, row, j);
+          cf1 = __builtin_amdgcn_mfma_f32_32x32x2f32(axc, bf, cf1, 0, 0, 0);
+          cg1 = __builtin_amdgcn_mfma_f32_32x32x2f32(axc, bg, cg1, 0, 0, 0);
+          cf0 = __builtin_amdgcn_mfma_f32_32x32x2f32(axp, bf, cf0, 0, 0, 0);
+          cg0 = __builtin_amdgcn_mfma_f32_32x32x2f32(axp, bg, cg0, 0, 0, 0);
+          tsf += bf;
+          tsg += bg;
+        }
+        sf += tsf;
+        sgs += tsg;
+        if (tile_colsum) {
+          const float ca = tsf + __shfl_xor(tsf, 32), cb = tsg + __shfl_xor(tsg, 32);
+          if (h == 0) {
+            tile_colsum[(size_t)tile * 64 + j] = ca;
+            tile_colsum[(size_t)tile * 64 + 32 + j] = cb;
+          }
+        }
+        WN_WAIT_LGKM0();                     // tiles free for the next tile's DMA
+        __builtin_amdgcn_wave_barrier();
+      }
+      // ---- weight-gradient slab of this (layer, group): fixed-order tree over
+      // the waves through LDS (see layer_bwd2d_kernel)
+      sf += __shfl_xor(sf, 32);
+      sgs += __shfl_xor(sgs, 32);
+      sd += __shfl_xor(sd, 32);
+      __syncthreads();                       // tiles and wl are free
+      if (l > 0) issue_wimg(l - 1);
+      float* red = tiles + (wave & (REG - 1)) * RS;
+      for (int ph = 0; ph < (WAVES > 4 ? 2 : 1); ++ph) {
+        if ((wave >> 2) == ph) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = 8 * (r >> 2) + 4 * h + (r & 3);
+            const int e = m * 32 + j;
+            if (ph == 0) {
+              red[0 * 1024 + e] = cf0[r];
+              red[1 * 1024 + e] = cf1[r];
+              red[2 * 1024 + e] = cg0[r];
+              red[3 * 1024 + e] = cg1[r];
+              red[4 * 1024 + e] = cd[r];
+            } else {
+              red[0 * 1024 + e] += cf0[r];
+              red[1 * 1024 + e] += cf1[r];
+              red[2 * 1024 + e] += cg0[r];
+              red[3 * 1024 + e] += cg1[r];
+              red[4 * 1024 + e] += cd[r];
+            }
+          }
+          if (h == 0) {
+            if (ph == 0) {
+              red[LAYER_W_FLOATS + j] = sf;
+              red[LAYER_W_FLOATS + 32 + j] = sgs;
+              red[LAYER_W_FLOATS + 64 + j] = sd;
+            } else {
+              red[LAYER_W_FLOATS + j] += sf;
+              red[LAYER_W_FLOATS + 32 + j] += sgs;
+              red[LAYER_W_FLOATS + 64 + j] += sd;
+            }
+          }
+        }
+        __syncthreads();
+      }
+      float* out = a.slabs + (size_t)l * a.slab_layer_stride +
+                   (size_t)g * LAYER_BLOCK_FLOATS;
+      for (int e = tid; e < LAYER_BLOCK_FLOATS; e += WAVES * 64) {
+        float v = tiles[e];
+        if (REG == 2) v += tiles[RS + e];
+        if (REG == 4) v = (v + tiles[RS + e]) + (tiles[2 * RS + e] + tiles[3 * RS + e]);
+        out[e] = v;
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const unsigned done = atomicAdd(a.ctl + 1, 1u);
+    if (done == gridDim.x - 1) {
+      __hip_atomic_store(a.ctl + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.ctl + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.ctl + 2, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 #ifdef STACK_STAMPS
 static unsigned long long* g_stack_dbg = nullptr;
 extern "C" int wn_diag_stack_dbg(unsigned long long* p) { g_stack_dbg = p; return WN_OK; }
@@ -409,6 +702,71 @@ int wn_stack_fwd(float* X, float* Z, float* SG, const float* params,
     default: LAUNCH(1); break;
   }
 #undef LAUNCH
+  return wn_check_launch();
+}
+
+// (waves per workgroup, tiles per wave and layer) of wn_stack_bwd for a shape:
+// big batches keep 8 waves and give every wave enough tiles that one pass of
+// at most one group per CU covers the batch; small batches use fewer waves so
+// that the tiles spread over the whole chip
+static void stack_bwd_shape(int B, int T, int* waves_out, int* tpw_out) {
+  const long ntiles = (long)B * ((T + 31) / 32);
+  const int cus = wn_device_cus();
+  long best = -1;
+  int bw = 8, bt = 1;
+  const int tmin = (int)((ntiles + 8L * cus - 1) / (8L * cus));
+  for (int w = 8; w >= 1; w >>= 1) {
+    for (int t = 1; t <= (w == 8 ? tmin + 1 : 1); ++t) {
+      const long groups = (ntiles + (long)w * t - 1) / ((long)w * t);
+      const long passes = (groups + cus - 1) / cus;
+      const long cost = passes * (t * (w == 8 ? 144 : 100) + 70);   // 0.1 us per layer
+      if (best < 0 || cost <= best) { best = cost; bw = w; bt = t; }
+    }
+  }
+  *waves_out = bw;
+  *tpw_out = bt;
+}
+
+// weight-gradient slabs per layer wn_stack_bwd writes (= tile groups)
+int wn_stack_bwd_slabs(int B, int T) {
+  if (B <= 0 || T <= 0) return 0;
+  int w, t;
+  stack_bwd_shape(B, T, &w, &t);
+  const long ntiles = (long)B * ((T + 31) / 32);
+  return (int)((ntiles + (long)w * t - 1) / ((long)w * t));
+}
+
+int wn_stack_bwd(const float* X, const float* Z, const float* SG,
+                 const float* dZ, float* DX, const float* wimg, float* slabs,
+                 long slab_layer_stride, float* tilesum, const int* dilations,
+                 unsigned* flags, unsigned* ctl, int L, int B, int T,
+                 void* stream) {
+  if (!X || !Z || !SG || !dZ || !DX || !wimg || !slabs || !dilations ||
+      !flags || !ctl)
+    return WN_ERR_NULL;
+  if (L <= 0 || B <= 0 || T <= 0) return WN_ERR_BAD_SHAPE;
+  const void* ptrs[] = {X, Z, SG, dZ, DX, wimg};
+  for (const void* p : ptrs)
+    if (!wn_aligned16(p)) return WN_ERR_MISALIGNED;
+  int waves, tpw;
+  stack_bwd_shape(B, T, &waves, &tpw);
+  const long ntiles = (long)B * ((T + 31) / 32);
+  const long groups = (ntiles + (long)waves * tpw - 1) / ((long)waves * tpw);
+  if (slab_layer_stride < groups * LAYER_BLOCK_FLOATS) return WN_ERR_BAD_SHAPE;
+  StackBwd a;
+  a.X = X; a.Z = Z; a.SG = SG; a.dZ = dZ; a.DX = DX; a.wimg = wimg;
+  a.slabs = slabs; a.slab_layer_stride = slab_layer_stride; a.tilesum = tilesum;
+  a.dil = dilations; a.flags = flags; a.ctl = ctl; a.L = L; a.B = B; a.T = T;
+  a.tpw = tpw; a.plane = (long)B * T * WN_CH;
+  const int cus = wn_device_cus();
+  dim3 grid((unsigned)(groups < cus ? groups : cus)), block(waves * 64);
+  hipStream_t s = (hipStream_t)stream;
+  switch (waves) {
+    case 8: hipLaunchKernelGGL((stack_bwd_kernel<8>), grid, block, 0, s, a); break;
+    case 4: hipLaunchKernelGGL((stack_bwd_kernel<4>), grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((stack_bwd_kernel<2>), grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL((stack_bwd_kernel<1>), grid, block, 0, s, a); break;
+  }
   return wn_check_launch();
 }
 

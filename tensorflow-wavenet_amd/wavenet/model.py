@@ -117,6 +117,17 @@ class _Workspace(object):
         self.c1 = alloc('c1', (N, S)) if net.residual_postproc else None
         self.da = alloc('da', (2, 2 * CB, N, CH)) if self.legacy else None
         alloc('dx', (2, CB, N, CH))
+        # persistent backward (wn_stack_bwd): dL/dx_l of EVERY layer (waves
+        # of different workgroups are up to a few layers apart, so two
+        # ping-pong planes are not enough), its flags and control block
+        self.stack_bwd = net._stack_bwd_ok()
+        if self.stack_bwd:
+            alloc('DX', (L, N, CH))
+            alloc('stack_flags_b', (lib.wn_stack_flag_count(B, T, L),),
+                  torch.int32, fill=0)
+            alloc('stack_ctl_b', (4,), torch.int32, fill=0)
+            if parent is None:
+                self.stack_ctl_b[2] = 1
         if CB > 1:                       # channel-block path scratch
             alloc('dzb', (CB, N, CH))
             alloc('wdT', (CHn, CHn))
@@ -129,9 +140,10 @@ class _Workspace(object):
         self.nslab = max(1, min(512, ntiles // 4))
         self.nslab_f = lib.wn_layer_bwdw_slabs(B, T)      # fused kernel
         self.nslab_2 = lib.wn_layer_bwd2_slabs(B, T)
+        self.nslab_s = lib.wn_stack_bwd_slabs(B, T) if self.stack_bwd else 0
         alloc('wimg', (L, lib.wn_layer_bwd2_wimg_floats()))
-        alloc('lslabs', (L, max(self.nslab, self.nslab_f, self.nslab_2),
-                         net.LAYER_BLOCK))
+        alloc('lslabs', (L, max(self.nslab, self.nslab_f, self.nslab_2,
+                                self.nslab_s), net.LAYER_BLOCK))
         need = 0
         self.splits = {}
         for key, (mw, nw) in dict(post2=(S, Q), post1=(S, S), skip=(L * CHn, S),
@@ -233,6 +245,9 @@ class WaveNetModel(object):
         # dilated taps are handed over through per-tile flags) instead of one
         # wn_layer_fwd launch per layer.  WN_STACK_FWD=0 selects the latter.
         self.stack_fwd = os.environ.get('WN_STACK_FWD', '1') != '0'
+        # the same for the backward of the stack (wn_stack_bwd instead of one
+        # wn_layer_bwd2 per layer); read when a workspace is created
+        self.stack_bwd = os.environ.get('WN_STACK_BWD', '1') != '0'
         # generate(): four kernels per sample over many CUs, replayed from a
         # hipGraph, instead of the single-workgroup persistent kernel
         self.fastgen_multi_cu = True
@@ -513,6 +528,10 @@ class WaveNetModel(object):
         return (self.layer_bwd != 'bwd2' or not self.fused_bwd
                 or self.generic_layers or self.overlap_wgrad or self.CB > 1)
 
+    def _stack_bwd_ok(self):
+        """wn_stack_bwd covers what wn_layer_bwd2 covers."""
+        return self.stack_bwd and not self._legacy_bwd() and self.L <= 256
+
     def _check_supported(self):
         if self._unsupported:
             raise NotImplementedError(self._unsupported)
@@ -632,7 +651,7 @@ class WaveNetModel(object):
     # ------------------------------------------------------------ launch plans
     def _plan_key(self, tag, ws, ids, extra):
         return (tag, extra, ids is not None, self.generic_layers,
-                self.fused_bwd, self.layer_bwd, self.overlap_tn, self.stack_fwd, self.gemm_mode, self.causal_wgrad_segsum, self.tf_xent_zero_label_quirk,
+                self.fused_bwd, self.layer_bwd, self.overlap_tn, self.stack_fwd, self.stack_bwd, self.gemm_mode, self.causal_wgrad_segsum, self.tf_xent_zero_label_quirk,
                 _lib.stream(), self.params.data_ptr(), self.grads.data_ptr())
 
     def _stage_ids(self, ws, ids):
@@ -853,6 +872,17 @@ class WaveNetModel(object):
             # into LDS): one small launch per step
             _lib.call('wn_layer_bwd2_pack', _lib.ptr(self._layer_block(P, 0)),
                       self.layer_stride, _lib.ptr(ws.wimg), L, st)
+            if self.stack_bwd and getattr(ws, 'stack_bwd', False):
+                # all L layers in one persistent launch (csrc/wn_stack.hip)
+                _lib.call('wn_stack_bwd', _lib.ptr(ws.X), _lib.ptr(ws.Z),
+                          _lib.ptr(ws.SG), _lib.ptr(ws.dZ), _lib.ptr(ws.DX),
+                          _lib.ptr(ws.wimg), _lib.ptr(ws.lslabs),
+                          ws.lslabs.shape[1] * self.LAYER_BLOCK,
+                          None if tsum is None else _lib.ptr(tsum),
+                          _lib.ptr(self._dil_dev), _lib.ptr(ws.stack_flags_b),
+                          _lib.ptr(ws.stack_ctl_b), L, B, T, st)
+                self._backward_tail(ws, ids, ws.DX[0], ws.nslab_s, True)
+                return
             for l in range(L - 1, -1, -1):
                 dxo = ws.dx[xp]
                 _lib.call('wn_layer_bwd2', _lib.ptr(ws.X[l]), _lib.ptr(ws.Z[l]),

@@ -30,6 +30,7 @@ def _pair(cfg):
     b, _ = build_pair(cfg)
     assert torch.equal(a.params, b.params)
     a.stack_fwd, b.stack_fwd = True, False
+    a.stack_bwd = b.stack_bwd = False
     return a, b
 
 
@@ -87,3 +88,35 @@ def test_stack_inference_forward(hip_lib):
     assert torch.equal(a.predict_proba(q), b.predict_proba(q))
     for ws in a._ws.values():
         assert ws.stack_ctl.cpu().tolist()[3] == 0
+
+
+@pytest.mark.parametrize('name,mk,B,T,kind', CASES, ids=[c[0] for c in CASES])
+def test_stack_backward_equals_per_layer(hip_lib, name, mk, B, T, kind):
+    """wn_stack_bwd vs one wn_layer_bwd2 per layer: dL/dx_0 bitwise (per-tile
+    arithmetic is identical), weight gradients to rounding (the tiles of a
+    slab are summed in another order), repeated runs bitwise."""
+    cfg = mk()
+    a, _ = build_pair(cfg)
+    b, _ = build_pair(cfg)
+    a.stack_bwd, b.stack_bwd = True, False
+    audio = synth_audio(B, T)
+    gc = np.array([(37 * i) % 377 for i in range(B)], np.int32) if kind == 'gc' else None
+    prev = None
+    for rep in range(3):
+        la = a.loss(audio, global_condition_batch=gc) if gc is not None else a.loss(audio)
+        lb = b.loss(audio, global_condition_batch=gc) if gc is not None else b.loss(audio)
+        torch.cuda.synchronize()
+        wa, wb = list(a._ws.values())[0], list(b._ws.values())[0]
+        if not wa.stack_bwd:
+            pytest.skip('configuration runs the generic backward kernels')
+        assert float(la) == float(lb)
+        assert torch.equal(wa.DX[0], wb.dx[0][0]) or torch.equal(wa.DX[0], wb.dx[1][0])
+        ga, gb = a.grads, b.grads
+        scale = float(gb.abs().max())
+        err = float((ga - gb).abs().max())
+        assert err <= 2e-6 * max(scale, 1e-30), (err, scale)
+        if prev is not None:
+            assert torch.equal(prev, ga)          # run-to-run determinism
+        prev = ga.clone()
+        ctl = wa.stack_ctl_b.cpu().tolist()
+        assert ctl[0] == 0 and ctl[1] == 0 and ctl[3] == 0 and ctl[2] == 2 + rep, ctl

@@ -169,6 +169,47 @@ int wn_layer_bwd2(const float* x, const float* z, const float* sg,
                   float* tile_colsum, int B, int T, int dilation,
                   void* stream);
 
+/* ---- the whole residual stack in ONE persistent launch (csrc/wn_stack.hip):
+ * replaces the per-layer loop of WaveNetModel._create_network
+ * (wavenet/model.py:417-428 over _create_dilation_layer, model.py:236-330) and
+ * its gradient; same arithmetic per 32-row tile as wn_layer_fwd / wn_layer_bwd2.
+ * A workgroup keeps a group of consecutive tiles for all L layers; the tile's
+ * own rows stay in registers (forward), the dilated tap of another tile is
+ * handed over through memory: sc1 stores, one flag per (layer, tile), sc1
+ * loads.  No grid barrier; groups are handed out by an atomic ticket in
+ * dependency order, so the launch completes whatever the residency.
+ *   X, Z, SG, dZ, DX : [L][B*T][32] planes, layer-major (X[0] = causal layer
+ *                      output; forward writes X[1..L-1], Z, SG; backward reads
+ *                      X, Z, SG, dZ and writes DX[l] = dL/dx_l for every l)
+ *   params/layer_stride : layer 0's parameter block and the float stride
+ *   bias             : [L][B or 1][64] filter|gate bias (+gc) of wn_gc_bias, or NULL
+ *   dilations        : [L] int32, DEVICE memory
+ *   flags            : wn_stack_flag_count(B, T, L) uint32, zero before first use
+ *   ctl              : 4 uint32 {0, 0, 1, 0} before first use: {group ticket,
+ *                      workgroups done, epoch, error}; the kernel re-arms the
+ *                      first three.  ctl[3] != 0 after a launch: a bounded flag
+ *                      wait (2 s) expired -- results are invalid
+ *   poison           : NULL, or one float (0 before first use) that is set to
+ *                      NaN in that case: summed into the loss reduction it
+ *                      makes the failure loud without a host synchronisation
+ *   forward and backward use SEPARATE flags / ctl buffers.
+ *   slabs            : [L][slab_layer_stride floats], slab g of layer l at
+ *                      l * slab_layer_stride + g * 5216, g < wn_stack_bwd_slabs(B, T)
+ *   wimg, tilesum    : as wn_layer_bwd2 (tilesum: [L][tiles][64] or NULL)
+ * L <= 256. */
+long wn_stack_flag_count(int B, int T, int L);
+int wn_stack_fwd(float* X, float* Z, float* SG, const float* params,
+                 long layer_stride, const float* bias, long bias_layer_stride,
+                 int bias_clip_stride, const int* dilations, unsigned* flags,
+                 unsigned* ctl, float* poison, int L, int B, int T, int save_sg,
+                 void* stream);
+int wn_stack_bwd_slabs(int B, int T);
+int wn_stack_bwd(const float* X, const float* Z, const float* SG,
+                 const float* dZ, float* DX, const float* wimg, float* slabs,
+                 long slab_layer_stride, float* tilesum, const int* dilations,
+                 unsigned* flags, unsigned* ctl, float* poison, int L, int B,
+                 int T, void* stream);
+
 /* ---- fp32 MFMA GEMMs: the skip sum + post-processing of
  * wavenet/model.py:303-305, 430-440 (_create_network) and their gradients */
 int wn_gemm_nn(const float* A, long lda, int a_planes, long a_plane_stride,

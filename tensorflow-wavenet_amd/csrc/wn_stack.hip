@@ -29,7 +29,9 @@
 // workgroup finishes all layers of its group before it takes another ticket --
 // so the lowest unfinished group can always run to completion.  Every poll is
 // additionally bounded (2 s of s_memrealtime): on expiry the wave records
-// ctl[3] = 1 and carries on without waiting, so the grid always drains.
+// ctl[3] = 1 and *poison = NaN (a float the host sums into the loss, which so
+// turns NaN instead of being silently wrong; the backward also poisons its dx)
+// and carries on without waiting, so the grid always drains.
 #include "wn_common.h"
 
 #define WN_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
@@ -50,6 +52,7 @@ struct StackFwd {
   const int* dil;      // [L] dilations (device)
   unsigned* flags;     // [L][ntiles]
   unsigned* ctl;       // [0] group ticket [1] workgroups done [2] epoch [3] error
+  float* poison;       // set to NaN when a bounded wait expires (or null)
   int L, B, T;
   long plane;          // N * 32 floats
 #ifdef STACK_STAMPS
@@ -96,7 +99,7 @@ __device__ __forceinline__ void rows_store_dev(float* tile0, int lane, int hi,
 // poll until flag[idx] == epoch on every lane that has an idx >= 0
 __device__ __forceinline__ void wait_flags(const unsigned* fl, int idx,
                                            unsigned epoch, unsigned* ctl,
-                                           bool& dead, int lane) {
+                                           float* poison, bool& dead, int lane) {
   if (dead) return;
   unsigned spins = 0;
   unsigned long long t_start = 0;
@@ -110,8 +113,10 @@ __device__ __forceinline__ void wait_flags(const unsigned* fl, int idx,
       const unsigned long long now = __builtin_amdgcn_s_memrealtime();
       if (t_start == 0) t_start = now;
       if (now - t_start > 200000000ull) {   // 2 s at 100 MHz
-        if (lane == 0)
+        if (lane == 0) {
           __hip_atomic_store(ctl + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (poison) *poison = __builtin_nanf("");   // summed into the loss by the host
+        }
         dead = true;
         break;
       }
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(WAVES * 64) void stack_fwd_kernel(StackFwd a) {
         int idx = -1;
         if (lane == 0 && first != tt) idx = b * tiles_per_clip + first;
         if (lane == 1 && last != first && last != tt) idx = b * tiles_per_clip + last;
-        wait_flags(a.flags + (size_t)l * ntiles, idx, epoch, a.ctl, dead, lane);
+        wait_flags(a.flags + (size_t)l * ntiles, idx, epoch, a.ctl, a.poison, dead, lane);
       }
       SSTAMP(l, 2);
       f32x16 xp;
@@ -373,8 +378,12 @@ struct StackBwd {
   const int* dil;
   unsigned* flags;     // [L][ntiles]
   unsigned* ctl;       // as StackFwd
+  float* poison;
   int L, B, T, tpw;    // tpw: tiles per wave and layer
   long plane;
+#ifdef STACK_STAMPS
+  unsigned long long* dbg;   // [grid][WAVES][L][12] + [grid][4]
+#endif
 };
 
 template <int WAVES>
@@ -402,6 +411,16 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
   const unsigned epoch =
       __hip_atomic_load(a.ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   bool dead = false;
+#ifdef STACK_STAMPS
+#define BSTAMP(l, i)                                                         \
+  if (lane == 0)                                                             \
+    a.dbg[(((size_t)blockIdx.x * 8 + wave) * L + (l)) * 12 + (i)] =          \
+        __builtin_amdgcn_s_memtime()
+  unsigned long long* cal = a.dbg + (size_t)gridDim.x * 8 * L * 12 + (size_t)blockIdx.x * 4;
+  if (tid == 0) { cal[0] = __builtin_amdgcn_s_memrealtime(); cal[1] = __builtin_amdgcn_s_memtime(); }
+#else
+#define BSTAMP(l, i)
+#endif
 
   auto issue_wimg = [&](int l) {
     const float* src = a.wimg + (size_t)l * B2_WIMG;
@@ -434,8 +453,10 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
       float* tile_colsum = a.tilesum ? a.tilesum + (size_t)l * ntiles * 64 : nullptr;
       // this layer's weight image has landed for every wave; the reduction of
       // the layer above no longer reads the tile area
+      BSTAMP(l, 0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      BSTAMP(l, 1);
       f32x16 cf0 = frag_zero(), cf1 = frag_zero(), cg0 = frag_zero(),
              cg1 = frag_zero(), cd = frag_zero();
       float sf = 0.f, sgs = 0.f, sd = 0.f;
@@ -455,7 +476,7 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
             int idx = -1;
             if (lane == 0 && first != tt) idx = b * tiles_per_clip + first;
             if (lane == 1 && last != first && last != tt) idx = b * tiles_per_clip + last;
-            wait_flags(fl_in, idx, epoch, a.ctl, dead, lane);
+            wait_flags(fl_in, idx, epoch, a.ctl, a.poison, dead, lane);
           }
           a0 = rows_load_dev(dxin + offd, lane, 0, hif);
         } else {
@@ -468,7 +489,9 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
         a3 = rows_load(sg + offd, lane, 0, hif);
       };
       load_shifted(tbase + wave);
+      BSTAMP(l, 2);
       for (int tile = tbase + wave; tile < tend; tile += WAVES) {
+        if (tile == tbase + wave + WAVES) { BSTAMP(l, 7); }
         int woff = j + 4 * h * LDT;  // opaque: no hoisting of the weight reads
         asm volatile("" : "+v"(woff));
         const float* wlane = wl + woff;
@@ -533,6 +556,7 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
           gate_grad(dz, zz, ss, df, dg);
           mma32<LDT>(dx, df, wlane + 1 * MT);        // da_f[t] * Wf[1]^T
           mma32<LDT>(dx, dg, wlane + 3 * MT);        // da_g[t] * Wg[1]^T
+          if (dead) dx[0] = __builtin_nanf("");      // a wait expired: NaN gradients
           frag_to_lds(t1, j, h, dx);
           __builtin_amdgcn_wave_barrier();
           rows_store_dev(dx_out + off0, lane, hi, rows_from_lds(t1, lane));
@@ -540,11 +564,14 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
           frag_to_lds(t1, j, h, df);                 // t1 / t3 now hold da[t]
           frag_to_lds(t3, j, h, dg);
         }
+        if (tile == tbase + wave) { BSTAMP(l, 8); }
         WN_WAIT_VM0();                               // x tiles in, dx_l out
         if (lane == 0)
           __hip_atomic_store(fl_out + tile, epoch, __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
+        if (tile == tbase + wave) { BSTAMP(l, 9); }
         load_shifted(tile + WAVES);
+        if (tile == tbase + wave) { BSTAMP(l, 10); }
         __builtin_amdgcn_wave_barrier();
         float tsf = 0.f, tsg = 0.f;          // this tile's column sums of da[t]
 #pragma unroll 4
@@ -576,7 +603,9 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
       sf += __shfl_xor(sf, 32);
       sgs += __shfl_xor(sgs, 32);
       sd += __shfl_xor(sd, 32);
+      BSTAMP(l, 3);
       __syncthreads();                       // tiles and wl are free
+      BSTAMP(l, 4);
       if (l > 0) issue_wimg(l - 1);
       float* red = tiles + (wave & (REG - 1)) * RS;
       for (int ph = 0; ph < (WAVES > 4 ? 2 : 1); ++ph) {
@@ -613,6 +642,7 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
         }
         __syncthreads();
       }
+      BSTAMP(l, 5);
       float* out = a.slabs + (size_t)l * a.slab_layer_stride +
                    (size_t)g * LAYER_BLOCK_FLOATS;
       for (int e = tid; e < LAYER_BLOCK_FLOATS; e += WAVES * 64) {
@@ -621,9 +651,13 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
         if (REG == 4) v = (v + tiles[RS + e]) + (tiles[2 * RS + e] + tiles[3 * RS + e]);
         out[e] = v;
       }
+      BSTAMP(l, 6);
     }
     __syncthreads();
   }
+#ifdef STACK_STAMPS
+  if (tid == 0) { cal[2] = __builtin_amdgcn_s_memrealtime(); cal[3] = __builtin_amdgcn_s_memtime(); }
+#endif
   if (tid == 0) {
     const unsigned done = atomicAdd(a.ctl + 1, 1u);
     if (done == gridDim.x - 1) {
@@ -636,7 +670,9 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
 
 #ifdef STACK_STAMPS
 static unsigned long long* g_stack_dbg = nullptr;
+static unsigned long long* g_stack_dbg_b = nullptr;
 extern "C" int wn_diag_stack_dbg(unsigned long long* p) { g_stack_dbg = p; return WN_OK; }
+extern "C" int wn_diag_stack_dbg_b(unsigned long long* p) { g_stack_dbg_b = p; return WN_OK; }
 #endif
 
 extern "C" {
@@ -650,7 +686,8 @@ long wn_stack_flag_count(int B, int T, int L) {
 int wn_stack_fwd(float* X, float* Z, float* SG, const float* params,
                  long layer_stride, const float* bias, long bias_layer_stride,
                  int bias_clip_stride, const int* dilations, unsigned* flags,
-                 unsigned* ctl, int L, int B, int T, int save_sg, void* stream) {
+                 unsigned* ctl, float* poison, int L, int B, int T, int save_sg,
+                 void* stream) {
   if (!X || !Z || !params || !dilations || !flags || !ctl) return WN_ERR_NULL;
   if (save_sg && !SG) return WN_ERR_NULL;
   if (L <= 0 || B <= 0 || T <= 0 || layer_stride < LAYER_BLOCK_FLOATS)
@@ -662,7 +699,8 @@ int wn_stack_fwd(float* X, float* Z, float* SG, const float* params,
   a.X = X; a.Z = Z; a.SG = SG; a.params = params; a.layer_stride = layer_stride;
   a.bias = bias; a.bias_layer_stride = bias_layer_stride;
   a.bias_clip_stride = bias_clip_stride; a.dil = dilations; a.flags = flags;
-  a.ctl = ctl; a.L = L; a.B = B; a.T = T; a.plane = (long)B * T * WN_CH;
+  a.ctl = ctl; a.poison = poison; a.L = L; a.B = B; a.T = T;
+  a.plane = (long)B * T * WN_CH;
 #ifdef STACK_STAMPS
   if (!g_stack_dbg) return WN_ERR_NULL;
   a.dbg = g_stack_dbg;
@@ -739,12 +777,13 @@ int wn_stack_bwd_slabs(int B, int T) {
 int wn_stack_bwd(const float* X, const float* Z, const float* SG,
                  const float* dZ, float* DX, const float* wimg, float* slabs,
                  long slab_layer_stride, float* tilesum, const int* dilations,
-                 unsigned* flags, unsigned* ctl, int L, int B, int T,
-                 void* stream) {
+                 unsigned* flags, unsigned* ctl, float* poison, int L, int B,
+                 int T, void* stream) {
   if (!X || !Z || !SG || !dZ || !DX || !wimg || !slabs || !dilations ||
       !flags || !ctl)
     return WN_ERR_NULL;
   if (L <= 0 || B <= 0 || T <= 0) return WN_ERR_BAD_SHAPE;
+  if (L > STACK_MAXL) return WN_ERR_UNSUPPORTED;
   const void* ptrs[] = {X, Z, SG, dZ, DX, wimg};
   for (const void* p : ptrs)
     if (!wn_aligned16(p)) return WN_ERR_MISALIGNED;
@@ -756,8 +795,13 @@ int wn_stack_bwd(const float* X, const float* Z, const float* SG,
   StackBwd a;
   a.X = X; a.Z = Z; a.SG = SG; a.dZ = dZ; a.DX = DX; a.wimg = wimg;
   a.slabs = slabs; a.slab_layer_stride = slab_layer_stride; a.tilesum = tilesum;
-  a.dil = dilations; a.flags = flags; a.ctl = ctl; a.L = L; a.B = B; a.T = T;
+  a.dil = dilations; a.flags = flags; a.ctl = ctl; a.poison = poison;
+  a.L = L; a.B = B; a.T = T;
   a.tpw = tpw; a.plane = (long)B * T * WN_CH;
+#ifdef STACK_STAMPS
+  if (!g_stack_dbg_b) return WN_ERR_NULL;
+  a.dbg = g_stack_dbg_b;
+#endif
   const int cus = wn_device_cus();
   dim3 grid((unsigned)(groups < cus ? groups : cus)), block(waves * 64);
   hipStream_t s = (hipStream_t)stream;

@@ -99,7 +99,11 @@ class _Workspace(object):
         alloc('bsum', (S,))
         self.total = alloc('total', (N, S)) if net.residual_postproc else None
         self.nparts = lib.wn_xent_partials(N)
-        alloc('loss_parts', (self.nparts,))
+        # (the first 2 words: the NaN "poison" of wn_stack_fwd / wn_stack_bwd,
+        # summed into the loss with the partials that follow them: an expired
+        # wait turns the loss NaN; in front so that a carved-out workspace
+        # shares them)
+        alloc('loss_parts', (2 + self.nparts,), fill=0.0)
         alloc('loss', (1,), fill=0.0)
         alloc('proba', (Q,))
         if not training:
@@ -729,6 +733,7 @@ class WaveNetModel(object):
                       0 if bias is None else bias.shape[1] * bias.shape[2],
                       bstride, _lib.ptr(self._dil_dev),
                       _lib.ptr(ws.stack_flags), _lib.ptr(ws.stack_ctl),
+                      _lib.ptr(ws.loss_parts),
                       L, B, T, 1 if save_ts else 0, st)
         for l, d in enumerate(self.dilations if self.CB == 1 and not stack
                               else []):
@@ -880,7 +885,8 @@ class WaveNetModel(object):
                           ws.lslabs.shape[1] * self.LAYER_BLOCK,
                           None if tsum is None else _lib.ptr(tsum),
                           _lib.ptr(self._dil_dev), _lib.ptr(ws.stack_flags_b),
-                          _lib.ptr(ws.stack_ctl_b), L, B, T, st)
+                          _lib.ptr(ws.stack_ctl_b),
+                          _lib.ptr(ws.loss_parts[1:]), L, B, T, st)
                 self._backward_tail(ws, ids, ws.DX[0], ws.nslab_s, True)
                 return
             for l in range(L - 1, -1, -1):
@@ -1107,9 +1113,9 @@ class WaveNetModel(object):
                       (1 if self._legacy_bwd() else 2))
         _lib.call('wn_xent', _lib.ptr(ws.logits), self.Q, _lib.ptr(ws.q),
                   _lib.ptr(ws.logits) if backward else None,
-                  _lib.ptr(ws.loss_parts), B, T, self.Q,
+                  _lib.ptr(ws.loss_parts[2:]), B, T, self.Q,
                   1 if self.tf_xent_zero_label_quirk else 0, st)
-        _lib.call('wn_reduce_slabs', _lib.ptr(ws.loss_parts), ws.nparts, 1, 1,
+        _lib.call('wn_reduce_slabs', _lib.ptr(ws.loss_parts), ws.nparts + 2, 1, 1,
                   0, 0, 1, _lib.ptr(ws.loss), 0, 1, 0, st)
         loss = ws.loss[0] / float(N)                    # reduce_mean, :666
         if backward:

@@ -59,6 +59,37 @@ def test_argument_validation_without_gpu(hip_lib):
                                   0, 1, None) == -2              # S > 512
 
 
+def test_stack_entries_validate_without_gpu(hip_lib):
+    """wn_stack_fwd / wn_stack_bwd: sizes and argument checks (no launch)."""
+    assert hip_lib.wn_stack_flag_count(8, 16000, 50) == 50 * 8 * 500
+    assert hip_lib.wn_stack_flag_count(2, 33, 3) == 3 * 2 * 2     # ragged tile counts
+    assert hip_lib.wn_stack_flag_count(0, 33, 3) == 0
+    assert hip_lib.wn_stack_bwd_slabs(8, 16000) == 250           # 16 tiles per group
+    assert hip_lib.wn_stack_bwd_slabs(0, 16000) == 0
+    buf = (ctypes.c_float * 64)()
+    a = ctypes.addressof(buf)
+    assert hip_lib.wn_stack_fwd(None, a, a, a, 5216, None, 0, 0, a, a, a, None,
+                                2, 1, 64, 1, None) == -5
+    assert hip_lib.wn_stack_fwd(a, a, None, a, 5216, None, 0, 0, a, a, a, None,
+                                2, 1, 64, 1, None) == -5          # save_sg without SG
+    assert hip_lib.wn_stack_fwd(a, a, a, a, 5216, None, 0, 0, a, a, a, None,
+                                0, 1, 64, 1, None) == -1          # L <= 0
+    assert hip_lib.wn_stack_fwd(a, a, a, a, 100, None, 0, 0, a, a, a, None,
+                                2, 1, 64, 1, None) == -1          # stride < block
+    assert hip_lib.wn_stack_fwd(a + 4, a, a, a, 5216, None, 0, 0, a, a, a, None,
+                                2, 1, 64, 1, None) == -3
+    assert hip_lib.wn_stack_fwd(a, a, a, a, 5216, None, 0, 0, a, a, a, None,
+                                257, 1, 64, 1, None) == -2        # L > 256
+    assert hip_lib.wn_stack_bwd(a, a, a, a, None, a, a, 5216, None, a, a, a,
+                                None, 2, 1, 64, None) == -5
+    assert hip_lib.wn_stack_bwd(a, a, a, a, a, a, a, 5216, None, a, a, a,
+                                None, 2, 0, 64, None) == -1
+    assert hip_lib.wn_stack_bwd(a, a, a, a, a, a, a, 100, None, a, a, a,
+                                None, 2, 1, 64, None) == -1       # slab stride too small
+    assert hip_lib.wn_stack_bwd(a, a + 4, a, a, a, a, a, 5216, None, a, a, a,
+                                None, 2, 1, 64, None) == -3
+
+
 @pytest.mark.parametrize('q', [2, 16, 123, 128, 256])
 def test_host_tables_equal_oracle(hip_lib, q):
     thr = np.empty(q - 1, np.float32)

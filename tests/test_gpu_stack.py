@@ -120,3 +120,34 @@ def test_stack_backward_equals_per_layer(hip_lib, name, mk, B, T, kind):
         prev = ga.clone()
         ctl = wa.stack_ctl_b.cpu().tolist()
         assert ctl[0] == 0 and ctl[1] == 0 and ctl[3] == 0 and ctl[2] == 2 + rep, ctl
+
+
+def test_bounded_wait_expires_loudly(hip_lib):
+    """A launch whose dependencies can never be satisfied (the ticket counter is
+    pre-advanced, so the first tile groups are never computed) must still
+    drain: every poll is bounded (2 s), the control block records the error,
+    the outputs are poisoned with NaN, and the block is re-armed so that the
+    next launch is correct again."""
+    cfg = default_cfg(1)
+    a, b = _pair(cfg)
+    a.stack_bwd = b.stack_bwd = False
+    audio = synth_audio(1, 4000)
+    a.loss(audio)                      # creates the workspace (epoch 1 -> 2)
+    b.loss(audio)
+    ws = list(a._ws.values())[0]
+    torch.cuda.synchronize()
+    ws.stack_ctl[0] = 3                # groups 0..2 will never be handed out
+    bad = a.loss(audio)
+    torch.cuda.synchronize()
+    ctl = ws.stack_ctl.cpu().tolist()
+    assert ctl[3] == 1 and ctl[0] == 0 and ctl[1] == 0, ctl
+    assert np.isnan(float(bad))        # the poison word is part of the loss sum
+    assert np.isnan(float(a.loss(audio)))          # ... and stays until cleared
+    ws.stack_ctl[3] = 0
+    ws.loss_parts[:2] = 0
+    good = a.loss(audio)
+    ref = b.loss(audio)
+    assert float(good) == float(ref)
+    wb = list(b._ws.values())[0]
+    assert torch.equal(ws.Z, wb.Z)
+    assert ws.stack_ctl.cpu().tolist()[3] == 0

@@ -34,10 +34,15 @@ grid = min(256, (B * (T // 32) + 15) // 16)
 dbg = torch.zeros(grid * 16 * L * 12 + grid * 4, dtype=torch.int64, device='cuda')
 lib.wn_diag_stack_dbg.argtypes = [ctypes.c_void_p]
 lib.wn_diag_stack_dbg(dbg.data_ptr())
+gridb = min(256, lib.wn_stack_bwd_slabs(B, T))
+dbgb = torch.zeros(gridb * 8 * L * 12 + gridb * 4, dtype=torch.int64, device='cuda')
+lib.wn_diag_stack_dbg_b.argtypes = [ctypes.c_void_p]
+lib.wn_diag_stack_dbg_b(dbgb.data_ptr())
 audio = synth_audio(B, T)
 fwd_only = os.environ.get('KB_FWDONLY', '0') == '1'     # no sigmoid planes (SAVE = 0)
 for it in range(4):
     dbg.zero_()
+    dbgb.zero_()
     net.loss(audio, backward=not fwd_only)
 torch.cuda.synchronize()
 raw = dbg.cpu().numpy()
@@ -74,3 +79,25 @@ for l in range(0, L - 1):
     if l < 12 or l % 10 == 0:
         wf = (s[:, 0, l, 2] - s[:, 0, l, 1]) / clk / 1e3
         print('layer %2d d=%3d: period %6.2f us, flag wait %5.2f us' % (l, dil[l], np.median(per[:, l]), np.median(wf)))
+
+# ---------------------------------------------------------------- backward
+if not fwd_only:
+    raw = dbgb.cpu().numpy()
+    s = raw[:gridb * 8 * L * 12].reshape(gridb, 8, L, 12).astype(np.float64)
+    cal = raw[gridb * 8 * L * 12:].reshape(gridb, 4).astype(np.float64)
+    clk = np.median((cal[:, 3] - cal[:, 1]) / ((cal[:, 2] - cal[:, 0]) * 10.0))
+    print('=== stack_bwd_kernel: clock %.2f GHz; workgroup entry -> exit median %.1f us, whole launch %.1f us' % (
+        clk, np.median(cal[:, 2] - cal[:, 0]) / 100.0, (cal[:, 2].max() - cal[:, 0].min()) / 100.0))
+    seq = [(0, 1, 'layer top: weight image landed, barrier'), (1, 2, 'first tile: flags + rows t+d requested'),
+           (2, 8, 'first tile until its dx is computed'), (8, 9, 'x tiles in, dx stored and drained, flag'),
+           (9, 10, 'next tile: flags + rows t+d requested'), (10, 7, 'first tile: weight-gradient MFMAs'),
+           (7, 3, 'second tile'), (3, 4, 'closing barrier'), (4, 5, 'reduction tree'), (5, 6, 'slab store')]
+    for wv in (0, 7):
+        print('--- wave %d: median over workgroups and layers 1..L-2 (p90), us' % wv)
+        for a_, b_, nm in seq:
+            dt = (s[:, wv, 1:L - 1, b_] - s[:, wv, 1:L - 1, a_]) / clk / 1e3
+            dt = dt[(s[:, wv, 1:L - 1, b_] > 0) & (s[:, wv, 1:L - 1, a_] > 0)]
+            if dt.size:
+                print('%-46s %6.2f   (%6.2f)' % (nm, np.median(dt), np.percentile(dt, 90)))
+        per = (s[:, wv, 1:L - 2, 0] - s[:, wv, 2:L - 1, 0]) / clk / 1e3     # layers run downwards
+        print('%-46s %6.2f' % ('layer period', np.median(per)))

@@ -124,7 +124,10 @@ class _Workspace(object):
         # persistent backward (wn_stack_bwd): dL/dx_l of EVERY layer (waves
         # of different workgroups are up to a few layers apart, so two
         # ping-pong planes are not enough), its flags and control block
-        self.stack_bwd = net._stack_bwd_ok()
+        # (allocated whenever the option could apply, so that switching
+        # `layer_bwd` / `fused_bwd` back and forth keeps one behaviour)
+        self.stack_bwd = (net.stack_bwd and CB == 1 and not net.generic_layers
+                          and L <= 256)
         if self.stack_bwd:
             alloc('DX', (L, N, CH))
             alloc('stack_flags_b', (lib.wn_stack_flag_count(B, T, L),),
@@ -877,7 +880,7 @@ class WaveNetModel(object):
             # into LDS): one small launch per step
             _lib.call('wn_layer_bwd2_pack', _lib.ptr(self._layer_block(P, 0)),
                       self.layer_stride, _lib.ptr(ws.wimg), L, st)
-            if self.stack_bwd and getattr(ws, 'stack_bwd', False):
+            if self._stack_bwd_ok() and getattr(ws, 'stack_bwd', False):
                 # all L layers in one persistent launch (csrc/wn_stack.hip)
                 _lib.call('wn_stack_bwd', _lib.ptr(ws.X), _lib.ptr(ws.Z),
                           _lib.ptr(ws.SG), _lib.ptr(ws.dZ), _lib.ptr(ws.DX),

@@ -8,7 +8,8 @@ Algorithmic FLOPs per launch at the bench shape (B*T = 128000, default stack):
             their data gradients); gemm_tn3<5,1>: dWs; <4,2>: dW1 and dW2;
   layer_fwd: 80 MFMA / 32-row tile = 10 240 FLOP per audio sample;
   layer_bwdw: 160 MFMA / tile = 20 480 FLOP per audio sample;
-  layer_bwd2d: 176 MFMA / tile = 22 528 FLOP per audio sample.
+  layer_bwd2d: 176 MFMA / tile = 22 528 FLOP per audio sample;
+  stack_fwd / stack_bwd: the same per layer, all 50 layers in one launch.
 With profiles/<tag>_mfma_util.json (tools/pmc_mfma.py) the table also carries
 the matrix-pipe utilisation in CYCLES and the clock the chip held.
 """
@@ -24,6 +25,10 @@ FLOPS = {
     'layer_bwdw_kernel<true, true>': N * 20480.0,
     'layer_fwd_kernel<true, 2>': N * 10240.0,
     'layer_bwd2d_kernel<true>': N * 22528.0,
+    # the persistent whole-stack launches (50 layers; the last layer has no
+    # dense 1x1: 64 instead of 80 MFMAs forward, 128 instead of 176 backward)
+    'stack_fwd_kernel<2, 16>': N * (49 * 10240.0 + 8192.0),
+    'stack_bwd_kernel<8>': N * (49 * 22528.0 + 16384.0),
 }
 MFMA_PEAK, HBM_SPEC, HBM_STREAM = 157.3e12, 8.0e12, 5.3e12
 rows = list(csv.DictReader(open(os.path.join(ROOT, 'profiles', tag + '_bench_kernel_stats.csv'))))
@@ -70,7 +75,7 @@ for r in rows[:12]:
         f1, f2 = '%.2f' % (hb / avg / HBM_SPEC), '%.2f' % (hb / avg / HBM_STREAM)
     else:
         mb = tb = f1 = f2 = '-'
-    bound = 'MFMA' if k.startswith('gemm') else ('latency / MFMA' if k.startswith('layer') else 'HBM')
+    bound = 'MFMA' if k.startswith('gemm') else ('latency / MFMA' if k.startswith(('layer', 'stack')) else 'HBM')
     mu = ck = '-'
     for kk, v in mfma.items():
         if key(kk) == k and v.get('mfma_util') is not None:

@@ -48,6 +48,14 @@ CASES = [
         4, global_condition_channels=32, global_condition_cardinality=377), 4, 7000, 'gc'),
     ('tiny_B2_T100', lambda: cfg_with(TINY, batch_size=2), 2, 100, None),
     ('default_nobias_B2_T4000', lambda: default_cfg(2, use_biases=False), 2, 4000, None),
+    # clips shorter than most dilations (taps entirely before the clip start),
+    # shorter than one tile, one row over a tile
+    ('default_B2_T40', lambda: default_cfg(2), 2, 40, None),
+    ('default_B1_T31', lambda: default_cfg(1), 1, 31, None),
+    ('default_B3_T33', lambda: default_cfg(3), 3, 33, None),
+    ('default_B300_T64', lambda: default_cfg(300), 300, 64, None),     # many clips of two tiles
+    ('one_layer_B2_T500', lambda: default_cfg(2, dilations=[4]), 2, 500, None),
+    ('two_layers_B2_T500', lambda: default_cfg(2, dilations=[64, 1]), 2, 500, None),
 ]
 
 

@@ -458,7 +458,7 @@ __device__ __forceinline__ int fgc_widx(int m, int n, int k) {
 // one-off: layer blocks -> ring-slot images (weights are constant while
 // generating).  Source matrices 1 (Wf[1]), 3 (Wg[1]), 4 (Wd) -> slots 0, 1, 2.
 __global__ void fg_pack_kernel(const float* __restrict__ layer0, long layer_stride,
-                               float* __restrict__ img, int L) {
+                               float* __restrict__ img) {
   const int l = blockIdx.x;
   const float* blk = layer0 + (long)l * layer_stride;
   for (int i = threadIdx.x; i < FGC_CW; i += blockDim.x) {
@@ -1015,7 +1015,7 @@ int wn_fastgen_pack(const float* layer0, long layer_stride, float* img, int L,
   if (!layer0 || !img) return WN_ERR_NULL;
   if (L <= 0) return WN_ERR_BAD_SHAPE;
   hipLaunchKernelGGL(fg_pack_kernel, dim3(L), dim3(256), 0,
-                     (hipStream_t)stream, layer0, layer_stride, img, L);
+                     (hipStream_t)stream, layer0, layer_stride, img);
   return wn_check_launch();
 }
 

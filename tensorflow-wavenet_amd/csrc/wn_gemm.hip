@@ -647,8 +647,7 @@ __device__ __forceinline__ void tn_load(const GemmTN& g, TnRegs<MF, NF>& R,
 // wave-uniform base pointers + 32-bit per-lane offsets (the common case: every
 // group but the last of a split, channel counts multiples of 32).
 template <int MF, int NF>
-__device__ __forceinline__ void tn_load_fast(const GemmTN& g,
-                                             TnRegs<MF, NF>& R,
+__device__ __forceinline__ void tn_load_fast(TnRegs<MF, NF>& R,
                                              const float* const* abase,
                                              const float* const* gbase,
                                              unsigned aoff, unsigned goff,
@@ -726,7 +725,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN g) {
 #define TN_LOAD(REG, R0)                                                       \
   do {                                                                         \
     if (fast && (R0) + GR <= r_end)                                            \
-      tn_load_fast<MF, NF>(g, REG, abase, gbase,                               \
+      tn_load_fast<MF, NF>(REG, abase, gbase,                               \
                            (unsigned)(((R0) + h) * a_ld) + i,                  \
                            (unsigned)(((R0) + h) * g.ldg) + i, astep, gstep);  \
     else                                                                       \

@@ -385,7 +385,7 @@ __global__ void l2_partials_kernel(const float* __restrict__ p, long n,
   }
   red[threadIdx.x] = s;
   __syncthreads();
-  for (int k = 128; k > 0; k >>= 1) {
+  for (unsigned k = 128; k > 0; k >>= 1) {
     if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
     __syncthreads();
   }

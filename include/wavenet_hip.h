@@ -181,7 +181,13 @@ int wn_layer_bwd2(const float* x, const float* z, const float* sg,
  *   X, Z, SG, dZ, DX : [L][B*T][32] planes, layer-major (X[0] = causal layer
  *                      output; forward writes X[1..L-1], Z, SG; backward reads
  *                      X, Z, SG, dZ and writes DX[l] = dL/dx_l for every l)
- *   params/layer_stride : layer 0's parameter block and the float stride
+ *   wimg             : [L][wn_stack_wimg_floats()] weight images out of
+ *                      wn_stack_pack (rows of 36 floats so that four MFMA
+ *                      operands are one 16-byte LDS read; forward: the five
+ *                      matrices transposed + the dense bias, backward: as they
+ *                      are; rebuilt whenever the parameters changed), pulled
+ *                      into LDS by LDS-DMA.  Forward and backward take their
+ *                      own image.
  *   bias             : [L][B or 1][64] filter|gate bias (+gc) of wn_gc_bias, or NULL
  *   dilations        : [L] int32, DEVICE memory
  *   flags            : wn_stack_flag_count(B, T, L) uint32, zero before first use
@@ -195,11 +201,14 @@ int wn_layer_bwd2(const float* x, const float* z, const float* sg,
  *   forward and backward use SEPARATE flags / ctl buffers.
  *   slabs            : [L][slab_layer_stride floats], slab g of layer l at
  *                      l * slab_layer_stride + g * 5216, g < wn_stack_bwd_slabs(B, T)
- *   wimg, tilesum    : as wn_layer_bwd2 (tilesum: [L][tiles][64] or NULL)
+ *   tilesum          : as wn_layer_bwd2 ([L][tiles][64] or NULL)
  * L <= 256. */
 long wn_stack_flag_count(int B, int T, int L);
-int wn_stack_fwd(float* X, float* Z, float* SG, const float* params,
-                 long layer_stride, const float* bias, long bias_layer_stride,
+int wn_stack_wimg_floats(void);
+int wn_stack_pack(const float* layer0, long layer_stride, float* wimg_fwd,
+                  float* wimg_bwd, int L, void* stream);
+int wn_stack_fwd(float* X, float* Z, float* SG, const float* wimg,
+                 const float* bias, long bias_layer_stride,
                  int bias_clip_stride, const int* dilations, unsigned* flags,
                  unsigned* ctl, float* poison, int L, int B, int T, int save_sg,
                  void* stream);

@@ -38,14 +38,23 @@
 #define WN_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 #define STACK_MAXL 256   // layers (LDS bookkeeping words per layer)
-#define STACK_WBUF (LAYER_W_FLOATS + 256)   // 21 KiB: keeps both halves 1 KiB aligned
+// Forward weight image of one layer (wn_stack_pack): the five 32 x 32
+// matrices TRANSPOSED, [m][cout][SF_LD] with the contraction index (cin)
+// contiguous and rows padded to 36 floats, then the dense bias.  A lane's four
+// consecutive A operands (cin = 8q+4h .. +3 of its cout row) are ONE
+// ds_read_b128 instead of four ds_read_b32 (row stride 36 floats: the eight
+// lanes of a 128-byte LDS beat hit 32 different banks), so a tile's 80 MFMAs
+// are fed by 20 LDS instructions.
+#define SF_LD 36
+#define SF_MT (32 * SF_LD)
+#define SF_OFF_BD (5 * SF_MT)                // 5760
+#define STACK_WBUF 5888                      // 23 KiB per layer (1 KiB multiple)
 
 struct StackFwd {
   float* X;            // [L][N][32]  X[l] = input of layer l (X[0]: causal layer)
   float* Z;            // [L][N][32]
   float* SG;           // [L][N][32] sigmoid planes (SAVE == 2) or null
-  const float* params; // layer 0's parameter block
-  long layer_stride;   // floats between layer blocks
+  const float* wimg;   // [L][STACK_WBUF] forward weight images (wn_stack_pack)
   const float* bias;   // [L][B or 1][64] filter|gate bias (+ gc), or null
   long bias_layer_stride;
   int bias_clip_stride;
@@ -126,6 +135,42 @@ __device__ __forceinline__ void wait_flags(const unsigned* fl, int idx,
   asm volatile("" ::: "memory");
 }
 
+// acc^T[cout = i, time] += sum_k W[k][i] * frag[time, k] with the TRANSPOSED
+// image: `wt_lane` = image + i * SF_LD + 4 * h; the four operands of
+// r = 4q .. 4q+3 (cin = 8q + 4h + e) are one 16-byte LDS read.  Same MFMA order
+// as mma32 (bitwise the same result).
+__device__ __forceinline__ void mma32t(f32x16& acc, const f32x16& frag,
+                                       const float* wt_lane) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 a4 = *reinterpret_cast<const f32x4*>(wt_lane + 8 * q);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], frag[4 * q + e], acc, 0, 0, 0);
+  }
+}
+
+// blockIdx.y == 0: forward image (transposed, + dense bias); 1: backward image
+// (the matrices as they are, [m][cin][SF_LD]: there the contraction runs over
+// cout, so again a lane's four consecutive operands are 16 contiguous bytes)
+__global__ void stack_pack_kernel(const float* __restrict__ layer0,
+                                  long layer_stride, float* __restrict__ img_f,
+                                  float* __restrict__ img_b) {
+  const bool bwd = blockIdx.y == 1;
+  float* img = bwd ? img_b : img_f;
+  if (!img) return;
+  const float* blk = layer0 + (long)blockIdx.x * layer_stride;
+  float* out = img + (size_t)blockIdx.x * STACK_WBUF;
+  for (int i = threadIdx.x; i < STACK_WBUF; i += blockDim.x) out[i] = 0.f;
+  __syncthreads();
+  for (int i = threadIdx.x; i < LAYER_W_FLOATS; i += blockDim.x) {
+    const int m = i >> 10, cin = (i >> 5) & 31, cout = i & 31;   // W[m][cin][cout]
+    out[m * SF_MT + (bwd ? cin * SF_LD + cout : cout * SF_LD + cin)] = blk[i];
+  }
+  if (!bwd && threadIdx.x < 32)
+    out[SF_OFF_BD + threadIdx.x] = blk[LAYER_OFF_BD + threadIdx.x];
+}
+
 // bounded spin on a workgroup-local LDS word
 __device__ __forceinline__ void wait_lds(const int* p, bool& dead) {
   unsigned spins = 0;
@@ -167,19 +212,13 @@ __global__ __launch_bounds__(WAVES * 64) void stack_fwd_kernel(StackFwd a) {
 #define SSTAMP(l, i)
 #endif
 
-  // pieces [p0, p0 + step, ...) of layer l's 20 KiB of weights by LDS-DMA, and
-  // (from the wave that takes piece 0) its dense bias as one 4-byte-per-lane
-  // piece: floats LAYER_OFF_BD .. +63 of the block (the second half belongs to
-  // the next layer's block and is never read; the last layer has no dense conv)
+  // pieces [p0, p0 + step, ...) of layer l's 23 KiB weight image by LDS-DMA
   auto issue_weights = [&](int l, int p0, int step) {
-    const float* wb = a.params + (long)l * a.layer_stride;
+    const float* wb = a.wimg + (size_t)l * STACK_WBUF;
     float* dst = wl + (l & 1) * STACK_WBUF;
-    for (int p = p0; p < LAYER_W_FLOATS / 256; p += step)
+    for (int p = p0; p < STACK_WBUF / 256; p += step)
       __builtin_amdgcn_global_load_lds((wn_gptr_t)(wb + p * 256 + lane * 4),
                                        (wn_lptr_t)(dst + p * 256), 16, 0, 0);
-    if (p0 == 0 && l + 1 < L)
-      __builtin_amdgcn_global_load_lds((wn_gptr_t)(wb + LAYER_OFF_BD + lane),
-                                       (wn_lptr_t)(dst + LAYER_W_FLOATS), 4, 0, 0);
   };
 
   for (;;) {
@@ -252,7 +291,7 @@ __global__ __launch_bounds__(WAVES * 64) void stack_fwd_kernel(StackFwd a) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
       SSTAMP(l, 3);
-      int woff = j + 4 * h * 32 + (l & 1) * STACK_WBUF;
+      int woff = j * SF_LD + 4 * h + (l & 1) * STACK_WBUF;
       asm volatile("" : "+v"(woff));
       const float* wlane = wl + woff;
       f32x16 af, ag;
@@ -266,13 +305,13 @@ __global__ __launch_bounds__(WAVES * 64) void stack_fwd_kernel(StackFwd a) {
         ag = frag_zero();
       }
 #ifndef STACK_NOMMA
-      mma32<32>(af, xp, wlane + 0 * 1024);  // Wf[0]: past tap
-      mma32<32>(af, xc, wlane + 1 * 1024);  // Wf[1]: current tap
-      mma32<32>(ag, xp, wlane + 2 * 1024);  // Wg[0]
-      mma32<32>(ag, xc, wlane + 3 * 1024);  // Wg[1]
+      mma32t(af, xp, wlane + 0 * SF_MT);  // Wf[0]: past tap
+      mma32t(af, xc, wlane + 1 * SF_MT);  // Wf[1]: current tap
+      mma32t(ag, xp, wlane + 2 * SF_MT);  // Wg[0]
+      mma32t(ag, xc, wlane + 3 * SF_MT);  // Wg[1]
 #else
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { af[r] += xp[r] * wlane[0]; ag[r] += xc[r] * wlane[1024]; }
+      for (int r = 0; r < 16; ++r) { af[r] += xp[r] * wlane[0]; ag[r] += xc[r] * wlane[SF_MT]; }
 #endif
       SSTAMP(l, 4);
       f32x16 zz;
@@ -287,14 +326,14 @@ __global__ __launch_bounds__(WAVES * 64) void stack_fwd_kernel(StackFwd a) {
       SSTAMP(l, 5);
       // x' first: it is what other waves wait for
       if (l + 1 < L) {
-        const f32x16 bd = frag_bcast(wl + (l & 1) * STACK_WBUF + LAYER_W_FLOATS, h);
+        const f32x16 bd = frag_bcast(wl + (l & 1) * STACK_WBUF + SF_OFF_BD, h);
 #pragma unroll
         for (int r = 0; r < 16; ++r) xc[r] += bd[r];
 #ifndef STACK_NOMMA
-        mma32<32>(xc, zz, wlane + 4 * 1024);  // Wd
+        mma32t(xc, zz, wlane + 4 * SF_MT);  // Wd
 #else
 #pragma unroll
-        for (int r = 0; r < 16; ++r) xc[r] += zz[r] * wlane[4096];
+        for (int r = 0; r < 16; ++r) xc[r] += zz[r] * wlane[4 * SF_MT];
 #endif
         SSTAMP(l, 6);
         __builtin_amdgcn_wave_barrier();
@@ -371,7 +410,7 @@ struct StackBwd {
   const float* SG;
   const float* dZ;
   float* DX;           // [L][N][32]  DX[l] = dL/dx_l
-  const float* wimg;   // [L][B2_WIMG] (wn_layer_bwd2_pack)
+  const float* wimg;   // [L][STACK_WBUF] backward weight images (wn_stack_pack)
   float* slabs;        // [L][>= groups][LAYER_BLOCK_FLOATS]
   long slab_layer_stride;
   float* tilesum;      // [L][ntiles][64] per-tile column sums of da, or null
@@ -388,11 +427,10 @@ struct StackBwd {
 
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
-  constexpr int LDT = 33, MT = 32 * LDT;
   constexpr int RS = 5248;                       // floats per reduction region
   constexpr int REG = WAVES >= 4 ? 4 : WAVES;    // reduction regions
   constexpr int TILE_FLOATS = WAVES * 4096 > REG * RS ? WAVES * 4096 : REG * RS;
-  __shared__ __attribute__((aligned(1024))) float wl[B2_WIMG];
+  __shared__ __attribute__((aligned(1024))) float wl[STACK_WBUF];
   __shared__ __attribute__((aligned(1024))) float tiles[TILE_FLOATS];
   __shared__ int s_group;
   const int tid = threadIdx.x;
@@ -423,8 +461,8 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
 #endif
 
   auto issue_wimg = [&](int l) {
-    const float* src = a.wimg + (size_t)l * B2_WIMG;
-    for (int p = wave; p < B2_WIMG / 256; p += WAVES)
+    const float* src = a.wimg + (size_t)l * STACK_WBUF;
+    for (int p = wave; p < STACK_WBUF / 256; p += WAVES)
       __builtin_amdgcn_global_load_lds((wn_gptr_t)(src + p * 256 + lane * 4),
                                        (wn_lptr_t)(wl + p * 256), 16, 0, 0);
   };
@@ -492,7 +530,7 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
       BSTAMP(l, 2);
       for (int tile = tbase + wave; tile < tend; tile += WAVES) {
         if (tile == tbase + wave + WAVES) { BSTAMP(l, 7); }
-        int woff = j + 4 * h * LDT;  // opaque: no hoisting of the weight reads
+        int woff = j * SF_LD + 4 * h;  // opaque: no hoisting of the weight reads
         asm volatile("" : "+v"(woff));
         const float* wlane = wl + woff;
         const int b = tile / tiles_per_clip;
@@ -522,11 +560,11 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
         tile_dma(t2, z + off0, lane, 0, hi);
         tile_dma(t3, sg + off0, lane, 0, hi);
         if (hi_f > 0) {
-          if (hx) mma32<LDT>(dz, di, wlane + 4 * MT);  // dx_{l+1}[t+d] * Wd^T
+          if (hx) mma32t(dz, di, wlane + 4 * SF_MT);  // dx_{l+1}[t+d] * Wd^T
           f32x16 df, dg;
           gate_grad(dz, zz, ss, df, dg);
-          mma32<LDT>(dx, df, wlane + 0 * MT);        // da_f[t+d] * Wf[0]^T
-          mma32<LDT>(dx, dg, wlane + 2 * MT);        // da_g[t+d] * Wg[0]^T
+          mma32t(dx, df, wlane + 0 * SF_MT);        // da_f[t+d] * Wf[0]^T
+          mma32t(dx, dg, wlane + 2 * SF_MT);        // da_g[t+d] * Wg[0]^T
         }
         WN_WAIT_VM0();
         if (hx) {                                    // dWd += z^T dx_{l+1}
@@ -550,12 +588,12 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
           if (hx) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) dx[r] += di[r];
-            mma32<LDT>(dz, di, wlane + 4 * MT);      // dx_{l+1}[t] * Wd^T
+            mma32t(dz, di, wlane + 4 * SF_MT);      // dx_{l+1}[t] * Wd^T
           }
           f32x16 df, dg;
           gate_grad(dz, zz, ss, df, dg);
-          mma32<LDT>(dx, df, wlane + 1 * MT);        // da_f[t] * Wf[1]^T
-          mma32<LDT>(dx, dg, wlane + 3 * MT);        // da_g[t] * Wg[1]^T
+          mma32t(dx, df, wlane + 1 * SF_MT);        // da_f[t] * Wf[1]^T
+          mma32t(dx, dg, wlane + 3 * SF_MT);        // da_g[t] * Wg[1]^T
           if (dead) dx[0] = __builtin_nanf("");      // a wait expired: NaN gradients
           frag_to_lds(t1, j, h, dx);
           __builtin_amdgcn_wave_barrier();
@@ -683,20 +721,32 @@ long wn_stack_flag_count(int B, int T, int L) {
   return (long)L * B * ((T + 31) / 32);
 }
 
-int wn_stack_fwd(float* X, float* Z, float* SG, const float* params,
-                 long layer_stride, const float* bias, long bias_layer_stride,
+int wn_stack_wimg_floats(void) { return STACK_WBUF; }
+
+int wn_stack_pack(const float* layer0, long layer_stride, float* wimg_fwd,
+                  float* wimg_bwd, int L, void* stream) {
+  if (!layer0 || (!wimg_fwd && !wimg_bwd)) return WN_ERR_NULL;
+  if (L <= 0 || layer_stride < LAYER_BLOCK_FLOATS) return WN_ERR_BAD_SHAPE;
+  if ((wimg_fwd && !wn_aligned16(wimg_fwd)) || (wimg_bwd && !wn_aligned16(wimg_bwd)))
+    return WN_ERR_MISALIGNED;
+  hipLaunchKernelGGL(stack_pack_kernel, dim3(L, 2), dim3(256), 0,
+                     (hipStream_t)stream, layer0, layer_stride, wimg_fwd, wimg_bwd);
+  return wn_check_launch();
+}
+
+int wn_stack_fwd(float* X, float* Z, float* SG, const float* wimg,
+                 const float* bias, long bias_layer_stride,
                  int bias_clip_stride, const int* dilations, unsigned* flags,
                  unsigned* ctl, float* poison, int L, int B, int T, int save_sg,
                  void* stream) {
-  if (!X || !Z || !params || !dilations || !flags || !ctl) return WN_ERR_NULL;
+  if (!X || !Z || !wimg || !dilations || !flags || !ctl) return WN_ERR_NULL;
   if (save_sg && !SG) return WN_ERR_NULL;
-  if (L <= 0 || B <= 0 || T <= 0 || layer_stride < LAYER_BLOCK_FLOATS)
-    return WN_ERR_BAD_SHAPE;
+  if (L <= 0 || B <= 0 || T <= 0) return WN_ERR_BAD_SHAPE;
   if (!wn_aligned16(X) || !wn_aligned16(Z) || (SG && !wn_aligned16(SG)) ||
-      !wn_aligned16(params) || (layer_stride & 3))
+      !wn_aligned16(wimg))
     return WN_ERR_MISALIGNED;
   StackFwd a;
-  a.X = X; a.Z = Z; a.SG = SG; a.params = params; a.layer_stride = layer_stride;
+  a.X = X; a.Z = Z; a.SG = SG; a.wimg = wimg;
   a.bias = bias; a.bias_layer_stride = bias_layer_stride;
   a.bias_clip_stride = bias_clip_stride; a.dil = dilations; a.flags = flags;
   a.ctl = ctl; a.poison = poison; a.L = L; a.B = B; a.T = T;

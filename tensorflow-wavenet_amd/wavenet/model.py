@@ -93,6 +93,7 @@ class _Workspace(object):
         # {group ticket, workgroups done, epoch, error}; epochs start at 1
         alloc('stack_flags', (lib.wn_stack_flag_count(B, T, L),), torch.int32,
               fill=0)
+        alloc('wimg_f', (L, lib.wn_stack_wimg_floats()))
         alloc('stack_ctl', (4,), torch.int32, fill=0)
         if parent is None:
             self.stack_ctl[2] = 1
@@ -130,6 +131,7 @@ class _Workspace(object):
                           and L <= 256)
         if self.stack_bwd:
             alloc('DX', (L, N, CH))
+            alloc('wimg_b', (L, lib.wn_stack_wimg_floats()))
             alloc('stack_flags_b', (lib.wn_stack_flag_count(B, T, L),),
                   torch.int32, fill=0)
             alloc('stack_ctl_b', (4,), torch.int32, fill=0)
@@ -729,9 +731,12 @@ class WaveNetModel(object):
                  and save_ts in (0, 2) and L <= 256)
         if stack:
             # all L layers in one persistent launch (csrc/wn_stack.hip)
+            # (its transposed weight images, one small launch per call)
+            _lib.call('wn_stack_pack', _lib.ptr(self._layer_block(P, 0)),
+                      self.layer_stride, _lib.ptr(ws.wimg_f), None, L, st)
             _lib.call('wn_stack_fwd', _lib.ptr(ws.X), _lib.ptr(ws.Z),
                       _lib.ptr(ws.SG) if save_ts else None,
-                      _lib.ptr(self._layer_block(P, 0)), self.layer_stride,
+                      _lib.ptr(ws.wimg_f),
                       None if bias is None else _lib.ptr(bias),
                       0 if bias is None else bias.shape[1] * bias.shape[2],
                       bstride, _lib.ptr(self._dil_dev),
@@ -876,15 +881,13 @@ class WaveNetModel(object):
             # one launch per layer; the launches are chained through dx only
             dxin, xp = None, 0
             tsum = None if ws.dsum is None else ws.tilesum
-            # transposed weight images of all layers (the kernels DMA them
-            # into LDS): one small launch per step
-            _lib.call('wn_layer_bwd2_pack', _lib.ptr(self._layer_block(P, 0)),
-                      self.layer_stride, _lib.ptr(ws.wimg), L, st)
             if self._stack_bwd_ok() and getattr(ws, 'stack_bwd', False):
                 # all L layers in one persistent launch (csrc/wn_stack.hip)
+                _lib.call('wn_stack_pack', _lib.ptr(self._layer_block(P, 0)),
+                          self.layer_stride, None, _lib.ptr(ws.wimg_b), L, st)
                 _lib.call('wn_stack_bwd', _lib.ptr(ws.X), _lib.ptr(ws.Z),
                           _lib.ptr(ws.SG), _lib.ptr(ws.dZ), _lib.ptr(ws.DX),
-                          _lib.ptr(ws.wimg), _lib.ptr(ws.lslabs),
+                          _lib.ptr(ws.wimg_b), _lib.ptr(ws.lslabs),
                           ws.lslabs.shape[1] * self.LAYER_BLOCK,
                           None if tsum is None else _lib.ptr(tsum),
                           _lib.ptr(self._dil_dev), _lib.ptr(ws.stack_flags_b),
@@ -892,6 +895,10 @@ class WaveNetModel(object):
                           _lib.ptr(ws.loss_parts[1:]), L, B, T, st)
                 self._backward_tail(ws, ids, ws.DX[0], ws.nslab_s, True)
                 return
+            # transposed weight images of all layers (the kernels DMA them
+            # into LDS): one small launch per step
+            _lib.call('wn_layer_bwd2_pack', _lib.ptr(self._layer_block(P, 0)),
+                      self.layer_stride, _lib.ptr(ws.wimg), L, st)
             for l in range(L - 1, -1, -1):
                 dxo = ws.dx[xp]
                 _lib.call('wn_layer_bwd2', _lib.ptr(ws.X[l]), _lib.ptr(ws.Z[l]),

@@ -68,17 +68,18 @@ def test_stack_entries_validate_without_gpu(hip_lib):
     assert hip_lib.wn_stack_bwd_slabs(0, 16000) == 0
     buf = (ctypes.c_float * 64)()
     a = ctypes.addressof(buf)
-    assert hip_lib.wn_stack_fwd(None, a, a, a, 5216, None, 0, 0, a, a, a, None,
+    assert hip_lib.wn_stack_fwd(None, a, a, a, None, 0, 0, a, a, a, None,
                                 2, 1, 64, 1, None) == -5
-    assert hip_lib.wn_stack_fwd(a, a, None, a, 5216, None, 0, 0, a, a, a, None,
+    assert hip_lib.wn_stack_fwd(a, a, None, a, None, 0, 0, a, a, a, None,
                                 2, 1, 64, 1, None) == -5          # save_sg without SG
-    assert hip_lib.wn_stack_fwd(a, a, a, a, 5216, None, 0, 0, a, a, a, None,
+    assert hip_lib.wn_stack_fwd(a, a, a, a, None, 0, 0, a, a, a, None,
                                 0, 1, 64, 1, None) == -1          # L <= 0
-    assert hip_lib.wn_stack_fwd(a, a, a, a, 100, None, 0, 0, a, a, a, None,
-                                2, 1, 64, 1, None) == -1          # stride < block
-    assert hip_lib.wn_stack_fwd(a + 4, a, a, a, 5216, None, 0, 0, a, a, a, None,
+    assert hip_lib.wn_stack_pack(a, 100, a, a, 2, None) == -1     # stride < block
+    assert hip_lib.wn_stack_pack(a, 5216, None, None, 2, None) == -5
+    assert hip_lib.wn_stack_wimg_floats() % 256 == 0
+    assert hip_lib.wn_stack_fwd(a + 4, a, a, a, None, 0, 0, a, a, a, None,
                                 2, 1, 64, 1, None) == -3
-    assert hip_lib.wn_stack_fwd(a, a, a, a, 5216, None, 0, 0, a, a, a, None,
+    assert hip_lib.wn_stack_fwd(a, a, a, a, None, 0, 0, a, a, a, None,
                                 257, 1, 64, 1, None) == -2        # L > 256
     assert hip_lib.wn_stack_bwd(a, a, a, a, None, a, a, 5216, None, a, a, a,
                                 None, 2, 1, 64, None) == -5

@@ -1446,6 +1446,25 @@ int wn_gemm_tn(const float* A, long lda, int a_planes, long a_plane_stride,
   return wn_check_launch();
 }
 
+// Few outputs, many slabs (the loss: one value out of ~1000 partials): one wave
+// per output, lane l sums slabs l, l + 64, ... in order, then a fixed xor tree.
+// Deterministic; replaces one thread walking 1000 dependent loads (26 us).
+__global__ __launch_bounds__(64) void reduce_slabs_wave_kernel(
+    const float* __restrict__ slabs, int num_slabs, long slab_stride,
+    long in_batch_stride, long offset, float* __restrict__ dst,
+    long out_batch_stride, int replicate, long rep_stride) {
+  const long e = blockIdx.x;
+  const int b = blockIdx.y;
+  const float* p = slabs + (long)b * in_batch_stride + offset + e;
+  float v = 0.f;
+  for (int s = threadIdx.x; s < num_slabs; s += 64) v += p[(long)s * slab_stride];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  if (threadIdx.x == 0)
+    for (int r = 0; r < replicate; ++r)
+      dst[(long)b * out_batch_stride + (long)r * rep_stride + e] = v;
+}
+
 int wn_reduce_slabs(const float* slabs, int num_slabs, long slab_stride,
                     int batch, long in_batch_stride, long offset, long n,
                     float* dst, long out_batch_stride, int replicate,
@@ -1453,6 +1472,13 @@ int wn_reduce_slabs(const float* slabs, int num_slabs, long slab_stride,
   if (!slabs || !dst) return WN_ERR_NULL;
   if (num_slabs <= 0 || n <= 0 || batch <= 0 || replicate <= 0)
     return WN_ERR_BAD_SHAPE;
+  if (n <= 4 && num_slabs >= 256) {
+    hipLaunchKernelGGL(reduce_slabs_wave_kernel, dim3((unsigned)n, batch),
+                       dim3(64), 0, (hipStream_t)stream, slabs, num_slabs,
+                       slab_stride, in_batch_stride, offset, dst,
+                       out_batch_stride, replicate, rep_stride);
+    return wn_check_launch();
+  }
   dim3 grid((unsigned)((n + 255) / 256), batch), block(256);
   hipLaunchKernelGGL(reduce_slabs_kernel, grid, block, 0, (hipStream_t)stream,
                      slabs, num_slabs, slab_stride, in_batch_stride, offset, n,

@@ -284,3 +284,29 @@ def test_causal_wgrad_segmented_sum(hip_lib, B, T, Q):
             if t >= 1:
                 ref[0, q[b, t - 1]] += Gr[b, t]
     assert np.abs(outs[0] - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize('nslab,n,batch,rep', [(1026, 1, 1, 1), (300, 3, 2, 2),
+                                               (255, 2, 1, 1), (2048, 4, 3, 1)])
+def test_reduce_slabs_few_outputs(hip_lib, nslab, n, batch, rep):
+    """wn_reduce_slabs with a handful of outputs and many slabs (the loss
+    partials): the wave-parallel path (>= 256 slabs) and the plain one give the
+    float64 sum to rounding, identically on every run."""
+    from wavenet import _lib
+    rng = np.random.default_rng(nslab + n)
+    stride, bstride, off = 7, nslab * 7 + 5, 2
+    src = rng.standard_normal(batch * bstride + 16).astype(np.float32)
+    d = dev(src)
+    out = torch.full((batch * 8 + rep * 16,), -1.0, device='cuda')
+    outs = []
+    for _ in range(2):
+        _lib.call('wn_reduce_slabs', d.data_ptr(), nslab, stride, batch, bstride,
+                  off, n, out.data_ptr(), 8, rep, 16, torch.cuda.current_stream().cuda_stream)
+        outs.append(out.clone())
+    assert torch.equal(outs[0], outs[1])
+    got = outs[0].cpu().numpy()
+    for b in range(batch):
+        for e in range(n):
+            ref = sum(float(src[b * bstride + off + e + s * stride]) for s in range(nslab))
+            for r in range(rep):
+                assert abs(got[b * 8 + r * 16 + e] - ref) <= 1e-5 * max(1.0, nslab ** 0.5)

@@ -537,6 +537,21 @@ class WaveNetModel(object):
         return (self.layer_bwd != 'bwd2' or not self.fused_bwd
                 or self.generic_layers or self.overlap_wgrad or self.CB > 1)
 
+    def check_device_errors(self):
+        """Raise if a persistent stack launch recorded an expired dependency
+        wait (its control word 3; the loss of that step is NaN by
+        construction, see _Workspace.loss_parts).  Synchronises the device:
+        meant for the moment a caller sees a non-finite loss."""
+        for ws in self._ws.values():
+            for name in ('stack_ctl', 'stack_ctl_b'):
+                ctl = getattr(ws, name, None)
+                if ctl is not None and int(ctl[3]) != 0:
+                    raise _lib.WaveNetHipError(
+                        '%s: a dependency wait inside the persistent residual-'
+                        'stack launch expired (2 s); the results of that step '
+                        'are invalid.  WN_STACK_FWD=0 / WN_STACK_BWD=0 select '
+                        'the one-launch-per-layer kernels.' % name)
+
     def _stack_bwd_ok(self):
         """wn_stack_bwd covers what wn_layer_bwd2 covers."""
         return self.stack_bwd and not self._legacy_bwd() and self.L <= 256

@@ -96,6 +96,7 @@ def test_stack_inference_forward(hip_lib):
     assert torch.equal(a.predict_proba(q), b.predict_proba(q))
     for ws in a._ws.values():
         assert ws.stack_ctl.cpu().tolist()[3] == 0
+    a.check_device_errors()
 
 
 @pytest.mark.parametrize('name,mk,B,T,kind', CASES, ids=[c[0] for c in CASES])
@@ -151,6 +152,9 @@ def test_bounded_wait_expires_loudly(hip_lib):
     assert ctl[3] == 1 and ctl[0] == 0 and ctl[1] == 0, ctl
     assert np.isnan(float(bad))        # the poison word is part of the loss sum
     assert np.isnan(float(a.loss(audio)))          # ... and stays until cleared
+    from wavenet._lib import WaveNetHipError
+    with pytest.raises(WaveNetHipError):
+        a.check_device_errors()
     ws.stack_ctl[3] = 0
     ws.loss_parts[:2] = 0
     good = a.loss(audio)
@@ -159,3 +163,4 @@ def test_bounded_wait_expires_loudly(hip_lib):
     wb = list(b._ws.values())[0]
     assert torch.equal(ws.Z, wb.Z)
     assert ws.stack_ctl.cpu().tolist()[3] == 0
+    a.check_device_errors()

@@ -301,6 +301,8 @@ def main(argv=None):
                             l2_regularization_strength=l2)
             optimizer.minimize(loss)
             loss_value = float(parallel.allreduce_mean_scalar(loss))
+            if not np.isfinite(loss_value):
+                net.check_device_errors()     # raises if a kernel reported one
             if trace:
                 prof.__exit__(None, None, None)
                 prof.export_chrome_trace(os.path.join(logdir,

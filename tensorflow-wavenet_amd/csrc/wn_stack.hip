@@ -304,6 +304,8 @@ __global__ __launch_bounds__(WAVES * 64) void stack_fwd_kernel(StackFwd a) {
         af = frag_zero();
         ag = frag_zero();
       }
+      // (-DSTACK_NOMMA / -DSTACK_NOACT: timing-only ablation builds, see
+      // DESIGN.md 3a; their results are meaningless)
 #ifndef STACK_NOMMA
       mma32t(af, xp, wlane + 0 * SF_MT);  // Wf[0]: past tap
       mma32t(af, xc, wlane + 1 * SF_MT);  // Wf[1]: current tap

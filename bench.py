@@ -15,8 +15,15 @@ all-reduce of ones.  WORLD_SIZE != --gpus is an error.
 Extra objects on the JSON line:
   roofline     - the dominant kernel (gemm_nn3_kernel: the skip-sum /
                  post-processing fp32 MFMA GEMMs and their data gradients),
-                 timed live with HIP events on the launch stream inside the
-                 timed region; achieved = algorithmic FLOPs / kernel time.
+                 timed live with HIP events on the launch stream in a short
+                 instrumented pass of the same step right after the headline
+                 loop (the headline loop itself carries no instrumentation);
+                 achieved = algorithmic FLOPs / kernel time.
+  step_tflops / step_frac - the WHOLE step against the fp32 MFMA peak
+                 (8.804 MFLOP per audio sample).
+  N > 1 only: allreduce_us_per_step (HIP events around the gradient
+                 all-reduce, instrumented pass), step_ms_min / step_ms_max
+                 over ranks.
   cpu_baseline - the reference graph restated op for op in PyTorch-CPU
                  (oracle/torch_graph.py, kind "port": TF 0.10 cannot be
                  installed here) timed on this host's cores on a bounded
@@ -37,6 +44,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+STEP_FLOP_PER_SAMPLE = 8.804e6  # fwd 2.935 MFLOP x 3, default stack
 
 
 def synth_audio(B, T, first_clip=0, seed=1234, sample_rate=16000):
@@ -68,6 +76,19 @@ def host_cores(cap=16):
     return max(1, min(n, int(os.environ.get('WN_CPU_THREADS', cap))))
 
 
+def cpu_model():
+    """CPU model string of this host (/proc/cpuinfo), SURVEY 8(d)."""
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.lower().startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine() or 'unknown'
+
+
 def log(msg):
     sys.stderr.write('[bench] %s\n' % msg)
     sys.stderr.flush()
@@ -96,7 +117,7 @@ def cpu_baseline(params, T, max_seconds=20.0, max_steps=20):
         log('cpu step %d done (%.1f s elapsed)' % (n, time.time() - t0))
     dt = (time.time() - t0) / max(n, 1)
     return {'value': T / dt, 'unit': 'audio samples/s', 'cores': cores,
-            'kind': 'port',
+            'cpu_model': cpu_model(), 'kind': 'port',
             'sample': '%d full training steps (fwd+bwd+TF-Adam) of the '
                       'op-for-op PyTorch-CPU restatement of the reference '
                       'graph, default wavenet_params.json, B=1, T=%d '
@@ -151,8 +172,40 @@ def secondary(net, audio, gc_ids, kw, B, T, gen_samples=16000, opt=None):
         optin = (time.perf_counter() - t0) / 10 * 1e3
         net.gemm_mode = 'fp32'
         log('opt-in bf16x6 GEMM mode: %.2f ms/step' % optin)
+    from wavenet import optimizer_factory
+
+    def timed_steps(model, a, ids, n=10, warm=3):
+        o = optimizer_factory['adam'](learning_rate=1e-3, momentum=0.9)
+        for _ in range(warm):
+            o.minimize(model.loss(a, ids))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            o.minimize(model.loss(a, ids))
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    # BASELINE.json configs[3] on ONE GPU: the same step with global
+    # conditioning 32 x 377 (skipped when the headline run already has it)
+    gc_ms = None
+    if not kw.get('global_condition_channels'):
+        kwg = dict(kw, global_condition_channels=32,
+                   global_condition_cardinality=377)
+        netg = WaveNetModel(seed=0, **kwg)
+        idsg = torch.tensor([(37 * b) % 377 for b in range(B)],
+                            dtype=torch.int32, device=audio.device)
+        gc_ms = timed_steps(netg, audio, idsg)
+        del netg
+        log('global conditioning 32x377: %.2f ms/step' % gc_ms)
+    # configs[0] shape (one clip) on the GPU
     kw1 = dict(kw)
     kw1['batch_size'] = 1
+    net1 = WaveNetModel(seed=0, **kw1)
+    ids1 = None if gc_ids is None else gc_ids[:1]
+    b1_ms = timed_steps(net1, audio[:1], ids1)
+    del net1
+    torch.cuda.empty_cache()
+    log('B=1: %.2f ms/step' % b1_ms)
     gen = WaveNetModel(seed=0, **kw1)
     gc = 5 if kw.get('global_condition_channels') else None
     gen.generate(200, seed_samples=[128], seed=1, global_condition=gc)  # warm-up
@@ -167,6 +220,10 @@ def secondary(net, audio, gc_ids, kw, B, T, gen_samples=16000, opt=None):
             'fastgen_samples_per_s': gen_samples / dt,
             'fastgen_us_per_sample': dt / gen_samples * 1e6,
             'fastgen_samples': gen_samples,
+            'gc_ms_per_step': gc_ms,
+            'gc_samples_per_s': None if gc_ms is None else B * T / gc_ms * 1e3,
+            'b1_ms_per_step': b1_ms,
+            'b1_samples_per_s': T / b1_ms * 1e3,
             'optin_bf16x6_ms_per_step': optin}
 
 
@@ -176,10 +233,12 @@ def launch_ranks(n):
     the worst exit status.  A rank that fails takes the others down."""
     import socket
     import subprocess
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
+    port = os.environ.get('MASTER_PORT')     # a preset port is honoured
+    if not port:
+        s = socket.socket()
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+        s.close()
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r),
@@ -294,20 +353,36 @@ def main():
         step()
     torch.cuda.synchronize()
     log('warm-up done, timing %d steps' % args.steps)
-    net._gemm_events = None if os.environ.get('WN_NO_EVENTS') else []  # live HIP-event timing of the GEMMs
+    net._gemm_events = None          # the headline loop is un-instrumented
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     sync_all()
     dt = time.perf_counter() - t0
+    # instrumented pass (NOT part of `value`): the same step with HIP events
+    # around every GEMM launch and around the gradient all-reduce
+    isteps = max(1, min(5, args.steps))
+    net._gemm_events = []
+    parallel.timing_events = [] if world > 1 else None
+    for _ in range(isteps):
+        step()
+    sync_all()
     events = net._gemm_events or []
     net._gemm_events = None
+    ar_events = parallel.timing_events or []
+    parallel.timing_events = None
+    ar_us = None
+    if ar_events:
+        ar_us = sum(a.elapsed_time(b) for a, b in ar_events) / isteps * 1e3
     ranks_seen = 1
+    dt_min = dt_max = dt
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt, -dt, ar_us or 0.0], dtype=torch.float64,
+                          device=dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt[0])
+        dt_max, dt_min, ar_us = float(tt[0]), -float(tt[1]), float(tt[2])
+        dt = dt_max
         ones = torch.ones(1, dtype=torch.float32, device=dev)
         torch.distributed.all_reduce(ones)          # RCCL: every rank adds 1
         ranks_seen = int(round(float(ones[0])))
@@ -322,10 +397,17 @@ def main():
 
     value = world * B * T * args.steps / dt
     log('gpu: %.0f samples/s, %.2f ms/step' % (value, dt / args.steps * 1e3))
-    flops = sum(e[2] for e in events)
-    ktime = sum(e[0].elapsed_time(e[1]) for e in events) * 1e-3
+    # dominant kernel = the NN GEMM launches (skip sum, post1, post2 and
+    # their data gradients); the TN weight-gradient GEMMs are reported beside
+    nn = [e for e in events if 'gemm_nn' in e[3]]
+    tn = [e for e in events if 'gemm_tn' in e[3]]
+    flops = sum(e[2] for e in nn)
+    ktime = sum(e[0].elapsed_time(e[1]) for e in nn) * 1e-3
     achieved = flops / ktime / 1e12 if ktime > 0 else 0.0
-    nlaunch = len(events)
+    nlaunch = len(nn)
+    tn_flops = sum(e[2] for e in tn)
+    tn_time = sum(e[0].elapsed_time(e[1]) for e in tn) * 1e-3
+    step_tflops = STEP_FLOP_PER_SAMPLE * B * T / (dt / args.steps) / 1e12
     peak = FP32_MFMA_PEAK_TFLOPS if args.gemm_mode == 'fp32' else \
         2500.0 / int(args.gemm_mode[-1])
     dom = 'gemm_nn3_kernel' if args.gemm_mode == 'fp32' else \
@@ -338,6 +420,11 @@ def main():
         'dist_backend': torch.distributed.get_backend() if world > 1 else None,
         'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+        'step_tflops': step_tflops,
+        'step_frac': step_tflops / FP32_MFMA_PEAK_TFLOPS,
+        'step_tflops_note': 'whole step per GPU: 8.804 MFLOP per audio sample '
+                            '(SURVEY 8d) x samples / step time, against the '
+                            '157.3 TFLOP/s fp32 MFMA peak',
         'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32' if args.gemm_mode == 'fp32' else
                  'f32 (NN GEMM products rebuilt from %s split pieces on bf16 '
@@ -361,10 +448,27 @@ def main():
                      'frac': achieved / peak,
                      'traffic': traffic, 'traffic_source': traffic_src,
                      'traffic_unit': 'bytes per launch (rocprofv3 PMC pass)',
-                     'launches_per_step': nlaunch // max(args.steps, 1),
+                     'launches_per_step': nlaunch // isteps,
                      'avg_launch_us': ktime / max(nlaunch, 1) * 1e6,
-                     'flops_per_step': flops / max(args.steps, 1)},
+                     'flops_per_step': flops / isteps,
+                     'measured_over': '%d instrumented steps after the timed '
+                                      'region' % isteps,
+                     'tn_gemms': {
+                         'kernel': 'gemm_tn3_kernel',
+                         'achieved': tn_flops / tn_time / 1e12
+                         if tn_time > 0 else None,
+                         'frac': tn_flops / tn_time / 1e12 / peak
+                         if tn_time > 0 else None,
+                         'launches_per_step': len(tn) // isteps,
+                         'us_per_step': tn_time / isteps * 1e6}},
     }
+    if world > 1:
+        out['allreduce_us_per_step'] = ar_us
+        out['allreduce_note'] = ('max over ranks of the HIP-event time around '
+                                 'the one flat-bucket gradient all-reduce '
+                                 '(includes waiting for the slowest rank)')
+        out['step_ms_min'] = dt_min / args.steps * 1e3
+        out['step_ms_max'] = dt_max / args.steps * 1e3
     if world == 1 and not args.no_secondary:
         out['secondary'] = secondary(net, audio, gc_ids, kw, B, T, opt=opt)
     if world == 1 and not args.no_cpu_baseline:

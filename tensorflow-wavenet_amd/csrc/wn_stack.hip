@@ -171,12 +171,20 @@ __global__ void stack_pack_kernel(const float* __restrict__ layer0,
     out[SF_OFF_BD + threadIdx.x] = blk[LAYER_OFF_BD + threadIdx.x];
 }
 
-// bounded spin on a workgroup-local LDS word
-__device__ __forceinline__ void wait_lds(const int* p, bool& dead) {
+// bounded spin on a workgroup-local LDS word; an expired wait is recorded like
+// an expired flag poll (ctl[3], NaN poison) -- the wave then runs on
+__device__ __forceinline__ void wait_lds(const int* p, bool& dead, unsigned* ctl,
+                                         float* poison, int lane) {
   unsigned spins = 0;
   while (!dead && __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
     __builtin_amdgcn_s_sleep(1);
-    if (++spins > (1u << 24)) dead = true;
+    if (++spins > (1u << 24)) {
+      dead = true;
+      if (lane == 0) {
+        __hip_atomic_store(ctl + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (poison) *poison = __builtin_nanf("");
+      }
+    }
   }
   asm volatile("" ::: "memory");
 }
@@ -256,7 +264,7 @@ __global__ __launch_bounds__(WAVES * 64) void stack_fwd_kernel(StackFwd a) {
     for (int l = 0; any && l < L; ++l) {
       const int d = a.dil[l];
       SSTAMP(l, 0);
-      wait_lds(s_ready + l, dead);
+      wait_lds(s_ready + l, dead, a.ctl, a.poison, lane);
       SSTAMP(l, 1);
       const float* xl = a.X + (size_t)l * a.plane;
       // ---- the dilated tap: rows t0-d .. t0-d+31 of x_l, written by the

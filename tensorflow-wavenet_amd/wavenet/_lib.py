@@ -219,7 +219,7 @@ def _timed(fn, args, name, flops, events):
         s.record()
         code = fn(*args)
         e.record()
-        events.append((s, e, flops))
+        events.append((s, e, flops, name))
     if code != 0:
         check(code, name)
 

@@ -70,12 +70,16 @@ class _Workspace(object):
             n = int(np.prod(shape))
             if parent is not None and getattr(parent, name, None) is not None:
                 t = getattr(parent, name).reshape(-1)[:n].view(shape)
-            elif fill is None:
-                t = torch.empty(shape, dtype=dtype, device=dev)
             else:
-                t = torch.full(shape, fill, dtype=dtype, device=dev)
+                fresh.add(name)
+                if fill is None:
+                    t = torch.empty(shape, dtype=dtype, device=dev)
+                else:
+                    t = torch.full(shape, fill, dtype=dtype, device=dev)
             setattr(self, name, t)
             return t
+
+        fresh = set()   # buffers this workspace owns (not views of the parent's)
 
         self.plans = {}
         alloc('q', (N,), torch.int32)
@@ -95,7 +99,7 @@ class _Workspace(object):
               fill=0)
         alloc('wimg_f', (L, lib.wn_stack_wimg_floats()))
         alloc('stack_ctl', (4,), torch.int32, fill=0)
-        if parent is None:
+        if 'stack_ctl' in fresh:         # (a view shares the owner's epoch)
             self.stack_ctl[2] = 1
         alloc('bsum', (S,))
         self.total = alloc('total', (N, S)) if net.residual_postproc else None
@@ -135,7 +139,9 @@ class _Workspace(object):
             alloc('stack_flags_b', (lib.wn_stack_flag_count(B, T, L),),
                   torch.int32, fill=0)
             alloc('stack_ctl_b', (4,), torch.int32, fill=0)
-            if parent is None:
+            # a child whose parent was built without the backward stack
+            # buffers owns fresh flags (all 0): its epoch must start at 1 too
+            if 'stack_ctl_b' in fresh:
                 self.stack_ctl_b[2] = 1
         if CB > 1:                       # channel-block path scratch
             alloc('dzb', (CB, N, CH))
@@ -552,6 +558,17 @@ class WaveNetModel(object):
                         'are invalid.  WN_STACK_FWD=0 / WN_STACK_BWD=0 select '
                         'the one-launch-per-layer kernels.' % name)
 
+    def reset_device_errors(self):
+        """Clear the expired-wait record (control word 3 and the NaN poison
+        words) of every workspace, e.g. after a caller has handled the error
+        `check_device_errors` raised."""
+        for ws in self._ws.values():
+            for name in ('stack_ctl', 'stack_ctl_b'):
+                ctl = getattr(ws, name, None)
+                if ctl is not None:
+                    ctl[3] = 0
+            ws.loss_parts[:2] = 0.0
+
     def _stack_bwd_ok(self):
         """wn_stack_bwd covers what wn_layer_bwd2 covers."""
         return self.stack_bwd and not self._legacy_bwd() and self.L <= 256
@@ -831,9 +848,11 @@ class WaveNetModel(object):
                           ldg, _lib.ptr(slabs), sp, N, mw, nw, ub,
                           int(self.gemm_mode[-1]), st)
             else:
-                _lib.call('wn_gemm_tn', A, lda, a_planes, a_pstride, codes,
-                          shift, T, Gm, ldg, _lib.ptr(slabs), sp, N, mw, nw,
-                          ub, st)
+                _lib.call_timed('wn_gemm_tn',
+                                (A, lda, a_planes, a_pstride, codes, shift, T,
+                                 Gm, ldg, _lib.ptr(slabs), sp, N, mw, nw, ub,
+                                 st), 2.0 * N * mw * nw,
+                                getattr(self, '_gemm_events', None))
             _lib.call('wn_reduce_slabs', _lib.ptr(slabs), sp, sl, 1, 0, 0,
                       mw * nw, dst, 0, 1, 0, st)
             if ub and dst_bias is not None:
@@ -1145,6 +1164,11 @@ class WaveNetModel(object):
         loss = ws.loss[0] / float(N)                    # reduce_mean, :666
         if backward:
             self._backward(ws, ids)
+            # the backward stack launch's poison word (0, or NaN when one of
+            # its dependency waits expired) is written after the loss
+            # reduction above: add it here so that THIS step's loss is NaN
+            # before the optimizer applies the step
+            loss = loss + ws.loss_parts[1]
         if l2_regularization_strength is not None:
             lam = float(l2_regularization_strength)
             mask = None if self.tf_bias_name_quirk else self._l2_mask()
@@ -1202,7 +1226,9 @@ class WaveNetModel(object):
         out = torch.empty(self.Q, dtype=torch.float32, device=self.device)
         _lib.call('wn_softmax64_row', _lib.ptr(ws.logits[B * T - 1]), self.Q,
                   _lib.ptr(out), _lib.stream())
-        return out
+        # 0, or NaN when a dependency wait of the forward stack launch
+        # expired: wrong probabilities are never returned silently
+        return out + ws.loss_parts[0]
 
     # ---------------------------------------------------------- fast generation
     def _generator(self, global_condition):
@@ -1256,6 +1282,14 @@ class WaveNetModel(object):
         single-workgroup kernel (also the push=False peek).  multi_cu=True:
         four kernels per step spread over many CUs, captured into a hipGraph
         and replayed (config 5 throughput path)."""
+        # (wn_fastgen_step reads both from the device control block and cannot
+        # reject them; the reference applies the temperature as log(p) / T,
+        # generate.py:229-233)
+        if not (np.isfinite(float(temperature)) and float(temperature) > 0.0):
+            raise ValueError('temperature must be a finite number > 0, got %r'
+                             % (temperature,))
+        if int(n_given) < 1:
+            raise ValueError('n_given must be >= 1, got %r' % (n_given,))
         g = self._generator(global_condition)
         ids = self._gc_ids(global_condition, 1) if self.card is not None \
             else None
@@ -1471,7 +1505,9 @@ class WaveNetModel(object):
         src = torch.from_numpy(np.concatenate(src)).to(self.device)
         dst = torch.from_numpy(np.concatenate(dst)).to(self.device)
         X = ws.X.reshape(-1, CH)[:self.L * n0]
-        g['state'].view(-1, CH).index_copy_(0, dst, X.index_select(0, src))
+        # (+ the forward launch's poison word: 0, or NaN after an expired wait)
+        g['state'].view(-1, CH).index_copy_(
+            0, dst, X.index_select(0, src) + ws.loss_parts[0])
         g['cursors'][0] = n0
         g['cursors'][1:2].copy_(w[-1:])
         g['steps'] = n0

@@ -65,12 +65,29 @@ def shard_range(global_batch, rank, world):
     return rank * per, (rank + 1) * per
 
 
+# bench.py's instrumented pass: a list here makes every gradient all-reduce
+# append a (start, end) pair of timing events recorded on the compute stream
+# (the collective runs on the backend's own stream; the compute stream waits
+# for it, so the pair brackets launch + wire time + the wait for the slowest
+# rank to arrive)
+timing_events = None
+
+
 def allreduce_flat_(flat):
     """In-place all-reduce(sum) of one flat bucket; returns the scale (1/N)
     the caller must apply (folded into the optimizer kernel)."""
     if not is_distributed():
         return 1.0
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    ev = timing_events
+    if ev is not None and flat.is_cuda:
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        e.record()
+        ev.append((s, e))
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return 1.0 / dist.get_world_size()
 
 
@@ -111,3 +128,14 @@ def agree_step(n_samples, ok=True, device='cpu'):
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     t = t.cpu()
     return int(t[0]), bool(int(t[1]))
+
+
+def any_rank(flag, device='cpu'):
+    """True on EVERY rank when `flag` is true on at least one (all-reduce MAX):
+    for decisions that must be taken by all ranks in the same step (aborting
+    on a device error one rank saw)."""
+    if not is_distributed():
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(int(t.cpu()[0]))

@@ -96,6 +96,33 @@ def test_bench_self_launches_two_ranks(hip_lib):
     assert r['n_gpus'] == 2 and r['ranks_seen'] == 2
     assert r['config']['global_batch'] == 4
     assert r['value'] > 0
+    # what the first multi-GPU run must tell: all-reduce share, rank spread
+    assert r['allreduce_us_per_step'] > 0
+    assert 0 < r['step_ms_min'] <= r['step_ms_max']
+    assert 0 < r['step_frac'] < 1 and r['roofline']['frac'] > 0
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2,
+                    reason='needs >= 2 GPUs (RCCL refuses two ranks per device)')
+def test_bench_two_gpus_over_rccl(hip_lib):
+    """On a multi-GPU box: `python bench.py --gpus 2` with the default
+    backend ("nccl" = RCCL over xGMI), one rank per device."""
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'WN_SHARE_GPU',
+              'WN_DIST_BACKEND', 'MASTER_PORT'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'),
+                        '--gpus', '2', '--steps', '3', '--warmup', '2',
+                        '--batch', '2', '--samples', '8000',
+                        '--no-secondary', '--no-cpu-baseline'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    line = [l for l in p.stdout.decode().splitlines() if l.startswith('{')][-1]
+    r = json.loads(line)
+    assert r['dist_backend'] == 'nccl'
+    assert r['n_gpus'] == 2 and r['ranks_seen'] == 2
+    assert r['allreduce_us_per_step'] > 0
 
 
 def test_train_py_two_ranks_on_wav_data(hip_lib, tmp_path):

@@ -65,6 +65,9 @@ def _worker(rank, world, port, out_dir):
     assert ok is False
     t_common, ok = parallel.agree_step(1 if rank == 0 else 500, True)
     assert t_common == 1            # every rank skips this step together
+    # collective abort decision (train.py): an error only rank 1 saw
+    assert parallel.any_rank(rank == 1) is True
+    assert parallel.any_rank(False) is False
     np.save(os.path.join(out_dir, 'g%d.npy' % rank), avg.numpy())
     np.save(os.path.join(out_dir, 'l%d.npy' % rank), mloss.numpy())
     dist.destroy_process_group()

@@ -302,7 +302,19 @@ def main(argv=None):
             optimizer.minimize(loss)
             loss_value = float(parallel.allreduce_mean_scalar(loss))
             if not np.isfinite(loss_value):
-                net.check_device_errors()     # raises if a kernel reported one
+                # every rank sees the same NaN mean: decide TOGETHER whether a
+                # kernel reported an error, so that no rank is left waiting in
+                # the next step's collectives
+                dev_err = None
+                try:
+                    net.check_device_errors()
+                except Exception as e:
+                    dev_err = e
+                if parallel.any_rank(dev_err is not None, net.device):
+                    raise dev_err or RuntimeError(
+                        'rank %d: another rank reported an expired dependency '
+                        'wait in a persistent stack launch at step %d'
+                        % (rank, step))
             if trace:
                 prof.__exit__(None, None, None)
                 prof.export_chrome_trace(os.path.join(logdir,

@@ -151,8 +151,9 @@ __device__ __forceinline__ void mma32t(f32x16& acc, const f32x16& frag,
 }
 
 // blockIdx.y == 0: forward image (transposed, + dense bias); 1: backward image
-// (the matrices as they are, [m][cin][SF_LD]: there the contraction runs over
-// cout, so again a lane's four consecutive operands are 16 contiguous bytes)
+// (the matrices as they are -- there the contraction runs over cout -- dense
+// [m][cin][32] with the 16-byte chunks of row cin at chunk ^ ((cin >> 1) & 7),
+// see mma32s)
 __global__ void stack_pack_kernel(const float* __restrict__ layer0,
                                   long layer_stride, float* __restrict__ img_f,
                                   float* __restrict__ img_b) {
@@ -165,7 +166,8 @@ __global__ void stack_pack_kernel(const float* __restrict__ layer0,
   __syncthreads();
   for (int i = threadIdx.x; i < LAYER_W_FLOATS; i += blockDim.x) {
     const int m = i >> 10, cin = (i >> 5) & 31, cout = i & 31;   // W[m][cin][cout]
-    out[m * SF_MT + (bwd ? cin * SF_LD + cout : cout * SF_LD + cin)] = blk[i];
+    out[bwd ? m * 1024 + cin * 32 + ((((cout >> 2) ^ ((cin >> 1) & 7)) << 2) | (cout & 3))
+            : m * SF_MT + cout * SF_LD + cin] = blk[i];
   }
   if (!bwd && threadIdx.x < 32)
     out[SF_OFF_BD + threadIdx.x] = blk[LAYER_OFF_BD + threadIdx.x];
@@ -408,12 +410,28 @@ __global__ __launch_bounds__(WAVES * 64) void stack_fwd_kernel(StackFwd a) {
 // consecutive tiles for all layers; groups are handed out in DECREASING order
 // (a group depends on rows of the same or HIGHER groups), so the highest
 // unfinished group can always finish whatever the residency.
-// The weight gradients are reduced over the workgroup's waves once per layer
-// (fixed-order tree through LDS, as in layer_bwd2d_kernel) into one slab per
-// (layer, group): bitwise reproducible whichever workgroup ran the group.
-// The layer's transposed weight image is fetched by LDS-DMA during the
-// previous layer's reduction.
+//
+// No workgroup barrier inside the stack (round 3; round 2 had four per layer):
+//   * weights: a two-layer LDS ring of dense, XOR-swizzled images (20 KiB
+//     each); the wave that is LAST through layer l's tiles refills that half
+//     with layer l-2 and marks it ready once its DMA has landed;
+//   * the weight gradients of a layer are summed over the workgroup's waves by
+//     an ORDERED accumulation through one LDS slab: wave 0 writes its sums,
+//     wave w adds its own after wave w-1's token, the last wave adds and
+//     stores the slab to memory -- a fixed order (bitwise reproducible
+//     whichever workgroup ran the group, whatever the timing) in which nobody
+//     waits for a slower wave except its successors in that chain; the waves
+//     settle into a stagger of one accumulation (~0.4 us) each and drift up to
+//     a layer apart, so one wave's flag / load / LDS latencies hide under the
+//     MFMAs of its SIMD partner instead of lining up behind a barrier;
+//   * three 4-KiB LDS tiles per wave instead of four (the ring and the slab
+//     need the room): the rows t+d pass through them before the rows-t DMA is
+//     issued, the sigmoid rows travel in registers, and the weight-gradient
+//     products run as two halves (da_f, then da_g through the same tile).
+// One slab per (layer, group).
 // ---------------------------------------------------------------------------
+#define SB_WIMG 5120                      // dense swizzled backward image (floats)
+
 struct StackBwd {
   const float* X;      // [L][N][32]
   const float* Z;
@@ -431,26 +449,176 @@ struct StackBwd {
   int L, B, T, tpw;    // tpw: tiles per wave and layer
   long plane;
 #ifdef STACK_STAMPS
-  unsigned long long* dbg;   // [grid][WAVES][L][12] + [grid][4]
+  unsigned long long* dbg;   // [grid][WAVES][L][16] + [grid][4]
 #endif
 };
 
+// bounded spin until the workgroup-local LDS word reaches `want`
+__device__ __forceinline__ void wait_lds_ge(const int* p, int want, bool& dead,
+                                            unsigned* ctl, float* poison, int lane) {
+  unsigned spins = 0;
+  while (!dead && __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > (1u << 24)) {
+      dead = true;
+      if (lane == 0) {
+        __hip_atomic_store(ctl + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (poison) *poison = __builtin_nanf("");
+      }
+    }
+  }
+  asm volatile("" ::: "memory");
+}
+
+// (timing-only ablations of the backward kernel, results meaningless:
+// -DSB_NOGATE skips the gate derivatives (2143 -> 1761 us: the 2 x 16 gate
+// evaluations per lane and tile sit on every tile's dependent path),
+// -DSB_FAKE_ADDR loads every tile from one L2-resident megabyte (2126 -> 2011
+// us: the kernel is not bound by memory))
+#define sb_mfma(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0)
+
+// acc^T[i, time] += sum_k A[i][k] * frag[time, k] from a dense swizzled image:
+// row i of a [32][32] matrix holds its eight 16-byte chunks at chunk ^ ((i >> 1)
+// & 7), so the sixteen lanes of a ds_read_b128 beat (i & 15 all different)
+// cover all 64 banks.  `wm` = matrix base + this lane's byte-swizzled offset of
+// chunk h (q = 0): chunk 2q + h sits at float offset  off0 ^ (q << 3).
+// The four 16-byte operand reads of a matrix are issued up front (one LDS
+// latency per 16 MFMAs; read-wait-4 MFMAs per chunk exposed it four times).
+__device__ __forceinline__ void mma32s(f32x16& acc, const f32x16& frag,
+                                       const float* mat, int off0) {
+  // chunk q + 1 is requested before the MFMAs of chunk q
+  f32x4 nxt = *reinterpret_cast<const f32x4*>(mat + off0);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 a4 = nxt;
+    if (q < 3) nxt = *reinterpret_cast<const f32x4*>(mat + (off0 ^ ((q + 1) << 3)));
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      acc = sb_mfma(a4[e], frag[4 * q + e], acc);
+  }
+}
+
+// Transposed products from LDS tiles (weight gradients): acc0 += A0^T B,
+// acc1 += A1^T B over the 32 rows of the tiles, bsum += column sums of B.
+// Element [row = 2 s + h][channel = lane j] of the wave's tile T (swizzled
+// layout of rows_to_lds) is  te[s & 3][T * 1024 + 64 * s]:  four per-lane
+// pointers (the four values of row & 7 a lane meets) serve all tiles and
+// steps with immediate offsets (the XOR swizzle written out per access costs
+// about 350 address instructions per tile).
+struct TileElemPtr {
+  const float* p[4];
+};
+__device__ __forceinline__ TileElemPtr tile_elem_ptrs(const float* t0, int j, int h) {
+  TileElemPtr te;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int off = 32 * h + ((((j >> 2) ^ (2 * k + h)) & 7) << 2) + (j & 3);
+    asm volatile("" : "+v"(off));
+    te.p[k] = t0 + off;
+  }
+  return te;
+}
+
+// ---- tile access through buffer resources: the plane base sits in four
+// SGPRs, the tile offset in one SGPR, the lane's part of the address in ONE
+// VGPR for all planes (instead of a 64-bit VGPR pointer pair per plane and
+// shift: the backward kernel has no registers to spare) ----
+typedef __amdgpu_buffer_rsrc_t wn_rsrc_t;
+__device__ __forceinline__ wn_rsrc_t plane_rsrc(const float* base) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+}
+
+// rows [lo, hi) of the 32-row tile at byte offset `soff` of the plane, row-
+// contiguous in registers (rows_load's lane <-> row mapping); `vrow` =
+// ((lane >> 3) * 32 + (lane & 7) * 4) * 4.  AUX 16 = sc1 (device scope).
+template <int AUX>
+__device__ __forceinline__ RowRegs rows_ld(wn_rsrc_t rs, int soff, int vrow,
+                                           int lane, int lo, int hi) {
+  RowRegs R;
+  if (lo <= 0 && hi >= 32) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      R.v[c] = __builtin_bit_cast(
+          f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vrow + c * 1024, soff, AUX));
+  } else {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int r = 8 * c + (lane >> 3);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r >= lo && r < hi)
+        v = __builtin_bit_cast(
+            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vrow + c * 1024, soff, AUX));
+      R.v[c] = v;
+    }
+  }
+  return R;
+}
+
+template <int AUX>
+__device__ __forceinline__ void rows_st(wn_rsrc_t rs, int soff, int vrow, int lane,
+                                        int hi, const RowRegs& R) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int r = 8 * c + (lane >> 3);
+    if (r < hi)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, R.v[c]), rs,
+                                             vrow + c * 1024, soff, AUX);
+  }
+}
+
+// tile_dma through a buffer resource; `vswz` = the lane's swizzled source
+// offset ((rr * 32 + (((lane & 7) ^ (rr & 7)) << 2)) * 4, rr = lane >> 3)
+template <int AUX>
+__device__ __forceinline__ void tile_dma_rs(float* lds_tile, wn_rsrc_t rs, int soff,
+                                            int vswz, int lane, int lo, int hi) {
+  if (lo <= 0 && hi >= 32) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (wn_lptr_t)(lds_tile + c * 256), 16,
+                                               vswz, soff + c * 1024, 0, AUX);
+  } else {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      *reinterpret_cast<f32x4*>(lds_tile + c * 256 + lane * 4) = zero;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int r = 8 * c + (lane >> 3);
+      // (the SGPR offset is added unsigned and only the VGPR offset is range
+      // checked: a negative start -- the tap begins before the first clip --
+      // goes into the lanes' offsets, where exactly the masked-off rows end up
+      // below zero)
+      const int sc = soff + c * 1024;
+      if (r >= lo && r < hi)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (wn_lptr_t)(lds_tile + c * 256), 16,
+                                                 vswz + min(sc, 0), max(sc, 0), 0, AUX);
+    }
+  }
+}
+
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
-  constexpr int RS = 5248;                       // floats per reduction region
-  constexpr int REG = WAVES >= 4 ? 4 : WAVES;    // reduction regions
-  constexpr int TILE_FLOATS = WAVES * 4096 > REG * RS ? WAVES * 4096 : REG * RS;
-  __shared__ __attribute__((aligned(1024))) float wl[STACK_WBUF];
-  __shared__ __attribute__((aligned(1024))) float tiles[TILE_FLOATS];
+  constexpr int SLAB = WAVES > 1 ? LAYER_BLOCK_FLOATS : 16;   // ordered-accumulation slab
+  __shared__ __attribute__((aligned(1024))) float wl[2 * SB_WIMG];
+  __shared__ __attribute__((aligned(1024))) float tiles[WAVES * 3072];
+  __shared__ __attribute__((aligned(16))) float slab[SLAB];
   __shared__ int s_group;
+  // per layer: waves through its tiles / its weights are in LDS
+  __shared__ int s_done[STACK_MAXL], s_ready[STACK_MAXL];
+  // accumulation tokens, one per (layer parity, matrix): (L - l) * 16 + the
+  // number of waves that have added their part of that matrix
+  __shared__ int s_tok[2][8];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, h = lane >> 5;
-  float* t0 = tiles + wave * 4096;
+  const int vrow = ((lane >> 3) * 32 + (lane & 7) * 4) * 4;
+  const int vswz = ((lane >> 3) * 32 + (((lane & 7) ^ ((lane >> 3) & 7)) << 2)) * 4;
+  float* t0 = tiles + wave * 3072;
   float* t1 = t0 + 1024;
   float* t2 = t1 + 1024;
-  float* t3 = t2 + 1024;
+  const TileElemPtr te = tile_elem_ptrs(t0, j, h);
   const int T = a.T, L = a.L;
   const int tiles_per_clip = (T + 31) >> 5;
   const int ntiles = tiles_per_clip * a.B;
@@ -462,19 +630,21 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
 #ifdef STACK_STAMPS
 #define BSTAMP(l, i)                                                         \
   if (lane == 0)                                                             \
-    a.dbg[(((size_t)blockIdx.x * 8 + wave) * L + (l)) * 12 + (i)] =          \
+    a.dbg[(((size_t)blockIdx.x * 8 + wave) * L + (l)) * 16 + (i)] =          \
         __builtin_amdgcn_s_memtime()
-  unsigned long long* cal = a.dbg + (size_t)gridDim.x * 8 * L * 12 + (size_t)blockIdx.x * 4;
+  unsigned long long* cal = a.dbg + (size_t)gridDim.x * 8 * L * 16 + (size_t)blockIdx.x * 4;
   if (tid == 0) { cal[0] = __builtin_amdgcn_s_memrealtime(); cal[1] = __builtin_amdgcn_s_memtime(); }
 #else
 #define BSTAMP(l, i)
 #endif
 
-  auto issue_wimg = [&](int l) {
+  // pieces [p0, p0 + step, ...) of layer l's 20 KiB image into its ring half
+  auto issue_wimg = [&](int l, int p0, int step) {
     const float* src = a.wimg + (size_t)l * STACK_WBUF;
-    for (int p = wave; p < STACK_WBUF / 256; p += WAVES)
+    float* dst = wl + (l & 1) * SB_WIMG;
+    for (int p = p0; p < SB_WIMG / 256; p += step)
       __builtin_amdgcn_global_load_lds((wn_gptr_t)(src + p * 256 + lane * 4),
-                                       (wn_lptr_t)(wl + p * 256), 16, 0, 0);
+                                       (wn_lptr_t)(dst + p * 256), 16, 0, 0);
   };
 
   for (;;) {
@@ -485,25 +655,30 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
     if (ticket >= ngroups) break;
     const int g = ngroups - 1 - ticket;
     const int tbase = g * GS, tend = min(ntiles, tbase + GS);
-    issue_wimg(L - 1);
+    for (int i = tid; i < L; i += WAVES * 64) {
+      s_done[i] = 0;
+      s_ready[i] = i >= L - 2;
+    }
+    if (tid < 16) s_tok[tid >> 3][tid & 7] = 0;
+    issue_wimg(L - 1, wave, WAVES);
+    if (L > 1) issue_wimg(L - 2, wave, WAVES);
+    WN_WAIT_VM0();
+    __syncthreads();        // weights of the two top layers are in LDS
 
     for (int l = L - 1; l >= 0; --l) {
       const int d = a.dil[l];
       const bool hx = l + 1 < L;              // a gradient flows into x_{l+1}
-      const float* x = a.X + (size_t)l * a.plane;
-      const float* z = a.Z + (size_t)l * a.plane;
-      const float* sg = a.SG + (size_t)l * a.plane;
-      const float* dZ = a.dZ + (size_t)l * a.plane;
-      const float* dxin = a.DX + (size_t)(hx ? l + 1 : l) * a.plane;
-      float* dx_out = a.DX + (size_t)l * a.plane;
+      const wn_rsrc_t x = plane_rsrc(a.X + (size_t)l * a.plane);
+      const wn_rsrc_t z = plane_rsrc(a.Z + (size_t)l * a.plane);
+      const wn_rsrc_t sg = plane_rsrc(a.SG + (size_t)l * a.plane);
+      const wn_rsrc_t dZ = plane_rsrc(a.dZ + (size_t)l * a.plane);
+      const wn_rsrc_t dxin = plane_rsrc(a.DX + (size_t)(hx ? l + 1 : l) * a.plane);
+      const wn_rsrc_t dx_out = plane_rsrc(a.DX + (size_t)l * a.plane);
       const unsigned* fl_in = a.flags + (size_t)(hx ? l + 1 : l) * ntiles;
       unsigned* fl_out = a.flags + (size_t)l * ntiles;
       float* tile_colsum = a.tilesum ? a.tilesum + (size_t)l * ntiles * 64 : nullptr;
-      // this layer's weight image has landed for every wave; the reduction of
-      // the layer above no longer reads the tile area
       BSTAMP(l, 0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      wait_lds_ge(s_ready + l, 1, dead, a.ctl, a.poison, lane);
       BSTAMP(l, 1);
       f32x16 cf0 = frag_zero(), cf1 = frag_zero(), cg0 = frag_zero(),
              cg1 = frag_zero(), cd = frag_zero();
@@ -511,106 +686,176 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
       RowRegs a0, a1, a2, a3;
       // rows t+d of a tile (always assigns a0..a3); the dx_{l+1} rows wait for
       // their owners' flags
-      auto load_shifted = [&](int tl) {
+      // lanes 0 / 1: index of the (at most two) flags the rows t+d of tile tl
+      // wait for, -1 on the other lanes / when there is nothing to wait for
+      auto flag_idx = [&](int tl) -> int {
+        if (!hx || tl >= tend) return -1;
+        const int b = tl / tiles_per_clip;
+        const int tt = tl - b * tiles_per_clip;
+        const int tt0 = tt * 32;
+        const int hif = min(min(32, T - tt0), T - d - tt0);
+        if (hif <= 0) return -1;
+        const int first = (tt0 + d) >> 5, last = (tt0 + d + hif - 1) >> 5;
+        int idx = -1;
+        if (lane == 0 && first != tt) idx = b * tiles_per_clip + first;
+        if (lane == 1 && last != first && last != tt) idx = b * tiles_per_clip + last;
+        return idx;
+      };
+      // `pre`: the flag value read ahead of time (anything but `epoch`: unknown)
+      auto load_shifted = [&](int tl, unsigned pre) {
         const bool any = tl < tend;
         const int b = any ? tl / tiles_per_clip : 0;
         const int tt = any ? tl - b * tiles_per_clip : 0;
         const int tt0 = tt * 32;
         const int hif = any ? min(min(32, T - tt0), T - d - tt0) : 0;
-        const size_t offd = ((size_t)b * T + tt0 + d) * WN_CH;
+#ifdef SB_FAKE_ADDR   // timing-only ablation: every load from one L2-resident megabyte
+        const int offd = ((b * T + tt0 + d) * (WN_CH * 4)) & 0xFFFFF;
+#else
+        const int offd = (b * T + tt0 + d) * (WN_CH * 4);   // bytes (< 2^31: host check)
+#endif
         if (hx) {
           if (hif > 0) {
             const int first = (tt0 + d) >> 5, last = (tt0 + d + hif - 1) >> 5;
             int idx = -1;
             if (lane == 0 && first != tt) idx = b * tiles_per_clip + first;
             if (lane == 1 && last != first && last != tt) idx = b * tiles_per_clip + last;
-            wait_flags(fl_in, idx, epoch, a.ctl, a.poison, dead, lane);
+            // (producers are usually a layer ahead: the value requested during
+            // the previous tile's math already shows the flag)
+            if (__builtin_amdgcn_ballot_w64(idx >= 0 && pre != epoch) != 0)
+              wait_flags(fl_in, idx, epoch, a.ctl, a.poison, dead, lane);
           }
-          a0 = rows_load_dev(dxin + offd, lane, 0, hif);
+          a0 = rows_ld<16>(dxin, offd, vrow, lane, 0, hif);
         } else {
           const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int c = 0; c < 4; ++c) a0.v[c] = zero;
         }
-        a1 = rows_load(dZ + offd, lane, 0, hif);
-        a2 = rows_load(z + offd, lane, 0, hif);
-        a3 = rows_load(sg + offd, lane, 0, hif);
+        a1 = rows_ld<0>(dZ, offd, vrow, lane, 0, hif);
+        a2 = rows_ld<0>(z, offd, vrow, lane, 0, hif);
+        a3 = rows_ld<0>(sg, offd, vrow, lane, 0, hif);
       };
-      load_shifted(tbase + wave);
+      load_shifted(tbase + wave, epoch - 1u);
       BSTAMP(l, 2);
+      // this lane's swizzled offset of chunk h in row j of a weight matrix
+      int woff = (j * 32 + ((h ^ ((j >> 1) & 7)) << 2)) + (l & 1) * SB_WIMG;
+      asm volatile("" : "+v"(woff));   // opaque: no hoisting of the weight reads
+      const float* const wm = wl;
       for (int tile = tbase + wave; tile < tend; tile += WAVES) {
         if (tile == tbase + wave + WAVES) { BSTAMP(l, 7); }
-        int woff = j * SF_LD + 4 * h;  // opaque: no hoisting of the weight reads
-        asm volatile("" : "+v"(woff));
-        const float* wlane = wl + woff;
         const int b = tile / tiles_per_clip;
         const int tt0 = (tile - b * tiles_per_clip) * 32;
         const int hi = min(32, T - tt0);
         const int hi_f = min(hi, T - d - tt0);  // rows whose t+d tap exists
         const int lo_p = max(0, d - tt0);       // rows whose t-d tap exists
-        const size_t off0 = ((size_t)b * T + tt0) * WN_CH;
+#ifdef SB_FAKE_ADDR
+        const int off0r = (b * T + tt0) * (WN_CH * 4);
+        const int off0 = off0r & 0xFFFFF;
+#else
+        const int off0 = (b * T + tt0) * (WN_CH * 4);       // bytes
+#endif
         f32x16 dx = frag_zero();
         f32x16 dz, di, zz, ss;
         if (hi_f > 0) {                         // rows t+d -> LDS -> fragments
           if (hx) rows_to_lds(t0, lane, a0);
           rows_to_lds(t1, lane, a1);
           rows_to_lds(t2, lane, a2);
-          rows_to_lds(t3, lane, a3);
           __builtin_amdgcn_wave_barrier();
-          dz = frag_from_lds(t1, j, h);
           if (hx) di = frag_from_lds(t0, j, h);
+          dz = frag_from_lds(t1, j, h);
           zz = frag_from_lds(t2, j, h);
-          ss = frag_from_lds(t3, j, h);
+          __builtin_amdgcn_wave_barrier();      // (a wave's DS operations run in order)
+          rows_to_lds(t0, lane, a3);
+          __builtin_amdgcn_wave_barrier();
+          ss = frag_from_lds(t0, j, h);
           WN_WAIT_LGKM0();                      // tiles free again
         }
         // rows t: in flight during the rows t+d math (dx_{l+1}[t] is this
-        // wave's own store of the layer above)
-        if (hx) tile_dma<16>(t0, dxin + off0, lane, 0, hi);
-        tile_dma(t1, dZ + off0, lane, 0, hi);
-        tile_dma(t2, z + off0, lane, 0, hi);
-        tile_dma(t3, sg + off0, lane, 0, hi);
-        if (hi_f > 0) {
-          if (hx) mma32t(dz, di, wlane + 4 * SF_MT);  // dx_{l+1}[t+d] * Wd^T
-          f32x16 df, dg;
-          gate_grad(dz, zz, ss, df, dg);
-          mma32t(dx, df, wlane + 0 * SF_MT);        // da_f[t+d] * Wf[0]^T
-          mma32t(dx, dg, wlane + 2 * SF_MT);        // da_g[t+d] * Wg[0]^T
+        // wave's own store of the layer above); the sigmoid rows in registers
+        if (tile == tbase + wave) { BSTAMP(l, 11); }
+        tile_dma_rs<0>(t0, z, off0, vswz, lane, 0, hi);
+        if (hx) tile_dma_rs<16>(t1, dxin, off0, vswz, lane, 0, hi);
+        tile_dma_rs<0>(t2, dZ, off0, vswz, lane, 0, hi);
+        // the next tile's flags: requested now, looked at after this tile's math
+        unsigned nfv = epoch;
+        {
+          const int nidx = flag_idx(tile + WAVES);
+          if (nidx >= 0)
+            nfv = __hip_atomic_load(fl_in + nidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (tile == tbase + wave) { BSTAMP(l, 12); }
+        if (hi_f > 0) {
+          if (hx) mma32s(dz, di, wm + 4 * 1024, woff);  // dx_{l+1}[t+d] * Wd^T
+          f32x16 df, dg;
+#ifdef SB_NOGATE
+          df = dz; dg = zz;
+          asm volatile("" :: "v"(ss[0]));
+#else
+          gate_grad(dz, zz, ss, df, dg);
+#endif
+          // (requested only now: sixteen registers fewer during the gate math)
+          a3 = rows_ld<0>(sg, off0, vrow, lane, 0, hi);
+          mma32s(dx, df, wm + 0 * 1024, woff);          // da_f[t+d] * Wf[0]^T
+          mma32s(dx, dg, wm + 2 * 1024, woff);          // da_g[t+d] * Wg[0]^T
+        } else {
+          a3 = rows_ld<0>(sg, off0, vrow, lane, 0, hi);
+        }
+        if (tile == tbase + wave) { BSTAMP(l, 13); }
         WN_WAIT_VM0();
+        if (tile == tbase + wave) { BSTAMP(l, 14); }
         if (hx) {                                    // dWd += z^T dx_{l+1}
-#pragma unroll 4
-          for (int s2 = 0; s2 < 16; ++s2) {
-            const int row = 2 * s2 + h;
-            const float az = tile_elem(t2, row, j), bd = tile_elem(t0, row, j);
-            cd = __builtin_amdgcn_mfma_f32_32x32x2f32(az, bd, cd, 0, 0, 0);
-            sd += bd;
+#pragma unroll 1
+          for (int it = 0; it < 4; ++it) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float az = te.p[k][0 * 1024 + 64 * k + 256 * it];
+              const float bd = te.p[k][1 * 1024 + 64 * k + 256 * it];
+              cd = sb_mfma(az, bd, cd);
+              sd += bd;
+            }
           }
         }
-        dz = frag_from_lds(t1, j, h);
-        if (hx) di = frag_from_lds(t0, j, h);
-        zz = frag_from_lds(t2, j, h);
-        ss = frag_from_lds(t3, j, h);
+        zz = frag_from_lds(t0, j, h);
+        if (hx) di = frag_from_lds(t1, j, h);
+        dz = frag_from_lds(t2, j, h);
+        __builtin_amdgcn_wave_barrier();
+        rows_to_lds(t2, lane, a3);
+        __builtin_amdgcn_wave_barrier();
+        ss = frag_from_lds(t2, j, h);
         WN_WAIT_LGKM0();
+        if (tile == tbase + wave) { BSTAMP(l, 15); }
         // the x tiles: in flight during the rows-t math
-        tile_dma(t2, x + off0, lane, 0, hi);
-        tile_dma(t0, x + off0 - (size_t)d * WN_CH, lane, lo_p, hi);
+        tile_dma_rs<0>(t0, x, off0, vswz, lane, 0, hi);
+#ifdef SB_FAKE_ADDR
+        tile_dma_rs<0>(t1, x, off0 + 4096, vswz, lane, lo_p, hi);
+#else
+        tile_dma_rs<0>(t1, x, off0 - d * (WN_CH * 4), vswz, lane, lo_p, hi);
+#endif
+        f32x16 dg;
         {
           if (hx) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) dx[r] += di[r];
-            mma32t(dz, di, wlane + 4 * SF_MT);      // dx_{l+1}[t] * Wd^T
+            mma32s(dz, di, wm + 4 * 1024, woff);    // dx_{l+1}[t] * Wd^T
           }
-          f32x16 df, dg;
+          f32x16 df;
+#ifdef SB_NOGATE
+          df = dz; dg = zz;
+          asm volatile("" :: "v"(ss[0]));
+#else
           gate_grad(dz, zz, ss, df, dg);
-          mma32t(dx, df, wlane + 1 * SF_MT);        // da_f[t] * Wf[1]^T
-          mma32t(dx, dg, wlane + 3 * SF_MT);        // da_g[t] * Wg[1]^T
+#endif
+          mma32s(dx, df, wm + 1 * 1024, woff);      // da_f[t] * Wf[1]^T
+          mma32s(dx, dg, wm + 3 * 1024, woff);      // da_g[t] * Wg[1]^T
           if (dead) dx[0] = __builtin_nanf("");      // a wait expired: NaN gradients
-          frag_to_lds(t1, j, h, dx);
+          frag_to_lds(t2, j, h, dx);
           __builtin_amdgcn_wave_barrier();
-          rows_store_dev(dx_out + off0, lane, hi, rows_from_lds(t1, lane));
+#ifdef SB_FAKE_ADDR
+          rows_st<16>(dx_out, off0r, vrow, lane, hi, rows_from_lds(t2, lane));
+#else
+          rows_st<16>(dx_out, off0, vrow, lane, hi, rows_from_lds(t2, lane));
+#endif
           __builtin_amdgcn_wave_barrier();
-          frag_to_lds(t1, j, h, df);                 // t1 / t3 now hold da[t]
-          frag_to_lds(t3, j, h, dg);
+          frag_to_lds(t2, j, h, df);                 // t2 now holds da_f[t]
         }
         if (tile == tbase + wave) { BSTAMP(l, 8); }
         WN_WAIT_VM0();                               // x tiles in, dx_l out
@@ -618,21 +863,37 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
           __hip_atomic_store(fl_out + tile, epoch, __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
         if (tile == tbase + wave) { BSTAMP(l, 9); }
-        load_shifted(tile + WAVES);
+        load_shifted(tile + WAVES, nfv);
         if (tile == tbase + wave) { BSTAMP(l, 10); }
         __builtin_amdgcn_wave_barrier();
         float tsf = 0.f, tsg = 0.f;          // this tile's column sums of da[t]
-#pragma unroll 4
-        for (int s2 = 0; s2 < 16; ++s2) {    // dW[1] += x[t]^T da, dW[0] += x[t-d]^T da
-          const int row = 2 * s2 + h;
-          const float axc = tile_elem(t2, row, j), axp = tile_elem(t0, row, j);
-          const float bf = tile_elem(t1, row, j), bg = tile_elem(t3, row, j);
-          cf1 = __builtin_amdgcn_mfma_f32_32x32x2f32(axc, bf, cf1, 0, 0, 0);
-          cg1 = __builtin_amdgcn_mfma_f32_32x32x2f32(axc, bg, cg1, 0, 0, 0);
-          cf0 = __builtin_amdgcn_mfma_f32_32x32x2f32(axp, bf, cf0, 0, 0, 0);
-          cg0 = __builtin_amdgcn_mfma_f32_32x32x2f32(axp, bg, cg0, 0, 0, 0);
-          tsf += bf;
-          tsg += bg;
+        // dWf[1] += x[t]^T da_f, dWf[0] += x[t-d]^T da_f
+#pragma unroll 1
+        for (int it = 0; it < 4; ++it) {     // dWf[1] += x[t]^T da_f, dWf[0] += x[t-d]^T da_f
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float axc = te.p[k][0 * 1024 + 64 * k + 256 * it];
+            const float axp = te.p[k][1 * 1024 + 64 * k + 256 * it];
+            const float bf = te.p[k][2 * 1024 + 64 * k + 256 * it];
+            cf1 = sb_mfma(axc, bf, cf1);
+            cf0 = sb_mfma(axp, bf, cf0);
+            tsf += bf;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        frag_to_lds(t2, j, h, dg);           // ... then da_g[t] through the same tile
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+        for (int it = 0; it < 4; ++it) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float axc = te.p[k][0 * 1024 + 64 * k + 256 * it];
+            const float axp = te.p[k][1 * 1024 + 64 * k + 256 * it];
+            const float bg = te.p[k][2 * 1024 + 64 * k + 256 * it];
+            cg1 = sb_mfma(axc, bg, cg1);
+            cg0 = sb_mfma(axp, bg, cg0);
+            tsg += bg;
+          }
         }
         sf += tsf;
         sgs += tsg;
@@ -646,62 +907,122 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
         WN_WAIT_LGKM0();                     // tiles free for the next tile's DMA
         __builtin_amdgcn_wave_barrier();
       }
-      // ---- weight-gradient slab of this (layer, group): fixed-order tree over
-      // the waves through LDS (see layer_bwd2d_kernel)
+      BSTAMP(l, 3);
+      // ---- this wave no longer reads layer l's weights; the last one to say
+      // so refills their ring half with layer l - 2
+      bool refill = false;
+      {
+        int old = 0;
+        if (lane == 0)
+          old = __hip_atomic_fetch_add(s_done + l, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old == WAVES - 1 && l >= 2) {
+          issue_wimg(l - 2, 0, 1);
+          refill = true;
+        }
+      }
+      // ---- weight-gradient slab of this (layer, group): ordered accumulation
+      // over the waves (wave 0 writes, wave w adds after wave w - 1, the last
+      // wave adds and stores to memory)
       sf += __shfl_xor(sf, 32);
       sgs += __shfl_xor(sgs, 32);
       sd += __shfl_xor(sd, 32);
-      BSTAMP(l, 3);
-      __syncthreads();                       // tiles and wl are free
-      BSTAMP(l, 4);
-      if (l > 0) issue_wimg(l - 1);
-      float* red = tiles + (wave & (REG - 1)) * RS;
-      for (int ph = 0; ph < (WAVES > 4 ? 2 : 1); ++ph) {
-        if ((wave >> 2) == ph) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int m = 8 * (r >> 2) + 4 * h + (r & 3);
-            const int e = m * 32 + j;
-            if (ph == 0) {
-              red[0 * 1024 + e] = cf0[r];
-              red[1 * 1024 + e] = cf1[r];
-              red[2 * 1024 + e] = cg0[r];
-              red[3 * 1024 + e] = cg1[r];
-              red[4 * 1024 + e] = cd[r];
-            } else {
-              red[0 * 1024 + e] += cf0[r];
-              red[1 * 1024 + e] += cf1[r];
-              red[2 * 1024 + e] += cg0[r];
-              red[3 * 1024 + e] += cg1[r];
-              red[4 * 1024 + e] += cd[r];
-            }
-          }
-          if (h == 0) {
-            if (ph == 0) {
-              red[LAYER_W_FLOATS + j] = sf;
-              red[LAYER_W_FLOATS + 32 + j] = sgs;
-              red[LAYER_W_FLOATS + 64 + j] = sd;
-            } else {
-              red[LAYER_W_FLOATS + j] += sf;
-              red[LAYER_W_FLOATS + 32 + j] += sgs;
-              red[LAYER_W_FLOATS + 64 + j] += sd;
-            }
-          }
-        }
-        __syncthreads();
-      }
-      BSTAMP(l, 5);
       float* out = a.slabs + (size_t)l * a.slab_layer_stride +
                    (size_t)g * LAYER_BLOCK_FLOATS;
-      for (int e = tid; e < LAYER_BLOCK_FLOATS; e += WAVES * 64) {
-        float v = tiles[e];
-        if (REG == 2) v += tiles[RS + e];
-        if (REG == 4) v = (v + tiles[RS + e]) + (tiles[2 * RS + e] + tiles[3 * RS + e]);
-        out[e] = v;
+      // The chain runs matrix by matrix (one token each), so wave w + 1 adds
+      // matrix m while wave w is at matrix m + 1: 8 + 5 - 1 steps per layer
+      // instead of 8 x 5.  It is the one serial path of the workgroup: raised
+      // priority while on it.
+      const int tbase_l = (L - l) * 16;
+      int* tok = s_tok[l & 1];
+      const int* tok_up = s_tok[(l + 1) & 1];
+      const int e0 = 4 * h * 32 + j;           // + (8 (r >> 2) + (r & 3)) * 32
+      __builtin_amdgcn_s_setprio(2);
+      BSTAMP(l, 4);
+      // copy matrix m (+ its bias row) of the finished slab to memory
+      auto slab_out = [&](float* dst, int m) {
+        f32x16 p;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          p[r] = slab[m * 1024 + e0 + (8 * (r >> 2) + (r & 3)) * 32];
+        float pb = 0.f;
+        if (m >= 2 && h == 0) pb = slab[LAYER_W_FLOATS + (m - 2) * 32 + j];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          dst[m * 1024 + e0 + (8 * (r >> 2) + (r & 3)) * 32] = p[r];
+        if (m >= 2 && h == 0) dst[LAYER_W_FLOATS + (m - 2) * 32 + j] = pb;
+      };
+      auto chain = [&](f32x16& c, int m, float& bsum) {
+        if (WAVES > 1) {
+          if (wave == 0) {
+            // The slab's matrix m still holds layer l + 1's finished sums once
+            // the last wave has added its part: wave 0 -- which would wait for
+            // the slab anyway, while the last wave is the one everybody waits
+            // for -- copies them to memory, then starts layer l's sums.
+            if (hx) {
+              wait_lds_ge(tok_up + m, tbase_l - 16 + WAVES, dead, a.ctl, a.poison, lane);
+              slab_out(out + a.slab_layer_stride, m);
+            }
+          } else {
+            wait_lds_ge(tok + m, tbase_l + wave, dead, a.ctl, a.poison, lane);
+            f32x16 p;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              p[r] = slab[m * 1024 + e0 + (8 * (r >> 2) + (r & 3)) * 32];
+            if (m >= 2 && h == 0) bsum += slab[LAYER_W_FLOATS + (m - 2) * 32 + j];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c[r] += p[r];
+          }
+        }
+        if (WAVES == 1) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            out[m * 1024 + e0 + (8 * (r >> 2) + (r & 3)) * 32] = c[r];
+          if (m >= 2 && h == 0) out[LAYER_W_FLOATS + (m - 2) * 32 + j] = bsum;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            slab[m * 1024 + e0 + (8 * (r >> 2) + (r & 3)) * 32] = c[r];
+          if (m >= 2 && h == 0) slab[LAYER_W_FLOATS + (m - 2) * 32 + j] = bsum;
+          WN_WAIT_LGKM0();                   // this wave's slab reads / writes are done
+          if (lane == 0)
+            __hip_atomic_store(tok + m, tbase_l + wave + 1, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      };
+      float nosum = 0.f;
+      chain(cf0, 0, nosum);
+      chain(cf1, 1, nosum);
+      chain(cg0, 2, sf);       // (the three bias sums ride with matrices 2, 3, 4)
+      chain(cg1, 3, sgs);
+      chain(cd, 4, sd);
+      __builtin_amdgcn_s_setprio(0);
+      BSTAMP(l, 5);
+      if (refill) {
+        WN_WAIT_VM0();                       // layer l - 2's image has landed
+        if (lane == 0)
+          __hip_atomic_store(s_ready + l - 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
       BSTAMP(l, 6);
     }
-    __syncthreads();
+    if (WAVES > 1 && wave == 0) {          // the bottom layer's finished slab
+      const int e0 = 4 * h * 32 + j;
+      float* dst = a.slabs + (size_t)g * LAYER_BLOCK_FLOATS;
+      for (int m = 0; m < 5; ++m) {
+        wait_lds_ge(s_tok[0] + m, L * 16 + WAVES, dead, a.ctl, a.poison, lane);
+        f32x16 p;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          p[r] = slab[m * 1024 + e0 + (8 * (r >> 2) + (r & 3)) * 32];
+        float pb = 0.f;
+        if (m >= 2 && h == 0) pb = slab[LAYER_W_FLOATS + (m - 2) * 32 + j];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          dst[m * 1024 + e0 + (8 * (r >> 2) + (r & 3)) * 32] = p[r];
+        if (m >= 2 && h == 0) dst[LAYER_W_FLOATS + (m - 2) * 32 + j] = pb;
+      }
+    }
+    __syncthreads();        // every wave is through layer 0: LDS is free again
   }
 #ifdef STACK_STAMPS
   if (tid == 0) { cal[2] = __builtin_amdgcn_s_memrealtime(); cal[3] = __builtin_amdgcn_s_memtime(); }
@@ -810,6 +1131,17 @@ int wn_stack_fwd(float* X, float* Z, float* SG, const float* wimg,
 static void stack_bwd_shape(int B, int T, int* waves_out, int* tpw_out) {
   const long ntiles = (long)B * ((T + 31) / 32);
   const int cus = wn_device_cus();
+#ifdef STACK_STAMPS
+  // diagnostic build only: WN_DIAG_BWD_WAVES=w forces w waves per workgroup
+  if (const char* e = getenv("WN_DIAG_BWD_WAVES")) {
+    const int w = atoi(e);
+    if (w == 1 || w == 2 || w == 4 || w == 8) {
+      *waves_out = w;
+      *tpw_out = (int)((ntiles + (long)w * cus - 1) / ((long)w * cus));
+      return;
+    }
+  }
+#endif
   long best = -1;
   int bw = 8, bt = 1;
   const int tmin = (int)((ntiles + 8L * cus - 1) / (8L * cus));
@@ -844,6 +1176,8 @@ int wn_stack_bwd(const float* X, const float* Z, const float* SG,
     return WN_ERR_NULL;
   if (L <= 0 || B <= 0 || T <= 0) return WN_ERR_BAD_SHAPE;
   if (L > STACK_MAXL) return WN_ERR_UNSUPPORTED;
+  // (tile offsets inside a plane are 32-bit byte offsets of a buffer resource)
+  if ((long)B * T * WN_CH * 4 >= (1L << 31)) return WN_ERR_UNSUPPORTED;
   const void* ptrs[] = {X, Z, SG, dZ, DX, wimg};
   for (const void* p : ptrs)
     if (!wn_aligned16(p)) return WN_ERR_MISALIGNED;

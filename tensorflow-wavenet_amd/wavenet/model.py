@@ -132,7 +132,7 @@ class _Workspace(object):
         # (allocated whenever the option could apply, so that switching
         # `layer_bwd` / `fused_bwd` back and forth keeps one behaviour)
         self.stack_bwd = (net.stack_bwd and CB == 1 and not net.generic_layers
-                          and L <= 256)
+                          and L <= 256 and N * CH * 4 < 2 ** 31)
         if self.stack_bwd:
             alloc('DX', (L, N, CH))
             alloc('wimg_b', (L, lib.wn_stack_wimg_floats()))

@@ -99,6 +99,74 @@ def test_stack_inference_forward(hip_lib):
     a.check_device_errors()
 
 
+def _f64_layer_grads(net, ws, l):
+    """float64 weight / bias gradients of residual block l from the planes the
+    stack launches leave in the workspace (hand-written gradient of
+    model.py:236-330; the anti-causal tap is the only coupling in time)."""
+    B, T, L = ws.B, ws.T, net.L
+    d = int(net.dilations[l])
+    f = lambda t: t.double().reshape(B, T, -1)
+    X, Z, SG, dZ = f(ws.X[l]), f(ws.Z[l]), f(ws.SG[l]), f(ws.dZ[l])
+    blk = net._layer_block(net.params, l).double()
+    Wd = blk[4096:5120].reshape(32, 32)
+    dz = dZ.clone()
+    dxn = None
+    if l + 1 < L:
+        dxn = f(ws.DX[l + 1])
+        dz = dz + dxn @ Wd.t()
+    th = torch.where(SG > 1e-30, Z / SG.clamp_min(1e-30), torch.zeros_like(Z))
+    da_f = dz * (SG - Z * th)
+    da_g = dz * Z * (1.0 - SG)
+    Xp = torch.zeros_like(X)
+    if d < T:
+        Xp[:, d:] = X[:, :T - d]
+    mm = lambda a_, b_: torch.einsum('btc,bte->ce', a_, b_).reshape(-1)
+    out = {'Wf0': mm(Xp, da_f), 'Wf1': mm(X, da_f), 'Wg0': mm(Xp, da_g),
+           'Wg1': mm(X, da_g), 'bf': da_f.sum((0, 1)), 'bg': da_g.sum((0, 1))}
+    if dxn is not None:
+        out['Wd'] = mm(Z, dxn)
+        out['bd'] = dxn.sum((0, 1))
+    return out
+
+
+_SECTIONS = [('Wf0', 0, 1024), ('Wf1', 1024, 2048), ('Wg0', 2048, 3072),
+             ('Wg1', 3072, 4096), ('Wd', 4096, 5120), ('bf', 5120, 5152),
+             ('bg', 5152, 5184), ('bd', 5184, 5216)]
+
+
+def _check_layer_grads(a, b, wa, name):
+    """Per variable of every residual block (Wf[0], Wf[1], Wg[0], Wg[1], Wd and
+    the three biases; 32 padded channels): the persistent launch and the
+    per-layer kernels sum the same per-tile products in different orders, so
+    both are compared with a float64 evaluation of the same planes -- each in
+    the norm of the VARIABLE (a bias or a small matrix cannot hide behind the
+    bucket's largest gradient), and the persistent launch may not be further
+    from float64 than 2.5 x the per-layer kernels plus 1e-6 of the variable
+    (fp32 summation noise of a 128000-row sum with cancellation reaches 2e-3
+    of a variable's largest entry in BOTH paths).  Everything outside the
+    residual blocks comes from the same kernels on bitwise equal inputs."""
+    ga, gb = a.grads, b.grads
+    L = a.L
+    worst = 0.0
+    for l in range(L):
+        ref = _f64_layer_grads(a, wa, l)
+        xa = a._layer_block(ga, l)[:5216].double()
+        xb = b._layer_block(gb, l)[:5216].double()
+        for nm, lo, hi in _SECTIONS:
+            if nm not in ref or (nm[0] == 'b' and not a.use_biases):
+                continue
+            r = ref[nm]
+            n = float(r.norm()) + 1e-300
+            ea = float((xa[lo:hi] - r).norm()) / n
+            eb = float((xb[lo:hi] - r).norm()) / n
+            worst = max(worst, ea)
+            assert ea <= 2.5 * eb + 1e-6, (name, l, nm, ea, eb)
+            assert ea <= 1e-4, (name, l, nm, ea)
+    # the other variables: same kernels, bitwise equal inputs (dx_0, dZ, ...)
+    scale = float(gb.abs().max())
+    assert float((ga - gb).abs().max()) <= 2e-6 * max(scale, 1e-30)
+
+
 @pytest.mark.parametrize('name,mk,B,T,kind', CASES, ids=[c[0] for c in CASES])
 def test_stack_backward_equals_per_layer(hip_lib, name, mk, B, T, kind):
     """wn_stack_bwd vs one wn_layer_bwd2 per layer: dL/dx_0 bitwise (per-tile
@@ -121,13 +189,7 @@ def test_stack_backward_equals_per_layer(hip_lib, name, mk, B, T, kind):
         assert float(la) == float(lb)
         assert torch.equal(wa.DX[0], wb.dx[0][0]) or torch.equal(wa.DX[0], wb.dx[1][0])
         ga, gb = a.grads, b.grads
-        # per variable, against that variable's own largest entry (a bias or
-        # GC weight must not hide behind the bucket's largest gradient)
-        ta, tb = a._views(ga), b._views(gb)
-        for (n, va), (_, vb) in zip(a.named_variables(ta), b.named_variables(tb)):
-            scale = float(vb.abs().max())
-            err = float((va - vb).abs().max())
-            assert err <= 1e-5 * scale + 1e-30, (n, err, scale)
+        _check_layer_grads(a, b, wa, name)
         if prev is not None:
             assert torch.equal(prev, ga)          # run-to-run determinism
         prev = ga.clone()
@@ -156,10 +218,7 @@ def test_child_workspace_owns_fresh_backward_control_block(hip_lib):
         pytest.skip('the shorter workspace did not take the stack backward')
     assert wa.stack_ctl_b.cpu().tolist()[2] == 2       # started at 1, one launch
     assert float(la) == float(lb)
-    ta, tb = a._views(a.grads), b._views(b.grads)
-    for (n, va), (_, vb) in zip(a.named_variables(ta), b.named_variables(tb)):
-        scale = float(vb.abs().max())
-        assert float((va - vb).abs().max()) <= 1e-5 * scale + 1e-30, n
+    _check_layer_grads(a, b, wa, 'child workspace')
     a.check_device_errors()
 
 

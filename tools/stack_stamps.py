@@ -35,7 +35,7 @@ dbg = torch.zeros(grid * 16 * L * 12 + grid * 4, dtype=torch.int64, device='cuda
 lib.wn_diag_stack_dbg.argtypes = [ctypes.c_void_p]
 lib.wn_diag_stack_dbg(dbg.data_ptr())
 gridb = min(256, lib.wn_stack_bwd_slabs(B, T))
-dbgb = torch.zeros(gridb * 8 * L * 12 + gridb * 4, dtype=torch.int64, device='cuda')
+dbgb = torch.zeros(gridb * 8 * L * 16 + gridb * 4, dtype=torch.int64, device='cuda')
 lib.wn_diag_stack_dbg_b.argtypes = [ctypes.c_void_p]
 lib.wn_diag_stack_dbg_b(dbgb.data_ptr())
 audio = synth_audio(B, T)
@@ -83,16 +83,20 @@ for l in range(0, L - 1):
 # ---------------------------------------------------------------- backward
 if not fwd_only:
     raw = dbgb.cpu().numpy()
-    s = raw[:gridb * 8 * L * 12].reshape(gridb, 8, L, 12).astype(np.float64)
-    cal = raw[gridb * 8 * L * 12:].reshape(gridb, 4).astype(np.float64)
+    s = raw[:gridb * 8 * L * 16].reshape(gridb, 8, L, 16).astype(np.float64)
+    cal = raw[gridb * 8 * L * 16:].reshape(gridb, 4).astype(np.float64)
     clk = np.median((cal[:, 3] - cal[:, 1]) / ((cal[:, 2] - cal[:, 0]) * 10.0))
     print('=== stack_bwd_kernel: clock %.2f GHz; workgroup entry -> exit median %.1f us, whole launch %.1f us' % (
         clk, np.median(cal[:, 2] - cal[:, 0]) / 100.0, (cal[:, 2].max() - cal[:, 0].min()) / 100.0))
-    seq = [(0, 1, 'layer top: weight image landed, barrier'), (1, 2, 'first tile: flags + rows t+d requested'),
-           (2, 8, 'first tile until its dx is computed'), (8, 9, 'x tiles in, dx stored and drained, flag'),
-           (9, 10, 'next tile: flags + rows t+d requested'), (10, 7, 'first tile: weight-gradient MFMAs'),
-           (7, 3, 'second tile'), (3, 4, 'closing barrier'), (4, 5, 'reduction tree'), (5, 6, 'slab store')]
-    for wv in (0, 7):
+    seq = [(0, 1, 'layer top: wait for the weight image'), (1, 2, 'first tile: flags + rows t+d requested'),
+           (2, 11, 'rows t+d: registers -> LDS -> fragments'), (11, 12, 'rows-t DMA issued'),
+           (12, 13, 'rows t+d math (48 MFMA + gates)'), (13, 14, 'wait for the rows-t DMA'),
+           (14, 15, 'dWd (16 MFMA), fragments of rows t'), (15, 8, 'x DMA issued, rows-t math (48 MFMA + gates), dx to LDS / store issued'),
+           (8, 9, 'x tiles in, dx stored and drained, flag'),
+           (9, 10, 'next tile: flags + rows t+d requested'), (10, 7, 'first tile: weight-gradient MFMAs (64)'),
+           (7, 3, 'second tile'), (3, 4, 'ring bookkeeping'), (4, 5, 'ordered accumulation chain (incl. token waits; last wave: slab store)'),
+           (5, 6, 'refill drain + ready mark (refilling wave only)')]
+    for wv in (0, 3, 7):
         print('--- wave %d: median over workgroups and layers 1..L-2 (p90), us' % wv)
         for a_, b_, nm in seq:
             dt = (s[:, wv, 1:L - 1, b_] - s[:, wv, 1:L - 1, a_]) / clk / 1e3
@@ -101,3 +105,13 @@ if not fwd_only:
                 print('%-46s %6.2f   (%6.2f)' % (nm, np.median(dt), np.percentile(dt, 90)))
         per = (s[:, wv, 1:L - 2, 0] - s[:, wv, 2:L - 1, 0]) / clk / 1e3     # layers run downwards
         print('%-46s %6.2f' % ('layer period', np.median(per)))
+
+    # raw timeline of one workgroup, one layer: every wave's stamps in us from
+    # the earliest one (which phases of the two waves of a SIMD coincide?)
+    if os.environ.get('KB_TIMELINE'):
+        g, l = gridb // 2, L // 2
+        order = [0, 1, 2, 11, 12, 13, 14, 15, 8, 9, 10, 7, 3, 4, 5, 6]
+        t0 = s[g, :, l, 0].min()
+        print('--- workgroup %d, layer %d: stamps (us) in program order: %s' % (g, l, order))
+        for wv in range(8):
+            print('wave %d: ' % wv + ' '.join('%6.2f' % ((s[g, wv, l, i] - t0) / clk / 1e3) for i in order))

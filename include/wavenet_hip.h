@@ -342,6 +342,23 @@ int wn_fastgen_run(const float* params_causal, const float* layer0,
                    float* proba_out, int proba_every, int use_biases,
                    int push, void* stream);
 
+/* The same generator for C = 32 * blocks > 32 padded residual / dilation
+ * channels (the reference's generator has no width limit, model.py:444-516):
+ * layer blocks Wf[2][C][C] Wg[2][C][C] Wd[C][C] bf[C] bg[C] bd[C], causal
+ * [2][Q][C], skip [L][C][S], gc_bias_fg [L][2 C], queue entries of C floats
+ * (state_floats = sum(dilations) * C, C <= 256).  One persistent workgroup,
+ * correctness first. */
+int wn_fastgen_run_wide(const float* params_causal, const float* layer0,
+                        long layer_stride, const float* skip_w,
+                        const float* skip_bsum, const float* post1_w,
+                        const float* post1_b, const float* post2_w,
+                        const float* post2_b, const float* gc_bias_fg,
+                        const int32_t* dilations_dev, int L, int C, int S, int Q,
+                        float* state, int32_t* cursors, int32_t* samples_io,
+                        int n_given, int n_steps, float temperature,
+                        uint64_t seed, float* proba_out, int proba_every,
+                        int use_biases, int push, void* stream);
+
 /* Multi-CU variant: enqueues ONE generation step as four kernels (chain on
  * one CU, current tap only, preceded by the previous step's float64 softmax +
  * draw; skip sum + the NEXT step's past-tap pre-activations, conv1 and conv2

@@ -379,6 +379,215 @@ __global__ __launch_bounds__(FG_THREADS, 1) void fastgen_kernel(FastGen g) {
 }
 
 // ===========================================================================
+// Wide fast generation: the same incremental generator for MORE than 32
+// residual / dilation channels (C = 32 * blocks padded channels, weights in the
+// reference's [K][C][C] layout of wavenet/blocked.py; the reference's
+// generator has no width limit, model.py:444-516).  One persistent workgroup,
+// correctness first: per layer three phases separated by workgroup barriers
+//   1. thread (which, c): a_which[c] = bias + st . W_which[0][:, c] + x . W_which[1][:, c]
+//   2. z = tanh(a_f) sigmoid(a_g); the queue entry is replaced by x (push)
+//   3. x += bd + z . Wd  (every layer, as model.py:377-380); total += z . Ws_l
+// then the post-processing mat-vecs, the float64 softmax and the same
+// counter-based draw as fastgen_kernel (same seed -> same uniform per step).
+// Queues: layer l's ring holds d_l rows of C floats at state + roff[l] * C.
+// ===========================================================================
+#define FGW_THREADS 256
+#define FGW_MAXC 256
+
+struct FastGenWide {
+  FastGen g;
+  int C;        // padded channels (multiple of 32, <= FGW_MAXC)
+};
+
+__global__ __launch_bounds__(FGW_THREADS, 1) void fastgen_wide_kernel(FastGenWide a) {
+  const FastGen& g = a.g;
+  __shared__ float xs[FGW_MAXC], sts[FGW_MAXC], zs[FGW_MAXC], apre[2 * FGW_MAXC];
+  __shared__ float hbuf[FG_MAXS], h2buf[FG_MAXS];
+  __shared__ double pd[FG_MAXQ];
+  __shared__ int s_code;
+  __shared__ int pos[FG_MAXL], sdil[FG_MAXL], roff[FG_MAXL];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int S = g.S, Q = g.Q, L = g.L, C = a.C;
+  const long CC = (long)C * C;
+  const int steps_done = g.cursors[0];
+  int prev_code = g.cursors[1];
+  if (tid == 0) s_code = g.samples[0];
+  for (int l = tid; l < L; l += FGW_THREADS) {
+    sdil[l] = g.dil[l];
+    pos[l] = steps_done % g.dil[l];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int off = 0;
+    for (int l = 0; l < L; ++l) { roff[l] = off; off += sdil[l]; }
+  }
+  __syncthreads();
+
+  for (int step = 0; step < g.n_steps; ++step) {
+    const int code = s_code;
+    const long tpos = (long)steps_done + step;
+    float acc[(FG_MAXS + FGW_THREADS - 1) / FGW_THREADS];
+#pragma unroll
+    for (int o = 0; o < (FG_MAXS + FGW_THREADS - 1) / FGW_THREADS; ++o) acc[o] = 0.f;
+    // causal layer: one-hot input = two table rows (model.py:341-346)
+    for (int c = tid; c < C; c += FGW_THREADS) {
+      float v = 0.f;
+      if (prev_code >= 0 && prev_code < Q) v = g.causal[(long)prev_code * C + c];
+      if (code >= 0 && code < Q) v += g.causal[((long)Q + code) * C + c];
+      xs[c] = v;
+    }
+    __syncthreads();
+    for (int l = 0; l < L; ++l) {
+      const float* blk = g.layer0 + (long)l * g.layer_stride;
+      float* ring = g.state + ((long)roff[l] + pos[l]) * C;
+      for (int c = tid; c < C; c += FGW_THREADS) sts[c] = ring[c];
+      __syncthreads();
+      // ---- 1. filter / gate pre-activations
+      for (int o = tid; o < 2 * C; o += FGW_THREADS) {
+        const int which = o / C, c = o - which * C;
+        const float* w0 = blk + (long)which * 2 * CC + c;   // W_which[0][:, c]
+        const float* w1 = w0 + CC;                          // W_which[1][:, c]
+        float s0 = g.bias_fg ? g.bias_fg[(long)l * 2 * C + o] : 0.f, s1 = 0.f;
+        for (int k = 0; k < C; ++k) {
+          s0 = fmaf(sts[k], w0[(long)k * C], s0);
+          s1 = fmaf(xs[k], w1[(long)k * C], s1);
+        }
+        apre[o] = s0 + s1;
+      }
+      __syncthreads();
+      // ---- 2. gate; enqueue x_l[t] in place of the entry just read
+      for (int c = tid; c < C; c += FGW_THREADS) {
+        zs[c] = wn_tanh(apre[c]) * wn_sigmoid(apre[C + c]);
+        if (g.push) ring[c] = xs[c];
+      }
+      __syncthreads();
+      // ---- 3. residual 1x1 conv and this layer's skip contribution
+      float xn = 0.f;
+      const bool has_x = tid < C;      // (C <= FGW_THREADS: one channel per thread)
+      if (has_x) {
+        const float* wd = blk + 4 * CC + tid;
+        float d0 = g.use_dense_bias ? blk[5 * CC + 2 * C + tid] : 0.f;
+        for (int k = 0; k < C; ++k) d0 = fmaf(zs[k], wd[(long)k * C], d0);
+        xn = xs[tid] + d0;
+      }
+      {
+        const float* ws = g.skip_w + (long)l * C * S;
+        int oi = 0;
+        for (int sc = tid; sc < S; sc += FGW_THREADS, ++oi) {
+          float t = acc[oi];
+          for (int k = 0; k < C; ++k) t = fmaf(zs[k], ws[(long)k * S + sc], t);
+          acc[oi] = t;
+        }
+      }
+      __syncthreads();
+      if (has_x) xs[tid] = xn;
+      __syncthreads();
+    }
+    if (g.push) {
+      for (int l = tid; l < L; l += FGW_THREADS) {
+        const int p = pos[l] + 1;
+        pos[l] = p == sdil[l] ? 0 : p;
+      }
+    }
+    // ---- post-processing (model.py:505-514)
+    {
+      int oi = 0;
+      for (int sc = tid; sc < S; sc += FGW_THREADS, ++oi)
+        hbuf[sc] = fmaxf(acc[oi] + (g.skip_bsum ? g.skip_bsum[sc] : 0.f), 0.f);
+    }
+    __syncthreads();
+    for (int sc = tid; sc < S; sc += FGW_THREADS) {
+      float c0 = g.post1_b ? g.post1_b[sc] : 0.f;
+      const float* w = g.post1_w + sc;
+      for (int k = 0; k < S; ++k) c0 = fmaf(hbuf[k], w[(long)k * S], c0);
+      h2buf[sc] = fmaxf(c0, 0.f);
+    }
+    __syncthreads();
+    for (int q = tid; q < Q; q += FGW_THREADS) {
+      float c0 = g.post2_b ? g.post2_b[q] : 0.f;
+      const float* w = g.post2_w + q;
+      for (int k = 0; k < S; ++k) c0 = fmaf(h2buf[k], w[(long)k * Q], c0);
+      pd[q] = (double)c0;
+    }
+    __syncthreads();
+    // ---- softmax in float64, temperature, draw: as fastgen_kernel
+    if (wave == 0) {
+      double m = -1e300;
+      for (int q = lane; q < Q; q += 64) m = fmax(m, pd[q]);
+      for (int o = 32; o >= 1; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+      double se = 0.0;
+      for (int q = lane; q < Q; q += 64) {
+        const double e = exp(pd[q] - m);
+        pd[q] = e;
+        se += e;
+      }
+      for (int o = 32; o >= 1; o >>= 1) se += __shfl_xor(se, o);
+      const bool want_p = g.proba_out && (step % g.proba_every == 0);
+      float* po = want_p ? g.proba_out + (long)(step / g.proba_every) * Q : nullptr;
+      for (int q = lane; q < Q; q += 64) {
+        const float p32 = (float)(pd[q] / se);
+        if (po) po[q] = p32;
+        pd[q] = (double)p32;
+      }
+    }
+    __syncthreads();
+    if (step + 1 >= g.n_given) {
+      if (wave == 0) {
+        const double tau = (double)g.temperature;
+        if (g.temperature != 1.0f) {
+          double mx = -1e300;
+          for (int q = lane; q < Q; q += 64) {
+            const double lp = log(pd[q] > 0.0 ? pd[q] : 1e-300) / tau;
+            pd[q] = lp;
+            mx = fmax(mx, lp);
+          }
+          for (int o = 32; o >= 1; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+          for (int q = lane; q < Q; q += 64) pd[q] = exp(pd[q] - mx);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int per = (Q + 63) / 64;
+        const int q0 = lane * per, q1 = min(Q, q0 + per);
+        double seg = 0.0;
+        for (int q = q0; q < q1; ++q) seg += pd[q];
+        double incl = seg;
+        for (int o = 1; o < 64; o <<= 1) {
+          const double v = __shfl_up(incl, o);
+          if (lane >= o) incl += v;
+        }
+        const double total = __shfl(incl, 63);
+        const uint64_t r = splitmix64(g.seed ^ splitmix64((uint64_t)tpos));
+        const double u = (double)(r >> 11) * (1.0 / 9007199254740992.0) * total;
+        const double excl = incl - seg;
+        int pick = -1;
+        if (u >= excl && u < incl) {
+          double c = excl;
+          pick = q1 - 1;
+          for (int q = q0; q < q1; ++q) {
+            c += pd[q];
+            if (u < c) { pick = q; break; }
+          }
+        }
+        int best = pick;
+        for (int o = 32; o >= 1; o >>= 1) best = max(best, __shfl_xor(best, o));
+        if (best < 0) best = Q - 1;
+        if (lane == 0) {
+          g.samples[step + 1] = best;
+          s_code = best;
+        }
+      }
+    } else if (tid == 0) {
+      s_code = g.samples[step + 1];
+    }
+    prev_code = code;
+    __syncthreads();
+  }
+  if (tid == 0 && g.push) {
+    g.cursors[0] = steps_done + g.n_steps;
+    g.cursors[1] = prev_code;
+  }
+}
+
+// ===========================================================================
 // Multi-CU fast generation: one generated sample = four small kernels on the
 // stream (captured into a hipGraph by the host, hundreds of samples per
 // replay):
@@ -929,6 +1138,49 @@ int wn_fastgen_run(const float* params_causal, const float* layer0,
   if (!push && n_steps != 1) return WN_ERR_BAD_SHAPE;
   hipLaunchKernelGGL(fastgen_kernel, dim3(1), dim3(FG_THREADS), 0,
                      (hipStream_t)stream, g);
+  return wn_check_launch();
+}
+
+
+// wn_fastgen_run for C = 32 * blocks > 32 padded channels (layer blocks
+// Wf[2][C][C] Wg[2][C][C] Wd[C][C] bf[C] bg[C] bd[C], causal [2][Q][C], skip
+// [L][C][S], gc_bias_fg [L][2 C], queues of C floats per entry:
+// state_floats = sum(dilations) * C).
+int wn_fastgen_run_wide(const float* params_causal, const float* layer0,
+                        long layer_stride, const float* skip_w,
+                        const float* skip_bsum, const float* post1_w,
+                        const float* post1_b, const float* post2_w,
+                        const float* post2_b, const float* gc_bias_fg,
+                        const int32_t* dilations_dev, int L, int C, int S, int Q,
+                        float* state, int32_t* cursors, int32_t* samples_io,
+                        int n_given, int n_steps, float temperature,
+                        uint64_t seed, float* proba_out, int proba_every,
+                        int use_biases, int push, void* stream) {
+  if (!params_causal || !layer0 || !skip_w || !post1_w || !post2_w ||
+      !dilations_dev || !state || !cursors || !samples_io)
+    return WN_ERR_NULL;
+  if (L <= 0 || S <= 0 || Q <= 0 || n_steps <= 0 || n_given < 1 || C <= 0 ||
+      C % 32 != 0)
+    return WN_ERR_BAD_SHAPE;
+  if (S > FG_MAXS || Q > FG_MAXQ || L > FG_MAXL || C > FGW_MAXC)
+    return WN_ERR_UNSUPPORTED;
+  if (!(temperature > 0.f)) return WN_ERR_BAD_SHAPE;
+  if (!push && n_steps != 1) return WN_ERR_BAD_SHAPE;
+  FastGenWide a;
+  FastGen& g = a.g;
+  g.causal = params_causal; g.layer0 = layer0; g.layer_stride = layer_stride;
+  g.skip_w = skip_w; g.skip_bsum = skip_bsum; g.post1_w = post1_w;
+  g.post1_b = post1_b; g.post2_w = post2_w; g.post2_b = post2_b;
+  g.bias_fg = gc_bias_fg; g.dil = dilations_dev; g.L = L; g.S = S; g.Q = Q;
+  g.state = state; g.cursors = cursors; g.samples = samples_io;
+  g.n_given = n_given; g.n_steps = n_steps; g.temperature = temperature;
+  g.seed = seed; g.proba_out = proba_out;
+  g.proba_every = proba_every > 0 ? proba_every : 1;
+  g.use_dense_bias = use_biases;
+  g.push = push;
+  a.C = C;
+  hipLaunchKernelGGL(fastgen_wide_kernel, dim3(1), dim3(FGW_THREADS), 0,
+                     (hipStream_t)stream, a);
   return wn_check_launch();
 }
 

@@ -33,6 +33,7 @@
 // turns NaN instead of being silently wrong; the backward also poisons its dx)
 // and carries on without waiting, so the grid always drains.
 #include "wn_common.h"
+#include <stdlib.h>
 
 #define WN_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define WN_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
@@ -1131,9 +1132,9 @@ int wn_stack_fwd(float* X, float* Z, float* SG, const float* wimg,
 static void stack_bwd_shape(int B, int T, int* waves_out, int* tpw_out) {
   const long ntiles = (long)B * ((T + 31) / 32);
   const int cus = wn_device_cus();
-#ifdef STACK_STAMPS
-  // diagnostic build only: WN_DIAG_BWD_WAVES=w forces w waves per workgroup
-  if (const char* e = getenv("WN_DIAG_BWD_WAVES")) {
+  // experiments (A/B of co-residency with a side-stream GEMM, stamps):
+  // WN_STACK_BWD_WAVES=w forces w waves per workgroup
+  if (const char* e = getenv("WN_STACK_BWD_WAVES")) {
     const int w = atoi(e);
     if (w == 1 || w == 2 || w == 4 || w == 8) {
       *waves_out = w;
@@ -1141,7 +1142,6 @@ static void stack_bwd_shape(int B, int T, int* waves_out, int* tpw_out) {
       return;
     }
   }
-#endif
   long best = -1;
   int bw = 8, bt = 1;
   const int tmin = (int)((ntiles + 8L * cus - 1) / (8L * cus));

@@ -108,6 +108,10 @@ SIGNATURES = {
     'wn_fastgen_run': (c_int, [P, P, c_long, P, P, P, P, P, P, P, P, c_int,
                                c_int, c_int, P, P, P, c_int, c_int, c_float,
                                c_u64, P, c_int, c_int, c_int, P]),
+    'wn_fastgen_run_wide': (c_int, [P, P, c_long, P, P, P, P, P, P, P, P,
+                                    c_int, c_int, c_int, c_int, P, P, P, c_int,
+                                    c_int, c_float, c_u64, P, c_int, c_int,
+                                    c_int, P]),
     'wn_fastgen_step': (c_int, [P, P, c_long, P, P, P, P, P, P, P, P, c_int,
                                 c_int, c_int, P, P, P, P, P, c_int, P, P, P,
                                 P, P, P, P]),

@@ -1237,14 +1237,15 @@ class WaveNetModel(object):
         if self._gen is None:
             lib = _lib.load()
             dil = np.asarray(self.dilations, dtype=np.int32)
-            nfl = lib.wn_fastgen_state_floats(dil.ctypes.data, self.L)
+            # (queue entries are rows of CHn = 32 * blocks floats)
+            nfl = lib.wn_fastgen_state_floats(dil.ctypes.data, self.L) * self.CB
             g = dict(
                 state=torch.zeros(nfl, dtype=torch.float32, device=self.device),
                 # [0] steps done, [1] previous code, [2] draw pending
                 cursors=torch.zeros(4, dtype=torch.int32, device=self.device),
                 dil=torch.from_numpy(dil).to(self.device),
-                bias=torch.zeros((self.L, 1, 64), dtype=torch.float32,
-                                 device=self.device),
+                bias=torch.zeros((self.L, 1, 2 * self.CHn),
+                                 dtype=torch.float32, device=self.device),
                 bsum=torch.zeros(self.S, dtype=torch.float32,
                                  device=self.device),
                 proba=torch.empty(self.Q, dtype=torch.float32,
@@ -1312,6 +1313,16 @@ class WaveNetModel(object):
                   self.L, self.S, self.Q, _lib.ptr(g['state']),
                   _lib.ptr(g['cursors']), _lib.ptr(samples_io))
         sd = int(seed) & (2**64 - 1)
+        if self.CB > 1:
+            # more than 32 channels: the wide single-workgroup generator
+            _lib.call('wn_fastgen_run_wide', *common[:11], self.L, self.CHn,
+                      self.S, self.Q, *common[14:], int(n_given), int(n_steps),
+                      float(temperature), sd, _lib.ptr(proba_out),
+                      int(proba_every), 1 if ub else 0, 1 if push else 0,
+                      _lib.stream())
+            if push:
+                g['steps'] += int(n_steps)
+            return
         if not multi_cu or not push:
             _lib.call('wn_fastgen_run', *common, int(n_given), int(n_steps),
                       float(temperature), sd, _lib.ptr(proba_out),
@@ -1411,9 +1422,6 @@ class WaveNetModel(object):
         if self.filter_width > 2:
             raise NotImplementedError("Incremental generation does not "
                                       "support filter_width > 2.")
-        if self.CB > 1:
-            raise NotImplementedError("Fast generation supports at most 32 "
-                                      "residual / dilation channels.")
         if self.scalar_input:
             raise NotImplementedError("Scalar input is not supported by "
                                       "fast generation.")
@@ -1441,10 +1449,9 @@ class WaveNetModel(object):
         Returns int32 codes [len(seed) + num_samples] (and the probabilities
         of every `return_proba_every`-th step when requested)."""
         self._check_supported()
-        if self.filter_width > 2 or self.scalar_input or self.CB > 1:
-            raise NotImplementedError('fast generation needs filter_width 2, '
-                                      'one-hot input and at most 32 residual / '
-                                      'dilation channels')
+        if self.filter_width > 2 or self.scalar_input:
+            raise NotImplementedError('fast generation needs filter_width 2 '
+                                      'and one-hot input (model.py:597-603)')
         if seed_samples is None:
             seed_samples = [self.Q // 2]
         s = torch.as_tensor(np.asarray(seed_samples), dtype=torch.int32).reshape(-1)
@@ -1480,10 +1487,9 @@ class WaveNetModel(object):
         ONE batch forward pass: layer l's queue (capacity d_l) holds the last
         d_l inputs x_l[t] of that layer (model.py:473-484), which are rows of
         the forward pass's per-layer activation planes."""
-        if self.filter_width > 2 or self.scalar_input or self.CB > 1:
-            raise NotImplementedError('fast generation needs filter_width 2, '
-                                      'one-hot input and at most 32 residual / '
-                                      'dilation channels')
+        if self.filter_width > 2 or self.scalar_input:
+            raise NotImplementedError('fast generation needs filter_width 2 '
+                                      'and one-hot input (model.py:597-603)')
         self._check_supported()
         g = self._generator(global_condition)
         self._gen_reset()
@@ -1496,15 +1502,19 @@ class WaveNetModel(object):
         ws.q.copy_(w)
         ids = self._gc_ids(global_condition, 1)
         self._forward(ws, ids, save_ts=0)
+        # a queue entry is a row of CB 32-wide blocks; block cb of layer l's
+        # input is activation plane l * CB + cb
+        CB = self.CB
         src, dst, roff = [], [], 0
         for l, d in enumerate(self.dilations):
             t = np.arange(max(0, n0 - d), n0, dtype=np.int64)
-            src.append(l * n0 + t)
-            dst.append(roff + t % d)
+            for cb in range(CB):
+                src.append((l * CB + cb) * n0 + t)
+                dst.append((roff + t % d) * CB + cb)
             roff += d
         src = torch.from_numpy(np.concatenate(src)).to(self.device)
         dst = torch.from_numpy(np.concatenate(dst)).to(self.device)
-        X = ws.X.reshape(-1, CH)[:self.L * n0]
+        X = ws.X.reshape(-1, CH)[:self.L * CB * n0]
         # (+ the forward launch's poison word: 0, or NaN after an expired wait)
         g['state'].view(-1, CH).index_copy_(
             0, dst, X.index_select(0, src) + ws.loss_parts[0])

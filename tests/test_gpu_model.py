@@ -456,6 +456,69 @@ def test_prime_generator_with_global_condition(hip_lib):
     assert np.abs(p_other - p_ref).max() > 1e-4
 
 
+WIDE_GEN = [
+    ('r64', cfg_with(MID, batch_size=1, residual_channels=64,
+                     dilation_channels=64), None),
+    ('r48_d40_gc', cfg_with(MID, batch_size=1, residual_channels=48,
+                            dilation_channels=40, global_condition_channels=4,
+                            global_condition_cardinality=5), 3),
+    ('r96_d128', cfg_with(TINY, batch_size=1, residual_channels=96,
+                          dilation_channels=128), None),
+]
+
+
+@pytest.mark.parametrize('name,cfg,gc', WIDE_GEN, ids=[c[0] for c in WIDE_GEN])
+def test_fast_generation_above_32_channels(hip_lib, name, cfg, gc):
+    """The incremental generator with 33 - 128 residual / dilation channels
+    (wn_fastgen_run_wide; the reference's generator has no width limit,
+    model.py:444-516): every step of a teacher-forced trace longer than the
+    receptive field against the float64 oracle, the no-push peek, forward-pass
+    priming, and deterministic sampling through generate()."""
+    net, var = build_pair(cfg)
+    Q = cfg['quantization_channels']
+    rf = sum(cfg['dilations']) + 2
+    rng = np.random.default_rng(9)
+    wave = rng.integers(0, Q, rf + 25).astype(np.int32)
+    gen = O.IncrementalGenerator(cfg, var, dtype=np.float64)
+    gids = None if gc is None else np.array([gc])
+    net.reset_generator()
+    worst = 0.0
+    for i, c in enumerate(wave):
+        p_ref = np.asarray(gen.step(int(c), gc_ids=gids)).reshape(-1)
+        if i == len(wave) - 1:
+            p = net.predict_proba_incremental(int(c), global_condition=gc,
+                                              push=False).cpu().numpy()
+            again = net.predict_proba_incremental(
+                int(c), global_condition=gc).cpu().numpy()
+            assert np.array_equal(p, again)
+        else:
+            p = net.predict_proba_incremental(
+                int(c), global_condition=gc).cpu().numpy()
+        worst = max(worst, float(np.abs(p - p_ref).max()))
+    assert worst < 1e-5, worst
+    # the naive windowed forward agrees too
+    naive = net.predict_proba(wave, global_condition=gc).cpu().numpy()
+    assert np.abs(naive - p).max() < 1e-5
+    # priming from ONE forward pass == stepping through the seed
+    st_ref = net._gen['state'].clone()
+    cur_ref = net._gen['cursors'].clone()
+    net.prime_generator(wave, global_condition=gc)
+    assert torch.equal(net._gen['cursors'][:2], cur_ref[:2])
+    assert (net._gen['state'] - st_ref).abs().max().item() < 1e-5
+    # generate(): teacher-forced trace, then deterministic draws
+    out, pr = net.generate(0, seed_samples=wave[:40], return_proba_every=1,
+                           global_condition=gc)
+    assert np.array_equal(out.cpu().numpy(), wave[:40])
+    a = net.generate(60, seed_samples=[Q // 2], seed=11,
+                     global_condition=gc).cpu().numpy()
+    b = net.generate(60, seed_samples=[Q // 2], seed=11,
+                     global_condition=gc).cpu().numpy()
+    c2 = net.generate(60, seed_samples=[Q // 2], seed=12,
+                      global_condition=gc).cpu().numpy()
+    assert a.shape == (61,) and np.array_equal(a, b) and not np.array_equal(a, c2)
+    assert a.min() >= 0 and a.max() < Q
+
+
 def test_unsupported_configs_raise(hip_lib):
     from wavenet import WaveNetModel
     for kw in (dict(filter_width=9), dict(residual_channels=129),

@@ -116,10 +116,12 @@ __global__ __launch_bounds__(LAYER_WG) void layer_fwd_kernel(
       af = frag_zero();
       ag = frag_zero();
     }
-    mma32<32>(af, xp, wlane + 0 * 1024);  // Wf[0]: past tap
+    // current tap first: the order of stack_fwd_kernel (wn_stack.hip), where
+    // these products run while the dilated tap is still on its way
     mma32<32>(af, xc, wlane + 1 * 1024);  // Wf[1]: current tap
-    mma32<32>(ag, xp, wlane + 2 * 1024);  // Wg[0]
     mma32<32>(ag, xc, wlane + 3 * 1024);  // Wg[1]
+    mma32<32>(af, xp, wlane + 0 * 1024);  // Wf[0]: past tap
+    mma32<32>(ag, xp, wlane + 2 * 1024);  // Wg[0]
     FWSTAMP(5);
     f32x16 zz;
 #pragma unroll

@@ -270,16 +270,43 @@ __global__ __launch_bounds__(WAVES * 64) void stack_fwd_kernel(StackFwd a) {
       wait_lds(s_ready + l, dead, a.ctl, a.poison, lane);
       SSTAMP(l, 1);
       const float* xl = a.X + (size_t)l * a.plane;
+      int woff = j * SF_LD + 4 * h + (l & 1) * STACK_WBUF;
+      asm volatile("" : "+v"(woff));
+      const float* wlane = wl + woff;
+      f32x16 af, ag;
+      if (a.bias) {
+        const float* bp = a.bias + (size_t)l * a.bias_layer_stride +
+                          (size_t)b * a.bias_clip_stride;
+        af = frag_bcast(bp, h);
+        ag = frag_bcast(bp + 32, h);
+      } else {
+        af = frag_zero();
+        ag = frag_zero();
+      }
       // ---- the dilated tap: rows t0-d .. t0-d+31 of x_l, written by the
-      // owners of (at most) two tiles of this clip
+      // owners of (at most) two tiles of this clip.  Their flags are requested
+      // FIRST and looked at after the current-tap products, which need only the
+      // wave's own rows: 32 of the layer's 80 MFMAs leave the tile-to-tile
+      // dependency chain and cover the flag's round trip.
       const int lo_row = t0 - d;
+      int fidx = -1;
+      unsigned fval = epoch;
       if (l > 0 && lo_row + 31 >= 0) {
         const int first = max(lo_row, 0) >> 5, last = (lo_row + 31) >> 5;
-        int idx = -1;
-        if (lane == 0 && first != tt) idx = b * tiles_per_clip + first;
-        if (lane == 1 && last != first && last != tt) idx = b * tiles_per_clip + last;
-        wait_flags(a.flags + (size_t)l * ntiles, idx, epoch, a.ctl, a.poison, dead, lane);
+        if (lane == 0 && first != tt) fidx = b * tiles_per_clip + first;
+        if (lane == 1 && last != first && last != tt) fidx = b * tiles_per_clip + last;
+        if (fidx >= 0)
+          fval = __hip_atomic_load(a.flags + (size_t)l * ntiles + fidx, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
       }
+      // (-DSTACK_NOMMA / -DSTACK_NOACT: timing-only ablation builds, see
+      // DESIGN.md 3a; their results are meaningless)
+#ifndef STACK_NOMMA
+      mma32t(af, xc, wlane + 1 * SF_MT);  // Wf[1]: current tap
+      mma32t(ag, xc, wlane + 3 * SF_MT);  // Wg[1]
+#endif
+      if (__builtin_amdgcn_ballot_w64(fval != epoch) != 0)
+        wait_flags(a.flags + (size_t)l * ntiles, fidx, epoch, a.ctl, a.poison, dead, lane);
       SSTAMP(l, 2);
       f32x16 xp;
       {
@@ -302,26 +329,9 @@ __global__ __launch_bounds__(WAVES * 64) void stack_fwd_kernel(StackFwd a) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
       SSTAMP(l, 3);
-      int woff = j * SF_LD + 4 * h + (l & 1) * STACK_WBUF;
-      asm volatile("" : "+v"(woff));
-      const float* wlane = wl + woff;
-      f32x16 af, ag;
-      if (a.bias) {
-        const float* bp = a.bias + (size_t)l * a.bias_layer_stride +
-                          (size_t)b * a.bias_clip_stride;
-        af = frag_bcast(bp, h);
-        ag = frag_bcast(bp + 32, h);
-      } else {
-        af = frag_zero();
-        ag = frag_zero();
-      }
-      // (-DSTACK_NOMMA / -DSTACK_NOACT: timing-only ablation builds, see
-      // DESIGN.md 3a; their results are meaningless)
 #ifndef STACK_NOMMA
       mma32t(af, xp, wlane + 0 * SF_MT);  // Wf[0]: past tap
-      mma32t(af, xc, wlane + 1 * SF_MT);  // Wf[1]: current tap
       mma32t(ag, xp, wlane + 2 * SF_MT);  // Wg[0]
-      mma32t(ag, xc, wlane + 3 * SF_MT);  // Wg[1]
 #else
 #pragma unroll
       for (int r = 0; r < 16; ++r) { af[r] += xp[r] * wlane[0]; ag[r] += xc[r] * wlane[SF_MT]; }

@@ -1160,7 +1160,9 @@ static void stack_bwd_shape(int B, int T, int* waves_out, int* tpw_out) {
       const long groups = (ntiles + (long)w * t - 1) / ((long)w * t);
       const long passes = (groups + cus - 1) / cus;
       const long cost = passes * (t * (w == 8 ? 144 : 100) + 70);   // 0.1 us per layer
-      if (best < 0 || cost <= best) { best = cost; bw = w; bt = t; }
+      // (ties: MORE waves per workgroup = fewer weight-gradient slabs to write
+      // and reduce; at B = 1 that is 125 instead of 250 per layer, 130 MB)
+      if (best < 0 || cost < best) { best = cost; bw = w; bt = t; }
     }
   }
   *waves_out = bw;

@@ -124,13 +124,21 @@ int wn_layer_wgrad_k(const float* x, const float* daf, const float* dag,
  * 32 jb of Wf / Wg; x is input block 0, block i at x + i * in_plane_stride.
  * bwd: dx plane of residual block rb from the da planes of all dilation
  * blocks; wf / wg point at row 32 rb; tap_stride = floats between taps.
- * K * blocks <= 8.  The 1x1 convs of such a layer are wn_gemm_nn calls in
+ * K * blocks <= 8 PER CALL; wider layers run in chunks of blocks: fwd with
+ * in_blocks = the chunk, x / wf / wg offset to its first block, tap_rows = the
+ * rows between two taps of the weight matrix (the padded channel count), the
+ * partial pre-activations handed from pre_out (planes af | ag, pre_plane_stride
+ * apart; no gate, z / th / sg untouched) to the next call's pre_in (which
+ * replaces the bias); bwd with da_blocks = the chunk and dxin = the previous
+ * chunk's dx_out.  The 1x1 convs of such a layer are wn_gemm_nn calls in
  * plane mode; its weight gradients come from wn_layer_wgrad_k per block pair. */
 int wn_layer_fwd_blk(const float* x, long in_plane_stride, int in_blocks,
                      float* z, float* th, float* sg, const float* wf,
                      const float* wg, int ldw, const float* bias_f,
                      const float* bias_g, int bias_clip_stride, int B, int T,
-                     int dilation, int K, int save_ts, void* stream);
+                     int dilation, int K, int save_ts, int tap_rows,
+                     const float* pre_in, float* pre_out, long pre_plane_stride,
+                     void* stream);
 int wn_layer_bwd_blk(const float* daf, const float* dag, long da_plane_stride,
                      int da_blocks, const float* dxin, float* dx_out,
                      const float* wf, const float* wg, int ldw, long tap_stride,

@@ -1379,15 +1379,23 @@ __global__ __launch_bounds__(GEN_WG) void layer_fwd_blk_kernel(
     float* __restrict__ z, float* __restrict__ th, float* __restrict__ sg,
     const float* __restrict__ wf, const float* __restrict__ wg, int ldw,
     const float* __restrict__ bias_f, const float* __restrict__ bias_g,
-    int bias_clip_stride, int B, int T, int d, int K) {
+    int bias_clip_stride, int B, int T, int d, int K, int tap_rows,
+    const float* __restrict__ pre_in, float* __restrict__ pre_out,
+    long pre_plane_stride) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int NV = K * in_blocks;               // virtual taps (k, i)
   float* wl = smem;                           // [2 NV][32][32]: filter, gate
   float* tiles = smem + 2 * NV * 1024;
   const int tid = threadIdx.x;
+  // `in_blocks` may be a CHUNK of the layer's input blocks (more than 8
+  // virtual taps do not fit the LDS): tap k's rows start at k * tap_rows, the
+  // caller offsets x / wf / wg to the chunk's first block, the partial
+  // pre-activations travel through pre_out -> pre_in (planes af | ag) and the
+  // last chunk applies the gate
   for (int i = tid; i < NV * 1024; i += GEN_WG) {
     const int v = i >> 10, r = (i >> 5) & 31, c = i & 31;
-    const long src = (long)(v * 32 + r) * ldw + c;   // row (k*in_blocks + i)*32 + r
+    const int k = v / in_blocks, ib = v - k * in_blocks;
+    const long src = (long)(k * tap_rows + ib * 32 + r) * ldw + c;
     wl[i] = wf[src];
     wl[NV * 1024 + i] = wg[src];
   }
@@ -1406,8 +1414,20 @@ __global__ __launch_bounds__(GEN_WG) void layer_fwd_blk_kernel(
     const int t0 = (tile - b * tiles_per_clip) * 32;
     const int hi = min(32, T - t0);
     const size_t off0 = ((size_t)b * T + t0) * WN_CH;
-    f32x16 af = bias_f ? frag_bcast(bias_f + (size_t)b * bias_clip_stride, h) : frag_zero();
-    f32x16 ag = bias_g ? frag_bcast(bias_g + (size_t)b * bias_clip_stride, h) : frag_zero();
+    f32x16 af, ag;
+    if (pre_in) {                              // sums of the chunks before this one
+      rows_to_lds(ta, lane, rows_load(pre_in + off0, lane, 0, hi));
+      __builtin_amdgcn_wave_barrier();
+      af = frag_from_lds(ta, j, h);
+      __builtin_amdgcn_wave_barrier();
+      rows_to_lds(ta, lane, rows_load(pre_in + pre_plane_stride + off0, lane, 0, hi));
+      __builtin_amdgcn_wave_barrier();
+      ag = frag_from_lds(ta, j, h);
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      af = bias_f ? frag_bcast(bias_f + (size_t)b * bias_clip_stride, h) : frag_zero();
+      ag = bias_g ? frag_bcast(bias_g + (size_t)b * bias_clip_stride, h) : frag_zero();
+    }
     for (int v = 0; v < NV; ++v) {
       const int k = v / in_blocks, i = v - k * in_blocks;
       const int sh = tap_shift(K, k, d);
@@ -1419,6 +1439,18 @@ __global__ __launch_bounds__(GEN_WG) void layer_fwd_blk_kernel(
       const f32x16 xk = frag_from_lds(ta, j, h);
       mma32<32>(af, xk, wlane + v * 1024);
       mma32<32>(ag, xk, wlane + (NV + v) * 1024);
+    }
+    if (pre_out) {                             // not the last chunk: raw sums
+      __builtin_amdgcn_wave_barrier();
+      frag_to_lds(ta, j, h, af);
+      __builtin_amdgcn_wave_barrier();
+      rows_store(pre_out + off0, lane, hi, rows_from_lds(ta, lane));
+      __builtin_amdgcn_wave_barrier();
+      frag_to_lds(ta, j, h, ag);
+      __builtin_amdgcn_wave_barrier();
+      rows_store(pre_out + pre_plane_stride + off0, lane, hi, rows_from_lds(ta, lane));
+      __builtin_amdgcn_wave_barrier();
+      continue;
     }
     f32x16 zz;
 #pragma unroll
@@ -1756,12 +1788,19 @@ int wn_layer_fwd_blk(const float* x, long in_plane_stride, int in_blocks,
                      float* z, float* th, float* sg, const float* wf,
                      const float* wg, int ldw, const float* bias_f,
                      const float* bias_g, int bias_clip_stride, int B, int T,
-                     int dilation, int K, int save_ts, void* stream) {
-  if (!x || !z || !wf || !wg) return WN_ERR_NULL;
-  if (B <= 0 || T <= 0 || dilation <= 0 || K < 2 || in_blocks < 1 || ldw < 32)
+                     int dilation, int K, int save_ts, int tap_rows,
+                     const float* pre_in, float* pre_out, long pre_plane_stride,
+                     void* stream) {
+  if (!x || !wf || !wg) return WN_ERR_NULL;
+  if (!pre_out && !z) return WN_ERR_NULL;
+  if (B <= 0 || T <= 0 || dilation <= 0 || K < 2 || in_blocks < 1 || ldw < 32 ||
+      tap_rows < in_blocks * 32)
     return WN_ERR_BAD_SHAPE;
   if (K * in_blocks > 8) return WN_ERR_UNSUPPORTED;
-  if (save_ts && (!th || !sg)) return WN_ERR_NULL;
+  if (!pre_out && save_ts && (!th || !sg)) return WN_ERR_NULL;
+  if ((pre_in && !wn_aligned16(pre_in)) || (pre_out && !wn_aligned16(pre_out)) ||
+      (pre_plane_stride & 3) != 0)
+    return WN_ERR_MISALIGNED;
   const void* ptrs[] = {x, z, th, sg};
   for (const void* p : ptrs)
     if (p && !wn_aligned16(p)) return WN_ERR_MISALIGNED;
@@ -1776,7 +1815,8 @@ int wn_layer_fwd_blk(const float* x, long in_plane_stride, int in_blocks,
     return WN_ERR_LAUNCH;                                                     \
   hipLaunchKernelGGL((layer_fwd_blk_kernel<TS>), grid, block, lds, s, x,      \
                      in_plane_stride, in_blocks, z, th, sg, wf, wg, ldw,      \
-                     bias_f, bias_g, bias_clip_stride, B, T, dilation, K)
+                     bias_f, bias_g, bias_clip_stride, B, T, dilation, K,     \
+                     tap_rows, pre_in, pre_out, pre_plane_stride)
   if (save_ts) { LAUNCH(true); } else { LAUNCH(false); }
 #undef LAUNCH
   return wn_check_launch();

@@ -51,7 +51,8 @@ SIGNATURES = {
     'wn_layer_wgrad_k': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int,
                                  c_int, P]),
     'wn_layer_fwd_blk': (c_int, [P, c_long, c_int, P, P, P, P, P, c_int, P, P,
-                                 c_int, c_int, c_int, c_int, c_int, c_int, P]),
+                                 c_int, c_int, c_int, c_int, c_int, c_int,
+                                 c_int, P, P, c_long, P]),
     'wn_layer_bwd_blk': (c_int, [P, P, c_long, c_int, P, P, P, P, c_int,
                                  c_long, c_int, c_int, c_int, c_int, P]),
     'wn_layer_bwdw_slabs': (c_int, [c_int, c_int]),

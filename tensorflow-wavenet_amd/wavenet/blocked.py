@@ -17,6 +17,9 @@ dWs GEMMs of model.py see L * CB planes and run unchanged.  Per layer:
 
 Weights stay in the reference's [K][Cin][Cout] layout (C = 32 * CB padded
 channels), so `net.variables` are plain views exactly as for <= 32 channels.
+Layers wider than 8 / K blocks (128 channels at filter width 2) run the two
+block kernels in chunks of blocks (partial pre-activations through `ws.pre`
+forward, dx chained from chunk to chunk backward).
 Correctness-first: this is an off-default configuration (the default
 wavenet_params.json has 32 / 32 channels and runs the fused kernels).
 """
@@ -36,6 +39,13 @@ def _blk(net, flat, l):
                 bd=b[net.OFF_BD:net.OFF_BD + C], all=b)
 
 
+def _chunks(CB, K):
+    """(first block, blocks) pieces of at most 8 // K blocks: the block
+    kernels keep K x blocks <= 8 "virtual taps" of weights in LDS."""
+    per = max(1, 8 // K)
+    return [(i, min(per, CB - i)) for i in range(0, CB, per)]
+
+
 def forward_layers(net, ws, bias, bstride, save_ts, st):
     """Layers 0..L-1 on ws.X[0:CB] (the causal layer's output planes)."""
     L, CB, K, C = net.L, net.CB, net.KW, net.CHn
@@ -45,18 +55,28 @@ def forward_layers(net, ws, bias, bstride, save_ts, st):
     for l, d in enumerate(net.dilations):
         w = _blk(net, P, l)
         x0 = ws.X[l * CB]
+        chunks = _chunks(CB, K)
         for jb in range(CB):
             bf = bg = None
             if bias is not None:
                 row = bias[l].reshape(-1)
                 bf, bg = row[jb * CH:], row[C + jb * CH:]
-            _lib.call('wn_layer_fwd_blk', _lib.ptr(x0), pstride, CB,
-                      _lib.ptr(ws.Z[l * CB + jb]),
-                      _lib.ptr(ws.TH[l * CB + jb]) if save_ts else None,
-                      _lib.ptr(ws.SG[l * CB + jb]) if save_ts else None,
-                      _lib.ptr(w['wf'][jb * CH:]), _lib.ptr(w['wg'][jb * CH:]),
-                      C, _lib.ptr(bf), _lib.ptr(bg), bstride, B, T, int(d), K,
-                      1 if save_ts else 0, st)
+            # input blocks in chunks of at most 8 // K (the kernel holds a
+            # chunk's 2 K weight blocks in LDS); partial pre-activations
+            # travel through ws.pre (planes af | ag)
+            for ci, (i0, nb) in enumerate(chunks):
+                last = ci == len(chunks) - 1
+                _lib.call('wn_layer_fwd_blk',
+                          _lib.ptr(ws.X[l * CB + i0]), pstride, nb,
+                          _lib.ptr(ws.Z[l * CB + jb]),
+                          _lib.ptr(ws.TH[l * CB + jb]) if save_ts else None,
+                          _lib.ptr(ws.SG[l * CB + jb]) if save_ts else None,
+                          _lib.ptr(w['wf'][i0 * CH * C + jb * CH:]),
+                          _lib.ptr(w['wg'][i0 * CH * C + jb * CH:]),
+                          C, _lib.ptr(bf), _lib.ptr(bg), bstride, B, T, int(d),
+                          K, 1 if save_ts else 0, C,
+                          _lib.ptr(ws.pre) if ci > 0 else None,
+                          None if last else _lib.ptr(ws.pre), pstride, st)
         if l == L - 1:
             break
         # x_{l+1}[rb] = x_l[rb] + z_l Wd[:, rb] (+ bd[rb])   model.py:294-300,330
@@ -140,10 +160,15 @@ def backward_layers(net, ws, ids, st):
         # ---- dx of every residual-channel block
         dxo = ws.dx[xp]
         for rb in range(CB):
-            _lib.call('wn_layer_bwd_blk', _lib.ptr(daf[0]), _lib.ptr(dag[0]),
-                      pstride, CB, None if dxin is None else _lib.ptr(dxin[rb]),
-                      _lib.ptr(dxo[rb]), _lib.ptr(w['wf'][rb * CH * C:]),
-                      _lib.ptr(w['wg'][rb * CH * C:]), C, M, B, T, d, K, st)
+            # dilation blocks in chunks: a chunk's dx is the next one's dxin
+            for ci, (j0, nb) in enumerate(_chunks(CB, K)):
+                src = dxo[rb] if ci > 0 else (None if dxin is None else dxin[rb])
+                _lib.call('wn_layer_bwd_blk', _lib.ptr(daf[j0]),
+                          _lib.ptr(dag[j0]), pstride, nb, _lib.ptr(src),
+                          _lib.ptr(dxo[rb]),
+                          _lib.ptr(w['wf'][rb * CH * C + j0 * CH:]),
+                          _lib.ptr(w['wg'][rb * CH * C + j0 * CH:]), C, M, B, T,
+                          d, K, st)
         dxin, xp = dxo, 1 - xp
     # ---- causal layer (model.py:227-234): one-hot contraction per tap / block
     gc_ = net._seg(Gr, 'causal').view(K, Q, C)

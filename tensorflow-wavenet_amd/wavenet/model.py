@@ -111,6 +111,10 @@ class _Workspace(object):
         alloc('loss_parts', (2 + self.nparts,), fill=0.0)
         alloc('loss', (1,), fill=0.0)
         alloc('proba', (Q,))
+        if CB > 1:
+            # partial pre-activations of a layer wider than one chunk of
+            # channel blocks (wavenet/blocked.py), planes af | ag
+            alloc('pre', (2, N, CH))
         if not training:
             return
         # legacy backward kernels (un-fused pair, wn_layer_bwdw, generic
@@ -300,14 +304,12 @@ class WaveNetModel(object):
             self._unsupported = 'filter_width must be in [2, 8] on the HIP path'
         elif scalar_input and initial_filter_width > 32:
             self._unsupported = 'initial_filter_width > 32 not supported yet'
-        elif max(self.R, self.D) > CH and (
-                filter_width * ((max(self.R, self.D) + CH - 1) // CH) > 8
-                or scalar_input):
-            # channel-block kernels: filter_width x blocks <= 8 "virtual taps"
-            # (128 channels at filter width 2, 64 at widths 3 and 4)
+        elif max(self.R, self.D) > CH and (max(self.R, self.D) > 256
+                                           or scalar_input):
+            # channel-block kernels (wavenet/blocked.py): 32-wide blocks, in
+            # chunks of 8 // filter_width blocks per kernel call
             self._unsupported = ('more than 32 residual/dilation channels needs '
-                                 'filter_width * ceil(channels / 32) <= 8 and '
-                                 'one-hot input')
+                                 'at most 256 channels and one-hot input')
         elif self.S % 4 or self.Q % 4:
             self._unsupported = 'skip/quantization channels must be multiples of 4'
         elif self.G is not None and self.card is None:

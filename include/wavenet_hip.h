@@ -59,10 +59,12 @@ int wn_causal_gather(const int32_t* q, const float* Wc, float* x0, int B,
                      int T, int Q, int K, int ldw, void* stream);
 
 /* ---- causal layer on scalar input (scalar_input=True): wavenet/model.py:
- * 143-153, 227-234, 646-648; W is [K0][32], K0 = initial_filter_width <= 32.
- * The wgrad writes [splits][K0*32] slabs for wn_reduce_slabs. */
-int wn_scalar_causal_fwd(const float* audio, const float* W, float* x0, int B,
-                         int T, int K0, void* stream);
+ * 143-153, 227-234, 646-648; W is [K0][ldw] (ldw = padded channel count; for
+ * more than 32 channels one call per 32-wide block with W + 32 * block and
+ * that block's plane), K0 = initial_filter_width <= 32.
+ * The wgrad writes [splits][K0*32] slabs for wn_reduce_slabs (per block). */
+int wn_scalar_causal_fwd(const float* audio, const float* W, int ldw, float* x0,
+                         int B, int T, int K0, void* stream);
 int wn_scalar_causal_wgrad(const float* audio, const float* dx0, float* slabs,
                            int splits, int B, int T, int K0, void* stream);
 /* one-hot causal layer, filter width 2: dWc[tap][v][32] as per-wave slabs

@@ -142,7 +142,7 @@ __global__ void causal_gather_kernel(const int32_t* __restrict__ q,
 __global__ void scalar_causal_fwd_kernel(const float* __restrict__ audio,
                                          const float* __restrict__ W,
                                          float* __restrict__ x0, long rows,
-                                         int T, int K0) {
+                                         int T, int K0, int ldw) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long row = idx >> 3;
   const int c4 = (idx & 7) * 4;
@@ -154,7 +154,7 @@ __global__ void scalar_causal_fwd_kernel(const float* __restrict__ audio,
     const int s = (K0 - 1 - k) + extra;
     if (t - s < 0) continue;
     const float a = audio[row - s];
-    const f32x4 w = *reinterpret_cast<const f32x4*>(W + (long)k * 32 + c4);
+    const f32x4 w = *reinterpret_cast<const f32x4*>(W + (long)k * ldw + c4);
     v += a * w;
   }
   *reinterpret_cast<f32x4*>(x0 + row * 32 + c4) = v;
@@ -689,15 +689,15 @@ int wn_causal_gather(const int32_t* q, const float* Wc, float* x0, int B,
   return wn_check_launch();
 }
 
-int wn_scalar_causal_fwd(const float* audio, const float* W, float* x0, int B,
-                         int T, int K0, void* stream) {
+int wn_scalar_causal_fwd(const float* audio, const float* W, int ldw, float* x0,
+                         int B, int T, int K0, void* stream) {
   if (!audio || !W || !x0) return WN_ERR_NULL;
-  if (B <= 0 || T <= 0 || K0 <= 0) return WN_ERR_BAD_SHAPE;
+  if (B <= 0 || T <= 0 || K0 <= 0 || ldw < 32 || (ldw & 3)) return WN_ERR_BAD_SHAPE;
   if (!wn_aligned16(W) || !wn_aligned16(x0)) return WN_ERR_MISALIGNED;
   const long rows = (long)B * T, threads = rows * 8;
   hipLaunchKernelGGL(scalar_causal_fwd_kernel,
                      dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, audio, W, x0, rows, T, K0);
+                     (hipStream_t)stream, audio, W, x0, rows, T, K0, ldw);
   return wn_check_launch();
 }
 

@@ -24,7 +24,7 @@ SIGNATURES = {
     'wn_mu_law_decode': (c_int, [P, P, c_long, P, c_int, P]),
     'wn_causal_gather': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int,
                                  P]),
-    'wn_scalar_causal_fwd': (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    'wn_scalar_causal_fwd': (c_int, [P, P, c_int, P, c_int, c_int, c_int, P]),
     'wn_scalar_causal_wgrad': (c_int, [P, P, P, c_int, c_int, c_int, c_int,
                                        P]),
     'wn_causal_wgrad_slabs': (c_int, [c_long]),

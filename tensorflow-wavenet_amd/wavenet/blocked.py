@@ -170,9 +170,21 @@ def backward_layers(net, ws, ids, st):
                           _lib.ptr(w['wg'][rb * CH * C + j0 * CH:]), C, M, B, T,
                           d, K, st)
         dxin, xp = dxo, 1 - xp
-    # ---- causal layer (model.py:227-234): one-hot contraction per tap / block
-    gc_ = net._seg(Gr, 'causal').view(K, Q, C)
     sp = ws.splits['causal']
+    if net.scalar_input:
+        # ---- causal layer on scalar input (model.py:143-153): per block
+        K0 = net.initial_filter_width
+        gs = net._seg(Gr, 'causal').view(K0, C)
+        for cb in range(CB):
+            _lib.call('wn_scalar_causal_wgrad', _lib.ptr(ws.audio),
+                      _lib.ptr(dxin[cb]), _lib.ptr(ws.slabs), sp, B, T, K0, st)
+            _lib.call('wn_reduce_slabs', _lib.ptr(ws.slabs), sp, K0 * CH, 1,
+                      0, 0, K0 * CH, _lib.ptr(ws.blk_tmp), 0, 1, 0, st)
+            gs[:, cb * CH:(cb + 1) * CH].copy_(
+                ws.blk_tmp[:K0 * CH].view(K0, CH))
+        K = 0                                  # no one-hot taps below
+    # ---- causal layer (model.py:227-234): one-hot contraction per tap / block
+    gc_ = None if net.scalar_input else net._seg(Gr, 'causal').view(K, Q, C)
     sl = lib.wn_gemm_tn_slab_floats(Q, CH)
     for tap in range(K):
         shift = (K - 1 - tap) + (K - 1) // 2

@@ -304,12 +304,11 @@ class WaveNetModel(object):
             self._unsupported = 'filter_width must be in [2, 8] on the HIP path'
         elif scalar_input and initial_filter_width > 32:
             self._unsupported = 'initial_filter_width > 32 not supported yet'
-        elif max(self.R, self.D) > CH and (max(self.R, self.D) > 256
-                                           or scalar_input):
+        elif max(self.R, self.D) > 256:
             # channel-block kernels (wavenet/blocked.py): 32-wide blocks, in
             # chunks of 8 // filter_width blocks per kernel call
-            self._unsupported = ('more than 32 residual/dilation channels needs '
-                                 'at most 256 channels and one-hot input')
+            self._unsupported = ('at most 256 residual / dilation channels on '
+                                 'the HIP path')
         elif self.S % 4 or self.Q % 4:
             self._unsupported = 'skip/quantization channels must be multiples of 4'
         elif self.G is not None and self.card is None:
@@ -748,9 +747,11 @@ class WaveNetModel(object):
         B, T, N, L, S, Q = ws.B, ws.T, ws.N, self.L, self.S, self.Q
         P = self.params
         if self.scalar_input:
-            _lib.call('wn_scalar_causal_fwd', _lib.ptr(ws.audio),
-                      _lib.ptr(self._seg(P, 'causal')), _lib.ptr(ws.X[0]), B,
-                      T, self.initial_filter_width, st)
+            wc = self._seg(P, 'causal')
+            for cb in range(self.CB):          # one plane per channel block
+                _lib.call('wn_scalar_causal_fwd', _lib.ptr(ws.audio),
+                          _lib.ptr(wc[cb * CH:]), self.CHn, _lib.ptr(ws.X[cb]),
+                          B, T, self.initial_filter_width, st)
         else:
             wc = self._seg(P, 'causal')
             for cb in range(self.CB):          # one plane per channel block

@@ -105,6 +105,9 @@ CASES = [
                            dilation_channels=136), 70, False, None),
     ('r64_k5', cfg_with(TINY, batch_size=1, residual_channels=64,
                         dilation_channels=48, filter_width=5), 90, False, None),
+    ('scalar_r64_d40', cfg_with(TINY, batch_size=2, scalar_input=True,
+                                initial_filter_width=4, residual_channels=64,
+                                dilation_channels=40), 70, False, None),
     ('r40_k3_nobias', cfg_with(TINY, batch_size=1, residual_channels=40,
                                dilation_channels=24, filter_width=3,
                                use_biases=False), 70, False, None),
@@ -469,6 +472,8 @@ WIDE_GEN = [
                             global_condition_cardinality=5), 3),
     ('r96_d128', cfg_with(TINY, batch_size=1, residual_channels=96,
                           dilation_channels=128), None),
+    ('r160_d136', cfg_with(TINY, batch_size=1, residual_channels=160,
+                           dilation_channels=136), None),
 ]
 
 
@@ -527,7 +532,7 @@ def test_fast_generation_above_32_channels(hip_lib, name, cfg, gc):
 def test_unsupported_configs_raise(hip_lib):
     from wavenet import WaveNetModel
     for kw in (dict(filter_width=9), dict(residual_channels=257),
-               dict(residual_channels=64, scalar_input=True),
+               dict(dilation_channels=300),
                dict(scalar_input=True, initial_filter_width=64)):
         cfg = cfg_with(TINY, batch_size=1, **kw)
         net = WaveNetModel(**model_kwargs(cfg))

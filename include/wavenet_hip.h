@@ -61,7 +61,7 @@ int wn_causal_gather(const int32_t* q, const float* Wc, float* x0, int B,
 /* ---- causal layer on scalar input (scalar_input=True): wavenet/model.py:
  * 143-153, 227-234, 646-648; W is [K0][ldw] (ldw = padded channel count; for
  * more than 32 channels one call per 32-wide block with W + 32 * block and
- * that block's plane), K0 = initial_filter_width <= 32.
+ * that block's plane), K0 = initial_filter_width (any).
  * The wgrad writes [splits][K0*32] slabs for wn_reduce_slabs (per block). */
 int wn_scalar_causal_fwd(const float* audio, const float* W, int ldw, float* x0,
                          int B, int T, int K0, void* stream);

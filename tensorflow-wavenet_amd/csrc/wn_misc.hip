@@ -164,13 +164,15 @@ __global__ void scalar_causal_fwd_kernel(const float* __restrict__ audio,
 __global__ __launch_bounds__(1024) void scalar_causal_wgrad_kernel(
     const float* __restrict__ audio, const float* __restrict__ dx0,
     float* __restrict__ slabs, long rows, long rows_per_split, int T, int K0) {
-  const int c = threadIdx.x & 31, k = threadIdx.x >> 5;   // k < 32
+  const int c = threadIdx.x & 31;
   const long r0 = (long)blockIdx.x * rows_per_split;
   long r1 = r0 + rows_per_split;
   if (r1 > rows) r1 = rows;
-  const int s = (K0 - 1 - k) + (K0 - 1) / 2;
-  float acc = 0.f;
-  if (k < K0) {
+  // thread (k, c): taps k, k + 32, ... (initial_filter_width > 32: one pass
+  // over the rows per 32 taps)
+  for (int k = threadIdx.x >> 5; k < K0; k += 32) {
+    const int s = (K0 - 1 - k) + (K0 - 1) / 2;
+    float acc = 0.f;
     int t = (int)(r0 % T);
     for (long r = r0; r < r1; ++r) {
       if (t >= s) acc = fmaf(audio[r - s], dx0[r * 32 + c], acc);
@@ -705,7 +707,6 @@ int wn_scalar_causal_wgrad(const float* audio, const float* dx0, float* slabs,
                            int splits, int B, int T, int K0, void* stream) {
   if (!audio || !dx0 || !slabs) return WN_ERR_NULL;
   if (B <= 0 || T <= 0 || K0 <= 0 || splits <= 0) return WN_ERR_BAD_SHAPE;
-  if (K0 > 32) return WN_ERR_UNSUPPORTED;
   const long rows = (long)B * T;
   const long rps = (rows + splits - 1) / splits;
   hipLaunchKernelGGL(scalar_causal_wgrad_kernel, dim3(splits), dim3(1024), 0,

@@ -150,7 +150,8 @@ class _Workspace(object):
         if CB > 1:                       # channel-block path scratch
             alloc('dzb', (CB, N, CH))
             alloc('wdT', (CHn, CHn))
-            alloc('blk_tmp', (max((2 * net.KW + 1) * 1024 + 96, Q * CH),))
+            alloc('blk_tmp', (max((2 * net.KW + 1) * 1024 + 96, Q * CH,
+                                  net.initial_filter_width * CH),))
             alloc('cs_tmp', (B, 64))
         alloc('w2t', (Q, S))
         alloc('w1t', (S, S))
@@ -171,7 +172,9 @@ class _Workspace(object):
             self.splits[key] = sp
             need = max(need, sp * lib.wn_gemm_tn_slab_floats(mw, nw))
         need_tn = need
-        need = max(need, 256 * 32 * CH)          # scalar-input causal wgrad
+        # scalar-input causal wgrad: [splits][initial_filter_width][32] slabs
+        need = max(need, max(256, self.splits['causal'])
+                   * max(32, net.initial_filter_width) * CH)
         self.nslab_c = lib.wn_causal_wgrad_slabs(N)
         need = max(need, self.nslab_c * 2 * Q * CH)
         alloc('slabs', (need,))
@@ -302,8 +305,6 @@ class WaveNetModel(object):
         self._unsupported = None
         if filter_width < 2 or filter_width > 8:
             self._unsupported = 'filter_width must be in [2, 8] on the HIP path'
-        elif scalar_input and initial_filter_width > 32:
-            self._unsupported = 'initial_filter_width > 32 not supported yet'
         elif max(self.R, self.D) > 256:
             # channel-block kernels (wavenet/blocked.py): 32-wide blocks, in
             # chunks of 8 // filter_width blocks per kernel call

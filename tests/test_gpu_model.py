@@ -90,6 +90,8 @@ CASES = [
                             initial_filter_width=32), 150, False, None),
     ('scalar_T_lt_k', cfg_with(TINY, batch_size=1, scalar_input=True,
                                initial_filter_width=32), 9, False, None),
+    ('scalar_k70', cfg_with(TINY, batch_size=2, scalar_input=True,
+                            initial_filter_width=70), 120, False, None),
     # more than 32 channels: two 32-wide channel blocks (wavenet/blocked.py)
     ('r64', cfg_with(MID, batch_size=2, residual_channels=64,
                      dilation_channels=64, skip_channels=32), 150, False, None),
@@ -532,8 +534,7 @@ def test_fast_generation_above_32_channels(hip_lib, name, cfg, gc):
 def test_unsupported_configs_raise(hip_lib):
     from wavenet import WaveNetModel
     for kw in (dict(filter_width=9), dict(residual_channels=257),
-               dict(dilation_channels=300),
-               dict(scalar_input=True, initial_filter_width=64)):
+               dict(dilation_channels=300)):
         cfg = cfg_with(TINY, batch_size=1, **kw)
         net = WaveNetModel(**model_kwargs(cfg))
         with pytest.raises(NotImplementedError):

@@ -133,3 +133,42 @@ def test_train_histogram_summaries(hip_lib, tmp_path, params):
         assert hi > lo
     assert 'layer%d_dense/counts' % (L - 1) not in z.files   # model.py:318
     assert z['layer0_filter/counts'].sum() == 2 * 32 * 32
+
+
+def test_bench_line_carries_the_contract(hip_lib):
+    """`python bench.py` (small shape): ONE JSON line with the driver's keys,
+    the roofline object measured live (NN GEMMs + the TN GEMMs beside them),
+    the whole-step fraction, the CPU baseline with its core count and CPU
+    model, and the secondary figures (GC step, B = 1 step, fast generation)."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, WN_CPU_THREADS='4')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'),
+                        '--steps', '2', '--warmup', '1', '--batch', '2',
+                        '--samples', '4000'], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup',
+              'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in r, k
+    assert r['n_gpus'] == 1 and r['steps'] == 2 and r['dtype'] == 'f32'
+    assert r['vs_baseline'] is None and 'workload' in r['config']
+    rf = r['roofline']
+    assert rf['bound'] == 'mfma' and rf['peak'] == 157.3
+    assert 0 < rf['frac'] < 1 and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9
+    assert rf['launches_per_step'] == 6 and rf['tn_gemms']['launches_per_step'] == 3
+    assert 0 < r['step_frac'] < 1
+    cb = r['cpu_baseline']
+    assert cb['kind'] == 'port' and cb['cores'] >= 1 and cb['cpu_model']
+    assert cb['value'] > 0 and r['gpu_over_cpu'] > 1
+    sec = r['secondary']
+    for k in ('forward_only_samples_per_s', 'fastgen_us_per_sample',
+              'gc_ms_per_step', 'b1_ms_per_step'):
+        assert sec[k] > 0, k

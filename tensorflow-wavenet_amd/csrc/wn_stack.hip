@@ -745,12 +745,17 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
         a2 = rows_ld<0>(z, offd, vrow, lane, 0, hif);
         a3 = rows_ld<0>(sg, offd, vrow, lane, 0, hif);
       };
-      load_shifted(tbase + wave, epoch - 1u);
       BSTAMP(l, 2);
       // this lane's swizzled offset of chunk h in row j of a weight matrix
       int woff = (j * 32 + ((h ^ ((j >> 1) & 7)) << 2)) + (l & 1) * SB_WIMG;
       asm volatile("" : "+v"(woff));   // opaque: no hoisting of the weight reads
       const float* const wm = wl;
+      // Order inside a tile (round 3): everything that needs only the tile's
+      // OWN rows first -- the rows-t half of dx and all weight-gradient
+      // products -- and the anti-causal tap (rows t+d of dx_{l+1}, another
+      // tile's output of the layer above) last: its flags are looked at five
+      // microseconds into the tile instead of at its start, and between "the
+      // tap has arrived" and "dx_l is published" lie 48 MFMAs instead of 112.
       for (int tile = tbase + wave; tile < tend; tile += WAVES) {
         if (tile == tbase + wave + WAVES) { BSTAMP(l, 7); }
         const int b = tile / tiles_per_clip;
@@ -764,53 +769,21 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
 #else
         const int off0 = (b * T + tt0) * (WN_CH * 4);       // bytes
 #endif
-        f32x16 dx = frag_zero();
-        f32x16 dz, di, zz, ss;
-        if (hi_f > 0) {                         // rows t+d -> LDS -> fragments
-          if (hx) rows_to_lds(t0, lane, a0);
-          rows_to_lds(t1, lane, a1);
-          rows_to_lds(t2, lane, a2);
-          __builtin_amdgcn_wave_barrier();
-          if (hx) di = frag_from_lds(t0, j, h);
-          dz = frag_from_lds(t1, j, h);
-          zz = frag_from_lds(t2, j, h);
-          __builtin_amdgcn_wave_barrier();      // (a wave's DS operations run in order)
-          rows_to_lds(t0, lane, a3);
-          __builtin_amdgcn_wave_barrier();
-          ss = frag_from_lds(t0, j, h);
-          WN_WAIT_LGKM0();                      // tiles free again
-        }
-        // rows t: in flight during the rows t+d math (dx_{l+1}[t] is this
-        // wave's own store of the layer above); the sigmoid rows in registers
+        // ---- rows t (dx_{l+1}[t] is this wave's own store of the layer
+        // above); the sigmoid rows travel in registers
         if (tile == tbase + wave) { BSTAMP(l, 11); }
         tile_dma_rs<0>(t0, z, off0, vswz, lane, 0, hi);
         if (hx) tile_dma_rs<16>(t1, dxin, off0, vswz, lane, 0, hi);
         tile_dma_rs<0>(t2, dZ, off0, vswz, lane, 0, hi);
-        // the next tile's flags: requested now, looked at after this tile's math
+        a3 = rows_ld<0>(sg, off0, vrow, lane, 0, hi);
+        // this tile's tap flags: requested now, looked at after the rows-t math
         unsigned nfv = epoch;
         {
-          const int nidx = flag_idx(tile + WAVES);
+          const int nidx = flag_idx(tile);
           if (nidx >= 0)
             nfv = __hip_atomic_load(fl_in + nidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (tile == tbase + wave) { BSTAMP(l, 12); }
-        if (hi_f > 0) {
-          if (hx) mma32s(dz, di, wm + 4 * 1024, woff);  // dx_{l+1}[t+d] * Wd^T
-          f32x16 df, dg;
-#ifdef SB_NOGATE
-          df = dz; dg = zz;
-          asm volatile("" :: "v"(ss[0]));
-#else
-          gate_grad(dz, zz, ss, df, dg);
-#endif
-          // (requested only now: sixteen registers fewer during the gate math)
-          a3 = rows_ld<0>(sg, off0, vrow, lane, 0, hi);
-          mma32s(dx, df, wm + 0 * 1024, woff);          // da_f[t+d] * Wf[0]^T
-          mma32s(dx, dg, wm + 2 * 1024, woff);          // da_g[t+d] * Wg[0]^T
-        } else {
-          a3 = rows_ld<0>(sg, off0, vrow, lane, 0, hi);
-        }
-        if (tile == tbase + wave) { BSTAMP(l, 13); }
         WN_WAIT_VM0();
         if (tile == tbase + wave) { BSTAMP(l, 14); }
         if (hx) {                                    // dWd += z^T dx_{l+1}
@@ -825,6 +798,7 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
             }
           }
         }
+        f32x16 dx, dz, di, zz, ss;
         zz = frag_from_lds(t0, j, h);
         if (hx) di = frag_from_lds(t1, j, h);
         dz = frag_from_lds(t2, j, h);
@@ -844,9 +818,10 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
         f32x16 dg;
         {
           if (hx) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dx[r] += di[r];
+            dx = di;
             mma32s(dz, di, wm + 4 * 1024, woff);    // dx_{l+1}[t] * Wd^T
+          } else {
+            dx = frag_zero();
           }
           f32x16 df;
 #ifdef SB_NOGATE
@@ -857,28 +832,15 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
 #endif
           mma32s(dx, df, wm + 1 * 1024, woff);      // da_f[t] * Wf[1]^T
           mma32s(dx, dg, wm + 3 * 1024, woff);      // da_g[t] * Wg[1]^T
-          if (dead) dx[0] = __builtin_nanf("");      // a wait expired: NaN gradients
-          frag_to_lds(t2, j, h, dx);
-          __builtin_amdgcn_wave_barrier();
-#ifdef SB_FAKE_ADDR
-          rows_st<16>(dx_out, off0r, vrow, lane, hi, rows_from_lds(t2, lane));
-#else
-          rows_st<16>(dx_out, off0, vrow, lane, hi, rows_from_lds(t2, lane));
-#endif
-          __builtin_amdgcn_wave_barrier();
           frag_to_lds(t2, j, h, df);                 // t2 now holds da_f[t]
         }
         if (tile == tbase + wave) { BSTAMP(l, 8); }
-        WN_WAIT_VM0();                               // x tiles in, dx_l out
-        if (lane == 0)
-          __hip_atomic_store(fl_out + tile, epoch, __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
-        if (tile == tbase + wave) { BSTAMP(l, 9); }
-        load_shifted(tile + WAVES, nfv);
+        WN_WAIT_VM0();                               // x tiles in
+        // ---- the tap's rows: requested now, used after the weight gradients
+        load_shifted(tile, nfv);
         if (tile == tbase + wave) { BSTAMP(l, 10); }
         __builtin_amdgcn_wave_barrier();
         float tsf = 0.f, tsg = 0.f;          // this tile's column sums of da[t]
-        // dWf[1] += x[t]^T da_f, dWf[0] += x[t-d]^T da_f
 #pragma unroll 1
         for (int it = 0; it < 4; ++it) {     // dWf[1] += x[t]^T da_f, dWf[0] += x[t-d]^T da_f
 #pragma unroll
@@ -915,6 +877,47 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
             tile_colsum[(size_t)tile * 64 + 32 + j] = cb;
           }
         }
+        WN_WAIT_LGKM0();                     // the three tiles are free
+        if (tile == tbase + wave) { BSTAMP(l, 13); }
+        // ---- rows t+d -> LDS -> fragments -> the tap's half of dx
+        if (hi_f > 0) {
+          WN_WAIT_VM0();
+          if (hx) rows_to_lds(t0, lane, a0);
+          rows_to_lds(t1, lane, a1);
+          rows_to_lds(t2, lane, a2);
+          __builtin_amdgcn_wave_barrier();
+          if (hx) di = frag_from_lds(t0, j, h);
+          dz = frag_from_lds(t1, j, h);
+          zz = frag_from_lds(t2, j, h);
+          __builtin_amdgcn_wave_barrier();      // (a wave's DS operations run in order)
+          rows_to_lds(t0, lane, a3);
+          __builtin_amdgcn_wave_barrier();
+          ss = frag_from_lds(t0, j, h);
+          WN_WAIT_LGKM0();
+          if (hx) mma32s(dz, di, wm + 4 * 1024, woff);  // dx_{l+1}[t+d] * Wd^T
+          f32x16 df, dg2;
+#ifdef SB_NOGATE
+          df = dz; dg2 = zz;
+          asm volatile("" :: "v"(ss[0]));
+#else
+          gate_grad(dz, zz, ss, df, dg2);
+#endif
+          mma32s(dx, df, wm + 0 * 1024, woff);          // da_f[t+d] * Wf[0]^T
+          mma32s(dx, dg2, wm + 2 * 1024, woff);         // da_g[t+d] * Wg[0]^T
+        }
+        if (dead) dx[0] = __builtin_nanf("");        // a wait expired: NaN gradients
+        frag_to_lds(t2, j, h, dx);
+        __builtin_amdgcn_wave_barrier();
+#ifdef SB_FAKE_ADDR
+        rows_st<16>(dx_out, off0r, vrow, lane, hi, rows_from_lds(t2, lane));
+#else
+        rows_st<16>(dx_out, off0, vrow, lane, hi, rows_from_lds(t2, lane));
+#endif
+        WN_WAIT_VM0();                               // dx_l is in memory: publish it
+        if (lane == 0)
+          __hip_atomic_store(fl_out + tile, epoch, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+        if (tile == tbase + wave) { BSTAMP(l, 9); }
         WN_WAIT_LGKM0();                     // tiles free for the next tile's DMA
         __builtin_amdgcn_wave_barrier();
       }

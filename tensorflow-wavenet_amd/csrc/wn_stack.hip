@@ -966,9 +966,13 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
           dst[m * 1024 + e0 + (8 * (r >> 2) + (r & 3)) * 32] = p[r];
         if (m >= 2 && h == 0) dst[LAYER_W_FLOATS + (m - 2) * 32 + j] = pb;
       };
+      // position of this wave in the accumulation order (0, 4, 1, 5, ... --
+      // SIMD partners next to each other -- and a static priority for either
+      // half of the waves were tried: +-1 %)
+      const int cpos = wave;
       auto chain = [&](f32x16& c, int m, float& bsum) {
         if (WAVES > 1) {
-          if (wave == 0) {
+          if (cpos == 0) {
             // The slab's matrix m still holds layer l + 1's finished sums once
             // the last wave has added its part: wave 0 -- which would wait for
             // the slab anyway, while the last wave is the one everybody waits
@@ -978,7 +982,7 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
               slab_out(out + a.slab_layer_stride, m);
             }
           } else {
-            wait_lds_ge(tok + m, tbase_l + wave, dead, a.ctl, a.poison, lane);
+            wait_lds_ge(tok + m, tbase_l + cpos, dead, a.ctl, a.poison, lane);
             f32x16 p;
 #pragma unroll
             for (int r = 0; r < 16; ++r)
@@ -1000,7 +1004,7 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
           if (m >= 2 && h == 0) slab[LAYER_W_FLOATS + (m - 2) * 32 + j] = bsum;
           WN_WAIT_LGKM0();                   // this wave's slab reads / writes are done
           if (lane == 0)
-            __hip_atomic_store(tok + m, tbase_l + wave + 1, __ATOMIC_RELAXED,
+            __hip_atomic_store(tok + m, tbase_l + cpos + 1, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       };
@@ -1019,7 +1023,7 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
       }
       BSTAMP(l, 6);
     }
-    if (WAVES > 1 && wave == 0) {          // the bottom layer's finished slab
+    if (WAVES > 1 && wave == 0) {          // the bottom layer's finished slab (position 0 is wave 0 in every order)
       const int e0 = 4 * h * 32 + j;
       float* dst = a.slabs + (size_t)g * LAYER_BLOCK_FLOATS;
       for (int m = 0; m < 5; ++m) {

@@ -88,13 +88,15 @@ if not fwd_only:
     clk = np.median((cal[:, 3] - cal[:, 1]) / ((cal[:, 2] - cal[:, 0]) * 10.0))
     print('=== stack_bwd_kernel: clock %.2f GHz; workgroup entry -> exit median %.1f us, whole launch %.1f us' % (
         clk, np.median(cal[:, 2] - cal[:, 0]) / 100.0, (cal[:, 2].max() - cal[:, 0].min()) / 100.0))
-    seq = [(0, 1, 'layer top: wait for the weight image'), (1, 2, 'first tile: flags + rows t+d requested'),
-           (2, 11, 'rows t+d: registers -> LDS -> fragments'), (11, 12, 'rows-t DMA issued'),
-           (12, 13, 'rows t+d math (48 MFMA + gates)'), (13, 14, 'wait for the rows-t DMA'),
-           (14, 15, 'dWd (16 MFMA), fragments of rows t'), (15, 8, 'x DMA issued, rows-t math (48 MFMA + gates), dx to LDS / store issued'),
-           (8, 9, 'x tiles in, dx stored and drained, flag'),
-           (9, 10, 'next tile: flags + rows t+d requested'), (10, 7, 'first tile: weight-gradient MFMAs (64)'),
-           (7, 3, 'second tile'), (3, 4, 'ring bookkeeping'), (4, 5, 'ordered accumulation chain (incl. token waits; last wave: slab store)'),
+    seq = [(0, 1, 'layer top: wait for the weight image'), (1, 11, 'tile start'),
+           (11, 12, 'rows-t DMA + tap flags requested'), (12, 14, 'wait for the rows-t DMA'),
+           (14, 15, 'dWd (16 MFMA), fragments of rows t'),
+           (15, 8, 'x DMA issued, rows-t math (48 MFMA + gates)'),
+           (8, 10, 'x tiles in; tap flags checked, rows t+d requested'),
+           (10, 13, 'weight-gradient MFMAs (64)'),
+           (13, 9, 'rows t+d: wait, LDS transit, 48 MFMA + gates, dx stored, drained, flag'),
+           (9, 7, 'tile end -> second tile start'),
+           (7, 3, 'second tile'), (3, 4, 'ring bookkeeping'), (4, 5, 'ordered accumulation chain (incl. token waits)'),
            (5, 6, 'refill drain + ready mark (refilling wave only)')]
     for wv in (0, 3, 7):
         print('--- wave %d: median over workgroups and layers 1..L-2 (p90), us' % wv)
@@ -110,7 +112,7 @@ if not fwd_only:
     # the earliest one (which phases of the two waves of a SIMD coincide?)
     if os.environ.get('KB_TIMELINE'):
         g, l = gridb // 2, L // 2
-        order = [0, 1, 2, 11, 12, 13, 14, 15, 8, 9, 10, 7, 3, 4, 5, 6]
+        order = [0, 1, 11, 12, 14, 15, 8, 10, 13, 9, 7, 3, 4, 5, 6]
         t0 = s[g, :, l, 0].min()
         print('--- workgroup %d, layer %d: stamps (us) in program order: %s' % (g, l, order))
         for wv in range(8):

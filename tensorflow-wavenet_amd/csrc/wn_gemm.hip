@@ -79,6 +79,19 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // chunk l&15).  Must be called after a __syncthreads() that retires every
 // read of the operand tiles (the LDS is reused).
 #define EP_LD 68
+// Round 3: every global access of the epilogue goes through a buffer resource
+// whose base is the wave's corner of the tile (64-bit arithmetic once per
+// 32-row half, on the scalar unit), the lane's part of the address is one
+// 32-bit VGPR per operand and the row step an SGPR: the first version spent
+// ~1000 vector instructions per wave and tile on 64-bit address arithmetic
+// (128 v_mul_lo_u32, 270 64-bit adds / mads) -- on gfx950 vector instructions
+// of a wave beside other workgroups' f32 MFMAs run at a quarter of their rate
+// (DESIGN.md 3b), and the epilogue took 22 - 30 us per tile.  Rows are handled
+// four at a time: LDS reads and mask / addend loads first, then the stores.
+typedef unsigned ep_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ep_rsrc(const float* base) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+}
 __device__ __forceinline__ void gemm_epilogue(const GemmNN& g, f32x16 (&acc)[2][2],
                                               float* lds, long m0, int n0,
                                               int wm, int wn, int wave, int lane,
@@ -87,9 +100,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmNN& g, f32x16 (&acc)[2][
   const int j = lane & 31, h = lane >> 5;
   float* tile = lds + wave * (32 * EP_LD);
   const int rr = lane >> 4, cc = (lane & 15) * 4;   // row-in-group, column
-  const int n = n0 + wn * 64 + cc;
+  const int nw = n0 + wn * 64;                      // the wave's first column
+  const bool ncol = nw + cc < g.N;
   f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-  if (g.bias && n < g.N) bias4 = *reinterpret_cast<const f32x4*>(g.bias + n);
+  if (g.bias && ncol) bias4 = *reinterpret_cast<const f32x4*>(g.bias + nw + cc);
+  // per-lane byte offsets inside the wave's 32-row half
+  const int vC = g.c_planes ? (int)(((long)(cc >> 5) * g.c_plane_stride + rr * 32 + (cc & 31)) * 4)
+                            : (int)((rr * g.ldc + cc) * 4);
+  const int sC = g.c_planes ? 4 * 32 * 4 : (int)(4 * g.ldc * 4);   // four rows further
+  const int vP = (int)((rr * g.ldc + cc) * 4);
+  const int sP = (int)(4 * g.ldc * 4);
+  const int vM = (int)((rr * g.ld_mask + cc) * 4), sM = (int)(4 * g.ld_mask * 4);
+  const int vA = (int)((rr * g.ld_add + cc) * 4), sA = (int)(4 * g.ld_add * 4);
 #pragma unroll
   for (int fm = 0; fm < 2; ++fm) {
     __builtin_amdgcn_wave_barrier();
@@ -103,28 +125,45 @@ __device__ __forceinline__ void gemm_epilogue(const GemmNN& g, f32x16 (&acc)[2][
       }
     __builtin_amdgcn_wave_barrier();
     const long mbase = m0 + wm * 64 + fm * 32;
+    const long left = m_end - mbase;                 // rows of this half that exist
+    const int nrows = left > 32 ? 32 : (left < 0 ? 0 : (int)left);
+    const __amdgpu_buffer_rsrc_t rC = ep_rsrc(
+        g.c_planes ? g.C + (long)(nw >> 5) * g.c_plane_stride + mbase * 32
+                   : g.C + mbase * g.ldc + nw);
+    const __amdgpu_buffer_rsrc_t rP = ep_rsrc(g.Cpre ? g.Cpre + mbase * g.ldc + nw : g.C);
+    const __amdgpu_buffer_rsrc_t rM = ep_rsrc(g.mask ? g.mask + mbase * g.ld_mask + nw : g.C);
+    const __amdgpu_buffer_rsrc_t rA = ep_rsrc(g.addend ? g.addend + mbase * g.ld_add + nw : g.C);
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int row = it * 4 + rr;
-      const long m = mbase + row;
-      f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * EP_LD + cc);
-      if (m >= m_end || n >= g.N) continue;
-      v += bias4;
-      if (g.Cpre) *reinterpret_cast<f32x4*>(g.Cpre + m * g.ldc + n) = v;
-      if (g.relu) {
+    for (int bt = 0; bt < 2; ++bt) {
+      f32x4 v[4], mk[4], ad[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      for (int q = 0; q < 4; ++q) {
+        const int it = bt * 4 + q, row = it * 4 + rr;
+        const bool ok = ncol && row < nrows;
+        v[q] = *reinterpret_cast<const f32x4*>(tile + row * EP_LD + cc);
+        if (g.mask && ok)
+          mk[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rM, vM, it * sM, 0));
+        if (g.addend && ok)
+          ad[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, vA, it * sA, 0));
       }
-      if (g.mask) {
-        const f32x4 mk = *reinterpret_cast<const f32x4*>(g.mask + m * g.ld_mask + n);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
+      for (int q = 0; q < 4; ++q) {
+        const int it = bt * 4 + q, row = it * 4 + rr;
+        if (!(ncol && row < nrows)) continue;
+        f32x4 x = v[q] + bias4;
+        if (g.Cpre)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ep_u32x4, x), rP, vP, it * sP, 0);
+        if (g.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[e] = fmaxf(x[e], 0.f);
+        }
+        if (g.mask) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[e] = mk[q][e] > 0.f ? x[e] : 0.f;
+        }
+        if (g.addend) x += ad[q];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ep_u32x4, x), rC, vC, it * sC, 0);
       }
-      if (g.addend) v += *reinterpret_cast<const f32x4*>(g.addend + m * g.ld_add + n);
-      float* dst = g.c_planes
-                       ? g.C + (long)(n >> 5) * g.c_plane_stride + m * 32 + (n & 31)
-                       : g.C + m * g.ldc + n;
-      *reinterpret_cast<f32x4*>(dst) = v;
     }
   }
 }

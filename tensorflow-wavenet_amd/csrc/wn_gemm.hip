@@ -962,26 +962,45 @@ __global__ __launch_bounds__(256, (MF * NF >= 10 ? 2 : MF * NF > 5 ? 3 : 4)) voi
   if (r_end > g.rows) r_end = g.rows;
   const int nchunks = r_end > r_begin ? (int)((r_end - r_begin) / KR) : 0;
 
+  // Staging addresses: a buffer resource per operand (base in SGPRs), per piece
+  // ONE loop-invariant 32-bit lane offset, per chunk one scalar row offset.
+  // (Round 2 rebuilt every piece's 64-bit address in vector registers in every
+  // chunk: 184 vector instructions per 40 MFMAs -- matrix-pipe time on gfx950.)
+  constexpr int NPA = (PA + 3) / 4, NPG = (PG + 3) / 4;   // pieces per wave
+  const __amdgpu_buffer_rsrc_t rsA = ep_rsrc(g.A), rsG = ep_rsrc(g.G);
+  int voA[3], voG[4];
+  static_assert(NPA <= 3 && NPG <= 4, "pieces per wave");
+#pragma unroll
+  for (int k = 0; k < NPA; ++k) {
+    const int e = (wave + 4 * k) * 256 + lane * 4;
+    const int row = e / TM, col = e - row * TM;
+    const int m = m0 + col;
+    voA[k] = g.a_planes ? (int)(((long)(m >> 5) * g.a_plane_stride + row * 32 + (m & 31)) * 4)
+                        : (int)(((long)row * g.lda + m) * 4);
+  }
+#pragma unroll
+  for (int k = 0; k < NPG; ++k) {
+    const int e = (wave + 4 * k) * 256 + lane * 4;
+    const int row = e / TNW, col = e - row * TNW;
+    voG[k] = (int)(((long)row * g.ldg + n0 + col) * 4);
+  }
+  const long rowA = g.a_planes ? 32 * 4 : g.lda * 4, rowG = g.ldg * 4;   // bytes per row
   auto stage = [&](int c, int st) {
     float* base = smem + st * STAGE;
     const long r0 = r_begin + (long)c * KR;
+    const unsigned sA = (unsigned)(r0 * rowA), sG = (unsigned)(r0 * rowG);
 #pragma unroll
-    for (int p = wave; p < PA; p += 4) {
-      const int e = p * 256 + lane * 4;
-      const int row = e / TM, col = e - row * TM;
-      const int m = m0 + col;
-      const float* src = g.a_planes
-                             ? g.A + (long)(m >> 5) * g.a_plane_stride + (r0 + row) * 32 + (m & 31)
-                             : g.A + (r0 + row) * g.lda + m;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + p * 256), 16, 0, 0);
+    for (int k = 0; k < NPA; ++k) {
+      const int p = wave + 4 * k;
+      if (p < PA)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(base + p * 256), 16, voA[k], sA, 0, 0);
     }
     float* gb = base + KR * TM;
 #pragma unroll
-    for (int p = wave; p < PG; p += 4) {
-      const int e = p * 256 + lane * 4;
-      const int row = e / TNW, col = e - row * TNW;
-      const float* src = g.G + (r0 + row) * g.ldg + n0 + col;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(gb + p * 256), 16, 0, 0);
+    for (int k = 0; k < NPG; ++k) {
+      const int p = wave + 4 * k;
+      if (p < PG)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsG, (lptr_t)(gb + p * 256), 16, voG[k], sG, 0, 0);
     }
   };
 
@@ -1441,7 +1460,10 @@ int wn_gemm_tn(const float* A, long lda, int a_planes, long a_plane_stride,
       // LDS-DMA kernel when every split is whole 16-row chunks
       // (WN_TN_MODE=reg selects the register-staged kernel)
       const char* tme = getenv("WN_TN_MODE");
-      const bool dma = (rows % 16 == 0) && !(tme && tme[0] == 'r');
+      // (its staging addresses are 32-bit byte offsets of a buffer resource)
+      const long a_bytes = (a_planes ? (long)a_planes * a_plane_stride : rows * lda) * 4;
+      const bool dma = (rows % 16 == 0) && !(tme && tme[0] == 'r') &&
+                       a_bytes < (1L << 31) && rows * ldg * 4 < (1L << 31);
 #define LAUNCH2(mf, nf)                                                          \
   do {                                                                           \
     if (dma) hipLaunchKernelGGL((gemm_tn3_kernel<mf, nf>), grid2, block2, 0, s, g); \

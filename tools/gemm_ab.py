@@ -17,9 +17,55 @@ from wavenet import _lib  # noqa: E402
 
 def open_lib(path):
     lib = ctypes.CDLL(os.path.abspath(path))
-    fn = lib.wn_gemm_nn
-    fn.restype, fn.argtypes = _lib.SIGNATURES['wn_gemm_nn']
+    for name in ('wn_gemm_nn', 'wn_gemm_tn', 'wn_gemm_tn_splits', 'wn_gemm_tn_slab_floats'):
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = _lib.SIGNATURES[name]
     return lib
+
+
+def tn(libs, N, reps, dev, st):
+    """the three weight-gradient (TN) GEMMs of a step: dWs (A = 50 planes), dW1, dW2"""
+    tot = {n: 0.0 for n, _ in libs}
+    for name, Mw, Nw, pa in (('dWs', 1600, 512, 50), ('dW1', 512, 512, 0), ('dW2', 512, 256, 0)):
+        A = torch.randn(N * Mw, device=dev)
+        G = torch.randn(N * Nw, device=dev)
+        lib0 = libs[0][1]
+        sp = lib0.wn_gemm_tn_splits(N, Mw, Nw, 0)
+        sl = lib0.wn_gemm_tn_slab_floats(Mw, Nw)
+        slabs = torch.zeros(sp * sl, device=dev)
+
+        def run(lib):
+            code = lib.wn_gemm_tn(A.data_ptr(), 0 if pa else Mw, pa, N * 32, None, 0, 16000,
+                                  G.data_ptr(), Nw, slabs.data_ptr(), sp, N, Mw, Nw, 1, st)
+            assert code == 0, code
+        ref = None
+        times = {n: [] for n, _ in libs}
+        for r in range(reps + 1):
+            for n, lib in libs:
+                slabs.zero_()
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(4):
+                    run(lib)
+                e1.record()
+                torch.cuda.synchronize()
+                if r:
+                    times[n].append(e0.elapsed_time(e1) * 1e3 / 4)
+                elif ref is None:
+                    ref = slabs.clone()
+                else:
+                    print('%-8s %-20s %s' % (name, n, 'bitwise' if torch.equal(slabs, ref) else
+                                             'DIFFERS %.3e' % float((slabs - ref).abs().max())))
+        line = '%-7s M=%4d N=%4d splits %3d:' % (name, Mw, Nw, sp)
+        for n, _ in libs:
+            t = float(np.median(times[n]))
+            tot[n] += t
+            line += '  %s %7.1f us %5.1f TF' % (n.replace('lib_', '').replace('.so', ''), t,
+                                                2.0 * N * Mw * Nw / t / 1e6)
+        print(line, flush=True)
+    print('sum TN: ' + '  '.join('%s %.1f us' % (n, t) for n, t in tot.items()))
 
 
 def main():
@@ -30,6 +76,10 @@ def main():
     reps = int(os.environ.get('KB_REPS', 7))
     dev = torch.device('cuda')
     st = torch.cuda.current_stream().cuda_stream
+    if os.environ.get('KB_ONLY', 'tn') == 'tn':
+        tn(libs, N, reps, dev, st)
+    if os.environ.get('KB_ONLY', 'nn') != 'nn':
+        return
     # (name, K, Nn, a_planes, c_planes, bias, relu, cpre, mask, addend)
     shapes = [('skip', 1600, 512, 50, 0, 1, 1, 0, 0, 0), ('post1', 512, 512, 0, 0, 1, 1, 1, 0, 0),
               ('post2', 512, 256, 0, 0, 1, 0, 0, 0, 0), ('dc1', 256, 512, 0, 0, 0, 0, 0, 1, 0),

@@ -407,24 +407,28 @@ __global__ __launch_bounds__(256, 4) void gemm_nn3_kernel(GemmNN g) {
   long am0 = m0 + 16 * wave + (lane >> 2), am1 = am0 + 64;
   am0 = am0 < g.M ? am0 : g.M - 1;
   am1 = am1 < g.M ? am1 : g.M - 1;
+  // staging addresses: buffer resources (bases in SGPRs), loop-invariant 32-bit
+  // lane offsets, one scalar offset per chunk -- no vector address arithmetic
+  // inside the K loop (it is matrix-pipe time on gfx950)
   const long lda = g.a_planes ? 32 : g.lda;
-  const float* a0 = g.A + am0 * lda + a_chunk * 4;
-  const float* a1 = g.A + am1 * lda + a_chunk * 4;
+  const __amdgpu_buffer_rsrc_t rsA = ep_rsrc(g.A), rsW = ep_rsrc(g.W);
+  const int va0 = (int)((am0 * lda + a_chunk * 4) * 4);
+  const int va1 = (int)((am1 * lda + a_chunk * 4) * 4);
   int wcol = n0 + (lane & 31) * 4;
   wcol = wcol < g.N ? wcol : 0;
-  const float* w0p = g.W + (long)(2 * wave + (lane >> 5)) * g.ldw + wcol;
-  const long w_piece = 8L * g.ldw, w_chunk = (long)N3_KC * g.ldw;
-  auto stage = [&](int kc, int st) {
-    float* base = smem + st * N3_STAGE;
+  const int vw0 = (int)(((long)(2 * wave + (lane >> 5)) * g.ldw + wcol) * 4);
+  const int vw1 = vw0 + (int)(8L * g.ldw * 4);
+  const long w_chunk = (long)N3_KC * g.ldw * 4;          // bytes
+  auto stage = [&](int kc, float* base) {
     // plane mode: chunk kc is half (kc & 1) of plane kc >> 1
-    const long aoff = g.a_planes ? (long)(kc >> 1) * g.a_plane_stride + (kc & 1) * 16
-                                 : (long)kc * N3_KC;
-    __builtin_amdgcn_global_load_lds((gptr_t)(a0 + aoff), (lptr_t)(base + wave * 256), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)(a1 + aoff), (lptr_t)(base + (wave + 4) * 256), 16, 0, 0);
-    const float* wp = w0p + kc * w_chunk;
+    const unsigned sa = (unsigned)((g.a_planes ? (long)(kc >> 1) * g.a_plane_stride + (kc & 1) * 16
+                                               : (long)kc * N3_KC) * 4);
+    const unsigned sw = (unsigned)(kc * w_chunk);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(base + wave * 256), 16, va0, sa, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(base + (wave + 4) * 256), 16, va1, sa, 0, 0);
     float* wb = base + NN_TM * N3_KC;
-    __builtin_amdgcn_global_load_lds((gptr_t)wp, (lptr_t)(wb + wave * 256), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)(wp + w_piece), (lptr_t)(wb + (wave + 4) * 256), 16, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lptr_t)(wb + wave * 256), 16, vw0, sw, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lptr_t)(wb + (wave + 4) * 256), 16, vw1, sw, 0, 0);
   };
 
   f32x16 acc[2][2];  // [fn][fm]
@@ -433,17 +437,20 @@ __global__ __launch_bounds__(256, 4) void gemm_nn3_kernel(GemmNN g) {
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = frag_zero();
 
-  stage(0, 0);
-  int st = 0;
+  stage(0, smem);
+  // (two copies of the loop body with compile-time LDS stages -- every LDS
+  // address a lane constant plus an immediate -- measured 2 % SLOWER over the
+  // six shapes of a step than this one body with the stage picked at run time)
   for (int kc = 0; kc < nk; ++kc) {
+    const int ST = kc & 1;
     // chunk kc landed (this wave's pieces), then everybody's; the barrier
     // also retires every wave's reads of the stage that is refilled next
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 #ifdef NN3_STAMPS
     if (kc == 0) { NSTAMP(1); }
 #endif
-    if (kc + 1 < nk) stage(kc + 1, st ^ 1);
-    const float* As = smem + st * N3_STAGE;
+    if (kc + 1 < nk) stage(kc + 1, smem + (ST ^ 1) * N3_STAGE);
+    const float* As = smem + ST * N3_STAGE;
     const float* Bs = As + NN_TM * N3_KC;
     f32x4 fa[2][2];
 #pragma unroll
@@ -469,7 +476,6 @@ __global__ __launch_bounds__(256, 4) void gemm_nn3_kernel(GemmNN g) {
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, x1, acc[1][1], 0, 0, 0);
     }
     __builtin_amdgcn_s_setprio(0);
-    st ^= 1;
   }
   // every wave is done with the operand stages before they become the
   // epilogue's staging tiles
@@ -1305,7 +1311,10 @@ static int gemm_nn_launch(const float* A, long lda, int a_planes, long a_plane_s
   const char* me = getenv("WN_NN_MODE");
   if (wsplit && (K % N3_KC) != 0) return WN_ERR_UNSUPPORTED;
   if (wsplit && !wn_aligned16(wsplit)) return WN_ERR_MISALIGNED;
-  if (!wsplit && ((me && me[0] == 't') || (K % N3_KC) != 0))
+  // (gemm_nn3_kernel stages through 32-bit byte offsets of buffer resources)
+  const long a_bytes = (a_planes ? (long)((K + 31) / 32) * a_plane_stride : M * lda) * 4;
+  const bool fits32 = a_bytes < (1L << 31) && (long)K * ldw * 4 < (1L << 31);
+  if (!wsplit && ((me && me[0] == 't') || (K % N3_KC) != 0 || !fits32))
     hipLaunchKernelGGL(gemm_nn_kernel<2>, dim3((unsigned)nwg), dim3(256), 0,
                        (hipStream_t)stream, g);
   else if (wsplit) {

@@ -1019,6 +1019,7 @@ __global__ __launch_bounds__(256, (MF * NF >= 10 ? 2 : MF * NF > 5 ? 3 : 4)) voi
 #pragma unroll
   for (int b = 0; b < NF; ++b) cs[b] = 0.f;
 
+  const bool do_cs = g.want_colsum && tm == 0;   // wave-uniform
   if (nchunks > 0) stage(0, 0);
   for (int c = 0; c < nchunks; ++c) {
     const int st = c & 1;
@@ -1036,7 +1037,9 @@ __global__ __launch_bounds__(256, (MF * NF >= 10 ? 2 : MF * NF > 5 ? 3 : 4)) voi
 #pragma unroll
       for (int b = 0; b < NF; ++b) {
         bv[b] = gl[2 * s * TNW + b * 32];
-        cs[b] += bv[b];
+        // (column sums are wanted from the first row of tiles only; a vector
+        // add per operand in every workgroup was 8 - 16 per chunk)
+        if (do_cs) cs[b] += bv[b];
       }
 #pragma unroll
       for (int a = 0; a < MF; ++a)

@@ -63,6 +63,9 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 #define NN_TM 128
 #define NN_TN 128
 #define NN_KC 32
+#ifndef NN3_PF
+#define NN3_PF 2   // steps the NN3 loop's weight-operand reads run ahead of their MFMAs
+#endif
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   // bijective "contiguous chunk per XCD" remap (8 XCDs, round-robin dispatch)
@@ -465,15 +468,35 @@ __global__ __launch_bounds__(256, 4) void gemm_nn3_kernel(GemmNN g) {
     // raised priority while this wave feeds the matrix pipe: the other
     // workgroups' waves on the SIMD do their staging / barrier work in the gaps
     __builtin_amdgcn_s_setprio(1);
+    // the weight operands of step r + PF are requested before the MFMAs of
+    // step r (pinned with scheduling barriers: left alone the compiler issues
+    // every read right before its use and waits for it -- an LDS round trip
+    // per four MFMAs that only other waves on the SIMD can cover; six shapes
+    // of a step 4641 -> 4608 us, at B = 1 672 -> 655 us; same MFMA order)
+    constexpr int PF = NN3_PF;
+    float wv[8][2];
+#pragma unroll
+    for (int r = 0; r < PF; ++r) {
+      const int ko = (8 * (r >> 2) + (r & 3)) * NN_TN;
+      wv[r][0] = bl[ko];
+      wv[r][1] = bl[ko + 32];
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      const int ko = (8 * (r >> 2) + (r & 3)) * NN_TN;
-      const float w0 = bl[ko], w1 = bl[ko + 32];
+      if (r + PF < 8) {
+        const int ko = (8 * ((r + PF) >> 2) + ((r + PF) & 3)) * NN_TN;
+        wv[r + PF][0] = bl[ko];
+        wv[r + PF][1] = bl[ko + 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const float w0 = wv[r][0], w1 = wv[r][1];
       const float x0 = fa[0][r >> 2][r & 3], x1 = fa[1][r >> 2][r & 3];
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, x0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, x1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, x0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, x1, acc[1][1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_s_setprio(0);
   }
@@ -945,7 +968,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn2_kernel(GemmTN g) {
 // the plain [row][TM] / [row][TNW] array and a DMA piece is 1 KiB of it.
 // Needs whole 16-row chunks (rows and rows_per_split multiples of 16).
 // ---------------------------------------------------------------------------
-template <int MF, int NF>
+template <int MF, int NF, bool CS>
 __global__ __launch_bounds__(256, (MF * NF >= 10 ? 2 : MF * NF > 5 ? 3 : 4)) void gemm_tn3_kernel(GemmTN g) {
   constexpr int TM = MF * 32, TNW = 4 * NF * 32, KR = 16;
   constexpr int STAGE = KR * TM + KR * TNW;     // floats
@@ -1019,7 +1042,6 @@ __global__ __launch_bounds__(256, (MF * NF >= 10 ? 2 : MF * NF > 5 ? 3 : 4)) voi
 #pragma unroll
   for (int b = 0; b < NF; ++b) cs[b] = 0.f;
 
-  const bool do_cs = g.want_colsum && tm == 0;   // wave-uniform
   if (nchunks > 0) stage(0, 0);
   for (int c = 0; c < nchunks; ++c) {
     const int st = c & 1;
@@ -1029,23 +1051,51 @@ __global__ __launch_bounds__(256, (MF * NF >= 10 ? 2 : MF * NF > 5 ? 3 : 4)) voi
     const float* al = smem + st * STAGE + h * TM + i;
     const float* gl = smem + st * STAGE + KR * TM + h * TNW + wave * (NF * 32) + i;
     __builtin_amdgcn_s_setprio(1);
+    // operands of step s + 1 are requested before the MFMAs of step s (as in
+    // gemm_nn3_kernel).  Column sums (CS: the bias gradients) are a template
+    // parameter: as a run-time flag their adds stayed in every launch's loop
+    // as add + select, and on gfx950 they are matrix-pipe time (a branch
+    // around two copies of the block sends the accumulators through memory).
+    if (CS) {
+      // (with the sums the pinned order below spills in the <4, 2> shape)
 #pragma unroll
-    for (int s = 0; s < KR / 2; ++s) {
-      float av[MF], bv[NF];
+      for (int s2 = 0; s2 < KR / 2; ++s2) {
+        float av[MF], bv[NF];
 #pragma unroll
-      for (int a = 0; a < MF; ++a) av[a] = al[2 * s * TM + a * 32];
+        for (int a = 0; a < MF; ++a) av[a] = al[2 * s2 * TM + a * 32];
 #pragma unroll
-      for (int b = 0; b < NF; ++b) {
-        bv[b] = gl[2 * s * TNW + b * 32];
-        // (column sums are wanted from the first row of tiles only; a vector
-        // add per operand in every workgroup was 8 - 16 per chunk)
-        if (do_cs) cs[b] += bv[b];
+        for (int b = 0; b < NF; ++b) {
+          bv[b] = gl[2 * s2 * TNW + b * 32];
+          cs[b] += bv[b];
+        }
+#pragma unroll
+        for (int a = 0; a < MF; ++a)
+#pragma unroll
+          for (int b = 0; b < NF; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
       }
+    } else {
+      float av[2][MF], bv[2][NF];
+      auto fetch = [&](int s2, float (&a_)[MF], float (&b_)[NF]) {
 #pragma unroll
-      for (int a = 0; a < MF; ++a)
+        for (int a = 0; a < MF; ++a) a_[a] = al[2 * s2 * TM + a * 32];
 #pragma unroll
-        for (int b = 0; b < NF; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < NF; ++b) b_[b] = gl[2 * s2 * TNW + b * 32];
+      };
+      fetch(0, av[0], bv[0]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s2 = 0; s2 < KR / 2; ++s2) {
+        if (s2 + 1 < KR / 2) fetch(s2 + 1, av[(s2 + 1) & 1], bv[(s2 + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < MF; ++a)
+#pragma unroll
+          for (int b = 0; b < NF; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2 & 1][a], bv[s2 & 1][b],
+                                                             acc[a][b], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     __builtin_amdgcn_s_setprio(0);
   }
@@ -1478,7 +1528,8 @@ int wn_gemm_tn(const float* A, long lda, int a_planes, long a_plane_stride,
                        a_bytes < (1L << 31) && rows * ldg * 4 < (1L << 31);
 #define LAUNCH2(mf, nf)                                                          \
   do {                                                                           \
-    if (dma) hipLaunchKernelGGL((gemm_tn3_kernel<mf, nf>), grid2, block2, 0, s, g); \
+    if (dma && want_colsum) hipLaunchKernelGGL((gemm_tn3_kernel<mf, nf, true>), grid2, block2, 0, s, g); \
+    else if (dma) hipLaunchKernelGGL((gemm_tn3_kernel<mf, nf, false>), grid2, block2, 0, s, g); \
     else hipLaunchKernelGGL((gemm_tn2_kernel<mf, nf>), grid2, block2, 0, s, g);  \
   } while (0)
       if (mf2 == 5 && nf2 == 2) LAUNCH2(5, 2);

@@ -36,7 +36,8 @@ def tn(libs, N, reps, dev, st):
 
         def run(lib):
             code = lib.wn_gemm_tn(A.data_ptr(), 0 if pa else Mw, pa, N * 32, None, 0, 16000,
-                                  G.data_ptr(), Nw, slabs.data_ptr(), sp, N, Mw, Nw, 1, st)
+                                  G.data_ptr(), Nw, slabs.data_ptr(), sp, N, Mw, Nw,
+                                  int(os.environ.get('KB_CS', 0)), st)
             assert code == 0, code
         ref = None
         times = {n: [] for n, _ in libs}

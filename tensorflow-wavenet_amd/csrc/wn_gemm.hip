@@ -968,7 +968,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn2_kernel(GemmTN g) {
 // the plain [row][TM] / [row][TNW] array and a DMA piece is 1 KiB of it.
 // Needs whole 16-row chunks (rows and rows_per_split multiples of 16).
 // ---------------------------------------------------------------------------
-template <int MF, int NF, bool CS>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct wn_true { static constexpr bool value = true; };
+struct wn_false { static constexpr bool value = false; };
+template <int MF, int NF>
 __global__ __launch_bounds__(256, (MF * NF >= 10 ? 2 : MF * NF > 5 ? 3 : 4)) void gemm_tn3_kernel(GemmTN g) {
   constexpr int TM = MF * 32, TNW = 4 * NF * 32, KR = 16;
   constexpr int STAGE = KR * TM + KR * TNW;     // floats
@@ -1039,43 +1042,55 @@ __global__ __launch_bounds__(256, (MF * NF >= 10 ? 2 : MF * NF > 5 ? 3 : 4)) voi
 #pragma unroll
     for (int b = 0; b < NF; ++b) acc[a][b] = frag_zero();
   float cs[NF];
+  f32x2 cs2[NF];   // the pinned loop's sums: even / odd steps
 #pragma unroll
-  for (int b = 0; b < NF; ++b) cs[b] = 0.f;
+  for (int b = 0; b < NF; ++b) {
+    cs[b] = 0.f;
+    cs2[b] = f32x2{0.f, 0.f};
+  }
 
   if (nchunks > 0) stage(0, 0);
-  for (int c = 0; c < nchunks; ++c) {
-    const int st = c & 1;
-    // chunk c landed for every wave; all reads of the other stage retired
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    if (c + 1 < nchunks) stage(c + 1, st ^ 1);
-    const float* al = smem + st * STAGE + h * TM + i;
-    const float* gl = smem + st * STAGE + KR * TM + h * TNW + wave * (NF * 32) + i;
-    __builtin_amdgcn_s_setprio(1);
-    // operands of step s + 1 are requested before the MFMAs of step s (as in
-    // gemm_nn3_kernel).  Column sums (CS: the bias gradients) are a template
-    // parameter: as a run-time flag their adds stayed in every launch's loop
-    // as add + select, and on gfx950 they are matrix-pipe time (a branch
-    // around two copies of the block sends the accumulators through memory).
-    if (CS) {
-      // (with the sums the pinned order below spills in the <4, 2> shape)
+  // Operands of step s + 1 are requested before the MFMAs of step s (as in
+  // gemm_nn3_kernel).  Column sums (the bias gradients) are wanted from the
+  // first row of tiles only: the K loop exists twice, with and without their
+  // adds, behind ONE workgroup-uniform branch.  (As a run-time flag inside the
+  // loop the adds stayed in every workgroup's loop as add + select, and on
+  // gfx950 they are matrix-pipe time; a branch per chunk sends the
+  // accumulators through memory.)
+  auto kloop = [&](auto cs_tag) {
+    constexpr bool SUM = decltype(cs_tag)::value;
+    for (int c = 0; c < nchunks; ++c) {
+      const int st = c & 1;
+      // chunk c landed for every wave; all reads of the other stage retired
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      if (c + 1 < nchunks) stage(c + 1, st ^ 1);
+      const float* al = smem + st * STAGE + h * TM + i;
+      const float* gl = smem + st * STAGE + KR * TM + h * TNW + wave * (NF * 32) + i;
+      __builtin_amdgcn_s_setprio(1);
+      if (SUM && MF * NF == 8) {
+        // (<4, 2> with the sums: the pinned order below spills 34 registers;
+        // the sums two steps at a time behind their MFMAs measured slower)
 #pragma unroll
-      for (int s2 = 0; s2 < KR / 2; ++s2) {
-        float av[MF], bv[NF];
+        for (int s2 = 0; s2 < KR / 2; ++s2) {
+          float a_[MF], b_[NF];
 #pragma unroll
-        for (int a = 0; a < MF; ++a) av[a] = al[2 * s2 * TM + a * 32];
+          for (int a = 0; a < MF; ++a) a_[a] = al[2 * s2 * TM + a * 32];
 #pragma unroll
-        for (int b = 0; b < NF; ++b) {
-          bv[b] = gl[2 * s2 * TNW + b * 32];
-          cs[b] += bv[b];
+          for (int b = 0; b < NF; ++b) {
+            b_[b] = gl[2 * s2 * TNW + b * 32];
+            cs[b] += b_[b];
+          }
+#pragma unroll
+          for (int a = 0; a < MF; ++a)
+#pragma unroll
+            for (int b = 0; b < NF; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[a], b_[b], acc[a][b], 0, 0, 0);
         }
-#pragma unroll
-        for (int a = 0; a < MF; ++a)
-#pragma unroll
-          for (int b = 0; b < NF; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        continue;
       }
-    } else {
-      float av[2][MF], bv[2][NF];
+      float av[2][MF], bv[2][NF], keep[KR / 2][NF];
+      static_assert(KR == 16, "column-sum tree");
       auto fetch = [&](int s2, float (&a_)[MF], float (&b_)[NF]) {
 #pragma unroll
         for (int a = 0; a < MF; ++a) a_[a] = al[2 * s2 * TM + a * 32];
@@ -1094,11 +1109,31 @@ __global__ __launch_bounds__(256, (MF * NF >= 10 ? 2 : MF * NF > 5 ? 3 : 4)) voi
           for (int b = 0; b < NF; ++b)
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2 & 1][a], bv[s2 & 1][b],
                                                              acc[a][b], 0, 0, 0);
+        if (SUM) {
+#pragma unroll
+          for (int b = 0; b < NF; ++b) keep[s2][b] = bv[s2 & 1][b];
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (SUM) {
+        // the chunk's column sums in one group behind its MFMAs (an add
+        // between two MFMAs costs the wave ~12 cycles of matrix-pipe time)
+#pragma unroll
+        for (int b = 0; b < NF; ++b) {
+          const f32x2 p0 = {keep[0][b], keep[1][b]}, p1 = {keep[2][b], keep[3][b]};
+          const f32x2 p2 = {keep[4][b], keep[5][b]}, p3 = {keep[6][b], keep[7][b]};
+          cs2[b] += (p0 + p1) + (p2 + p3);
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
     }
-    __builtin_amdgcn_s_setprio(0);
-  }
+  };
+  // (which row of tiles sums the columns rotates with the split and the column
+  // tile: with tm == 0 the workgroups that carry the extra adds have
+  // consecutive ids, share CUs and set the time of a one-round launch)
+  const bool do_cs = g.want_colsum && tm == (split + 3 * tn) % g.tiles_m;
+  if (do_cs) kloop(wn_true{});
+  else kloop(wn_false{});
 
   float* slab = g.slabs + (long)split * g.slab_stride;
 #pragma unroll
@@ -1112,9 +1147,10 @@ __global__ __launch_bounds__(256, (MF * NF >= 10 ? 2 : MF * NF > 5 ? 3 : 4)) voi
         slab[(long)m * g.Nw + n] = acc[a][b][rr];
       }
     }
-  if (g.want_colsum && tm == 0) {
+  if (do_cs) {
 #pragma unroll
     for (int b = 0; b < NF; ++b) {
+      cs[b] += cs2[b].x + cs2[b].y;
       float v = cs[b] + __shfl_xor(cs[b], 32);
       const int n = n0 + wave * (NF * 32) + b * 32 + i;
       if (h == 0) slab[(long)g.Mw * g.Nw + n] = v;
@@ -1528,8 +1564,7 @@ int wn_gemm_tn(const float* A, long lda, int a_planes, long a_plane_stride,
                        a_bytes < (1L << 31) && rows * ldg * 4 < (1L << 31);
 #define LAUNCH2(mf, nf)                                                          \
   do {                                                                           \
-    if (dma && want_colsum) hipLaunchKernelGGL((gemm_tn3_kernel<mf, nf, true>), grid2, block2, 0, s, g); \
-    else if (dma) hipLaunchKernelGGL((gemm_tn3_kernel<mf, nf, false>), grid2, block2, 0, s, g); \
+    if (dma) hipLaunchKernelGGL((gemm_tn3_kernel<mf, nf>), grid2, block2, 0, s, g); \
     else hipLaunchKernelGGL((gemm_tn2_kernel<mf, nf>), grid2, block2, 0, s, g);  \
   } while (0)
       if (mf2 == 5 && nf2 == 2) LAUNCH2(5, 2);

@@ -3,6 +3,7 @@
 // cross-entropy, optimizers with TensorFlow update rules, global-conditioning
 // helpers, and the thin exported ops (causal_conv, time_to_batch, ...).
 #include "wn_common.h"
+#include <stdlib.h>
 #include <cmath>
 
 // ---------------------------------------------------------------------------
@@ -722,18 +723,28 @@ int wn_scalar_causal_wgrad(const float* audio, const float* dx0, float* slabs,
 // LDS and walks a contiguous range of rows in program order, which keeps the
 // result independent of scheduling; the per-wave tables go out as slabs for
 // wn_reduce_slabs.  Replaces two one-hot MFMA contractions (2 x 110 us at
-// B*T = 128000).
+// B*T = 128000).  Round 3: 90 -> 34 us (one wave per SIMD: what bounds it is
+// the number of instructions on the row chain, not HBM and not the LDS round
+// trip: four rows per LDS round trip took 45 -> 43 us, a deeper load ring
+// nothing, the per-row address arithmetic out of the vector unit 42 -> 34).
 // ---------------------------------------------------------------------------
 #define CWG_QMAX 256
+#define CWG_NB 32     // rows per batch
 __global__ __launch_bounds__(128) void causal_wgrad_kernel(
     const int32_t* __restrict__ q, const float* __restrict__ dx0,
     float* __restrict__ slabs, long rows, long rows_per_slab, int T, int Q) {
-  __shared__ float tab[2 * 2 * CWG_QMAX * 32];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // per wave: [2 taps][Q + 1][32]; row Q of a tap table is a dump for rows
+  // without a code (the first sample of a clip for tap 0, rows past the range)
+  __shared__ __attribute__((aligned(16))) float tab[2 * 2 * (CWG_QMAX + 1) * 32];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 31, h = lane >> 5;        // channel, tap
-  float* wtab = tab + (size_t)wave * 2 * Q * 32;
-  float* mine = wtab + (size_t)h * Q * 32;       // this half-wave's tap table
-  for (int i = lane; i < 2 * Q * 32; i += 64) wtab[i] = 0.f;
+  const int trows = Q + 1;
+  float* wtab = tab + (size_t)wave * 2 * trows * 32;
+  {
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    for (int i = lane; i < 2 * trows * 8; i += 64) reinterpret_cast<f32x4*>(wtab)[i] = z4;
+  }
   __builtin_amdgcn_wave_barrier();
   const long slab = (long)blockIdx.x * 2 + wave;
   const long r0 = slab * rows_per_slab;
@@ -741,52 +752,112 @@ __global__ __launch_bounds__(128) void causal_wgrad_kernel(
   if (r1 > rows) r1 = rows;
   // Half-wave h accumulates tap h (tap 0 pairs dx0[t] with the PREVIOUS code),
   // lane c owns channel c: one row per step, 32 consecutive floats of one
-  // table row, plain read-add-write (a wave's LDS operations execute in
-  // program order, so rows that share a code simply chain).  LDS float
-  // atomics measured ~400 cycles per instruction here, hence none.  Batches of
-  // NB rows are loaded while the previous batch is accumulated.
-  constexpr int NB = 16;
+  // table row, plain read-add-write in program order (a wave's LDS operations
+  // execute in order, so rows that share a code simply chain; LDS float
+  // atomics measured ~400 cycles per instruction here, hence none).  Nothing
+  // on that chain but the LDS round trip: a batch's 32 rows of dx0 and its
+  // codes are requested one batch ahead (one coalesced code load per lane:
+  // lane (j, h) holds the table offset of row j for tap h), the 32 table
+  // addresses are spread to the lanes before the chain starts, rows without a
+  // code go to the dump row instead of around a branch.
   const int shift = 1 - h;
-  float v[NB], vn[NB];
-  int code[NB], coden[NB];
-  int tb = r0 < r1 ? (int)(r0 % T) : 0;          // clip position of the batch
-  auto fetch = [&](long r, int t0, float (&vv)[NB], int (&cc)[NB]) {
-#pragma unroll
-    for (int u = 0; u < NB; ++u) {
-      const long rr = r + u;
-      cc[u] = -1;
-      vv[u] = 0.f;
-      if (rr < r1) {
-        int t = t0 + u;
-        if (t >= T) t %= T;
-        if (t - shift >= 0) cc[u] = q[rr - shift];
-        vv[u] = dx0[rr * 32 + c];
+  const int lane_off = (h * trows * 32 + c) * 4;            // bytes inside wtab
+  auto fetch_codes = [&](long rb, int tb) -> int {
+    const long row = rb + c;                                // this lane's row
+    int code = Q;
+    if (row < r1) {
+      int t = tb + c;                                       // tb: clip position of row rb
+      if (t >= T) t %= T;
+      if (t - shift >= 0) {
+        const int v = q[row - shift];
+        if (v >= 0 && v < Q) code = v;
       }
     }
+    return code * 128;                                      // byte offset of the table row
   };
-  if (r0 < r1) fetch(r0, tb, v, code);
-  for (long r = r0; r < r1; r += NB) {
-    tb += NB;
+  // dx0 rows through a buffer resource based at the slab's first row: the
+  // row offset is scalar, the lane's part (c * 4) loop-invariant, rows past
+  // the slab read as zero (their code is the dump row) -- no vector address
+  // arithmetic per row (one wave per SIMD: the kernel is bound by the number
+  // of instructions it issues)
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(dx0 + (r0 < r1 ? r0 : 0) * 32), 0,
+      r0 < r1 ? (int)((r1 - r0) * 128) : 0, 0x00020000);
+  auto fetch_rows = [&](long rb, float (&vv)[CWG_NB]) {
+    const int so = __builtin_amdgcn_readfirstlane((int)((rb - r0) * 128));
+#pragma unroll
+    for (int u = 0; u < CWG_NB; ++u)
+      vv[u] = __builtin_bit_cast(
+          float, __builtin_amdgcn_raw_buffer_load_b32(rs, c * 4, so + u * 128, 0));
+  };
+  // a ring of four batches: three are in flight while one is accumulated (a
+  // batch of 32 rows is worked off in ~0.7 us, a load takes ~2 us to arrive)
+  float ring[4][CWG_NB];
+  int codes[4] = {0, 0, 0, 0};
+  long fb = r0;                                  // next batch to request
+  int tb = r0 < r1 ? (int)(r0 % T) : 0;          // its clip position
+  auto request = [&](int slot) {
+    if (fb < r1) {
+      codes[slot] = fetch_codes(fb, tb);
+      fetch_rows(fb, ring[slot]);
+    }
+    fb += CWG_NB;
+    tb += CWG_NB;
     if (tb >= T) tb %= T;
-    if (r + NB < r1) fetch(r + NB, tb, vn, coden);
+  };
+  request(0);
+  request(1);
+  request(2);
+  for (long rb = r0; rb < r1; rb += 4 * CWG_NB) {
 #pragma unroll
-    for (int u = 0; u < NB; ++u)
-      if (code[u] >= 0 && code[u] < Q) mine[code[u] * 32 + c] += v[u];
+    for (int sl = 0; sl < 4; ++sl) {
+      if (rb + sl * CWG_NB >= r1) break;
+      request((sl + 3) & 3);
+      const float (&v)[CWG_NB] = ring[sl];
+      // table address of row u for this lane's tap: lane (u, h)'s offset
+      int addr[CWG_NB];
 #pragma unroll
-    for (int u = 0; u < NB; ++u) {
-      v[u] = vn[u];
-      code[u] = coden[u];
+      for (int u = 0; u < CWG_NB; ++u)
+        addr[u] = __builtin_amdgcn_ds_bpermute(((lane & 32) | u) * 4, codes[sl]) + lane_off;
+      // four rows per LDS round trip: the four cells are read together, row k
+      // continues from the newest earlier row of the group with the same cell
+      // (else from the value read), the four results are written in row order
+      // -- bit for bit the row-by-row chain
+#pragma unroll
+      for (int u = 0; u < CWG_NB; u += 4) {
+        float* cell[4];
+        float x[4], y[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          cell[k] = reinterpret_cast<float*>(reinterpret_cast<char*>(wtab) + addr[u + k]);
+          x[k] = *cell[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float from = x[k];
+#pragma unroll
+          for (int m = 0; m < k; ++m)       // ascending: the newest match wins
+            from = addr[u + m] == addr[u + k] ? y[m] : from;
+          y[k] = from + v[u + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *cell[k] = y[k];
+      }
     }
   }
   __builtin_amdgcn_wave_barrier();
   // (a slab whose row range is empty still writes its zeros)
   f32x4* out = reinterpret_cast<f32x4*>(slabs + slab * (2L * Q * 32));
-  const f32x4* src = reinterpret_cast<const f32x4*>(wtab);
-  for (int i = lane; i < 2 * Q * 8; i += 64) out[i] = src[i];
+#pragma unroll
+  for (int tap = 0; tap < 2; ++tap) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(wtab + tap * trows * 32);
+    for (int i = lane; i < Q * 8; i += 64) out[tap * Q * 8 + i] = src[i];
+  }
 }
 
 int wn_causal_wgrad_slabs(long rows) {
   long n = rows / 256;           // >= 256 rows per wave
+  // (500 slabs: kernel 34 -> 23 us, their reduction 11 -> 19 us)
   if (n > 256) n = 256;
   if (n < 2) n = 2;
   return (int)(n & ~1L);         // two waves per workgroup

@@ -292,11 +292,14 @@ __device__ __forceinline__ void gate_grad(const f32x16& dz, const f32x16& zz,
                                           f32x16& dg) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    // seven vector instructions per element (max, rcp, mul, fma, mul, fma,
+    // seven vector instructions per element (add, rcp, mul, fma, mul, fma,
     // mul): on gfx950 the f32 MFMA and the vector ALU are one resource, so
-    // every instruction here is matrix-pipe time (tools/ubench/mfma_valu.hip)
+    // every instruction here is matrix-pipe time (tools/ubench/mfma_valu.hip).
+    // A sigmoid that underflowed to 0 must not turn 0 * inf into NaN: + 1e-30
+    // (no change to any sigmoid above 1e-22; fmaxf compiles to TWO v_max, the
+    // first one canonicalising its operand).
     const float sgm = ss[r];
-    const float th = zz[r] * __builtin_amdgcn_rcpf(__builtin_fmaxf(sgm, 1e-30f));
+    const float th = zz[r] * __builtin_amdgcn_rcpf(sgm + 1e-30f);
     df[r] = dz[r] * __builtin_fmaf(-zz[r], th, sgm);      // dz * sig * (1 - tanh^2)
     dg[r] = dz[r] * __builtin_fmaf(-zz[r], sgm, zz[r]);   // dz * tanh * sig * (1 - sig)
   }

@@ -142,12 +142,19 @@ __device__ __forceinline__ void wait_flags(const unsigned* fl, int idx,
 // as mma32 (bitwise the same result).
 __device__ __forceinline__ void mma32t(f32x16& acc, const f32x16& frag,
                                        const float* wt_lane) {
+  // chunk q + 1 is requested before the MFMAs of chunk q, order pinned (left
+  // alone the compiler reads two chunks, waits, issues eight MFMAs: B = 8
+  // 829 -> 810 us)
+  f32x4 nxt = *reinterpret_cast<const f32x4*>(wt_lane);
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const f32x4 a4 = *reinterpret_cast<const f32x4*>(wt_lane + 8 * q);
+    const f32x4 a4 = nxt;
+    if (q < 3) nxt = *reinterpret_cast<const f32x4*>(wt_lane + 8 * (q + 1));
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int e = 0; e < 4; ++e)
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], frag[4 * q + e], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -503,9 +510,14 @@ __device__ __forceinline__ void mma32s(f32x16& acc, const f32x16& frag,
   for (int q = 0; q < 4; ++q) {
     const f32x4 a4 = nxt;
     if (q < 3) nxt = *reinterpret_cast<const f32x4*>(mat + (off0 ^ ((q + 1) << 3)));
+    // (order pinned: left alone the compiler moves the read behind the MFMAs
+    // and waits for it there at some call sites; B = 8 1650 -> 1637 us,
+    // B = 1 685 -> 660 us)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int e = 0; e < 4; ++e)
       acc = sb_mfma(a4[e], frag[4 * q + e], acc);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -787,14 +799,22 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
         WN_WAIT_VM0();
         if (tile == tbase + wave) { BSTAMP(l, 14); }
         if (hx) {                                    // dWd += z^T dx_{l+1}
+          // (operands of step s + 1 requested before the MFMA of step s,
+          // pinned: see wgrad2 below)
+          float az = te.p[0][0 * 1024], bd = te.p[0][1 * 1024];
 #pragma unroll 1
           for (int it = 0; it < 4; ++it) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-              const float az = te.p[k][0 * 1024 + 64 * k + 256 * it];
-              const float bd = te.p[k][1 * 1024 + 64 * k + 256 * it];
+              const int kn = (k + 1) & 3, o = 64 * kn + 256 * ((it + (k == 3)) & 3);
+              const float naz = te.p[kn][0 * 1024 + o];
+              const float nbd = te.p[kn][1 * 1024 + o];
+              __builtin_amdgcn_sched_barrier(0);
               cd = sb_mfma(az, bd, cd);
               sd += bd;
+              __builtin_amdgcn_sched_barrier(0);
+              az = naz;
+              bd = nbd;
             }
           }
         }
@@ -841,33 +861,39 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
         if (tile == tbase + wave) { BSTAMP(l, 10); }
         __builtin_amdgcn_wave_barrier();
         float tsf = 0.f, tsg = 0.f;          // this tile's column sums of da[t]
+        // c1 += x[t]^T da, c0 += x[t-d]^T da, ts += column sums of da over the
+        // tile's 32 rows (16 steps of two rows).  The three operands of step
+        // s + 1 are requested before the MFMAs of step s and the order is
+        // pinned: left alone the compiler reads right before use and waits --
+        // an LDS round trip per two MFMAs with one partner wave to cover it.
+        // (The last step requests step 0 again: harmless, keeps the loop one
+        // body.)
+        auto wgrad2 = [&](f32x16& c1, f32x16& c0, float& ts) {
+          float axc = te.p[0][0 * 1024], axp = te.p[0][1 * 1024], b = te.p[0][2 * 1024];
 #pragma unroll 1
-        for (int it = 0; it < 4; ++it) {     // dWf[1] += x[t]^T da_f, dWf[0] += x[t-d]^T da_f
+          for (int it = 0; it < 4; ++it) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float axc = te.p[k][0 * 1024 + 64 * k + 256 * it];
-            const float axp = te.p[k][1 * 1024 + 64 * k + 256 * it];
-            const float bf = te.p[k][2 * 1024 + 64 * k + 256 * it];
-            cf1 = sb_mfma(axc, bf, cf1);
-            cf0 = sb_mfma(axp, bf, cf0);
-            tsf += bf;
+            for (int k = 0; k < 4; ++k) {
+              const int kn = (k + 1) & 3, o = 64 * kn + 256 * ((it + (k == 3)) & 3);
+              const float naxc = te.p[kn][0 * 1024 + o];
+              const float naxp = te.p[kn][1 * 1024 + o];
+              const float nb = te.p[kn][2 * 1024 + o];
+              __builtin_amdgcn_sched_barrier(0);
+              c1 = sb_mfma(axc, b, c1);
+              c0 = sb_mfma(axp, b, c0);
+              ts += b;
+              __builtin_amdgcn_sched_barrier(0);
+              axc = naxc;
+              axp = naxp;
+              b = nb;
+            }
           }
-        }
+        };
+        wgrad2(cf1, cf0, tsf);               // dWf[1] += x[t]^T da_f, dWf[0] += x[t-d]^T da_f
         __builtin_amdgcn_wave_barrier();
         frag_to_lds(t2, j, h, dg);           // ... then da_g[t] through the same tile
         __builtin_amdgcn_wave_barrier();
-#pragma unroll 1
-        for (int it = 0; it < 4; ++it) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float axc = te.p[k][0 * 1024 + 64 * k + 256 * it];
-            const float axp = te.p[k][1 * 1024 + 64 * k + 256 * it];
-            const float bg = te.p[k][2 * 1024 + 64 * k + 256 * it];
-            cg1 = sb_mfma(axc, bg, cg1);
-            cg0 = sb_mfma(axp, bg, cg0);
-            tsg += bg;
-          }
-        }
+        wgrad2(cg1, cg0, tsg);
         sf += tsf;
         sgs += tsg;
         if (tile_colsum) {

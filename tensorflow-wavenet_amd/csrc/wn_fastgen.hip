@@ -816,19 +816,31 @@ __global__ __launch_bounds__(FGC_THREADS) void fg_chain_kernel(FgStep g) {
       if (l < L) {
         const float* wl = wring[l % FGC_SLOTS];
         FSTAMP(8 + l * 8 + 0);
+        // the layer's weights do not depend on x: their LDS reads are issued
+        // before the broadcast of x (and the dense conv's before that of z)
+        // instead of behind the wave barriers, where each costs the chain an
+        // LDS round trip
+        const float* w1 = wl + gsel * 1024 + nn * 32;
+        const float* wd = wl + 2 * 1024 + nn * 32;
+        f32x4 qw[8], pw[4];
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          qw[c] = *reinterpret_cast<const f32x4*>(w1 + ((c ^ (nn & 7)) << 2));
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+          pw[cc] = *reinterpret_cast<const f32x4*>(wd + (((gsel * 4 + cc) ^ (nn & 7)) << 2));
+        float a0 = wl[FGC_CW + lane], a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        const float bdl = wl[FGC_CW + 64 + (lane & 31)];
         if (lane < 32) {
           g.state[((long)roff[l] + pos[l]) * 32 + lane] = x;  // enqueue x_l[t]
           inv[lane] = x;
         }
         __builtin_amdgcn_wave_barrier();
         // current tap: lane -> output nn of filter (gsel 0) or gate (gsel 1)
-        const float* w1 = wl + gsel * 1024 + nn * 32;
-        float a0 = wl[FGC_CW + lane], a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-          const int sw = (c ^ (nn & 7)) << 2;
           const f32x4 xv = *reinterpret_cast<const f32x4*>(inv + 4 * c);
-          const f32x4 q = *reinterpret_cast<const f32x4*>(w1 + sw);
+          const f32x4 q = qw[c];
           a0 = fmaf(xv[0], q[0], a0); a1 = fmaf(xv[1], q[1], a1);
           a2 = fmaf(xv[2], q[2], a2); a3 = fmaf(xv[3], q[3], a3);
         }
@@ -850,14 +862,12 @@ __global__ __launch_bounds__(FGC_THREADS) void fg_chain_kernel(FgStep g) {
         if (l + 1 < L) {
           __builtin_amdgcn_wave_barrier();
           // dense 32 x 32: each half takes 16 of the 32 inputs
-          const float* wd = wl + 2 * 1024 + nn * 32;
           float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
 #pragma unroll
           for (int cc = 0; cc < 4; ++cc) {
             const int c = gsel * 4 + cc;
-            const int sw = (c ^ (nn & 7)) << 2;
             const f32x4 zz = *reinterpret_cast<const f32x4*>(zv + 4 * c);
-            const f32x4 p = *reinterpret_cast<const f32x4*>(wd + sw);
+            const f32x4 p = pw[cc];
             d0 = fmaf(zz[0], p[0], d0); d1 = fmaf(zz[1], p[1], d1);
             d2 = fmaf(zz[2], p[2], d2); d3 = fmaf(zz[3], p[3], d3);
           }
@@ -865,7 +875,7 @@ __global__ __launch_bounds__(FGC_THREADS) void fg_chain_kernel(FgStep g) {
           const auto pd = __builtin_amdgcn_permlane32_swap(
               __float_as_uint(dh), __float_as_uint(dh), false, false);
           if (lane < 32)
-            x += wl[FGC_CW + 64 + lane] + (__uint_as_float(pd[0]) + __uint_as_float(pd[1]));
+            x += bdl + (__uint_as_float(pd[0]) + __uint_as_float(pd[1]));
         }
         FSTAMP(8 + l * 8 + 3);
       }

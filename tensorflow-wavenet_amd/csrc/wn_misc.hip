@@ -776,19 +776,21 @@ __global__ __launch_bounds__(128) void causal_wgrad_kernel(
     return code * 128;                                      // byte offset of the table row
   };
   // dx0 rows through a buffer resource based at the slab's first row: the
-  // row offset is scalar, the lane's part (c * 4) loop-invariant, rows past
-  // the slab read as zero (their code is the dump row) -- no vector address
-  // arithmetic per row (one wave per SIMD: the kernel is bound by the number
-  // of instructions it issues)
+  // row offset is scalar, the lane's part (c * 4) loop-invariant -- no vector
+  // address arithmetic per row (one wave per SIMD: the kernel is bound by the
+  // number of instructions it issues).  Rows past the slab re-read its last
+  // row (their code is the dump row): the scalar offset is clamped on the
+  // scalar unit, the hardware's range check covers the VGPR offset only.
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(dx0 + (r0 < r1 ? r0 : 0) * 32), 0,
       r0 < r1 ? (int)((r1 - r0) * 128) : 0, 0x00020000);
+  const int so_last = r0 < r1 ? (int)((r1 - r0 - 1) * 128) : 0;
   auto fetch_rows = [&](long rb, float (&vv)[CWG_NB]) {
     const int so = __builtin_amdgcn_readfirstlane((int)((rb - r0) * 128));
 #pragma unroll
     for (int u = 0; u < CWG_NB; ++u)
       vv[u] = __builtin_bit_cast(
-          float, __builtin_amdgcn_raw_buffer_load_b32(rs, c * 4, so + u * 128, 0));
+          float, __builtin_amdgcn_raw_buffer_load_b32(rs, c * 4, min(so + u * 128, so_last), 0));
   };
   // a ring of four batches: three are in flight while one is accumulated (a
   // batch of 32 rows is worked off in ~0.7 us, a load takes ~2 us to arrive)

@@ -980,11 +980,18 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
       __builtin_amdgcn_s_setprio(2);
       BSTAMP(l, 4);
       // copy matrix m (+ its bias row) of the finished slab to memory
+      // (the slab holds a matrix in the accumulators' own layout, lane-linear
+      // 16-byte pieces [m][q][lane]: a chain step is 4 + 4 LDS instructions
+      // instead of 16 + 16; only the copy to memory uses the parameter layout)
+      const f32x4* slab4 = reinterpret_cast<const f32x4*>(slab) + lane;
       auto slab_out = [&](float* dst, int m) {
         f32x16 p;
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          p[r] = slab[m * 1024 + e0 + (8 * (r >> 2) + (r & 3)) * 32];
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = slab4[(m * 4 + q) * 64];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) p[4 * q + e] = v[e];
+        }
         float pb = 0.f;
         if (m >= 2 && h == 0) pb = slab[LAYER_W_FLOATS + (m - 2) * 32 + j];
 #pragma unroll
@@ -1009,13 +1016,14 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
             }
           } else {
             wait_lds_ge(tok + m, tbase_l + cpos, dead, a.ctl, a.poison, lane);
-            f32x16 p;
+            f32x4 v[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-              p[r] = slab[m * 1024 + e0 + (8 * (r >> 2) + (r & 3)) * 32];
+            for (int q = 0; q < 4; ++q) v[q] = slab4[(m * 4 + q) * 64];
             if (m >= 2 && h == 0) bsum += slab[LAYER_W_FLOATS + (m - 2) * 32 + j];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) c[r] += p[r];
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) c[4 * q + e] += v[q][e];
           }
         }
         if (WAVES == 1) {
@@ -1025,8 +1033,9 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
           if (m >= 2 && h == 0) out[LAYER_W_FLOATS + (m - 2) * 32 + j] = bsum;
         } else {
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            slab[m * 1024 + e0 + (8 * (r >> 2) + (r & 3)) * 32] = c[r];
+          for (int q = 0; q < 4; ++q)
+            reinterpret_cast<f32x4*>(slab)[(m * 4 + q) * 64 + lane] =
+                f32x4{c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]};
           if (m >= 2 && h == 0) slab[LAYER_W_FLOATS + (m - 2) * 32 + j] = bsum;
           WN_WAIT_LGKM0();                   // this wave's slab reads / writes are done
           if (lane == 0)
@@ -1056,8 +1065,11 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
         wait_lds_ge(s_tok[0] + m, L * 16 + WAVES, dead, a.ctl, a.poison, lane);
         f32x16 p;
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          p[r] = slab[m * 1024 + e0 + (8 * (r >> 2) + (r & 3)) * 32];
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = reinterpret_cast<const f32x4*>(slab)[(m * 4 + q) * 64 + lane];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) p[4 * q + e] = v[e];
+        }
         float pb = 0.f;
         if (m >= 2 && h == 0) pb = slab[LAYER_W_FLOATS + (m - 2) * 32 + j];
 #pragma unroll

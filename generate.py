@@ -22,6 +22,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tensorflow-wavenet_amd'))
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
+from wavenet import tf_checkpoint  # noqa: E402
 
 SAMPLES = 16000
 TEMPERATURE = 1.0
@@ -116,8 +117,12 @@ def main(argv=None):
         global_condition_cardinality=args.gc_cardinality,
         residual_postproc=wavenet_params.get("residual_postproc", False))
     print('Restoring model from {}'.format(args.checkpoint))
-    net.load_state_dict(torch.load(args.checkpoint,
-                                   map_location='cpu')['variables'])
+    if tf_checkpoint.checkpoint_format(args.checkpoint):
+        # a checkpoint written by the reference itself (tf.train.Saver)
+        tf_checkpoint.load_into(net, args.checkpoint)
+    else:
+        net.load_state_dict(torch.load(args.checkpoint,
+                                       map_location='cpu')['variables'])
     Q = wavenet_params['quantization_channels']
     rate = wavenet_params['sample_rate']
     gc = None if args.gc_id is None else [args.gc_id]

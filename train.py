@@ -27,6 +27,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tensorflow-wavenet_amd'))
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
+from wavenet import tf_checkpoint  # noqa: E402
 
 BATCH_SIZE = 1
 DATA_DIRECTORY = './VCTK-Corpus'
@@ -110,9 +111,11 @@ def latest_checkpoint(logdir):
     if os.path.exists(marker):
         name = open(marker).read().split('"')[1]
         path = os.path.join(logdir, name)
-        if os.path.exists(path):
+        # (a TensorFlow V2 checkpoint is a prefix: model.ckpt-N.index / .data-*)
+        if os.path.exists(path) or tf_checkpoint.checkpoint_format(path):
             return path
     found = glob.glob(os.path.join(logdir, 'model.ckpt-*'))
+    found = sorted({f[:-len('.index')] if f.endswith('.index') else f for f in found})
     found = [f for f in found if f.rsplit('-', 1)[-1].isdigit()]
     return max(found, key=lambda f: int(f.rsplit('-', 1)[-1])) if found \
         else None
@@ -129,7 +132,11 @@ def load(net, logdir):
     global_step = int(path.split('/')[-1].split('-')[-1])
     print("  Global step was: {}".format(global_step))
     print("  Restoring...", end="")
-    net.load_state_dict(torch.load(path, map_location='cpu')['variables'])
+    if tf_checkpoint.checkpoint_format(path):
+        # written by the reference's tf.train.Saver (train.py:104-114 there)
+        tf_checkpoint.load_into(net, path)
+    else:
+        net.load_state_dict(torch.load(path, map_location='cpu')['variables'])
     print(" Done.")
     return global_step
 

@@ -1294,6 +1294,41 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs,
     dst[(long)b * out_batch_stride + (long)r * rep_stride + e] = v;
 }
 
+// the same with 16-byte loads and eight slabs in flight per thread (every
+// stride / offset / count a multiple of 4 floats): a thread's loads are the
+// only memory-level parallelism these launches have (at B = 1 they are pure
+// load latency, at B = 8 four-byte loads leave HBM bandwidth on the table).
+// Fixed order: partial sums over s = k mod 8, then a fixed tree.
+__global__ void reduce_slabs4_kernel(const float* __restrict__ slabs,
+                                     int num_slabs, long slab_stride,
+                                     long in_batch_stride, long offset, long n4,
+                                     float* __restrict__ dst,
+                                     long out_batch_stride, int replicate,
+                                     long rep_stride) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n4) return;
+  const int b = blockIdx.y;
+  const f32x4* p = reinterpret_cast<const f32x4*>(slabs + (long)b * in_batch_stride + offset) + e;
+  const long st = slab_stride / 4;
+  f32x4 acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int s = 0;
+  for (; s + 7 < num_slabs; s += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = p[(long)(s + k) * st];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += v[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 7; ++k)
+    if (s + k < num_slabs) acc[k] += p[(long)(s + k) * st];
+  const f32x4 v = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  for (int r = 0; r < replicate; ++r)
+    *reinterpret_cast<f32x4*>(dst + (long)b * out_batch_stride + (long)r * rep_stride + 4 * e) = v;
+}
+
 __global__ void transpose_pad_kernel(const float* __restrict__ in, int rows,
                                      int cols, long in_ld,
                                      float* __restrict__ out, long out_ld) {
@@ -1636,6 +1671,16 @@ int wn_reduce_slabs(const float* slabs, int num_slabs, long slab_stride,
                        dim3(64), 0, (hipStream_t)stream, slabs, num_slabs,
                        slab_stride, in_batch_stride, offset, dst,
                        out_batch_stride, replicate, rep_stride);
+    return wn_check_launch();
+  }
+  if (((n | offset | slab_stride | in_batch_stride | out_batch_stride | rep_stride) & 3) == 0 &&
+      wn_aligned16(slabs) && wn_aligned16(dst)) {
+    const long n4 = n / 4;
+    const int bs = n4 >= 256 * 256 ? 256 : 64;      // small counts: more workgroups
+    dim3 grid4((unsigned)((n4 + bs - 1) / bs), batch);
+    hipLaunchKernelGGL(reduce_slabs4_kernel, grid4, dim3(bs), 0, (hipStream_t)stream,
+                       slabs, num_slabs, slab_stride, in_batch_stride, offset, n4,
+                       dst, out_batch_stride, replicate, rep_stride);
     return wn_check_launch();
   }
   dim3 grid((unsigned)((n + 255) / 256), batch), block(256);

@@ -571,6 +571,15 @@ class WaveNetModel(object):
                     ctl[3] = 0
             ws.loss_parts[:2] = 0.0
 
+    def _bwd_image_with_fwd(self, ws):
+        """True when the training forward runs the persistent stack launch and
+        the backward will too: wn_stack_pack then writes both weight images in
+        the forward's launch (the parameters do not change in between)."""
+        return bool(self.stack_fwd and self.CB == 1 and not self.generic_layers
+                    and self.L <= 256 and not self._legacy_bwd()
+                    and self._stack_bwd_ok() and getattr(ws, 'stack_bwd', False)
+                    and getattr(ws, 'wimg_b', None) is not None)
+
     def _stack_bwd_ok(self):
         """wn_stack_bwd covers what wn_layer_bwd2 covers."""
         return self.stack_bwd and not self._legacy_bwd() and self.L <= 256
@@ -768,8 +777,12 @@ class WaveNetModel(object):
         if stack:
             # all L layers in one persistent launch (csrc/wn_stack.hip)
             # (its transposed weight images, one small launch per call)
+            # (a training forward packs the backward stack's image in the
+            # same launch: one launch per step instead of two)
+            both = save_ts == 2 and self._bwd_image_with_fwd(ws)
             _lib.call('wn_stack_pack', _lib.ptr(self._layer_block(P, 0)),
-                      self.layer_stride, _lib.ptr(ws.wimg_f), None, L, st)
+                      self.layer_stride, _lib.ptr(ws.wimg_f),
+                      _lib.ptr(ws.wimg_b) if both else None, L, st)
             _lib.call('wn_stack_fwd', _lib.ptr(ws.X), _lib.ptr(ws.Z),
                       _lib.ptr(ws.SG) if save_ts else None,
                       _lib.ptr(ws.wimg_f),
@@ -921,8 +934,9 @@ class WaveNetModel(object):
             tsum = None if ws.dsum is None else ws.tilesum
             if self._stack_bwd_ok() and getattr(ws, 'stack_bwd', False):
                 # all L layers in one persistent launch (csrc/wn_stack.hip)
-                _lib.call('wn_stack_pack', _lib.ptr(self._layer_block(P, 0)),
-                          self.layer_stride, None, _lib.ptr(ws.wimg_b), L, st)
+                if not self._bwd_image_with_fwd(ws):
+                    _lib.call('wn_stack_pack', _lib.ptr(self._layer_block(P, 0)),
+                              self.layer_stride, None, _lib.ptr(ws.wimg_b), L, st)
                 _lib.call('wn_stack_bwd', _lib.ptr(ws.X), _lib.ptr(ws.Z),
                           _lib.ptr(ws.SG), _lib.ptr(ws.dZ), _lib.ptr(ws.DX),
                           _lib.ptr(ws.wimg_b), _lib.ptr(ws.lslabs),

@@ -178,12 +178,17 @@ def secondary(net, audio, gc_ids, kw, B, T, gen_samples=16000, opt=None):
         o = optimizer_factory['adam'](learning_rate=1e-3, momentum=0.9)
         for _ in range(warm):
             o.minimize(model.loss(a, ids))
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            o.minimize(model.loss(a, ids))
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / n * 1e3
+        # median of three timed rounds: a round is only 20 - 100 ms, one host
+        # hiccup (allocator, garbage collection) would double it
+        rounds = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                o.minimize(model.loss(a, ids))
+            torch.cuda.synchronize()
+            rounds.append((time.perf_counter() - t0) / n * 1e3)
+        return sorted(rounds)[1]
 
     # BASELINE.json configs[3] on ONE GPU: the same step with global
     # conditioning 32 x 377 (skipped when the headline run already has it)

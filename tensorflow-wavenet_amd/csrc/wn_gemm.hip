@@ -1299,32 +1299,49 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs,
 // only memory-level parallelism these launches have (at B = 1 they are pure
 // load latency, at B = 8 four-byte loads leave HBM bandwidth on the table).
 // Fixed order: partial sums over s = k mod 8, then a fixed tree.
+template <int PARTS>
 __global__ void reduce_slabs4_kernel(const float* __restrict__ slabs,
                                      int num_slabs, long slab_stride,
                                      long in_batch_stride, long offset, long n4,
                                      float* __restrict__ dst,
                                      long out_batch_stride, int replicate,
                                      long rep_stride) {
-  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n4) return;
+  // blockDim.x = 64 * PARTS: 64 columns of four floats, the slabs cut into
+  // PARTS contiguous ranges (fixed: ceil(num_slabs / PARTS) each) that are
+  // summed side by side and combined through LDS in a fixed tree
+  __shared__ f32x4 part[PARTS > 1 ? PARTS : 1][64];
+  const int col = threadIdx.x & 63, pt = threadIdx.x >> 6;
+  const long e = (long)blockIdx.x * 64 + col;
   const int b = blockIdx.y;
-  const f32x4* p = reinterpret_cast<const f32x4*>(slabs + (long)b * in_batch_stride + offset) + e;
-  const long st = slab_stride / 4;
+  const int per = (num_slabs + PARTS - 1) / PARTS;
+  const int s0 = pt * per, s1 = min(num_slabs, s0 + per);
   f32x4 acc[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-  int s = 0;
-  for (; s + 7 < num_slabs; s += 8) {
-    f32x4 v[8];
+  if (e < n4) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(slabs + (long)b * in_batch_stride + offset) + e;
+    const long st = slab_stride / 4;
+    int s = s0;
+    for (; s + 7 < s1; s += 8) {
+      f32x4 v[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = p[(long)(s + k) * st];
+      for (int k = 0; k < 8; ++k) v[k] = p[(long)(s + k) * st];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] += v[k];
+      for (int k = 0; k < 8; ++k) acc[k] += v[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+      if (s + k < s1) acc[k] += p[(long)(s + k) * st];
   }
-#pragma unroll
-  for (int k = 0; k < 7; ++k)
-    if (s + k < num_slabs) acc[k] += p[(long)(s + k) * st];
-  const f32x4 v = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  f32x4 v = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  if (PARTS > 1) {
+    part[pt][col] = v;
+    __syncthreads();
+    if (pt != 0) return;
+    if (PARTS == 4) v = (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
+    else v = part[0][col] + part[1][col];
+  }
+  if (e >= n4) return;
   for (int r = 0; r < replicate; ++r)
     *reinterpret_cast<f32x4*>(dst + (long)b * out_batch_stride + (long)r * rep_stride + 4 * e) = v;
 }
@@ -1676,11 +1693,18 @@ int wn_reduce_slabs(const float* slabs, int num_slabs, long slab_stride,
   if (((n | offset | slab_stride | in_batch_stride | out_batch_stride | rep_stride) & 3) == 0 &&
       wn_aligned16(slabs) && wn_aligned16(dst)) {
     const long n4 = n / 4;
-    const int bs = n4 >= 256 * 256 ? 256 : 64;      // small counts: more workgroups
-    dim3 grid4((unsigned)((n4 + bs - 1) / bs), batch);
-    hipLaunchKernelGGL(reduce_slabs4_kernel, grid4, dim3(bs), 0, (hipStream_t)stream,
-                       slabs, num_slabs, slab_stride, in_batch_stride, offset, n4,
-                       dst, out_batch_stride, replicate, rep_stride);
+    dim3 grid4((unsigned)((n4 + 63) / 64), batch);
+    // few output elements and many slabs: a thread's serial loop over the
+    // slabs is the launch's duration -- cut the slabs over four threads
+    const bool split = num_slabs >= 32 && (long)grid4.x * batch <= 4096;
+    if (split)
+      hipLaunchKernelGGL(reduce_slabs4_kernel<4>, grid4, dim3(256), 0, (hipStream_t)stream,
+                         slabs, num_slabs, slab_stride, in_batch_stride, offset, n4,
+                         dst, out_batch_stride, replicate, rep_stride);
+    else
+      hipLaunchKernelGGL(reduce_slabs4_kernel<1>, grid4, dim3(64), 0, (hipStream_t)stream,
+                         slabs, num_slabs, slab_stride, in_batch_stride, offset, n4,
+                         dst, out_batch_stride, replicate, rep_stride);
     return wn_check_launch();
   }
   dim3 grid((unsigned)((n + 255) / 256), batch), block(256);

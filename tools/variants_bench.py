@@ -20,7 +20,13 @@ cases = [('default', {}, None, None),
          ('scalar_input k32', dict(scalar_input=True, initial_filter_width=32), None, None),
          ('no biases', dict(use_biases=False), None, None),
          ('filter_width 3', dict(filter_width=3), None, None),
+         ('64 channels', dict(residual_channels=64, dilation_channels=64), None, None),
+         ('128 channels', dict(residual_channels=128, dilation_channels=128), None, None),
+         ('256 channels', dict(residual_channels=256, dilation_channels=256), None, None),
          ('momentum', {}, None, None), ('rmsprop', {}, None, None)]
+only = os.environ.get('KB_ONLY')
+if only:
+    cases = [c for c in cases if only in c[0]]
 for name, kw, gc, l2 in cases:
     cfg = dict(base); cfg.update(kw)
     net = WaveNetModel(seed=0, **cfg)

@@ -267,6 +267,15 @@ int wn_reduce_slabs(const float* slabs, int num_slabs, long slab_stride,
                     int batch, long in_batch_stride, long offset, long n,
                     float* dst, long out_batch_stride, int replicate,
                     long rep_stride, void* stream);
+/* channel-block models (more than 32 residual / dilation channels,
+ * model.py:46-60 puts no limit on them): the wn_layer_wgrad_k slabs of the
+ * CB x CB block pairs of one layer, slabs[pair = a * CB + b][num_slabs]
+ * [(2K+1)*1024 + 96], summed in a fixed order and written into the layer's
+ * gradient block (Wf [K][C][C], Wg, Wd [C][C] at 0; bf | bg | bd [C] each at
+ * off_bias, from the pairs with a == 0) */
+int wn_reduce_pair_slabs(const float* slabs, int num_slabs, int CB, int K,
+                         int has_dense, int use_bias, float* layer_grad, int C,
+                         long off_bias, void* stream);
 int wn_transpose(const float* in, int rows, int cols, long in_ld, float* out,
                  long out_ld, void* stream);
 

@@ -114,7 +114,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmNN& g, f32x16 (&acc)[2][
   const int vP = (int)((rr * g.ldc + cc) * 4);
   const int sP = (int)(4 * g.ldc * 4);
   const int vM = (int)((rr * g.ld_mask + cc) * 4), sM = (int)(4 * g.ld_mask * 4);
-  const int vA = (int)((rr * g.ld_add + cc) * 4), sA = (int)(4 * g.ld_add * 4);
+  // (addend in the output's plane layout when ld_add == 0 and c_planes > 0:
+  // x_{l+1} planes = x_l planes + z_l Wd of the channel-block models)
+  const bool addp = g.addend && g.c_planes && g.ld_add == 0;
+  const int vA = addp ? vC : (int)((rr * g.ld_add + cc) * 4);
+  const int sA = addp ? sC : (int)(4 * g.ld_add * 4);
 #pragma unroll
   for (int fm = 0; fm < 2; ++fm) {
     __builtin_amdgcn_wave_barrier();
@@ -135,7 +139,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmNN& g, f32x16 (&acc)[2][
                    : g.C + mbase * g.ldc + nw);
     const __amdgpu_buffer_rsrc_t rP = ep_rsrc(g.Cpre ? g.Cpre + mbase * g.ldc + nw : g.C);
     const __amdgpu_buffer_rsrc_t rM = ep_rsrc(g.mask ? g.mask + mbase * g.ld_mask + nw : g.C);
-    const __amdgpu_buffer_rsrc_t rA = ep_rsrc(g.addend ? g.addend + mbase * g.ld_add + nw : g.C);
+    const __amdgpu_buffer_rsrc_t rA = ep_rsrc(
+        !g.addend ? g.C
+        : addp ? g.addend + (long)(nw >> 5) * g.c_plane_stride + mbase * 32
+               : g.addend + mbase * g.ld_add + nw);
 #pragma unroll
     for (int bt = 0; bt < 2; ++bt) {
       f32x4 v[4], mk[4], ad[4];
@@ -1346,6 +1353,58 @@ __global__ void reduce_slabs4_kernel(const float* __restrict__ slabs,
     *reinterpret_cast<f32x4*>(dst + (long)b * out_batch_stride + (long)r * rep_stride + 4 * e) = v;
 }
 
+// Channel-block models (wavenet/blocked.py): the weight-gradient slabs of the
+// CB x CB (input block a, output block b) pairs of one layer,
+// slabs[pair][slab][(2K+1) * 1024 + 96] (wn_layer_wgrad_k's layout: Wf taps,
+// Wg taps, Wd, bf | bg | bd), summed in the fixed order of reduce_slabs4<4> and
+// written straight into the layer's [K][C][C] / [C][C] gradient matrices and
+// (pairs with a == 0) bias vectors -- one launch per layer instead of one
+// reduction plus three to six strided copies per pair.
+__global__ __launch_bounds__(256) void reduce_pair_slabs_kernel(
+    const float* __restrict__ slabs, int num_slabs, int CB, int K, int has_dense,
+    int use_bias, float* __restrict__ g, int C, long off_bias) {
+  __shared__ f32x4 part[4][64];
+  const int WF = (2 * K + 1) * 1024, n4 = (WF + 96) / 4;
+  const int col = threadIdx.x & 63, pt = threadIdx.x >> 6;
+  const int e4 = blockIdx.x * 64 + col;
+  const int pair = blockIdx.y, a = pair / CB, b = pair - a * CB;
+  const int per = (num_slabs + 3) / 4;
+  const int s0 = pt * per, s1 = min(num_slabs, s0 + per);
+  f32x4 acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (e4 < n4) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(
+                         slabs + (size_t)pair * num_slabs * (WF + 96)) + e4;
+    const long st = (WF + 96) / 4;
+    int s = s0;
+    for (; s + 7 < s1; s += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = p[(long)(s + k) * st];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += v[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+      if (s + k < s1) acc[k] += p[(long)(s + k) * st];
+  }
+  part[pt][col] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  if (pt != 0 || e4 >= n4) return;
+  const f32x4 v = (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
+  const int e = 4 * e4;
+  if (e < WF) {
+    const int m = e >> 10, r = (e >> 5) & 31, c = e & 31;   // matrix (Wf taps, Wg taps, Wd)
+    if (m == 2 * K && !has_dense) return;
+    *reinterpret_cast<f32x4*>(g + ((size_t)m * C + a * 32 + r) * C + b * 32 + c) = v;
+  } else if (a == 0 && use_bias) {
+    const int q = (e - WF) >> 5, c = (e - WF) & 31;         // bf, bg, bd
+    if (q == 2 && !has_dense) return;
+    *reinterpret_cast<f32x4*>(g + off_bias + (size_t)q * C + b * 32 + c) = v;
+  }
+}
+
 __global__ void transpose_pad_kernel(const float* __restrict__ in, int rows,
                                      int cols, long in_ld,
                                      float* __restrict__ out, long out_ld) {
@@ -1431,6 +1490,10 @@ static int gemm_nn_launch(const float* A, long lda, int a_planes, long a_plane_s
   }
   if ((mask && (ld_mask & 3)) || (addend && (ld_add & 3)))
     return WN_ERR_UNSUPPORTED;
+  // (addend with ld_add == 0: in the output's plane layout, needs c_planes;
+  // the epilogue addresses a lane's neighbour plane with a 32-bit byte offset)
+  if (addend && ld_add == 0 && !c_planes) return WN_ERR_BAD_SHAPE;
+  if (c_planes && c_plane_stride * 4 >= (1L << 31)) return WN_ERR_UNSUPPORTED;
   const void* ptrs[] = {A, W, bias, mask, addend, C, Cpre};
   for (const void* p : ptrs)
     if (p && !wn_aligned16(p)) return WN_ERR_MISALIGNED;
@@ -1711,6 +1774,20 @@ int wn_reduce_slabs(const float* slabs, int num_slabs, long slab_stride,
   hipLaunchKernelGGL(reduce_slabs_kernel, grid, block, 0, (hipStream_t)stream,
                      slabs, num_slabs, slab_stride, in_batch_stride, offset, n,
                      dst, out_batch_stride, replicate, rep_stride);
+  return wn_check_launch();
+}
+
+int wn_reduce_pair_slabs(const float* slabs, int num_slabs, int CB, int K,
+                         int has_dense, int use_bias, float* layer_grad, int C,
+                         long off_bias, void* stream) {
+  if (!slabs || !layer_grad) return WN_ERR_NULL;
+  if (num_slabs <= 0 || CB <= 0 || K < 1 || C != CB * 32 || off_bias < 0 || (off_bias & 3))
+    return WN_ERR_BAD_SHAPE;
+  if (!wn_aligned16(slabs) || !wn_aligned16(layer_grad)) return WN_ERR_MISALIGNED;
+  const int n4 = ((2 * K + 1) * 1024 + 96) / 4;
+  hipLaunchKernelGGL(reduce_pair_slabs_kernel, dim3((n4 + 63) / 64, CB * CB), dim3(256), 0,
+                     (hipStream_t)stream, slabs, num_slabs, CB, K, has_dense, use_bias,
+                     layer_grad, C, off_bias);
   return wn_check_launch();
 }
 

@@ -78,6 +78,8 @@ SIGNATURES = {
                            c_long, P, c_int, c_long, c_int, c_int, c_int, P]),
     'wn_reduce_slabs': (c_int, [P, c_int, c_long, c_int, c_long, c_long,
                                 c_long, P, c_long, c_int, c_long, P]),
+    'wn_reduce_pair_slabs': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P,
+                                     c_int, c_long, P]),
     'wn_transpose': (c_int, [P, c_int, c_int, c_long, P, c_long, P]),
     'wn_xent_partials': (c_int, [c_long]),
     'wn_xent': (c_int, [P, c_long, P, P, P, c_int, c_int, c_int, c_int, P]),

@@ -79,14 +79,15 @@ def forward_layers(net, ws, bias, bstride, save_ts, st):
                           None if last else _lib.ptr(ws.pre), pstride, st)
         if l == L - 1:
             break
-        # x_{l+1}[rb] = x_l[rb] + z_l Wd[:, rb] (+ bd[rb])   model.py:294-300,330
-        for rb in range(CB):
-            _lib.call('wn_gemm_nn', _lib.ptr(ws.Z[l * CB]), 0, CB, pstride,
-                      _lib.ptr(w['wd'][rb * CH:]), C,
-                      _lib.ptr(w['bd'][rb * CH:]) if net.use_biases else None,
-                      None, 0, _lib.ptr(ws.X[l * CB + rb]), CH,
-                      _lib.ptr(ws.X[(l + 1) * CB + rb]), CH, 0, 0, None,
-                      N, CH, C, 0, st)
+        # x_{l+1} = x_l + z_l Wd (+ bd)   model.py:294-300,330 -- ONE plane-mode
+        # GEMM for all residual-channel blocks (planes in, planes out, the
+        # addend x_l in the output's plane layout: ld_add = 0)
+        _lib.call('wn_gemm_nn', _lib.ptr(ws.Z[l * CB]), 0, CB, pstride,
+                  _lib.ptr(w['wd']), C,
+                  _lib.ptr(w['bd']) if net.use_biases else None,
+                  None, 0, _lib.ptr(ws.X[l * CB]), 0,
+                  _lib.ptr(ws.X[(l + 1) * CB]), 0, CB, pstride, None,
+                  N, C, C, 0, st)
 
 
 def backward_layers(net, ws, ids, st):
@@ -110,22 +111,19 @@ def backward_layers(net, ws, ids, st):
         d = int(net.dilations[l])
         w, g = _blk(net, P, l), _blk(net, Gr, l)
         M = C * C
-        gf = g['wf'].view(K, C, C)
-        gg = g['wg'].view(K, C, C)
-        gd = g['wd'].view(C, C)
         if dxin is not None:
             _lib.call('wn_transpose', _lib.ptr(w['wd']), C, C, C,
                       _lib.ptr(ws.wdT), C, st)
+        if dxin is not None:
+            # dz = dZ + dx' Wd^T for all dilation-channel blocks in one
+            # plane-mode GEMM (Wd^T as [res][dil]; addend dZ in plane layout)
+            _lib.call('wn_gemm_nn', _lib.ptr(dxin[0]), 0, CB, pstride,
+                      _lib.ptr(ws.wdT), C, None, None, 0,
+                      _lib.ptr(ws.dZ[l * CB]), 0, _lib.ptr(ws.dzb[0]), 0, CB,
+                      pstride, None, N, C, C, 0, st)
         # ---- gate gradients of every dilation-channel block
         for jb in range(CB):
-            dz = ws.dZ[l * CB + jb]
-            if dxin is not None:
-                # dz = dZ + dx' Wd^T   (Wd^T as [res][dil], columns of block jb)
-                _lib.call('wn_gemm_nn', _lib.ptr(dxin[0]), 0, CB, pstride,
-                          _lib.ptr(ws.wdT.view(-1)[jb * CH:]), C, None, None, 0,
-                          _lib.ptr(dz), CH, _lib.ptr(ws.dzb[jb]), CH, 0, 0,
-                          None, N, CH, C, 0, st)
-                dz = ws.dzb[jb]
+            dz = ws.dZ[l * CB + jb] if dxin is None else ws.dzb[jb]
             _lib.call('wn_layer_bwd_k', None, None, None, None, None,
                       _lib.ptr(dz), _lib.ptr(ws.TH[l * CB + jb]),
                       _lib.ptr(ws.SG[l * CB + jb]), _lib.ptr(w['all']),
@@ -136,27 +134,19 @@ def backward_layers(net, ws, ids, st):
                 dv = ws.dsum[l].view(B, 2, CB, CH)
                 dv[:, 0, jb].copy_(ws.cs_tmp[:, :CH])
                 dv[:, 1, jb].copy_(ws.cs_tmp[:, CH:])
-        # ---- weight gradients per (input block a, output block b) pair
+        # ---- weight gradients per (input block a, output block b) pair into
+        # the pair's slab region, then ONE fixed-order reduction per layer that
+        # writes the [K][C][C] / [C][C] matrices and the bias vectors directly
         for a in range(CB):
             for b in range(CB):
                 _lib.call('wn_layer_wgrad_k', _lib.ptr(ws.X[l * CB + a]),
                           _lib.ptr(daf[b]), _lib.ptr(dag[b]),
                           None if dxin is None else _lib.ptr(ws.Z[l * CB + a]),
                           None if dxin is None else _lib.ptr(dxin[b]),
-                          _lib.ptr(ws.lslabs), nslab, B, T, d, K, st)
-                tmp = ws.blk_tmp
-                _lib.call('wn_reduce_slabs', _lib.ptr(ws.lslabs), nslab,
-                          WF + 96, 1, 0, 0, WF + 96, _lib.ptr(tmp), 0, 1, 0, st)
-                ra, rb_ = slice(a * CH, (a + 1) * CH), slice(b * CH, (b + 1) * CH)
-                gf[:, ra, rb_].copy_(tmp[0:K * 1024].view(K, CH, CH))
-                gg[:, ra, rb_].copy_(tmp[K * 1024:2 * K * 1024].view(K, CH, CH))
-                if dxin is not None:
-                    gd[ra, rb_].copy_(tmp[2 * K * 1024:WF].view(CH, CH))
-                if a == 0 and ub:
-                    g['bf'][rb_].copy_(tmp[WF:WF + CH])
-                    g['bg'][rb_].copy_(tmp[WF + CH:WF + 2 * CH])
-                    if dxin is not None:
-                        g['bd'][rb_].copy_(tmp[WF + 2 * CH:WF + 3 * CH])
+                          _lib.ptr(ws.pslabs[a * CB + b]), nslab, B, T, d, K, st)
+        _lib.call('wn_reduce_pair_slabs', _lib.ptr(ws.pslabs), nslab, CB, K,
+                  0 if dxin is None else 1, 1 if ub else 0, _lib.ptr(g['all']),
+                  C, net.OFF_BF, st)
         # ---- dx of every residual-channel block
         dxo = ws.dx[xp]
         for rb in range(CB):

@@ -162,8 +162,15 @@ class _Workspace(object):
         self.nslab_2 = lib.wn_layer_bwd2_slabs(B, T)
         self.nslab_s = lib.wn_stack_bwd_slabs(B, T) if self.stack_bwd else 0
         alloc('wimg', (L, lib.wn_layer_bwd2_wimg_floats()))
-        alloc('lslabs', (L, max(self.nslab, self.nslab_f, self.nslab_2,
-                                self.nslab_s), net.LAYER_BLOCK))
+        if CB > 1:
+            # channel-block path: one slab region per (input, output) block
+            # pair of ONE layer (wavenet/blocked.py); the per-layer slabs of the
+            # 32-channel kernels are not used
+            alloc('pslabs', (CB * CB, self.nslab, (2 * net.KW + 1) * 1024 + 96))
+            alloc('lslabs', (1, 1, 4))
+        else:
+            alloc('lslabs', (L, max(self.nslab, self.nslab_f, self.nslab_2,
+                                    self.nslab_s), net.LAYER_BLOCK))
         need = 0
         self.splits = {}
         for key, (mw, nw) in dict(post2=(S, Q), post1=(S, S), skip=(L * CHn, S),

@@ -230,7 +230,12 @@ int wn_stack_bwd(const float* X, const float* Z, const float* SG,
                  int T, void* stream);
 
 /* ---- fp32 MFMA GEMMs: the skip sum + post-processing of
- * wavenet/model.py:303-305, 430-440 (_create_network) and their gradients */
+ * wavenet/model.py:303-305, 430-440 (_create_network) and their gradients.
+ * C = epi(A W): + bias, relu, * (mask > 0), + addend.  A dense [M][lda] or
+ * a_planes planes of [M][32]; C dense [M][ldc] or c_planes planes of [M][32]
+ * (c_plane_stride floats apart); an addend passed with ld_add == 0 is in C's
+ * plane layout (needs c_planes > 0): the 1x1 residual conv of the
+ * channel-block models, x_{l+1} planes = x_l planes + z_l Wd. */
 int wn_gemm_nn(const float* A, long lda, int a_planes, long a_plane_stride,
                const float* W, int ldw, const float* bias, const float* mask,
                long ld_mask, const float* addend, long ld_add, float* C,

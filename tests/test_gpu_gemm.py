@@ -310,3 +310,67 @@ def test_reduce_slabs_few_outputs(hip_lib, nslab, n, batch, rep):
             ref = sum(float(src[b * bstride + off + e + s * stride]) for s in range(nslab))
             for r in range(rep):
                 assert abs(got[b * 8 + r * 16 + e] - ref) <= 1e-5 * max(1.0, nslab ** 0.5)
+
+
+@pytest.mark.parametrize('M,P', [(300, 2), (4099, 4), (129, 8)])
+def test_gemm_plane_addend(hip_lib, M, P):
+    """planes in, planes out, the addend in the OUTPUT's plane layout
+    (ld_add = 0): x_{l+1} planes = x_l planes + z_l Wd (+ bd) of the
+    channel-block models (model.py:294-300, 330 with more than 32 channels)."""
+    from wavenet import _lib
+    rng = np.random.default_rng(M + P)
+    C = 32 * P
+    Z = rng.standard_normal((P, M, 32)).astype(np.float32)
+    X = rng.standard_normal((P, M, 32)).astype(np.float32)
+    W = rng.standard_normal((C, C)).astype(np.float32)
+    bias = rng.standard_normal(C).astype(np.float32)
+    dZ, dX, dW, db = dev(Z), dev(X), dev(W), dev(bias)
+    out = torch.zeros((P, M, 32), device='cuda')
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.call('wn_gemm_nn', dZ.data_ptr(), 0, P, M * 32, dW.data_ptr(), C,
+              db.data_ptr(), None, 0, dX.data_ptr(), 0, out.data_ptr(), 0, P,
+              M * 32, None, M, C, C, 0, st)
+    zd = Z.transpose(1, 0, 2).reshape(M, C).astype(np.float64)
+    xd = X.transpose(1, 0, 2).reshape(M, C).astype(np.float64)
+    ref = xd + zd @ W.astype(np.float64) + bias
+    got = out.cpu().numpy().transpose(1, 0, 2).reshape(M, C)
+    assert np.abs(got - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+    # a dense output cannot take a plane addend
+    lib = _lib.load()
+    assert lib.wn_gemm_nn(dZ.data_ptr(), 0, P, M * 32, dW.data_ptr(), C, None, None, 0,
+                          dX.data_ptr(), 0, out.data_ptr(), C, 0, 0, None, M, C, C, 0,
+                          st) != 0
+
+
+@pytest.mark.parametrize('CB,K,dense,ub', [(2, 2, 1, 1), (3, 3, 0, 1), (2, 4, 1, 0), (5, 2, 1, 1)])
+def test_reduce_pair_slabs(hip_lib, CB, K, dense, ub):
+    """wn_reduce_pair_slabs: the CB x CB block pairs' weight-gradient slabs of
+    one layer summed into the layer's [K][C][C] / [C][C] matrices and bias
+    vectors (fixed order: two runs are bitwise equal)."""
+    from wavenet import _lib
+    rng = np.random.default_rng(CB * 10 + K)
+    C, ns = 32 * CB, 37
+    WF = (2 * K + 1) * 1024
+    slabs = rng.standard_normal((CB * CB, ns, WF + 96)).astype(np.float32)
+    d = dev(slabs)
+    off_b = (2 * K + 1) * C * C
+    g = torch.full((off_b + 3 * C,), 7.0, device='cuda')
+    g2 = g.clone()
+    st = torch.cuda.current_stream().cuda_stream
+    for t in (g, g2):
+        _lib.call('wn_reduce_pair_slabs', d.data_ptr(), ns, CB, K, dense, ub, t.data_ptr(),
+                  C, off_b, st)
+    assert torch.equal(g, g2)
+    tot = slabs.astype(np.float64).sum(1)                    # [pair][WF + 96]
+    want = np.full(off_b + 3 * C, 7.0)
+    mats = want[:off_b].reshape(2 * K + 1, C, C)
+    for a in range(CB):
+        for b in range(CB):
+            blk = tot[a * CB + b, :WF].reshape(2 * K + 1, 32, 32)
+            nm = 2 * K + 1 if dense else 2 * K
+            mats[:nm, a * 32:(a + 1) * 32, b * 32:(b + 1) * 32] = blk[:nm]
+            if a == 0 and ub:
+                for q in range(3 if dense else 2):
+                    want[off_b + q * C + b * 32:off_b + q * C + (b + 1) * 32] = \
+                        tot[b, WF + q * 32:WF + (q + 1) * 32]
+    assert np.abs(g.cpu().numpy() - want).max() < 1e-4

@@ -312,10 +312,11 @@ class WaveNetModel(object):
         self._unsupported = None
         if filter_width < 2 or filter_width > 8:
             self._unsupported = 'filter_width must be in [2, 8] on the HIP path'
-        elif max(self.R, self.D) > 256:
+        elif max(self.R, self.D) > 1024:
             # channel-block kernels (wavenet/blocked.py): 32-wide blocks, in
-            # chunks of 8 // filter_width blocks per kernel call
-            self._unsupported = ('at most 256 residual / dilation channels on '
+            # chunks of 8 // filter_width blocks per kernel call; tested up to
+            # 320 channels, capped at 32 blocks
+            self._unsupported = ('at most 1024 residual / dilation channels on '
                                  'the HIP path')
         elif self.S % 4 or self.Q % 4:
             self._unsupported = 'skip/quantization channels must be multiples of 4'
@@ -1256,9 +1257,17 @@ class WaveNetModel(object):
         return out + ws.loss_parts[0]
 
     # ---------------------------------------------------------- fast generation
+    FASTGEN_MAX_CHANNELS = 256     # wn_fastgen_run_wide: one channel per thread
+
     def _generator(self, global_condition):
         """Device-resident incremental-generation state (_create_generator,
         model.py:444-516): ring buffers standing in for the FIFO queues."""
+        if self.CHn > self.FASTGEN_MAX_CHANNELS:
+            raise NotImplementedError(
+                'fast (incremental) generation supports at most %d residual / '
+                'dilation channels on the HIP path; predict_proba (generate.py '
+                'without --fast_generation) has no such limit'
+                % self.FASTGEN_MAX_CHANNELS)
         if self._gen is None:
             lib = _lib.load()
             dil = np.asarray(self.dilations, dtype=np.int32)

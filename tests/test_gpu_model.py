@@ -105,6 +105,10 @@ CASES = [
     # more than 8 / K channel blocks per layer: the block kernels run in chunks
     ('r160_d136', cfg_with(TINY, batch_size=1, residual_channels=160,
                            dilation_channels=136), 70, False, None),
+    # more than 256 channels (9 / 10 blocks): training and predict_proba only
+    ('r288_d320', cfg_with(TINY, batch_size=1, residual_channels=288,
+                           dilation_channels=320, skip_channels=32,
+                           quantization_channels=32), 40, False, None),
     ('r64_k5', cfg_with(TINY, batch_size=1, residual_channels=64,
                         dilation_channels=48, filter_width=5), 90, False, None),
     ('scalar_r64_d40', cfg_with(TINY, batch_size=2, scalar_input=True,
@@ -533,12 +537,20 @@ def test_fast_generation_above_32_channels(hip_lib, name, cfg, gc):
 
 def test_unsupported_configs_raise(hip_lib):
     from wavenet import WaveNetModel
-    for kw in (dict(filter_width=9), dict(residual_channels=257),
-               dict(dilation_channels=300)):
+    for kw in (dict(filter_width=9), dict(residual_channels=1025),
+               dict(dilation_channels=1200)):
         cfg = cfg_with(TINY, batch_size=1, **kw)
         net = WaveNetModel(**model_kwargs(cfg))
         with pytest.raises(NotImplementedError):
             net.loss(np.zeros(16, np.float32))
+    # above 256 channels the incremental generator refuses, predict_proba works
+    wide = WaveNetModel(**model_kwargs(cfg_with(
+        TINY, batch_size=1, residual_channels=288, dilation_channels=264,
+        skip_channels=32, quantization_channels=32)))
+    with pytest.raises(NotImplementedError):
+        wide.predict_proba_incremental(3)
+    p = wide.predict_proba(np.arange(20) % 32).cpu().numpy()
+    assert p.shape == (32,) and abs(float(p.sum()) - 1.0) < 1e-5
     net = WaveNetModel(**model_kwargs(cfg_with(
         TINY, batch_size=2, global_condition_channels=4,
         global_condition_cardinality=5)))

@@ -113,10 +113,12 @@ int wn_layer_bwd_k(const float* daf_cur, const float* dag_cur,
                    const float* wblock_a, float* daf_next, float* dag_next,
                    int B, int T, int dilation, int K, int do_b, int do_a,
                    void* stream);
+/* (k0 / Ktot: the K taps k0 .. k0 + K - 1 of a filter of Ktot taps; slab
+ * layout [(2K+1) * 1024 + 96]: Wf taps, Wg taps, Wd, bf | bg | bd) */
 int wn_layer_wgrad_k(const float* x, const float* daf, const float* dag,
                      const float* z, const float* dxin, float* slabs,
-                     int num_slabs, int B, int T, int dilation, int K,
-                     void* stream);
+                     int num_slabs, int B, int T, int dilation, int K, int k0,
+                     int Ktot, void* stream);
 
 /* more than 32 residual / dilation channels: channels are cut into 32-wide
  * blocks, each block of an activation is its own [B*T][32] plane, and one
@@ -133,18 +135,23 @@ int wn_layer_wgrad_k(const float* x, const float* daf, const float* dag,
  * apart; no gate, z / th / sg untouched) to the next call's pre_in (which
  * replaces the bias); bwd with da_blocks = the chunk and dxin = the previous
  * chunk's dx_out.  The 1x1 convs of such a layer are wn_gemm_nn calls in
- * plane mode; its weight gradients come from wn_layer_wgrad_k per block pair. */
+ * plane mode; its weight gradients come from wn_layer_wgrad_k per block pair.
+ * K / k0 / Ktot: the call covers taps k0 .. k0 + K - 1 of a filter of Ktot
+ * taps (K * blocks <= 8 per call: wide layers run in chunks of blocks, filter
+ * widths above 8 in groups of taps, chained through pre_in / pre_out and
+ * dxin / dx_out). */
 int wn_layer_fwd_blk(const float* x, long in_plane_stride, int in_blocks,
                      float* z, float* th, float* sg, const float* wf,
                      const float* wg, int ldw, const float* bias_f,
                      const float* bias_g, int bias_clip_stride, int B, int T,
                      int dilation, int K, int save_ts, int tap_rows,
                      const float* pre_in, float* pre_out, long pre_plane_stride,
-                     void* stream);
+                     int k0, int Ktot, void* stream);
 int wn_layer_bwd_blk(const float* daf, const float* dag, long da_plane_stride,
                      int da_blocks, const float* dxin, float* dx_out,
                      const float* wf, const float* wg, int ldw, long tap_stride,
-                     int B, int T, int dilation, int K, void* stream);
+                     int B, int T, int dilation, int K, int k0, int Ktot,
+                     void* stream);
 
 /* fused backward of one block: phase B + all weight gradients of layer l and
  * phase A of layer l-1 in one pass (reads da_l / dx_{l+1} once).
@@ -277,10 +284,11 @@ int wn_reduce_slabs(const float* slabs, int num_slabs, long slab_stride,
  * CB x CB block pairs of one layer, slabs[pair = a * CB + b][num_slabs]
  * [(2K+1)*1024 + 96], summed in a fixed order and written into the layer's
  * gradient block (Wf [K][C][C], Wg, Wd [C][C] at 0; bf | bg | bd [C] each at
- * off_bias, from the pairs with a == 0) */
+ * off_bias, from the pairs with a == 0).  The slabs hold taps tap0 .. tap0 +
+ * K - 1 of a filter of Ktot taps (filter widths above 8 run in tap groups). */
 int wn_reduce_pair_slabs(const float* slabs, int num_slabs, int CB, int K,
                          int has_dense, int use_bias, float* layer_grad, int C,
-                         long off_bias, void* stream);
+                         long off_bias, int tap0, int Ktot, void* stream);
 int wn_transpose(const float* in, int rows, int cols, long in_ld, float* out,
                  long out_ld, void* stream);
 

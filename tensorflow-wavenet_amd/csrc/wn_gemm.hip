@@ -1362,7 +1362,7 @@ __global__ void reduce_slabs4_kernel(const float* __restrict__ slabs,
 // reduction plus three to six strided copies per pair.
 __global__ __launch_bounds__(256) void reduce_pair_slabs_kernel(
     const float* __restrict__ slabs, int num_slabs, int CB, int K, int has_dense,
-    int use_bias, float* __restrict__ g, int C, long off_bias) {
+    int use_bias, float* __restrict__ g, int C, long off_bias, int tap0, int Ktot) {
   __shared__ f32x4 part[4][64];
   const int WF = (2 * K + 1) * 1024, n4 = (WF + 96) / 4;
   const int col = threadIdx.x & 63, pt = threadIdx.x >> 6;
@@ -1397,7 +1397,9 @@ __global__ __launch_bounds__(256) void reduce_pair_slabs_kernel(
   if (e < WF) {
     const int m = e >> 10, r = (e >> 5) & 31, c = e & 31;   // matrix (Wf taps, Wg taps, Wd)
     if (m == 2 * K && !has_dense) return;
-    *reinterpret_cast<f32x4*>(g + ((size_t)m * C + a * 32 + r) * C + b * 32 + c) = v;
+    // (the slab holds taps tap0 .. tap0 + K - 1 of a filter of Ktot taps)
+    const int md = m < K ? tap0 + m : m < 2 * K ? Ktot + tap0 + (m - K) : 2 * Ktot;
+    *reinterpret_cast<f32x4*>(g + ((size_t)md * C + a * 32 + r) * C + b * 32 + c) = v;
   } else if (a == 0 && use_bias) {
     const int q = (e - WF) >> 5, c = (e - WF) & 31;         // bf, bg, bd
     if (q == 2 && !has_dense) return;
@@ -1779,15 +1781,16 @@ int wn_reduce_slabs(const float* slabs, int num_slabs, long slab_stride,
 
 int wn_reduce_pair_slabs(const float* slabs, int num_slabs, int CB, int K,
                          int has_dense, int use_bias, float* layer_grad, int C,
-                         long off_bias, void* stream) {
+                         long off_bias, int tap0, int Ktot, void* stream) {
   if (!slabs || !layer_grad) return WN_ERR_NULL;
-  if (num_slabs <= 0 || CB <= 0 || K < 1 || C != CB * 32 || off_bias < 0 || (off_bias & 3))
+  if (num_slabs <= 0 || CB <= 0 || K < 1 || C != CB * 32 || off_bias < 0 || (off_bias & 3) ||
+      tap0 < 0 || Ktot < tap0 + K)
     return WN_ERR_BAD_SHAPE;
   if (!wn_aligned16(slabs) || !wn_aligned16(layer_grad)) return WN_ERR_MISALIGNED;
   const int n4 = ((2 * K + 1) * 1024 + 96) / 4;
   hipLaunchKernelGGL(reduce_pair_slabs_kernel, dim3((n4 + 63) / 64, CB * CB), dim3(256), 0,
                      (hipStream_t)stream, slabs, num_slabs, CB, K, has_dense, use_bias,
-                     layer_grad, C, off_bias);
+                     layer_grad, C, off_bias, tap0, Ktot);
   return wn_check_launch();
 }
 

@@ -1381,7 +1381,9 @@ __global__ __launch_bounds__(GEN_WG) void layer_fwd_blk_kernel(
     const float* __restrict__ bias_f, const float* __restrict__ bias_g,
     int bias_clip_stride, int B, int T, int d, int K, int tap_rows,
     const float* __restrict__ pre_in, float* __restrict__ pre_out,
-    long pre_plane_stride) {
+    long pre_plane_stride, int k0, int Ktot) {
+  // (K taps k0 .. k0 + K - 1 of a filter of Ktot taps: filter widths above 8
+  // run in groups of taps like wide layers run in chunks of blocks)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int NV = K * in_blocks;               // virtual taps (k, i)
   float* wl = smem;                           // [2 NV][32][32]: filter, gate
@@ -1430,7 +1432,7 @@ __global__ __launch_bounds__(GEN_WG) void layer_fwd_blk_kernel(
     }
     for (int v = 0; v < NV; ++v) {
       const int k = v / in_blocks, i = v - k * in_blocks;
-      const int sh = tap_shift(K, k, d);
+      const int sh = tap_shift(Ktot, k0 + k, d);
       const RowRegs r = rows_load(x + (size_t)i * in_plane_stride + off0 - (size_t)sh * WN_CH,
                                   lane, max(0, sh - t0), hi);
       __builtin_amdgcn_wave_barrier();
@@ -1485,7 +1487,7 @@ __global__ __launch_bounds__(GEN_WG) void layer_bwd_blk_kernel(
     long da_plane_stride, int da_blocks, const float* __restrict__ dxin,
     float* __restrict__ dx_out, const float* __restrict__ wf,
     const float* __restrict__ wg, int ldw, long tap_stride, int B, int T, int d,
-    int K) {
+    int K, int k0, int Ktot) {
   constexpr int LDT = 33, MT = 32 * LDT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int NV = K * da_blocks;               // virtual taps (k, jb)
@@ -1526,7 +1528,7 @@ __global__ __launch_bounds__(GEN_WG) void layer_bwd_blk_kernel(
     }
     for (int v = 0; v < NV; ++v) {
       const int k = v / da_blocks, jb = v - k * da_blocks;
-      const int sh = tap_shift(K, k, d);
+      const int sh = tap_shift(Ktot, k0 + k, d);
       const int hi_f = min(hi, T - sh - t0);
       const size_t o = (size_t)jb * da_plane_stride + off0 + (size_t)sh * WN_CH;
       const RowRegs rf = rows_load(daf + o, lane, 0, hi_f);
@@ -1554,7 +1556,7 @@ __global__ __launch_bounds__(256) void layer_wgrad_gen_kernel(
     const float* __restrict__ x, const float* __restrict__ daf,
     const float* __restrict__ dag, const float* __restrict__ z,
     const float* __restrict__ dxin, float* __restrict__ slabs, int B, int T,
-    int d, int K) {
+    int d, int K, int k0, int Ktot) {
   __shared__ __attribute__((aligned(16))) float lds[4 * 3 * 1024];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
@@ -1567,7 +1569,7 @@ __global__ __launch_bounds__(256) void layer_wgrad_gen_kernel(
   const int WF = (2 * K + 1) * 1024;
   float* out = slabs + (size_t)blockIdx.x * (WF + 96);
   for (int k = 0; k < K; ++k) {
-    const int sh = tap_shift(K, k, d);
+    const int sh = tap_shift(Ktot, k0 + k, d);
     f32x16 cf = frag_zero(), cg = frag_zero(), cd = frag_zero();
     float sf = 0.f, sgs = 0.f, sd = 0.f;
     for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += nwaves) {
@@ -1790,10 +1792,11 @@ int wn_layer_fwd_blk(const float* x, long in_plane_stride, int in_blocks,
                      const float* bias_g, int bias_clip_stride, int B, int T,
                      int dilation, int K, int save_ts, int tap_rows,
                      const float* pre_in, float* pre_out, long pre_plane_stride,
-                     void* stream) {
+                     int k0, int Ktot, void* stream) {
   if (!x || !wf || !wg) return WN_ERR_NULL;
+  if (k0 < 0 || Ktot < k0 + K) return WN_ERR_BAD_SHAPE;
   if (!pre_out && !z) return WN_ERR_NULL;
-  if (B <= 0 || T <= 0 || dilation <= 0 || K < 2 || in_blocks < 1 || ldw < 32 ||
+  if (B <= 0 || T <= 0 || dilation <= 0 || K < 1 || in_blocks < 1 || ldw < 32 ||
       tap_rows < in_blocks * 32)
     return WN_ERR_BAD_SHAPE;
   if (K * in_blocks > 8) return WN_ERR_UNSUPPORTED;
@@ -1816,7 +1819,7 @@ int wn_layer_fwd_blk(const float* x, long in_plane_stride, int in_blocks,
   hipLaunchKernelGGL((layer_fwd_blk_kernel<TS>), grid, block, lds, s, x,      \
                      in_plane_stride, in_blocks, z, th, sg, wf, wg, ldw,      \
                      bias_f, bias_g, bias_clip_stride, B, T, dilation, K,     \
-                     tap_rows, pre_in, pre_out, pre_plane_stride)
+                     tap_rows, pre_in, pre_out, pre_plane_stride, k0, Ktot)
   if (save_ts) { LAUNCH(true); } else { LAUNCH(false); }
 #undef LAUNCH
   return wn_check_launch();
@@ -1825,9 +1828,11 @@ int wn_layer_fwd_blk(const float* x, long in_plane_stride, int in_blocks,
 int wn_layer_bwd_blk(const float* daf, const float* dag, long da_plane_stride,
                      int da_blocks, const float* dxin, float* dx_out,
                      const float* wf, const float* wg, int ldw, long tap_stride,
-                     int B, int T, int dilation, int K, void* stream) {
+                     int B, int T, int dilation, int K, int k0, int Ktot,
+                     void* stream) {
   if (!daf || !dag || !dx_out || !wf || !wg) return WN_ERR_NULL;
-  if (B <= 0 || T <= 0 || dilation <= 0 || K < 2 || da_blocks < 1 || ldw < 32)
+  if (B <= 0 || T <= 0 || dilation <= 0 || K < 1 || da_blocks < 1 || ldw < 32 ||
+      k0 < 0 || Ktot < k0 + K)
     return WN_ERR_BAD_SHAPE;
   if (K * da_blocks > 8) return WN_ERR_UNSUPPORTED;
   const void* ptrs[] = {daf, dag, dxin, dx_out};
@@ -1845,7 +1850,7 @@ int wn_layer_bwd_blk(const float* daf, const float* dag, long da_plane_stride,
     return WN_ERR_LAUNCH;                                                     \
   hipLaunchKernelGGL((layer_bwd_blk_kernel<HX>), grid, block, lds, s, daf,    \
                      dag, da_plane_stride, da_blocks, dxin, dx_out, wf, wg,   \
-                     ldw, tap_stride, B, T, dilation, K)
+                     ldw, tap_stride, B, T, dilation, K, k0, Ktot)
   if (dxin) { LAUNCH(true); } else { LAUNCH(false); }
 #undef LAUNCH
   return wn_check_launch();
@@ -1853,10 +1858,11 @@ int wn_layer_bwd_blk(const float* daf, const float* dag, long da_plane_stride,
 
 int wn_layer_wgrad_k(const float* x, const float* daf, const float* dag,
                      const float* z, const float* dxin, float* slabs,
-                     int num_slabs, int B, int T, int dilation, int K,
-                     void* stream) {
+                     int num_slabs, int B, int T, int dilation, int K, int k0,
+                     int Ktot, void* stream) {
   if (!x || !daf || !dag || !slabs) return WN_ERR_NULL;
-  if (B <= 0 || T <= 0 || dilation <= 0 || num_slabs <= 0 || K < 2)
+  if (B <= 0 || T <= 0 || dilation <= 0 || num_slabs <= 0 || K < 1 || k0 < 0 ||
+      Ktot < k0 + K)
     return WN_ERR_BAD_SHAPE;
   if (K > 8) return WN_ERR_UNSUPPORTED;
   if ((dxin != nullptr) != (z != nullptr)) return WN_ERR_NULL;
@@ -1864,10 +1870,10 @@ int wn_layer_wgrad_k(const float* x, const float* daf, const float* dag,
   dim3 grid(num_slabs), block(256);
   if (dxin)
     hipLaunchKernelGGL((layer_wgrad_gen_kernel<true>), grid, block, 0, s, x,
-                       daf, dag, z, dxin, slabs, B, T, dilation, K);
+                       daf, dag, z, dxin, slabs, B, T, dilation, K, k0, Ktot);
   else
     hipLaunchKernelGGL((layer_wgrad_gen_kernel<false>), grid, block, 0, s, x,
-                       daf, dag, z, dxin, slabs, B, T, dilation, K);
+                       daf, dag, z, dxin, slabs, B, T, dilation, K, k0, Ktot);
   return wn_check_launch();
 }
 

@@ -49,12 +49,13 @@ SIGNATURES = {
     'wn_layer_bwd_k': (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int,
                                c_int, c_int, c_int, c_int, P]),
     'wn_layer_wgrad_k': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int,
-                                 c_int, P]),
+                                 c_int, c_int, c_int, P]),
     'wn_layer_fwd_blk': (c_int, [P, c_long, c_int, P, P, P, P, P, c_int, P, P,
                                  c_int, c_int, c_int, c_int, c_int, c_int,
-                                 c_int, P, P, c_long, P]),
+                                 c_int, P, P, c_long, c_int, c_int, P]),
     'wn_layer_bwd_blk': (c_int, [P, P, c_long, c_int, P, P, P, P, c_int,
-                                 c_long, c_int, c_int, c_int, c_int, P]),
+                                 c_long, c_int, c_int, c_int, c_int, c_int,
+                                 c_int, P]),
     'wn_layer_bwdw_slabs': (c_int, [c_int, c_int]),
     'wn_layer_bwdw': (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
                               c_int, c_int, c_int, c_int, P]),
@@ -79,7 +80,7 @@ SIGNATURES = {
     'wn_reduce_slabs': (c_int, [P, c_int, c_long, c_int, c_long, c_long,
                                 c_long, P, c_long, c_int, c_long, P]),
     'wn_reduce_pair_slabs': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P,
-                                     c_int, c_long, P]),
+                                     c_int, c_long, c_int, c_int, P]),
     'wn_transpose': (c_int, [P, c_int, c_int, c_long, P, c_long, P]),
     'wn_xent_partials': (c_int, [c_long]),
     'wn_xent': (c_int, [P, c_long, P, P, P, c_int, c_int, c_int, c_int, P]),

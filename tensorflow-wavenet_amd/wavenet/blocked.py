@@ -18,8 +18,9 @@ dWs GEMMs of model.py see L * CB planes and run unchanged.  Per layer:
 Weights stay in the reference's [K][Cin][Cout] layout (C = 32 * CB padded
 channels), so `net.variables` are plain views exactly as for <= 32 channels.
 Layers wider than 8 / K blocks (128 channels at filter width 2) run the two
-block kernels in chunks of blocks (partial pre-activations through `ws.pre`
-forward, dx chained from chunk to chunk backward).
+block kernels in chunks of blocks, filter widths above 8 (any channel count,
+one block included) in groups of 8 taps (partial pre-activations through
+`ws.pre` forward, dx chained from chunk to chunk backward).
 Correctness-first: this is an off-default configuration (the default
 wavenet_params.json has 32 / 32 channels and runs the fused kernels).
 """
@@ -40,10 +41,18 @@ def _blk(net, flat, l):
 
 
 def _chunks(CB, K):
-    """(first block, blocks) pieces of at most 8 // K blocks: the block
-    kernels keep K x blocks <= 8 "virtual taps" of weights in LDS."""
-    per = max(1, 8 // K)
-    return [(i, min(per, CB - i)) for i in range(0, CB, per)]
+    """(first tap, taps, first block, blocks) pieces with taps x blocks <= 8:
+    the block kernels keep that many "virtual taps" of weights in LDS.  Layers
+    wider than 8 // K blocks run in chunks of blocks, filter widths above 8 in
+    groups of 8 taps (one block each)."""
+    per_k = min(K, 8)
+    per_b = max(1, 8 // per_k)
+    return [(k0, min(per_k, K - k0), i0, min(per_b, CB - i0))
+            for k0 in range(0, K, per_k) for i0 in range(0, CB, per_b)]
+
+
+def _tap_groups(K):
+    return [(k0, min(8, K - k0)) for k0 in range(0, K, 8)]
 
 
 def forward_layers(net, ws, bias, bstride, save_ts, st):
@@ -64,19 +73,20 @@ def forward_layers(net, ws, bias, bstride, save_ts, st):
             # input blocks in chunks of at most 8 // K (the kernel holds a
             # chunk's 2 K weight blocks in LDS); partial pre-activations
             # travel through ws.pre (planes af | ag)
-            for ci, (i0, nb) in enumerate(chunks):
+            for ci, (k0, nk, i0, nb) in enumerate(chunks):
                 last = ci == len(chunks) - 1
+                wo = (k0 * C + i0 * CH) * C + jb * CH
                 _lib.call('wn_layer_fwd_blk',
                           _lib.ptr(ws.X[l * CB + i0]), pstride, nb,
                           _lib.ptr(ws.Z[l * CB + jb]),
                           _lib.ptr(ws.TH[l * CB + jb]) if save_ts else None,
                           _lib.ptr(ws.SG[l * CB + jb]) if save_ts else None,
-                          _lib.ptr(w['wf'][i0 * CH * C + jb * CH:]),
-                          _lib.ptr(w['wg'][i0 * CH * C + jb * CH:]),
+                          _lib.ptr(w['wf'][wo:]), _lib.ptr(w['wg'][wo:]),
                           C, _lib.ptr(bf), _lib.ptr(bg), bstride, B, T, int(d),
-                          K, 1 if save_ts else 0, C,
+                          nk, 1 if save_ts else 0, C,
                           _lib.ptr(ws.pre) if ci > 0 else None,
-                          None if last else _lib.ptr(ws.pre), pstride, st)
+                          None if last else _lib.ptr(ws.pre), pstride, k0, K,
+                          st)
         if l == L - 1:
             break
         # x_{l+1} = x_l + z_l Wd (+ bd)   model.py:294-300,330 -- ONE plane-mode
@@ -124,10 +134,13 @@ def backward_layers(net, ws, ids, st):
         # ---- gate gradients of every dilation-channel block
         for jb in range(CB):
             dz = ws.dZ[l * CB + jb] if dxin is None else ws.dzb[jb]
+            # (gate gradients only: the filter width just sizes a weight
+            # staging area this mode does not read)
             _lib.call('wn_layer_bwd_k', None, None, None, None, None,
                       _lib.ptr(dz), _lib.ptr(ws.TH[l * CB + jb]),
                       _lib.ptr(ws.SG[l * CB + jb]), _lib.ptr(w['all']),
-                      _lib.ptr(daf[jb]), _lib.ptr(dag[jb]), B, T, d, K, 0, 1, st)
+                      _lib.ptr(daf[jb]), _lib.ptr(dag[jb]), B, T, d,
+                      min(K, 8), 0, 1, st)
             if ws.dsum is not None:
                 _lib.call('wn_colsum_clip', _lib.ptr(daf[jb]), _lib.ptr(dag[jb]),
                           B, T, _lib.ptr(ws.dsum_part), _lib.ptr(ws.cs_tmp), st)
@@ -135,30 +148,35 @@ def backward_layers(net, ws, ids, st):
                 dv[:, 0, jb].copy_(ws.cs_tmp[:, :CH])
                 dv[:, 1, jb].copy_(ws.cs_tmp[:, CH:])
         # ---- weight gradients per (input block a, output block b) pair into
-        # the pair's slab region, then ONE fixed-order reduction per layer that
-        # writes the [K][C][C] / [C][C] matrices and the bias vectors directly
-        for a in range(CB):
-            for b in range(CB):
-                _lib.call('wn_layer_wgrad_k', _lib.ptr(ws.X[l * CB + a]),
-                          _lib.ptr(daf[b]), _lib.ptr(dag[b]),
-                          None if dxin is None else _lib.ptr(ws.Z[l * CB + a]),
-                          None if dxin is None else _lib.ptr(dxin[b]),
-                          _lib.ptr(ws.pslabs[a * CB + b]), nslab, B, T, d, K, st)
-        _lib.call('wn_reduce_pair_slabs', _lib.ptr(ws.pslabs), nslab, CB, K,
-                  0 if dxin is None else 1, 1 if ub else 0, _lib.ptr(g['all']),
-                  C, net.OFF_BF, st)
+        # the pair's slab region, then ONE fixed-order reduction per layer (and
+        # group of 8 taps) that writes the [K][C][C] / [C][C] matrices and the
+        # bias vectors directly
+        flat = ws.pslabs.view(-1)
+        for k0, nk in _tap_groups(K):
+            dense = dxin is not None and k0 == 0
+            per_pair = nslab * ((2 * nk + 1) * 1024 + 96)
+            for a in range(CB):
+                for b in range(CB):
+                    _lib.call('wn_layer_wgrad_k', _lib.ptr(ws.X[l * CB + a]),
+                              _lib.ptr(daf[b]), _lib.ptr(dag[b]),
+                              _lib.ptr(ws.Z[l * CB + a]) if dense else None,
+                              _lib.ptr(dxin[b]) if dense else None,
+                              _lib.ptr(flat[(a * CB + b) * per_pair:]), nslab,
+                              B, T, d, nk, k0, K, st)
+            _lib.call('wn_reduce_pair_slabs', _lib.ptr(flat), nslab, CB, nk,
+                      1 if dense else 0, 1 if (ub and k0 == 0) else 0,
+                      _lib.ptr(g['all']), C, net.OFF_BF, k0, K, st)
         # ---- dx of every residual-channel block
         dxo = ws.dx[xp]
         for rb in range(CB):
             # dilation blocks in chunks: a chunk's dx is the next one's dxin
-            for ci, (j0, nb) in enumerate(_chunks(CB, K)):
+            for ci, (k0, nk, j0, nb) in enumerate(_chunks(CB, K)):
                 src = dxo[rb] if ci > 0 else (None if dxin is None else dxin[rb])
+                wo = k0 * M + rb * CH * C + j0 * CH
                 _lib.call('wn_layer_bwd_blk', _lib.ptr(daf[j0]),
                           _lib.ptr(dag[j0]), pstride, nb, _lib.ptr(src),
-                          _lib.ptr(dxo[rb]),
-                          _lib.ptr(w['wf'][rb * CH * C + j0 * CH:]),
-                          _lib.ptr(w['wg'][rb * CH * C + j0 * CH:]), C, M, B, T,
-                          d, K, st)
+                          _lib.ptr(dxo[rb]), _lib.ptr(w['wf'][wo:]),
+                          _lib.ptr(w['wg'][wo:]), C, M, B, T, d, nk, k0, K, st)
         dxin, xp = dxo, 1 - xp
     sp = ws.splits['causal']
     if net.scalar_input:

@@ -111,7 +111,7 @@ class _Workspace(object):
         alloc('loss_parts', (2 + self.nparts,), fill=0.0)
         alloc('loss', (1,), fill=0.0)
         alloc('proba', (Q,))
-        if CB > 1:
+        if net.blocked:
             # partial pre-activations of a layer wider than one chunk of
             # channel blocks (wavenet/blocked.py), planes af | ag
             alloc('pre', (2, N, CH))
@@ -135,7 +135,7 @@ class _Workspace(object):
         # ping-pong planes are not enough), its flags and control block
         # (allocated whenever the option could apply, so that switching
         # `layer_bwd` / `fused_bwd` back and forth keeps one behaviour)
-        self.stack_bwd = (net.stack_bwd and CB == 1 and not net.generic_layers
+        self.stack_bwd = (net.stack_bwd and not net.blocked and not net.generic_layers
                           and L <= 256 and N * CH * 4 < 2 ** 31)
         if self.stack_bwd:
             alloc('DX', (L, N, CH))
@@ -147,7 +147,7 @@ class _Workspace(object):
             # buffers owns fresh flags (all 0): its epoch must start at 1 too
             if 'stack_ctl_b' in fresh:
                 self.stack_ctl_b[2] = 1
-        if CB > 1:                       # channel-block path scratch
+        if net.blocked:                  # channel-block path scratch
             alloc('dzb', (CB, N, CH))
             alloc('wdT', (CHn, CHn))
             alloc('blk_tmp', (max((2 * net.KW + 1) * 1024 + 96, Q * CH,
@@ -162,11 +162,12 @@ class _Workspace(object):
         self.nslab_2 = lib.wn_layer_bwd2_slabs(B, T)
         self.nslab_s = lib.wn_stack_bwd_slabs(B, T) if self.stack_bwd else 0
         alloc('wimg', (L, lib.wn_layer_bwd2_wimg_floats()))
-        if CB > 1:
+        if net.blocked:
             # channel-block path: one slab region per (input, output) block
             # pair of ONE layer (wavenet/blocked.py); the per-layer slabs of the
             # 32-channel kernels are not used
-            alloc('pslabs', (CB * CB, self.nslab, (2 * net.KW + 1) * 1024 + 96))
+            alloc('pslabs', (CB * CB, self.nslab,
+                             (2 * min(net.KW, 8) + 1) * 1024 + 96))
             alloc('lslabs', (1, 1, 4))
         else:
             alloc('lslabs', (L, max(self.nslab, self.nslab_f, self.nslab_2,
@@ -310,8 +311,10 @@ class WaveNetModel(object):
         self.G = global_condition_channels
         self.card = global_condition_cardinality
         self._unsupported = None
-        if filter_width < 2 or filter_width > 8:
-            self._unsupported = 'filter_width must be in [2, 8] on the HIP path'
+        if filter_width < 2 or filter_width > 64:
+            # (above 8 the layers run in groups of 8 taps, wavenet/blocked.py;
+            # tested at 11 and 19)
+            self._unsupported = 'filter_width must be in [2, 64] on the HIP path'
         elif max(self.R, self.D) > 1024:
             # channel-block kernels (wavenet/blocked.py): 32-wide blocks, in
             # chunks of 8 // filter_width blocks per kernel call; tested up to
@@ -331,6 +334,9 @@ class WaveNetModel(object):
         # K = 2 runs the tuned kernels; other widths (or forcing it, for
         # tests) the generic-tap kernels
         self.generic_layers = K != 2
+        # channel-block kernels (wavenet/blocked.py): more than 32 channels, or
+        # a filter wider than the generic-tap kernels' 8 taps
+        self.blocked = self.CB > 1 or K > 8
         self.LAYER_W = layer_w(K, C)
         self.OFF_BF = self.LAYER_W
         self.OFF_BG = self.LAYER_W + C
@@ -551,7 +557,7 @@ class WaveNetModel(object):
 
     def _legacy_bwd(self):
         return (self.layer_bwd != 'bwd2' or not self.fused_bwd
-                or self.generic_layers or self.overlap_wgrad or self.CB > 1)
+                or self.generic_layers or self.overlap_wgrad or self.blocked)
 
     def check_device_errors(self):
         """Raise if a persistent stack launch recorded an expired dependency
@@ -583,7 +589,7 @@ class WaveNetModel(object):
         """True when the training forward runs the persistent stack launch and
         the backward will too: wn_stack_pack then writes both weight images in
         the forward's launch (the parameters do not change in between)."""
-        return bool(self.stack_fwd and self.CB == 1 and not self.generic_layers
+        return bool(self.stack_fwd and not self.blocked and not self.generic_layers
                     and self.L <= 256 and not self._legacy_bwd()
                     and self._stack_bwd_ok() and getattr(ws, 'stack_bwd', False)
                     and getattr(ws, 'wimg_b', None) is not None)
@@ -742,7 +748,7 @@ class WaveNetModel(object):
 
     def _backward(self, ws, ids):
         ids = self._stage_ids(ws, ids)
-        if not self.use_launch_plans or self.overlap_wgrad or self.CB > 1:
+        if not self.use_launch_plans or self.overlap_wgrad or self.blocked:
             # (side stream with torch events / the channel-block path, whose
             # gradient-block copies are torch ops a launch plan cannot replay)
             return self._backward_eager(ws, ids)
@@ -777,10 +783,10 @@ class WaveNetModel(object):
                           _lib.ptr(wc[cb * CH:]), _lib.ptr(ws.X[cb]), B, T, Q,
                           self.KW, self.CHn, st)
         bias, bstride = self._bias_fg(ws.bias_fg, ids, B)
-        if self.CB > 1:
+        if self.blocked:
             from . import blocked
             blocked.forward_layers(self, ws, bias, bstride, bool(save_ts), st)
-        stack = (self.stack_fwd and self.CB == 1 and not self.generic_layers
+        stack = (self.stack_fwd and not self.blocked and not self.generic_layers
                  and save_ts in (0, 2) and L <= 256)
         if stack:
             # all L layers in one persistent launch (csrc/wn_stack.hip)
@@ -800,7 +806,7 @@ class WaveNetModel(object):
                       _lib.ptr(ws.stack_flags), _lib.ptr(ws.stack_ctl),
                       _lib.ptr(ws.loss_parts),
                       L, B, T, 1 if save_ts else 0, st)
-        for l, d in enumerate(self.dilations if self.CB == 1 and not stack
+        for l, d in enumerate(self.dilations if not self.blocked and not stack
                               else []):
             last = l == L - 1
             fargs = (_lib.ptr(ws.X[l]),
@@ -925,7 +931,7 @@ class WaveNetModel(object):
         self._nn(_lib.ptr(ws.dtotal), S, 0, 0, _lib.ptr(ws.wst),
                   L * C, None, None, 0, None, 0, _lib.ptr(ws.dZ), 0, LP,
                   N * CH, None, N, L * C, S, 0, st)
-        if self.CB > 1:
+        if self.blocked:
             # channel-block path: residual stack, causal layer and global
             # conditioning gradients (wavenet/blocked.py)
             from . import blocked
@@ -984,7 +990,8 @@ class WaveNetModel(object):
 
         def layer_wgrad(*a):         # (..., nslab, B, T, d, stream)
             if gen:
-                _lib.call('wn_layer_wgrad_k', *a[:10], self.KW, a[10])
+                _lib.call('wn_layer_wgrad_k', *a[:10], self.KW, 0, self.KW,
+                          a[10])
             else:
                 _lib.call('wn_layer_wgrad', *a)
         cur = 0

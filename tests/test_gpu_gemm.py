@@ -359,7 +359,7 @@ def test_reduce_pair_slabs(hip_lib, CB, K, dense, ub):
     st = torch.cuda.current_stream().cuda_stream
     for t in (g, g2):
         _lib.call('wn_reduce_pair_slabs', d.data_ptr(), ns, CB, K, dense, ub, t.data_ptr(),
-                  C, off_b, st)
+                  C, off_b, 0, K, st)
     assert torch.equal(g, g2)
     tot = slabs.astype(np.float64).sum(1)                    # [pair][WF + 96]
     want = np.full(off_b + 3 * C, 7.0)
@@ -374,3 +374,17 @@ def test_reduce_pair_slabs(hip_lib, CB, K, dense, ub):
                     want[off_b + q * C + b * 32:off_b + q * C + (b + 1) * 32] = \
                         tot[b, WF + q * 32:WF + (q + 1) * 32]
     assert np.abs(g.cpu().numpy() - want).max() < 1e-4
+    # a group of taps of a wider filter: taps 3 .. 3 + K - 1 of K + 5
+    Kt = K + 5
+    off_t = (2 * Kt + 1) * C * C
+    gt = torch.full((off_t + 3 * C,), 7.0, device='cuda')
+    _lib.call('wn_reduce_pair_slabs', d.data_ptr(), ns, CB, K, 0, 0, gt.data_ptr(), C,
+              off_t, 3, Kt, st)
+    wt = np.full(off_t + 3 * C, 7.0)
+    mt = wt[:off_t].reshape(2 * Kt + 1, C, C)
+    for a in range(CB):
+        for b in range(CB):
+            blk = tot[a * CB + b, :WF].reshape(2 * K + 1, 32, 32)
+            mt[3:3 + K, a * 32:(a + 1) * 32, b * 32:(b + 1) * 32] = blk[:K]
+            mt[Kt + 3:Kt + 3 + K, a * 32:(a + 1) * 32, b * 32:(b + 1) * 32] = blk[K:2 * K]
+    assert np.abs(gt.cpu().numpy() - wt).max() < 1e-4

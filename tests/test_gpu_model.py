@@ -109,6 +109,11 @@ CASES = [
     ('r288_d320', cfg_with(TINY, batch_size=1, residual_channels=288,
                            dilation_channels=320, skip_channels=32,
                            quantization_channels=32), 40, False, None),
+    # filter widths above 8: groups of 8 taps (wavenet/blocked.py)
+    ('k11', cfg_with(TINY, batch_size=2, filter_width=11), 120, False, None),
+    ('k19_r64_d40', cfg_with(TINY, batch_size=1, filter_width=19,
+                             residual_channels=64, dilation_channels=40),
+     150, False, None),
     ('r64_k5', cfg_with(TINY, batch_size=1, residual_channels=64,
                         dilation_channels=48, filter_width=5), 90, False, None),
     ('scalar_r64_d40', cfg_with(TINY, batch_size=2, scalar_input=True,
@@ -537,7 +542,7 @@ def test_fast_generation_above_32_channels(hip_lib, name, cfg, gc):
 
 def test_unsupported_configs_raise(hip_lib):
     from wavenet import WaveNetModel
-    for kw in (dict(filter_width=9), dict(residual_channels=1025),
+    for kw in (dict(filter_width=65), dict(residual_channels=1025),
                dict(dilation_channels=1200)):
         cfg = cfg_with(TINY, batch_size=1, **kw)
         net = WaveNetModel(**model_kwargs(cfg))

@@ -140,22 +140,25 @@ __device__ __forceinline__ void wait_flags(const unsigned* fl, int idx,
 // image: `wt_lane` = image + i * SF_LD + 4 * h; the four operands of
 // r = 4q .. 4q+3 (cin = 8q + 4h + e) are one 16-byte LDS read.  Same MFMA order
 // as mma32 (bitwise the same result).
-__device__ __forceinline__ void mma32t(f32x16& acc, const f32x16& frag,
-                                       const float* wt_lane) {
-  // chunk q + 1 is requested before the MFMAs of chunk q, order pinned (left
-  // alone the compiler reads two chunks, waits, issues eight MFMAs: B = 8
-  // 829 -> 810 us)
-  f32x4 nxt = *reinterpret_cast<const f32x4*>(wt_lane);
+// Chunk q + 1 is requested before the MFMAs of chunk q, order pinned (left
+// alone the compiler reads two chunks, waits, issues eight MFMAs: B = 8 829 ->
+// 810 us).  The matrix's first chunk arrives in `pre`; the first chunk of the
+// NEXT matrix (`wt_next`) is requested before this one's last MFMAs.
+__device__ __forceinline__ void mma32t_chain(f32x16& acc, const f32x16& frag,
+                                             const float* wt_lane, f32x4& pre,
+                                             const float* wt_next) {
+  f32x4 nxt = pre;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const f32x4 a4 = nxt;
-    if (q < 3) nxt = *reinterpret_cast<const f32x4*>(wt_lane + 8 * (q + 1));
+    nxt = *reinterpret_cast<const f32x4*>(q < 3 ? wt_lane + 8 * (q + 1) : wt_next);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int e = 0; e < 4; ++e)
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], frag[4 * q + e], acc, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
   }
+  pre = nxt;
 }
 
 // blockIdx.y == 0: forward image (transposed, + dense bias); 1: backward image
@@ -309,8 +312,11 @@ __global__ __launch_bounds__(WAVES * 64) void stack_fwd_kernel(StackFwd a) {
       // (-DSTACK_NOMMA / -DSTACK_NOACT: timing-only ablation builds, see
       // DESIGN.md 3a; their results are meaningless)
 #ifndef STACK_NOMMA
-      mma32t(af, xc, wlane + 1 * SF_MT);  // Wf[1]: current tap
-      mma32t(ag, xc, wlane + 3 * SF_MT);  // Wg[1]
+      // (the first chunk of each weight matrix is requested during the matrix
+      // before it: 777 -> 772 us)
+      f32x4 wpre = *reinterpret_cast<const f32x4*>(wlane + 1 * SF_MT);
+      mma32t_chain(af, xc, wlane + 1 * SF_MT, wpre, wlane + 3 * SF_MT);  // Wf[1]: current tap
+      mma32t_chain(ag, xc, wlane + 3 * SF_MT, wpre, wlane + 0 * SF_MT);  // Wg[1]
 #endif
       if (__builtin_amdgcn_ballot_w64(fval != epoch) != 0)
         wait_flags(a.flags + (size_t)l * ntiles, fidx, epoch, a.ctl, a.poison, dead, lane);
@@ -337,8 +343,8 @@ __global__ __launch_bounds__(WAVES * 64) void stack_fwd_kernel(StackFwd a) {
 #endif
       SSTAMP(l, 3);
 #ifndef STACK_NOMMA
-      mma32t(af, xp, wlane + 0 * SF_MT);  // Wf[0]: past tap
-      mma32t(ag, xp, wlane + 2 * SF_MT);  // Wg[0]
+      mma32t_chain(af, xp, wlane + 0 * SF_MT, wpre, wlane + 2 * SF_MT);  // Wf[0]: past tap
+      mma32t_chain(ag, xp, wlane + 2 * SF_MT, wpre, wlane + 4 * SF_MT);  // Wg[0]
 #else
 #pragma unroll
       for (int r = 0; r < 16; ++r) { af[r] += xp[r] * wlane[0]; ag[r] += xc[r] * wlane[SF_MT]; }
@@ -360,7 +366,7 @@ __global__ __launch_bounds__(WAVES * 64) void stack_fwd_kernel(StackFwd a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) xc[r] += bd[r];
 #ifndef STACK_NOMMA
-        mma32t(xc, zz, wlane + 4 * SF_MT);  // Wd
+        mma32t_chain(xc, zz, wlane + 4 * SF_MT, wpre, wlane + 4 * SF_MT);  // Wd
 #else
 #pragma unroll
         for (int r = 0; r < 16; ++r) xc[r] += zz[r] * wlane[4 * SF_MT];

@@ -527,6 +527,26 @@ __device__ __forceinline__ void mma32s(f32x16& acc, const f32x16& frag,
   }
 }
 
+// the same for a matrix whose first chunk is already in `pre`; the first chunk
+// of the NEXT matrix is requested before this one's last MFMAs
+__device__ __forceinline__ void mma32s_chain(f32x16& acc, const f32x16& frag,
+                                             const float* mat, int off0, f32x4& pre,
+                                             const float* next_mat) {
+  f32x4 nxt = pre;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 a4 = nxt;
+    nxt = *reinterpret_cast<const f32x4*>(q < 3 ? mat + (off0 ^ ((q + 1) << 3))
+                                                : next_mat + off0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      acc = sb_mfma(a4[e], frag[4 * q + e], acc);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  pre = nxt;
+}
+
 // Transposed products from LDS tiles (weight gradients): acc0 += A0^T B,
 // acc1 += A1^T B over the 32 rows of the tiles, bsum += column sums of B.
 // Element [row = 2 s + h][channel = lane j] of the wave's tile T (swizzled
@@ -856,8 +876,10 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
 #else
           gate_grad(dz, zz, ss, df, dg);
 #endif
-          mma32s(dx, df, wm + 1 * 1024, woff);      // da_f[t] * Wf[1]^T
-          mma32s(dx, dg, wm + 3 * 1024, woff);      // da_g[t] * Wg[1]^T
+          // (Wg's first chunk requested during Wf's last MFMAs: 1637 -> 1622 us)
+          f32x4 wpre = *reinterpret_cast<const f32x4*>(wm + 1 * 1024 + woff);
+          mma32s_chain(dx, df, wm + 1 * 1024, woff, wpre, wm + 3 * 1024);  // da_f[t] * Wf[1]^T
+          mma32s_chain(dx, dg, wm + 3 * 1024, woff, wpre, wm + 3 * 1024);  // da_g[t] * Wg[1]^T
           frag_to_lds(t2, j, h, df);                 // t2 now holds da_f[t]
         }
         if (tile == tbase + wave) { BSTAMP(l, 8); }
@@ -934,8 +956,9 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
 #else
           gate_grad(dz, zz, ss, df, dg2);
 #endif
-          mma32s(dx, df, wm + 0 * 1024, woff);          // da_f[t+d] * Wf[0]^T
-          mma32s(dx, dg2, wm + 2 * 1024, woff);         // da_g[t+d] * Wg[0]^T
+          f32x4 wpre = *reinterpret_cast<const f32x4*>(wm + 0 * 1024 + woff);
+          mma32s_chain(dx, df, wm + 0 * 1024, woff, wpre, wm + 2 * 1024);   // da_f[t+d] * Wf[0]^T
+          mma32s_chain(dx, dg2, wm + 2 * 1024, woff, wpre, wm + 2 * 1024);  // da_g[t+d] * Wg[0]^T
         }
         if (dead) dx[0] = __builtin_nanf("");        // a wait expired: NaN gradients
         frag_to_lds(t2, j, h, dx);

@@ -231,7 +231,7 @@ int wn_stack_fwd(float* X, float* Z, float* SG, const float* wimg,
                  void* stream);
 int wn_stack_bwd_slabs(int B, int T);
 int wn_stack_bwd(const float* X, const float* Z, const float* SG,
-                 const float* dZ, float* DX, const float* wimg, float* slabs,
+                 const float* dZ, float* DX, float* Q, const float* wimg, float* slabs,
                  long slab_layer_stride, float* tilesum, const int* dilations,
                  unsigned* flags, unsigned* ctl, float* poison, int L, int B,
                  int T, void* stream);

@@ -461,7 +461,8 @@ struct StackBwd {
   const float* Z;
   const float* SG;
   const float* dZ;
-  float* DX;           // [L][N][32]  DX[l] = dL/dx_l
+  float* DX;           // [L][N][32]  DX[l] = dL/dx_l (PUSH: without the tap's term, l > 0)
+  float* Q;            // [L][N][32]  PUSH: q_l[s] = da_l[s] W[0]^T, the term row s sends to row s - d
   const float* wimg;   // [L][STACK_WBUF] backward weight images (wn_stack_pack)
   float* slabs;        // [L][>= groups][LAYER_BLOCK_FLOATS]
   long slab_layer_stride;
@@ -646,7 +647,16 @@ __device__ __forceinline__ void tile_dma_rs(float* lds_tile, wn_rsrc_t rs, int s
   }
 }
 
-template <int WAVES>
+// PUSH (round 3, default): dx_l[t] = own_l[t] + q_l[t + d] with
+//   own_l[t] = dx_{l+1}[t] + da_l[t] W[1]^T   and   q_l[s] = da_l[s] W[0]^T.
+// A tile computes da for ITS OWN rows only and publishes q (what its rows
+// contribute to the rows d earlier) instead of every tile re-reading four
+// planes at rows t + d and re-deriving da there: per tile and layer one gate
+// evaluation instead of two, 160 instead of 176 MFMAs, 9 instead of 11 plane
+// passes through memory, and the hand-over is published in the middle of a
+// tile (before its weight-gradient products) instead of at its end.
+// !PUSH: the first formulation (kept for A/B: WN_STACK_BWD_PULL=1).
+template <int WAVES, bool PUSH>
 __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
   constexpr int SLAB = WAVES > 1 ? LAYER_BLOCK_FLOATS : 16;   // ordered-accumulation slab
   __shared__ __attribute__((aligned(1024))) float wl[2 * SB_WIMG];
@@ -714,9 +724,28 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
     WN_WAIT_VM0();
     __syncthreads();        // weights of the two top layers are in LDS
 
+    unsigned nfv_push = epoch;    // PUSH: flag value(s) requested ahead for the next tile
+    // lanes 0 / 1: index of the (at most two) flags the rows t + dd of tile tl
+    // wait for, -1 on the other lanes / when there is nothing to wait for
+    auto flag_idx2 = [&](int tl, int dd) -> int {
+      if (tl >= tend) return -1;
+      const int b = tl / tiles_per_clip;
+      const int tt = tl - b * tiles_per_clip;
+      const int tt0 = tt * 32;
+      const int hif = min(min(32, T - tt0), T - dd - tt0);
+      if (hif <= 0) return -1;
+      const int first = (tt0 + dd) >> 5, last = (tt0 + dd + hif - 1) >> 5;
+      int idx = -1;
+      if (lane == 0 && first != tt) idx = b * tiles_per_clip + first;
+      if (lane == 1 && last != first && last != tt) idx = b * tiles_per_clip + last;
+      return idx;
+    };
     for (int l = L - 1; l >= 0; --l) {
       const int d = a.dil[l];
       const bool hx = l + 1 < L;              // a gradient flows into x_{l+1}
+      const int dn = hx ? a.dil[l + 1] : 0;   // PUSH: the tap distance of dx_{l+1}
+      const wn_rsrc_t qin = plane_rsrc(PUSH ? a.Q + (size_t)(hx ? l + 1 : l) * a.plane : a.DX);
+      const wn_rsrc_t q_out = plane_rsrc(PUSH ? a.Q + (size_t)l * a.plane : a.DX);
       const wn_rsrc_t x = plane_rsrc(a.X + (size_t)l * a.plane);
       const wn_rsrc_t z = plane_rsrc(a.Z + (size_t)l * a.plane);
       const wn_rsrc_t sg = plane_rsrc(a.SG + (size_t)l * a.plane);
@@ -811,18 +840,38 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
         // above); the sigmoid rows travel in registers
         if (tile == tbase + wave) { BSTAMP(l, 11); }
         tile_dma_rs<0>(t0, z, off0, vswz, lane, 0, hi);
-        if (hx) tile_dma_rs<16>(t1, dxin, off0, vswz, lane, 0, hi);
+        if (hx && !PUSH) tile_dma_rs<16>(t1, dxin, off0, vswz, lane, 0, hi);
         tile_dma_rs<0>(t2, dZ, off0, vswz, lane, 0, hi);
         a3 = rows_ld<0>(sg, off0, vrow, lane, 0, hi);
         // this tile's tap flags: requested now, looked at after the rows-t math
         unsigned nfv = epoch;
-        {
+        if (!PUSH) {
           const int nidx = flag_idx(tile);
           if (nidx >= 0)
             nfv = __hip_atomic_load(fl_in + nidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (PUSH && hx) {
+          // complete dx_{l+1}[t] = own rows (this wave's store of the layer
+          // above) + q_{l+1}[t + dn] of the tiles d rows later, whose flags were
+          // requested during the previous tile (they published q in the
+          // middle of their tile of the layer above: normally long set)
+          a0 = rows_ld<16>(dxin, off0, vrow, lane, 0, hi);
+          const int hi_q = min(hi, T - dn - tt0);
+          if (hi_q > 0) {
+            const int idx = flag_idx2(tile, dn);
+            if (__builtin_amdgcn_ballot_w64(idx >= 0 && nfv_push != epoch) != 0)
+              wait_flags(fl_in, idx, epoch, a.ctl, a.poison, dead, lane);
+          }
+          a1 = rows_ld<16>(qin, off0 + dn * (WN_CH * 4), vrow, lane, 0, hi_q);
+        }
         if (tile == tbase + wave) { BSTAMP(l, 12); }
         WN_WAIT_VM0();
+        if (PUSH && hx) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) a0.v[c] += a1.v[c];
+          rows_to_lds(t1, lane, a0);
+          __builtin_amdgcn_wave_barrier();
+        }
         if (tile == tbase + wave) { BSTAMP(l, 14); }
         if (hx) {                                    // dWd += z^T dx_{l+1}
           // (operands of step s + 1 requested before the MFMA of step s,
@@ -878,14 +927,48 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
 #endif
           // (Wg's first chunk requested during Wf's last MFMAs: 1637 -> 1622 us)
           f32x4 wpre = *reinterpret_cast<const f32x4*>(wm + 1 * 1024 + woff);
-          mma32s_chain(dx, df, wm + 1 * 1024, woff, wpre, wm + 3 * 1024);  // da_f[t] * Wf[1]^T
-          mma32s_chain(dx, dg, wm + 3 * 1024, woff, wpre, wm + 3 * 1024);  // da_g[t] * Wg[1]^T
+          mma32s_chain(dx, df, wm + 1 * 1024, woff, wpre, PUSH ? wm + 0 * 1024 : wm + 3 * 1024);  // da_f[t] * Wf[1]^T
+          if (PUSH) {
+            // q_l[t] = da[t] W[0]^T, then own_l[t]: both to memory through t2
+            // before it takes da_f (a wave's DS operations run in order)
+            f32x16 qf = frag_zero();
+            mma32s_chain(qf, df, wm + 0 * 1024, woff, wpre, wm + 3 * 1024);  // da_f[t] * Wf[0]^T
+            mma32s_chain(dx, dg, wm + 3 * 1024, woff, wpre, wm + 2 * 1024);  // da_g[t] * Wg[1]^T
+            mma32s_chain(qf, dg, wm + 2 * 1024, woff, wpre, wm + 2 * 1024);  // da_g[t] * Wg[0]^T
+            if (dead) { qf[0] = __builtin_nanf(""); dx[0] = __builtin_nanf(""); }
+            frag_to_lds(t2, j, h, qf);
+            __builtin_amdgcn_wave_barrier();
+            rows_st<16>(q_out, off0, vrow, lane, hi, rows_from_lds(t2, lane));
+            __builtin_amdgcn_wave_barrier();
+            frag_to_lds(t2, j, h, dx);
+            __builtin_amdgcn_wave_barrier();
+            rows_st<16>(dx_out, off0, vrow, lane, hi, rows_from_lds(t2, lane));
+            __builtin_amdgcn_wave_barrier();
+          } else {
+            mma32s_chain(dx, dg, wm + 3 * 1024, woff, wpre, wm + 3 * 1024);  // da_g[t] * Wg[1]^T
+          }
           frag_to_lds(t2, j, h, df);                 // t2 now holds da_f[t]
         }
         if (tile == tbase + wave) { BSTAMP(l, 8); }
-        WN_WAIT_VM0();                               // x tiles in
-        // ---- the tap's rows: requested now, used after the weight gradients
-        load_shifted(tile, nfv);
+        WN_WAIT_VM0();                               // x tiles in (PUSH: q and own rows stored)
+        if (PUSH) {
+          if (lane == 0)
+            __hip_atomic_store(fl_out + tile, epoch, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+          // the flags the NEXT tile of this wave will look at: requested now
+          int ntile = tile + WAVES, nl = l;
+          if (ntile >= tend) { ntile = tbase + wave; nl = l - 1; }
+          nfv_push = epoch;
+          if (nl + 1 < L) {
+            const int nidx = flag_idx2(ntile, a.dil[nl + 1]);
+            if (nidx >= 0)
+              nfv_push = __hip_atomic_load(a.flags + (size_t)(nl + 1) * ntiles + nidx,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        } else {
+          // ---- the tap's rows: requested now, used after the weight gradients
+          load_shifted(tile, nfv);
+        }
         if (tile == tbase + wave) { BSTAMP(l, 10); }
         __builtin_amdgcn_wave_barrier();
         float tsf = 0.f, tsg = 0.f;          // this tile's column sums of da[t]
@@ -933,6 +1016,10 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
         }
         WN_WAIT_LGKM0();                     // the three tiles are free
         if (tile == tbase + wave) { BSTAMP(l, 13); }
+        if (PUSH) {
+          __builtin_amdgcn_wave_barrier();
+          continue;
+        }
         // ---- rows t+d -> LDS -> fragments -> the tap's half of dx
         if (hi_f > 0) {
           WN_WAIT_VM0();
@@ -1086,6 +1173,33 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
           __hip_atomic_store(s_ready + l - 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
       BSTAMP(l, 6);
+    }
+    if (PUSH) {
+      // dx_0[t] = own_0[t] + q_0[t + d_0]: completed in place for the causal
+      // layer's weight gradient (nobody reads DX[0] through a flag)
+      const int d0 = a.dil[0];
+      const wn_rsrc_t dx0 = plane_rsrc(a.DX), q0 = plane_rsrc(a.Q);
+      for (int tile = tbase + wave; tile < tend; tile += WAVES) {
+        const int b = tile / tiles_per_clip;
+        const int tt0 = (tile - b * tiles_per_clip) * 32;
+        const int hi = min(32, T - tt0);
+        const int hi_q = min(hi, T - d0 - tt0);
+        const int off0 = (b * T + tt0) * (WN_CH * 4);
+        RowRegs ro = rows_ld<16>(dx0, off0, vrow, lane, 0, hi);
+        if (hi_q > 0) {
+          const int idx = flag_idx2(tile, d0);
+          const bool ahead = tile == tbase + wave;      // (only the first one was requested ahead)
+          if (__builtin_amdgcn_ballot_w64(idx >= 0 && (!ahead || nfv_push != epoch)) != 0)
+            wait_flags(a.flags, idx, epoch, a.ctl, a.poison, dead, lane);
+          const RowRegs rq = rows_ld<16>(q0, off0 + d0 * (WN_CH * 4), vrow, lane, 0, hi_q);
+          WN_WAIT_VM0();
+#pragma unroll
+          for (int c = 0; c < 4; ++c) ro.v[c] += rq.v[c];
+        }
+        WN_WAIT_VM0();
+        if (dead) ro.v[0][0] = __builtin_nanf("");
+        rows_st<0>(dx0, off0, vrow, lane, hi, ro);
+      }
     }
     if (WAVES > 1 && wave == 0) {          // the bottom layer's finished slab (position 0 is wave 0 in every order)
       const int e0 = 4 * h * 32 + j;
@@ -1253,7 +1367,7 @@ int wn_stack_bwd_slabs(int B, int T) {
 }
 
 int wn_stack_bwd(const float* X, const float* Z, const float* SG,
-                 const float* dZ, float* DX, const float* wimg, float* slabs,
+                 const float* dZ, float* DX, float* Q, const float* wimg, float* slabs,
                  long slab_layer_stride, float* tilesum, const int* dilations,
                  unsigned* flags, unsigned* ctl, float* poison, int L, int B,
                  int T, void* stream) {
@@ -1267,13 +1381,14 @@ int wn_stack_bwd(const float* X, const float* Z, const float* SG,
   const void* ptrs[] = {X, Z, SG, dZ, DX, wimg};
   for (const void* p : ptrs)
     if (!wn_aligned16(p)) return WN_ERR_MISALIGNED;
+  if (Q && !wn_aligned16(Q)) return WN_ERR_MISALIGNED;
   int waves, tpw;
   stack_bwd_shape(B, T, &waves, &tpw);
   const long ntiles = (long)B * ((T + 31) / 32);
   const long groups = (ntiles + (long)waves * tpw - 1) / ((long)waves * tpw);
   if (slab_layer_stride < groups * LAYER_BLOCK_FLOATS) return WN_ERR_BAD_SHAPE;
   StackBwd a;
-  a.X = X; a.Z = Z; a.SG = SG; a.dZ = dZ; a.DX = DX; a.wimg = wimg;
+  a.X = X; a.Z = Z; a.SG = SG; a.dZ = dZ; a.DX = DX; a.Q = Q; a.wimg = wimg;
   a.slabs = slabs; a.slab_layer_stride = slab_layer_stride; a.tilesum = tilesum;
   a.dil = dilations; a.flags = flags; a.ctl = ctl; a.poison = poison;
   a.L = L; a.B = B; a.T = T;
@@ -1285,12 +1400,22 @@ int wn_stack_bwd(const float* X, const float* Z, const float* SG,
   const int cus = wn_device_cus();
   dim3 grid((unsigned)(groups < cus ? groups : cus)), block(waves * 64);
   hipStream_t s = (hipStream_t)stream;
+  // Q (an [L][N][32] scratch like DX): the "push" formulation; without it (or
+  // with WN_STACK_BWD_PULL=1, for A/B) the first, "pull" one
+  const char* pe = getenv("WN_STACK_BWD_PULL");
+  const bool push = Q != nullptr && !(pe && pe[0] == '1');
+#define LAUNCH(W)                                                               \
+  do {                                                                          \
+    if (push) hipLaunchKernelGGL((stack_bwd_kernel<W, true>), grid, block, 0, s, a);   \
+    else hipLaunchKernelGGL((stack_bwd_kernel<W, false>), grid, block, 0, s, a);       \
+  } while (0)
   switch (waves) {
-    case 8: hipLaunchKernelGGL((stack_bwd_kernel<8>), grid, block, 0, s, a); break;
-    case 4: hipLaunchKernelGGL((stack_bwd_kernel<4>), grid, block, 0, s, a); break;
-    case 2: hipLaunchKernelGGL((stack_bwd_kernel<2>), grid, block, 0, s, a); break;
-    default: hipLaunchKernelGGL((stack_bwd_kernel<1>), grid, block, 0, s, a); break;
+    case 8: LAUNCH(8); break;
+    case 4: LAUNCH(4); break;
+    case 2: LAUNCH(2); break;
+    default: LAUNCH(1); break;
   }
+#undef LAUNCH
   return wn_check_launch();
 }
 

@@ -139,6 +139,9 @@ class _Workspace(object):
                           and L <= 256 and N * CH * 4 < 2 ** 31)
         if self.stack_bwd:
             alloc('DX', (L, N, CH))
+            # q_l planes of the "push" formulation: what a tile's rows send to
+            # the rows d earlier (csrc/wn_stack.hip)
+            alloc('DQ', (L, N, CH))
             alloc('wimg_b', (L, lib.wn_stack_wimg_floats()))
             alloc('stack_flags_b', (lib.wn_stack_flag_count(B, T, L),),
                   torch.int32, fill=0)
@@ -953,7 +956,7 @@ class WaveNetModel(object):
                               self.layer_stride, None, _lib.ptr(ws.wimg_b), L, st)
                 _lib.call('wn_stack_bwd', _lib.ptr(ws.X), _lib.ptr(ws.Z),
                           _lib.ptr(ws.SG), _lib.ptr(ws.dZ), _lib.ptr(ws.DX),
-                          _lib.ptr(ws.wimg_b), _lib.ptr(ws.lslabs),
+                          _lib.ptr(ws.DQ), _lib.ptr(ws.wimg_b), _lib.ptr(ws.lslabs),
                           ws.lslabs.shape[1] * self.LAYER_BLOCK,
                           None if tsum is None else _lib.ptr(tsum),
                           _lib.ptr(self._dil_dev), _lib.ptr(ws.stack_flags_b),

@@ -113,6 +113,13 @@ def _f64_layer_grads(net, ws, l):
     dxn = None
     if l + 1 < L:
         dxn = f(ws.DX[l + 1])
+        if getattr(ws, 'DQ', None) is not None and os.environ.get('WN_STACK_BWD_PULL') != '1':
+            # "push" formulation: DX[l+1] holds dx_{l+1} without the term of
+            # the tap, which sits in DQ[l+1] at the rows d_{l+1} later
+            dd = int(net.dilations[l + 1])
+            dxn = dxn.clone()
+            if dd < T:
+                dxn[:, :T - dd] += f(ws.DQ[l + 1])[:, dd:]
         dz = dz + dxn @ Wd.t()
     th = torch.where(SG > 1e-30, Z / SG.clamp_min(1e-30), torch.zeros_like(Z))
     da_f = dz * (SG - Z * th)
@@ -202,6 +209,34 @@ def test_stack_backward_equals_per_layer(hip_lib, name, mk, B, T, kind):
         prev = ga.clone()
         ctl = wa.stack_ctl_b.cpu().tolist()
         assert ctl[0] == 0 and ctl[1] == 0 and ctl[3] == 0 and ctl[2] == 2 + rep, ctl
+
+
+@pytest.mark.parametrize('name,mk,B,T,kind', CASES[1:6] + CASES[7:], ids=[c[0] for c in CASES[1:6] + CASES[7:]])
+def test_stack_backward_push_equals_pull(hip_lib, monkeypatch, name, mk, B, T, kind):
+    """The two formulations of the backward stack launch -- "push" (default: a
+    tile publishes what its rows contribute to the rows d earlier) and "pull"
+    (WN_STACK_BWD_PULL=1: every tile re-derives the gate gradients at the rows d
+    later) -- give the same gradients to rounding."""
+    cfg = mk()
+    audio = synth_audio(B, T)
+    gc = np.array([(37 * i) % 377 for i in range(B)], np.int32) if kind == 'gc' else None
+    grads = []
+    for pull in ('0', '1'):
+        monkeypatch.setenv('WN_STACK_BWD_PULL', pull)
+        net, _ = build_pair(cfg)
+        net.use_launch_plans = False
+        loss = net.loss(audio, global_condition_batch=gc) if gc is not None else net.loss(audio)
+        torch.cuda.synchronize()
+        ws = list(net._ws.values())[0]
+        if not ws.stack_bwd:
+            pytest.skip('configuration runs the generic backward kernels')
+        assert int(ws.stack_ctl_b[3]) == 0
+        grads.append((float(loss), net.grads.clone(), ws.DX[0].clone()))
+    assert grads[0][0] == grads[1][0]
+    sc = float(grads[1][1].abs().max())
+    assert float((grads[0][1] - grads[1][1]).abs().max()) <= 2e-6 * sc
+    sx = float(grads[1][2].abs().max())
+    assert float((grads[0][2] - grads[1][2]).abs().max()) <= 1e-5 * sx + 1e-30
 
 
 def test_child_workspace_owns_fresh_backward_control_block(hip_lib):

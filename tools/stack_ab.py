@@ -53,16 +53,23 @@ def main():
     st = _lib.stream()
     ptr = _lib.ptr
     libs = [(os.path.basename(q), open_lib(q)) for q in paths]
+    if os.environ.get('KB_PULL'):
+        # one library, both formulations of the backward stack (the launch
+        # reads WN_STACK_BWD_PULL): "pull" first = the reference of the diffs
+        lib = libs[0][1]
+        libs = [('pull', lib), ('push', lib)]
     nslab = max(l.wn_stack_bwd_slabs(B, T) for _, l in libs)
     slabs = torch.zeros(L, nslab, net.LAYER_BLOCK, device='cuda')
     wimg = torch.zeros(L, max(l.wn_stack_wimg_floats() for _, l in libs), device='cuda')
     bias = ws.bias_fg if net.use_biases else None
 
-    def run_bwd(lib):
+    def run_bwd(lib, name=''):
+        if os.environ.get('KB_PULL'):
+            os.environ['WN_STACK_BWD_PULL'] = '1' if name == 'pull' else '0'
         lib.wn_stack_pack(ptr(net._layer_block(P, 0)), net.layer_stride, None,
                           ptr(wimg), L, st)
         code = lib.wn_stack_bwd(ptr(ws.X), ptr(ws.Z), ptr(ws.SG), ptr(ws.dZ),
-                                ptr(ws.DX), ptr(wimg), ptr(slabs),
+                                ptr(ws.DX), ptr(ws.DQ), ptr(wimg), ptr(slabs),
                                 slabs.shape[1] * net.LAYER_BLOCK, None,
                                 ptr(net._dil_dev), ptr(ws.stack_flags_b),
                                 ptr(ws.stack_ctl_b), ptr(ws.loss_parts[1:]),
@@ -93,7 +100,7 @@ def main():
                 e1 = torch.cuda.Event(enable_timing=True)
                 torch.cuda.synchronize()
                 e0.record()
-                run(lib)
+                run(lib, n) if what == 'bwd' else run(lib)
                 e1.record()
                 torch.cuda.synchronize()
                 if r:

@@ -197,7 +197,15 @@ int wn_layer_bwd2(const float* x, const float* z, const float* sg,
  * dependency order, so the launch completes whatever the residency.
  *   X, Z, SG, dZ, DX : [L][B*T][32] planes, layer-major (X[0] = causal layer
  *                      output; forward writes X[1..L-1], Z, SG; backward reads
- *                      X, Z, SG, dZ and writes DX[l] = dL/dx_l for every l)
+ *                      X, Z, SG, dZ and writes DX: DX[0] = dL/dx_0; for
+ *                      l > 0 dL/dx_l when Q is NULL, else dL/dx_l WITHOUT the
+ *                      anti-causal tap's term, which is Q[l] at the rows d_l
+ *                      later)
+ *   Q                : NULL, or an [L][B*T][32] scratch like DX: the backward
+ *                      then runs its "push" formulation (a tile publishes
+ *                      q_l[s] = da_l[s] W[0]^T, what its rows contribute to the
+ *                      rows d earlier, instead of every tile re-deriving da at
+ *                      the rows d later; fewer bytes and MFMAs)
  *   wimg             : [L][wn_stack_wimg_floats()] weight images out of
  *                      wn_stack_pack (rows of 36 floats so that four MFMA
  *                      operands are one 16-byte LDS read; forward: the five

@@ -455,6 +455,14 @@ __global__ __launch_bounds__(WAVES * 64) void stack_fwd_kernel(StackFwd a) {
 // One slab per (layer, group).
 // ---------------------------------------------------------------------------
 #define SB_WIMG 5120                      // dense swizzled backward image (floats)
+// cache policy of a wave's own dx rows in the push formulation (store, load):
+// 0 = plain, 1 = sc0 (past the vector L1), 16 = sc1 (device scope)
+#ifndef SB_OWN_ST
+#define SB_OWN_ST 0
+#endif
+#ifndef SB_OWN_LD
+#define SB_OWN_LD 1
+#endif
 
 struct StackBwd {
   const float* X;      // [L][N][32]
@@ -855,7 +863,9 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
           // above) + q_{l+1}[t + dn] of the tiles d rows later, whose flags were
           // requested during the previous tile (they published q in the
           // middle of their tile of the layer above: normally long set)
-          a0 = rows_ld<16>(dxin, off0, vrow, lane, 0, hi);
+          // (own rows: this wave's own store of one layer ago, same CU, same
+          // L2 -- no device-scope access needed, only past the vector L1)
+          a0 = rows_ld<SB_OWN_LD>(dxin, off0, vrow, lane, 0, hi);
           const int hi_q = min(hi, T - dn - tt0);
           if (hi_q > 0) {
             const int idx = flag_idx2(tile, dn);
@@ -942,7 +952,7 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
             __builtin_amdgcn_wave_barrier();
             frag_to_lds(t2, j, h, dx);
             __builtin_amdgcn_wave_barrier();
-            rows_st<16>(dx_out, off0, vrow, lane, hi, rows_from_lds(t2, lane));
+            rows_st<SB_OWN_ST>(dx_out, off0, vrow, lane, hi, rows_from_lds(t2, lane));
             __builtin_amdgcn_wave_barrier();
           } else {
             mma32s_chain(dx, dg, wm + 3 * 1024, woff, wpre, wm + 3 * 1024);  // da_g[t] * Wg[1]^T
@@ -1185,7 +1195,7 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
         const int hi = min(32, T - tt0);
         const int hi_q = min(hi, T - d0 - tt0);
         const int off0 = (b * T + tt0) * (WN_CH * 4);
-        RowRegs ro = rows_ld<16>(dx0, off0, vrow, lane, 0, hi);
+        RowRegs ro = rows_ld<SB_OWN_LD>(dx0, off0, vrow, lane, 0, hi);
         if (hi_q > 0) {
           const int idx = flag_idx2(tile, d0);
           const bool ahead = tile == tbase + wave;      // (only the first one was requested ahead)

@@ -46,6 +46,7 @@
 // ds_read_b128 instead of four ds_read_b32 (row stride 36 floats: the eight
 // lanes of a 128-byte LDS beat hit 32 different banks), so a tile's 80 MFMAs
 // are fed by 20 LDS instructions.
+// (the z / sigmoid plane stores with an nt hint: 760 -> 772 us, not kept)
 #define SF_LD 36
 #define SF_MT (32 * SF_LD)
 #define SF_OFF_BD (5 * SF_MT)                // 5760
@@ -92,7 +93,8 @@ __device__ __forceinline__ RowRegs rows_load_dev(const float* tile0, int lane,
   return R;
 }
 
-__device__ __forceinline__ void rows_store_dev(float* tile0, int lane, int hi,
+template <int AUX>   // 16 = sc1 (device scope)
+__device__ __forceinline__ void rows_store_aux(float* tile0, int lane, int hi,
                                                const RowRegs& R) {
   __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)tile0, 0, 0x7fffffff, 0x00020000);
@@ -102,8 +104,12 @@ __device__ __forceinline__ void rows_store_dev(float* tile0, int lane, int hi,
     const int r = 8 * c + (lane >> 3);
     if (r < hi)
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, R.v[c]),
-                                             rs, vo + c * 1024, 0, 16);
+                                             rs, vo + c * 1024, 0, AUX);
   }
+}
+__device__ __forceinline__ void rows_store_dev(float* tile0, int lane, int hi,
+                                               const RowRegs& R) {
+  rows_store_aux<16>(tile0, lane, hi, R);
 }
 
 // poll until flag[idx] == epoch on every lane that has an idx >= 0
@@ -457,6 +463,10 @@ __global__ __launch_bounds__(WAVES * 64) void stack_fwd_kernel(StackFwd a) {
 #define SB_WIMG 5120                      // dense swizzled backward image (floats)
 // cache policy of a wave's own dx rows in the push formulation (store, load):
 // 0 = plain, 1 = sc0 (past the vector L1), 16 = sc1 (device scope)
+// (push) planes read exactly once per launch (z, dZ, sigmoid): 2 = nt hint
+#ifndef SB_STREAM
+#define SB_STREAM 2     // (1591 -> 1564 us)
+#endif
 #ifndef SB_OWN_ST
 #define SB_OWN_ST 0
 #endif
@@ -847,10 +857,10 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
         // ---- rows t (dx_{l+1}[t] is this wave's own store of the layer
         // above); the sigmoid rows travel in registers
         if (tile == tbase + wave) { BSTAMP(l, 11); }
-        tile_dma_rs<0>(t0, z, off0, vswz, lane, 0, hi);
+        tile_dma_rs<(PUSH ? SB_STREAM : 0)>(t0, z, off0, vswz, lane, 0, hi);
         if (hx && !PUSH) tile_dma_rs<16>(t1, dxin, off0, vswz, lane, 0, hi);
-        tile_dma_rs<0>(t2, dZ, off0, vswz, lane, 0, hi);
-        a3 = rows_ld<0>(sg, off0, vrow, lane, 0, hi);
+        tile_dma_rs<(PUSH ? SB_STREAM : 0)>(t2, dZ, off0, vswz, lane, 0, hi);
+        a3 = rows_ld<(PUSH ? SB_STREAM : 0)>(sg, off0, vrow, lane, 0, hi);
         // this tile's tap flags: requested now, looked at after the rows-t math
         unsigned nfv = epoch;
         if (!PUSH) {

@@ -1132,7 +1132,7 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
         if (m >= 2 && h == 0) pb = slab[LAYER_W_FLOATS + (m - 2) * 32 + j];
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          dst[m * 1024 + e0 + (8 * (r >> 2) + (r & 3)) * 32] = p[r];
+          dst[m * 1024 + e0 + (8 * (r >> 2) + (r & 3)) * 32] = p[r];   // (nt hint: no change)
         if (m >= 2 && h == 0) dst[LAYER_W_FLOATS + (m - 2) * 32 + j] = pb;
       };
       // position of this wave in the accumulation order (0, 4, 1, 5, ... --

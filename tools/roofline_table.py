@@ -29,6 +29,9 @@ FLOPS = {
     # dense 1x1: 64 instead of 80 MFMAs forward, 128 instead of 176 backward)
     'stack_fwd_kernel<2, 16>': N * (49 * 10240.0 + 8192.0),
     'stack_bwd_kernel<8>': N * (49 * 22528.0 + 16384.0),
+    # "push" formulation (round 3): 160 MFMA / tile, the algorithmic minimum
+    'stack_bwd_kernel<8, true>': N * (49 * 20480.0 + 16384.0),
+    'stack_bwd_kernel<8, false>': N * (49 * 22528.0 + 16384.0),
 }
 MFMA_PEAK, HBM_SPEC, HBM_STREAM = 157.3e12, 8.0e12, 5.3e12
 rows = list(csv.DictReader(open(os.path.join(ROOT, 'profiles', tag + '_bench_kernel_stats.csv'))))

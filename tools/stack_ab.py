@@ -3,6 +3,8 @@
 
     python tools/stack_ab.py [lib_a.so lib_b.so ...]     (default: build/ab/lib_*.so)
     KB_B=1 python tools/stack_ab.py ...                  (clips per batch)
+    KB_PULL=1 python tools/stack_ab.py lib.so            (one library: the "pull" and the
+                                                          "push" formulation of wn_stack_bwd)
 
 The planes the kernels read are produced once by the default library's own
 training step; every variant then runs pack + launch on the same inputs

@@ -79,6 +79,10 @@ for r in rows[:12]:
     else:
         mb = tb = f1 = f2 = '-'
     bound = 'MFMA' if k.startswith('gemm') else ('latency / MFMA' if k.startswith(('layer', 'stack')) else 'HBM')
+    if k.startswith('stack') and p and hb / avg / HBM_STREAM >= 0.8:
+        # a persistent stack launch that moves its bytes at >= 0.8 of what a
+        # streaming copy reaches on this part is bound by memory, not latency
+        bound = 'HBM (streaming rate) / MFMA issue'
     mu = ck = '-'
     for kk, v in mfma.items():
         if key(kk) == k and v.get('mfma_util') is not None:

@@ -420,6 +420,22 @@ def main():
     # (the committed PMC summary was collected at the default shape only)
     traffic, traffic_src = pmc_traffic(dom) if (B, T) == (8, 16000) \
         else (None, None)
+    # the two persistent residual-stack launches: HBM roofline (bytes per
+    # launch from the committed PMC summary, time live)
+    stacks = {}
+    for ev_name, kname in (('wn_stack_fwd', 'void stack_fwd_kernel<2, 16>'),
+                           ('wn_stack_bwd', 'void stack_bwd_kernel<8, true>')):
+        evs = [e for e in events if e[3] == ev_name]
+        if not evs:
+            continue
+        us = sum(e[0].elapsed_time(e[1]) for e in evs) / len(evs) * 1e3
+        by, src = pmc_traffic(kname) if (B, T) == (8, 16000) else (None, None)
+        stacks[ev_name] = {
+            'kernel': kname.replace('void ', ''), 'avg_launch_us': us,
+            'bound': 'hbm', 'traffic': by, 'traffic_source': src,
+            'achieved_tb_s': None if by is None else by / us / 1e6,
+            'frac_of_spec_8tb_s': None if by is None else by / us / 1e6 / 8.0,
+            'frac_of_streaming_5p3tb_s': None if by is None else by / us / 1e6 / 5.3}
     out = {
         'metric': 'audio samples/sec (train, default wavenet_params.json)',
         'value': value, 'unit': 'audio samples/s', 'n_gpus': world,
@@ -467,7 +483,8 @@ def main():
                          'frac': tn_flops / tn_time / 1e12 / peak
                          if tn_time > 0 else None,
                          'launches_per_step': len(tn) // isteps,
-                         'us_per_step': tn_time / isteps * 1e6}},
+                         'us_per_step': tn_time / isteps * 1e6},
+                     'stack_launches': stacks},
     }
     if world > 1:
         out['allreduce_us_per_step'] = ar_us

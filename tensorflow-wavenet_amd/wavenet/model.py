@@ -800,7 +800,8 @@ class WaveNetModel(object):
             _lib.call('wn_stack_pack', _lib.ptr(self._layer_block(P, 0)),
                       self.layer_stride, _lib.ptr(ws.wimg_f),
                       _lib.ptr(ws.wimg_b) if both else None, L, st)
-            _lib.call('wn_stack_fwd', _lib.ptr(ws.X), _lib.ptr(ws.Z),
+            # (flops 0: timed in bench.py's instrumented pass for its HBM roofline)
+            _lib.call_timed('wn_stack_fwd', (_lib.ptr(ws.X), _lib.ptr(ws.Z),
                       _lib.ptr(ws.SG) if save_ts else None,
                       _lib.ptr(ws.wimg_f),
                       None if bias is None else _lib.ptr(bias),
@@ -808,7 +809,8 @@ class WaveNetModel(object):
                       bstride, _lib.ptr(self._dil_dev),
                       _lib.ptr(ws.stack_flags), _lib.ptr(ws.stack_ctl),
                       _lib.ptr(ws.loss_parts),
-                      L, B, T, 1 if save_ts else 0, st)
+                      L, B, T, 1 if save_ts else 0, st), 0.0,
+                      getattr(self, '_gemm_events', None))
         for l, d in enumerate(self.dilations if not self.blocked and not stack
                               else []):
             last = l == L - 1
@@ -954,14 +956,16 @@ class WaveNetModel(object):
                 if not self._bwd_image_with_fwd(ws):
                     _lib.call('wn_stack_pack', _lib.ptr(self._layer_block(P, 0)),
                               self.layer_stride, None, _lib.ptr(ws.wimg_b), L, st)
-                _lib.call('wn_stack_bwd', _lib.ptr(ws.X), _lib.ptr(ws.Z),
-                          _lib.ptr(ws.SG), _lib.ptr(ws.dZ), _lib.ptr(ws.DX),
-                          _lib.ptr(ws.DQ), _lib.ptr(ws.wimg_b), _lib.ptr(ws.lslabs),
-                          ws.lslabs.shape[1] * self.LAYER_BLOCK,
-                          None if tsum is None else _lib.ptr(tsum),
-                          _lib.ptr(self._dil_dev), _lib.ptr(ws.stack_flags_b),
-                          _lib.ptr(ws.stack_ctl_b),
-                          _lib.ptr(ws.loss_parts[1:]), L, B, T, st)
+                _lib.call_timed('wn_stack_bwd', (
+                    _lib.ptr(ws.X), _lib.ptr(ws.Z),
+                    _lib.ptr(ws.SG), _lib.ptr(ws.dZ), _lib.ptr(ws.DX),
+                    _lib.ptr(ws.DQ), _lib.ptr(ws.wimg_b), _lib.ptr(ws.lslabs),
+                    ws.lslabs.shape[1] * self.LAYER_BLOCK,
+                    None if tsum is None else _lib.ptr(tsum),
+                    _lib.ptr(self._dil_dev), _lib.ptr(ws.stack_flags_b),
+                    _lib.ptr(ws.stack_ctl_b),
+                    _lib.ptr(ws.loss_parts[1:]), L, B, T, st), 0.0,
+                    getattr(self, '_gemm_events', None))
                 self._backward_tail(ws, ids, ws.DX[0], ws.nslab_s, True)
                 return
             # transposed weight images of all layers (the kernels DMA them

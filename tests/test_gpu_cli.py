@@ -164,6 +164,11 @@ def test_bench_line_carries_the_contract(hip_lib):
     assert rf['bound'] == 'mfma' and rf['peak'] == 157.3
     assert 0 < rf['frac'] < 1 and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9
     assert rf['launches_per_step'] == 6 and rf['tn_gemms']['launches_per_step'] == 3
+    # the two persistent stack launches are timed live too (their HBM bytes
+    # are quoted at the default shape only)
+    sl = rf['stack_launches']
+    assert sl['wn_stack_fwd']['avg_launch_us'] > 0 and sl['wn_stack_bwd']['avg_launch_us'] > 0
+    assert sl['wn_stack_bwd']['bound'] == 'hbm' and sl['wn_stack_bwd']['traffic'] is None
     assert 0 < r['step_frac'] < 1
     cb = r['cpu_baseline']
     assert cb['kind'] == 'port' and cb['cores'] >= 1 and cb['cpu_model']

@@ -287,6 +287,13 @@ int wn_reduce_slabs(const float* slabs, int num_slabs, long slab_stride,
                     int batch, long in_batch_stride, long offset, long n,
                     float* dst, long out_batch_stride, int replicate,
                     long rep_stride, void* stream);
+/* the slabs of one wn_gemm_tn in ONE launch: elements [0, n_main) of every
+ * slab (the matrix) -> dst_main, the n_tail elements behind them (column sums
+ * = bias gradient) -> dst_tail, `replicate` copies rep_stride floats apart.
+ * All counts / strides multiples of 4 floats, pointers 16-byte aligned. */
+int wn_reduce_slabs_mt(const float* slabs, int num_slabs, long slab_stride,
+                       long n_main, float* dst_main, long n_tail, float* dst_tail,
+                       int replicate, long rep_stride, void* stream);
 /* channel-block models (more than 32 residual / dilation channels,
  * model.py:46-60 puts no limit on them): the wn_layer_wgrad_k slabs of the
  * CB x CB block pairs of one layer, slabs[pair = a * CB + b][num_slabs]

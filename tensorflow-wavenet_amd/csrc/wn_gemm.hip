@@ -1365,6 +1365,51 @@ __global__ void reduce_slabs4_kernel(const float* __restrict__ slabs,
     *reinterpret_cast<f32x4*>(dst + (long)b * out_batch_stride + (long)r * rep_stride + 4 * e) = v;
 }
 
+// A weight-gradient GEMM's slabs in ONE launch: elements [0, n_main) of every
+// slab (the matrix) to dst_main, the n_tail elements behind them (the column
+// sums = bias gradient) to dst_tail, `replicate` copies rep_stride apart (the
+// skip convs' bias gradients are the same row for every layer).  Same fixed
+// order as reduce_slabs4<4>.
+__global__ __launch_bounds__(256) void reduce_slabs_mt_kernel(
+    const float* __restrict__ slabs, int num_slabs, long slab_stride, long n_main4,
+    float* __restrict__ dst_main, long n_tail4, float* __restrict__ dst_tail,
+    int replicate, long rep_stride) {
+  __shared__ f32x4 part[4][64];
+  const int col = threadIdx.x & 63, pt = threadIdx.x >> 6;
+  const long e = (long)blockIdx.x * 64 + col;
+  const long n4 = n_main4 + n_tail4;
+  const int per = (num_slabs + 3) / 4;
+  const int s0 = pt * per, s1 = min(num_slabs, s0 + per);
+  f32x4 acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (e < n4) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(slabs) + e;
+    const long st = slab_stride / 4;
+    int s = s0;
+    for (; s + 7 < s1; s += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = p[(long)(s + k) * st];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += v[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+      if (s + k < s1) acc[k] += p[(long)(s + k) * st];
+  }
+  part[pt][col] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  if (pt != 0 || e >= n4) return;
+  const f32x4 v = (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
+  if (e < n_main4) {
+    reinterpret_cast<f32x4*>(dst_main)[e] = v;
+  } else {
+    for (int r = 0; r < replicate; ++r)
+      *reinterpret_cast<f32x4*>(dst_tail + (long)r * rep_stride + 4 * (e - n_main4)) = v;
+  }
+}
+
 // Channel-block models (wavenet/blocked.py): the weight-gradient slabs of the
 // CB x CB (input block a, output block b) pairs of one layer,
 // slabs[pair][slab][(2K+1) * 1024 + 96] (wn_layer_wgrad_k's layout: Wf taps,
@@ -1788,6 +1833,23 @@ int wn_reduce_slabs(const float* slabs, int num_slabs, long slab_stride,
   hipLaunchKernelGGL(reduce_slabs_kernel, grid, block, 0, (hipStream_t)stream,
                      slabs, num_slabs, slab_stride, in_batch_stride, offset, n,
                      dst, out_batch_stride, replicate, rep_stride);
+  return wn_check_launch();
+}
+
+int wn_reduce_slabs_mt(const float* slabs, int num_slabs, long slab_stride,
+                       long n_main, float* dst_main, long n_tail, float* dst_tail,
+                       int replicate, long rep_stride, void* stream) {
+  if (!slabs || !dst_main || (n_tail > 0 && !dst_tail)) return WN_ERR_NULL;
+  if (num_slabs <= 0 || n_main <= 0 || n_tail < 0 || replicate < 1 ||
+      slab_stride < n_main + n_tail)
+    return WN_ERR_BAD_SHAPE;
+  if (((n_main | n_tail | slab_stride | rep_stride) & 3) != 0) return WN_ERR_UNSUPPORTED;
+  if (!wn_aligned16(slabs) || !wn_aligned16(dst_main) || (dst_tail && !wn_aligned16(dst_tail)))
+    return WN_ERR_MISALIGNED;
+  const long n4 = (n_main + n_tail) / 4;
+  hipLaunchKernelGGL(reduce_slabs_mt_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0,
+                     (hipStream_t)stream, slabs, num_slabs, slab_stride, n_main / 4, dst_main,
+                     n_tail / 4, dst_tail, replicate, rep_stride);
   return wn_check_launch();
 }
 

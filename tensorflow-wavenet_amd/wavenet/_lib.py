@@ -79,6 +79,8 @@ SIGNATURES = {
                            c_long, P, c_int, c_long, c_int, c_int, c_int, P]),
     'wn_reduce_slabs': (c_int, [P, c_int, c_long, c_int, c_long, c_long,
                                 c_long, P, c_long, c_int, c_long, P]),
+    'wn_reduce_slabs_mt': (c_int, [P, c_int, c_long, c_long, P, c_long, P, c_int,
+                                   c_long, P]),
     'wn_reduce_pair_slabs': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P,
                                      c_int, c_long, c_int, c_int, P]),
     'wn_transpose': (c_int, [P, c_int, c_int, c_long, P, c_long, P]),

@@ -889,6 +889,12 @@ class WaveNetModel(object):
                                  Gm, ldg, _lib.ptr(slabs), sp, N, mw, nw, ub,
                                  st), 2.0 * N * mw * nw,
                                 getattr(self, '_gemm_events', None))
+            if ub and dst_bias is not None and (mw * nw) % 4 == 0 and \
+                    nw % 4 == 0 and sl % 4 == 0 and rep_stride % 4 == 0:
+                # matrix and column sums (bias gradient) in one launch
+                _lib.call('wn_reduce_slabs_mt', _lib.ptr(slabs), sp, sl,
+                          mw * nw, dst, nw, dst_bias, replicate, rep_stride, st)
+                return
             _lib.call('wn_reduce_slabs', _lib.ptr(slabs), sp, sl, 1, 0, 0,
                       mw * nw, dst, 0, 1, 0, st)
             if ub and dst_bias is not None:

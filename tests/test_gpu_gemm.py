@@ -388,3 +388,31 @@ def test_reduce_pair_slabs(hip_lib, CB, K, dense, ub):
             mt[3:3 + K, a * 32:(a + 1) * 32, b * 32:(b + 1) * 32] = blk[:K]
             mt[Kt + 3:Kt + 3 + K, a * 32:(a + 1) * 32, b * 32:(b + 1) * 32] = blk[K:2 * K]
     assert np.abs(gt.cpu().numpy() - wt).max() < 1e-4
+
+
+@pytest.mark.parametrize('ns,n_main,n_tail,rep', [(25, 4096, 64, 1), (96, 1024, 32, 5), (3, 64, 0, 1)])
+def test_reduce_slabs_matrix_and_tail(hip_lib, ns, n_main, n_tail, rep):
+    """wn_reduce_slabs_mt: a weight-gradient GEMM's slabs summed in one launch,
+    the matrix part and the column-sum tail (bias gradient, replicated) to
+    their own destinations; fixed order (two runs bitwise equal)."""
+    from wavenet import _lib
+    rng = np.random.default_rng(ns + n_main)
+    stride = n_main + n_tail + 8
+    slabs = rng.standard_normal((ns, stride)).astype(np.float32)
+    d = dev(slabs)
+    st = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for _ in range(2):
+        m = torch.full((n_main,), 3.0, device='cuda')
+        t = torch.full((rep, n_tail + 4), 3.0, device='cuda')
+        _lib.call('wn_reduce_slabs_mt', d.data_ptr(), ns, stride, n_main, m.data_ptr(),
+                  n_tail, t.data_ptr() if n_tail else None, rep, n_tail + 4, st)
+        outs.append((m, t))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    tot = slabs.astype(np.float64).sum(0)
+    assert np.abs(outs[0][0].cpu().numpy() - tot[:n_main]).max() < 1e-4
+    tt = outs[0][1].cpu().numpy()
+    if n_tail:
+        for r in range(rep):
+            assert np.abs(tt[r, :n_tail] - tot[n_main:n_main + n_tail]).max() < 1e-4
+    assert np.all(tt[:, n_tail:] == 3.0)

@@ -114,11 +114,14 @@ int wn_layer_bwd_k(const float* daf_cur, const float* dag_cur,
                    int B, int T, int dilation, int K, int do_b, int do_a,
                    void* stream);
 /* (k0 / Ktot: the K taps k0 .. k0 + K - 1 of a filter of Ktot taps; slab
- * layout [(2K+1) * 1024 + 96]: Wf taps, Wg taps, Wd, bf | bg | bd) */
+ * layout [(2K+1) * 1024 + 96]: Wf taps, Wg taps, Wd, bf | bg | bd.  CB > 1: all
+ * CB x CB (input block a, output block b) pairs of a channel-block layer in one
+ * launch -- x / z are the first input plane, daf / dag / dxin the first output
+ * plane, planes plane_stride floats apart, slabs [pair = a * CB + b][num_slabs]) */
 int wn_layer_wgrad_k(const float* x, const float* daf, const float* dag,
                      const float* z, const float* dxin, float* slabs,
                      int num_slabs, int B, int T, int dilation, int K, int k0,
-                     int Ktot, void* stream);
+                     int Ktot, int CB, long plane_stride, void* stream);
 
 /* more than 32 residual / dilation channels: channels are cut into 32-wide
  * blocks, each block of an activation is its own [B*T][32] plane, and one

@@ -1556,7 +1556,7 @@ __global__ __launch_bounds__(256) void layer_wgrad_gen_kernel(
     const float* __restrict__ x, const float* __restrict__ daf,
     const float* __restrict__ dag, const float* __restrict__ z,
     const float* __restrict__ dxin, float* __restrict__ slabs, int B, int T,
-    int d, int K, int k0, int Ktot) {
+    int d, int K, int k0, int Ktot, int CB, long plane_stride) {
   __shared__ __attribute__((aligned(16))) float lds[4 * 3 * 1024];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
@@ -1567,7 +1567,19 @@ __global__ __launch_bounds__(256) void layer_wgrad_gen_kernel(
   const int ntiles = tiles_per_clip * B;
   const int nwaves = gridDim.x * 4;
   const int WF = (2 * K + 1) * 1024;
-  float* out = slabs + (size_t)blockIdx.x * (WF + 96);
+  // blockIdx.y: the (input block a, output block b) pair of a channel-block
+  // layer (planes plane_stride floats apart; slabs [pair][slab][WF + 96])
+  {
+    const int pair = blockIdx.y, pa = pair / CB, pb = pair - pa * CB;
+    x += (size_t)pa * plane_stride;
+    daf += (size_t)pb * plane_stride;
+    dag += (size_t)pb * plane_stride;
+    if (HAS_DENSE) {
+      z += (size_t)pa * plane_stride;
+      dxin += (size_t)pb * plane_stride;
+    }
+  }
+  float* out = slabs + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (WF + 96);
   for (int k = 0; k < K; ++k) {
     const int sh = tap_shift(Ktot, k0 + k, d);
     f32x16 cf = frag_zero(), cg = frag_zero(), cd = frag_zero();
@@ -1859,21 +1871,23 @@ int wn_layer_bwd_blk(const float* daf, const float* dag, long da_plane_stride,
 int wn_layer_wgrad_k(const float* x, const float* daf, const float* dag,
                      const float* z, const float* dxin, float* slabs,
                      int num_slabs, int B, int T, int dilation, int K, int k0,
-                     int Ktot, void* stream) {
+                     int Ktot, int CB, long plane_stride, void* stream) {
   if (!x || !daf || !dag || !slabs) return WN_ERR_NULL;
   if (B <= 0 || T <= 0 || dilation <= 0 || num_slabs <= 0 || K < 1 || k0 < 0 ||
-      Ktot < k0 + K)
+      Ktot < k0 + K || CB < 1 || (CB > 1 && plane_stride < (long)B * T * 32))
     return WN_ERR_BAD_SHAPE;
   if (K > 8) return WN_ERR_UNSUPPORTED;
   if ((dxin != nullptr) != (z != nullptr)) return WN_ERR_NULL;
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid(num_slabs), block(256);
+  dim3 grid(num_slabs, CB * CB), block(256);
   if (dxin)
     hipLaunchKernelGGL((layer_wgrad_gen_kernel<true>), grid, block, 0, s, x,
-                       daf, dag, z, dxin, slabs, B, T, dilation, K, k0, Ktot);
+                       daf, dag, z, dxin, slabs, B, T, dilation, K, k0, Ktot, CB,
+                       plane_stride);
   else
     hipLaunchKernelGGL((layer_wgrad_gen_kernel<false>), grid, block, 0, s, x,
-                       daf, dag, z, dxin, slabs, B, T, dilation, K, k0, Ktot);
+                       daf, dag, z, dxin, slabs, B, T, dilation, K, k0, Ktot, CB,
+                       plane_stride);
   return wn_check_launch();
 }
 

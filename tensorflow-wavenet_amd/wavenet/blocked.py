@@ -154,15 +154,12 @@ def backward_layers(net, ws, ids, st):
         flat = ws.pslabs.view(-1)
         for k0, nk in _tap_groups(K):
             dense = dxin is not None and k0 == 0
-            per_pair = nslab * ((2 * nk + 1) * 1024 + 96)
-            for a in range(CB):
-                for b in range(CB):
-                    _lib.call('wn_layer_wgrad_k', _lib.ptr(ws.X[l * CB + a]),
-                              _lib.ptr(daf[b]), _lib.ptr(dag[b]),
-                              _lib.ptr(ws.Z[l * CB + a]) if dense else None,
-                              _lib.ptr(dxin[b]) if dense else None,
-                              _lib.ptr(flat[(a * CB + b) * per_pair:]), nslab,
-                              B, T, d, nk, k0, K, st)
+            # (all CB x CB pairs in one launch: blockIdx.y = pair)
+            _lib.call('wn_layer_wgrad_k', _lib.ptr(ws.X[l * CB]),
+                      _lib.ptr(daf[0]), _lib.ptr(dag[0]),
+                      _lib.ptr(ws.Z[l * CB]) if dense else None,
+                      _lib.ptr(dxin[0]) if dense else None,
+                      _lib.ptr(flat), nslab, B, T, d, nk, k0, K, CB, pstride, st)
             _lib.call('wn_reduce_pair_slabs', _lib.ptr(flat), nslab, CB, nk,
                       1 if dense else 0, 1 if (ub and k0 == 0) else 0,
                       _lib.ptr(g['all']), C, net.OFF_BF, k0, K, st)

@@ -1004,7 +1004,7 @@ class WaveNetModel(object):
         def layer_wgrad(*a):         # (..., nslab, B, T, d, stream)
             if gen:
                 _lib.call('wn_layer_wgrad_k', *a[:10], self.KW, 0, self.KW,
-                          a[10])
+                          1, 0, a[10])
             else:
                 _lib.call('wn_layer_wgrad', *a)
         cur = 0

@@ -142,19 +142,23 @@ int wn_layer_wgrad_k(const float* x, const float* daf, const float* dag,
  * K / k0 / Ktot: the call covers taps k0 .. k0 + K - 1 of a filter of Ktot
  * taps (K * blocks <= 8 per call: wide layers run in chunks of blocks, filter
  * widths above 8 in groups of taps, chained through pre_in / pre_out and
- * dxin / dx_out). */
+ * dxin / dx_out).  out_blocks / dx_blocks > 1: that many consecutive output
+ * (residual) blocks in one launch -- planes out_plane_stride (dx_plane_stride)
+ * floats apart, weight columns (rows) and bias entries 32 further per block,
+ * partial pre-activation planes [block][af | ag]. */
 int wn_layer_fwd_blk(const float* x, long in_plane_stride, int in_blocks,
                      float* z, float* th, float* sg, const float* wf,
                      const float* wg, int ldw, const float* bias_f,
                      const float* bias_g, int bias_clip_stride, int B, int T,
                      int dilation, int K, int save_ts, int tap_rows,
                      const float* pre_in, float* pre_out, long pre_plane_stride,
-                     int k0, int Ktot, void* stream);
+                     int k0, int Ktot, int out_blocks, long out_plane_stride,
+                     void* stream);
 int wn_layer_bwd_blk(const float* daf, const float* dag, long da_plane_stride,
                      int da_blocks, const float* dxin, float* dx_out,
                      const float* wf, const float* wg, int ldw, long tap_stride,
                      int B, int T, int dilation, int K, int k0, int Ktot,
-                     void* stream);
+                     int dx_blocks, long dx_plane_stride, void* stream);
 
 /* fused backward of one block: phase B + all weight gradients of layer l and
  * phase A of layer l-1 in one pass (reads da_l / dx_{l+1} once).

@@ -1381,10 +1381,25 @@ __global__ __launch_bounds__(GEN_WG) void layer_fwd_blk_kernel(
     const float* __restrict__ bias_f, const float* __restrict__ bias_g,
     int bias_clip_stride, int B, int T, int d, int K, int tap_rows,
     const float* __restrict__ pre_in, float* __restrict__ pre_out,
-    long pre_plane_stride, int k0, int Ktot) {
+    long pre_plane_stride, int k0, int Ktot, long out_plane_stride) {
   // (K taps k0 .. k0 + K - 1 of a filter of Ktot taps: filter widths above 8
   // run in groups of taps like wide layers run in chunks of blocks)
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  // blockIdx.y: the 32-wide OUTPUT block (its z / tanh / sigmoid planes
+  // out_plane_stride floats apart, its weight columns and bias entries 32
+  // further, its partial pre-activation planes 2 * pre_plane_stride further)
+  {
+    const int jb = blockIdx.y;
+    if (z) z += (size_t)jb * out_plane_stride;
+    if (th) th += (size_t)jb * out_plane_stride;
+    if (sg) sg += (size_t)jb * out_plane_stride;
+    wf += jb * 32;
+    wg += jb * 32;
+    if (bias_f) bias_f += jb * 32;
+    if (bias_g) bias_g += jb * 32;
+    if (pre_in) pre_in += (size_t)jb * 2 * pre_plane_stride;
+    if (pre_out) pre_out += (size_t)jb * 2 * pre_plane_stride;
+  }
   const int NV = K * in_blocks;               // virtual taps (k, i)
   float* wl = smem;                           // [2 NV][32][32]: filter, gate
   float* tiles = smem + 2 * NV * 1024;
@@ -1487,9 +1502,18 @@ __global__ __launch_bounds__(GEN_WG) void layer_bwd_blk_kernel(
     long da_plane_stride, int da_blocks, const float* __restrict__ dxin,
     float* __restrict__ dx_out, const float* __restrict__ wf,
     const float* __restrict__ wg, int ldw, long tap_stride, int B, int T, int d,
-    int K, int k0, int Ktot) {
+    int K, int k0, int Ktot, long dx_plane_stride) {
   constexpr int LDT = 33, MT = 32 * LDT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  // blockIdx.y: the residual-channel block (its dx planes dx_plane_stride
+  // floats apart, its weight rows 32 further)
+  {
+    const int rb = blockIdx.y;
+    if (HAS_DXIN) dxin += (size_t)rb * dx_plane_stride;
+    dx_out += (size_t)rb * dx_plane_stride;
+    wf += (size_t)rb * 32 * ldw;
+    wg += (size_t)rb * 32 * ldw;
+  }
   const int NV = K * da_blocks;               // virtual taps (k, jb)
   float* wl = smem;                           // [2 NV] transposed blocks
   float* tiles = smem + (2 * NV * MT + 3) / 4 * 4;
@@ -1804,9 +1828,12 @@ int wn_layer_fwd_blk(const float* x, long in_plane_stride, int in_blocks,
                      const float* bias_g, int bias_clip_stride, int B, int T,
                      int dilation, int K, int save_ts, int tap_rows,
                      const float* pre_in, float* pre_out, long pre_plane_stride,
-                     int k0, int Ktot, void* stream) {
+                     int k0, int Ktot, int out_blocks, long out_plane_stride,
+                     void* stream) {
   if (!x || !wf || !wg) return WN_ERR_NULL;
-  if (k0 < 0 || Ktot < k0 + K) return WN_ERR_BAD_SHAPE;
+  if (k0 < 0 || Ktot < k0 + K || out_blocks < 1 ||
+      (out_blocks > 1 && (out_plane_stride < (long)B * T * 32 || (out_plane_stride & 3))))
+    return WN_ERR_BAD_SHAPE;
   if (!pre_out && !z) return WN_ERR_NULL;
   if (B <= 0 || T <= 0 || dilation <= 0 || K < 1 || in_blocks < 1 || ldw < 32 ||
       tap_rows < in_blocks * 32)
@@ -1820,7 +1847,7 @@ int wn_layer_fwd_blk(const float* x, long in_plane_stride, int in_blocks,
   for (const void* p : ptrs)
     if (p && !wn_aligned16(p)) return WN_ERR_MISALIGNED;
   if ((in_plane_stride & 3) != 0) return WN_ERR_MISALIGNED;
-  dim3 grid(layer_grid(B, T, GEN_WAVES)), block(GEN_WG);
+  dim3 grid(layer_grid(B, T, GEN_WAVES), out_blocks), block(GEN_WG);
   const size_t lds = ((size_t)2 * K * in_blocks * 1024 + GEN_WAVES * 1024) * 4;
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(TS)                                                            \
@@ -1831,7 +1858,8 @@ int wn_layer_fwd_blk(const float* x, long in_plane_stride, int in_blocks,
   hipLaunchKernelGGL((layer_fwd_blk_kernel<TS>), grid, block, lds, s, x,      \
                      in_plane_stride, in_blocks, z, th, sg, wf, wg, ldw,      \
                      bias_f, bias_g, bias_clip_stride, B, T, dilation, K,     \
-                     tap_rows, pre_in, pre_out, pre_plane_stride, k0, Ktot)
+                     tap_rows, pre_in, pre_out, pre_plane_stride, k0, Ktot,     \
+                     out_plane_stride)
   if (save_ts) { LAUNCH(true); } else { LAUNCH(false); }
 #undef LAUNCH
   return wn_check_launch();
@@ -1841,17 +1869,18 @@ int wn_layer_bwd_blk(const float* daf, const float* dag, long da_plane_stride,
                      int da_blocks, const float* dxin, float* dx_out,
                      const float* wf, const float* wg, int ldw, long tap_stride,
                      int B, int T, int dilation, int K, int k0, int Ktot,
-                     void* stream) {
+                     int dx_blocks, long dx_plane_stride, void* stream) {
   if (!daf || !dag || !dx_out || !wf || !wg) return WN_ERR_NULL;
   if (B <= 0 || T <= 0 || dilation <= 0 || K < 1 || da_blocks < 1 || ldw < 32 ||
-      k0 < 0 || Ktot < k0 + K)
+      k0 < 0 || Ktot < k0 + K || dx_blocks < 1 ||
+      (dx_blocks > 1 && (dx_plane_stride < (long)B * T * 32 || (dx_plane_stride & 3))))
     return WN_ERR_BAD_SHAPE;
   if (K * da_blocks > 8) return WN_ERR_UNSUPPORTED;
   const void* ptrs[] = {daf, dag, dxin, dx_out};
   for (const void* p : ptrs)
     if (p && !wn_aligned16(p)) return WN_ERR_MISALIGNED;
   if ((da_plane_stride & 3) != 0) return WN_ERR_MISALIGNED;
-  dim3 grid(layer_grid(B, T, GEN_WAVES)), block(GEN_WG);
+  dim3 grid(layer_grid(B, T, GEN_WAVES), dx_blocks), block(GEN_WG);
   const size_t lds = (((size_t)2 * K * da_blocks * 33 * 32 + 3) / 4 * 4 +
                       GEN_WAVES * 2048) * 4;
   hipStream_t s = (hipStream_t)stream;
@@ -1862,7 +1891,8 @@ int wn_layer_bwd_blk(const float* daf, const float* dag, long da_plane_stride,
     return WN_ERR_LAUNCH;                                                     \
   hipLaunchKernelGGL((layer_bwd_blk_kernel<HX>), grid, block, lds, s, daf,    \
                      dag, da_plane_stride, da_blocks, dxin, dx_out, wf, wg,   \
-                     ldw, tap_stride, B, T, dilation, K, k0, Ktot)
+                     ldw, tap_stride, B, T, dilation, K, k0, Ktot,              \
+                     dx_plane_stride)
   if (dxin) { LAUNCH(true); } else { LAUNCH(false); }
 #undef LAUNCH
   return wn_check_launch();

@@ -52,10 +52,11 @@ SIGNATURES = {
                                  c_int, c_int, c_int, c_int, c_long, P]),
     'wn_layer_fwd_blk': (c_int, [P, c_long, c_int, P, P, P, P, P, c_int, P, P,
                                  c_int, c_int, c_int, c_int, c_int, c_int,
-                                 c_int, P, P, c_long, c_int, c_int, P]),
+                                 c_int, P, P, c_long, c_int, c_int, c_int,
+                                 c_long, P]),
     'wn_layer_bwd_blk': (c_int, [P, P, c_long, c_int, P, P, P, P, c_int,
                                  c_long, c_int, c_int, c_int, c_int, c_int,
-                                 c_int, P]),
+                                 c_int, c_int, c_long, P]),
     'wn_layer_bwdw_slabs': (c_int, [c_int, c_int]),
     'wn_layer_bwdw': (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
                               c_int, c_int, c_int, c_int, P]),

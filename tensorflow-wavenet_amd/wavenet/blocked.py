@@ -65,28 +65,28 @@ def forward_layers(net, ws, bias, bstride, save_ts, st):
         w = _blk(net, P, l)
         x0 = ws.X[l * CB]
         chunks = _chunks(CB, K)
-        for jb in range(CB):
-            bf = bg = None
-            if bias is not None:
-                row = bias[l].reshape(-1)
-                bf, bg = row[jb * CH:], row[C + jb * CH:]
-            # input blocks in chunks of at most 8 // K (the kernel holds a
-            # chunk's 2 K weight blocks in LDS); partial pre-activations
-            # travel through ws.pre (planes af | ag)
-            for ci, (k0, nk, i0, nb) in enumerate(chunks):
-                last = ci == len(chunks) - 1
-                wo = (k0 * C + i0 * CH) * C + jb * CH
-                _lib.call('wn_layer_fwd_blk',
-                          _lib.ptr(ws.X[l * CB + i0]), pstride, nb,
-                          _lib.ptr(ws.Z[l * CB + jb]),
-                          _lib.ptr(ws.TH[l * CB + jb]) if save_ts else None,
-                          _lib.ptr(ws.SG[l * CB + jb]) if save_ts else None,
-                          _lib.ptr(w['wf'][wo:]), _lib.ptr(w['wg'][wo:]),
-                          C, _lib.ptr(bf), _lib.ptr(bg), bstride, B, T, int(d),
-                          nk, 1 if save_ts else 0, C,
-                          _lib.ptr(ws.pre) if ci > 0 else None,
-                          None if last else _lib.ptr(ws.pre), pstride, k0, K,
-                          st)
+        bf = bg = None
+        if bias is not None:
+            row = bias[l].reshape(-1)
+            bf, bg = row, row[C:]
+        # ALL output blocks per launch (blockIdx.y); input blocks in chunks of
+        # at most 8 // K and filter widths above 8 in groups of 8 taps (the
+        # kernel holds a chunk's 2 x taps x blocks weight blocks in LDS);
+        # partial pre-activations travel through ws.pre ([block][af | ag])
+        for ci, (k0, nk, i0, nb) in enumerate(chunks):
+            last = ci == len(chunks) - 1
+            wo = (k0 * C + i0 * CH) * C
+            _lib.call('wn_layer_fwd_blk',
+                      _lib.ptr(ws.X[l * CB + i0]), pstride, nb,
+                      _lib.ptr(ws.Z[l * CB]),
+                      _lib.ptr(ws.TH[l * CB]) if save_ts else None,
+                      _lib.ptr(ws.SG[l * CB]) if save_ts else None,
+                      _lib.ptr(w['wf'][wo:]), _lib.ptr(w['wg'][wo:]),
+                      C, _lib.ptr(bf), _lib.ptr(bg), bstride, B, T, int(d),
+                      nk, 1 if save_ts else 0, C,
+                      _lib.ptr(ws.pre) if ci > 0 else None,
+                      None if last else _lib.ptr(ws.pre), pstride, k0, K,
+                      CB, pstride, st)
         if l == L - 1:
             break
         # x_{l+1} = x_l + z_l Wd (+ bd)   model.py:294-300,330 -- ONE plane-mode
@@ -165,15 +165,16 @@ def backward_layers(net, ws, ids, st):
                       _lib.ptr(g['all']), C, net.OFF_BF, k0, K, st)
         # ---- dx of every residual-channel block
         dxo = ws.dx[xp]
-        for rb in range(CB):
-            # dilation blocks in chunks: a chunk's dx is the next one's dxin
-            for ci, (k0, nk, j0, nb) in enumerate(_chunks(CB, K)):
-                src = dxo[rb] if ci > 0 else (None if dxin is None else dxin[rb])
-                wo = k0 * M + rb * CH * C + j0 * CH
-                _lib.call('wn_layer_bwd_blk', _lib.ptr(daf[j0]),
-                          _lib.ptr(dag[j0]), pstride, nb, _lib.ptr(src),
-                          _lib.ptr(dxo[rb]), _lib.ptr(w['wf'][wo:]),
-                          _lib.ptr(w['wg'][wo:]), C, M, B, T, d, nk, k0, K, st)
+        # ALL residual-channel blocks per launch (blockIdx.y); dilation blocks /
+        # taps in chunks: a chunk's dx is the next one's dxin
+        for ci, (k0, nk, j0, nb) in enumerate(_chunks(CB, K)):
+            src = dxo[0] if ci > 0 else (None if dxin is None else dxin[0])
+            wo = k0 * M + j0 * CH
+            _lib.call('wn_layer_bwd_blk', _lib.ptr(daf[j0]),
+                      _lib.ptr(dag[j0]), pstride, nb, _lib.ptr(src),
+                      _lib.ptr(dxo[0]), _lib.ptr(w['wf'][wo:]),
+                      _lib.ptr(w['wg'][wo:]), C, M, B, T, d, nk, k0, K, CB,
+                      pstride, st)
         dxin, xp = dxo, 1 - xp
     sp = ws.splits['causal']
     if net.scalar_input:

@@ -114,7 +114,7 @@ class _Workspace(object):
         if net.blocked:
             # partial pre-activations of a layer wider than one chunk of
             # channel blocks (wavenet/blocked.py), planes af | ag
-            alloc('pre', (2, N, CH))
+            alloc('pre', (2 * CB, N, CH))
         if not training:
             return
         # legacy backward kernels (un-fused pair, wn_layer_bwdw, generic

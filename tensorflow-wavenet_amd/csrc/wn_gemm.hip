@@ -431,24 +431,25 @@ __global__ __launch_bounds__(256, 4) void gemm_nn3_kernel(GemmNN g) {
   // lane offsets, one scalar offset per chunk -- no vector address arithmetic
   // inside the K loop (it is matrix-pipe time on gfx950)
   const long lda = g.a_planes ? 32 : g.lda;
-  const __amdgpu_buffer_rsrc_t rsA = ep_rsrc(g.A), rsW = ep_rsrc(g.W);
   const int va0 = (int)((am0 * lda + a_chunk * 4) * 4);
   const int va1 = (int)((am1 * lda + a_chunk * 4) * 4);
   int wcol = n0 + (lane & 31) * 4;
   wcol = wcol < g.N ? wcol : 0;
   const int vw0 = (int)(((long)(2 * wave + (lane >> 5)) * g.ldw + wcol) * 4);
   const int vw1 = vw0 + (int)(8L * g.ldw * 4);
-  const long w_chunk = (long)N3_KC * g.ldw * 4;          // bytes
   auto stage = [&](int kc, float* base) {
-    // plane mode: chunk kc is half (kc & 1) of plane kc >> 1
-    const unsigned sa = (unsigned)((g.a_planes ? (long)(kc >> 1) * g.a_plane_stride + (kc & 1) * 16
-                                               : (long)kc * N3_KC) * 4);
-    const unsigned sw = (unsigned)(kc * w_chunk);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(base + wave * 256), 16, va0, sa, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(base + (wave + 4) * 256), 16, va1, sa, 0, 0);
+    // the chunk's first element as a 64-bit SCALAR base (plane mode: chunk kc
+    // is half (kc & 1) of plane kc >> 1): operands larger than 2 GB -- many or
+    // long planes, wide models -- stay on this kernel; only a lane's own
+    // offset (its row inside the operand) has to fit 32 bits
+    const __amdgpu_buffer_rsrc_t rsA = ep_rsrc(
+        g.A + (g.a_planes ? (long)(kc >> 1) * g.a_plane_stride + (kc & 1) * 16 : (long)kc * N3_KC));
+    const __amdgpu_buffer_rsrc_t rsW = ep_rsrc(g.W + (long)kc * N3_KC * g.ldw);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(base + wave * 256), 16, va0, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(base + (wave + 4) * 256), 16, va1, 0, 0, 0);
     float* wb = base + NN_TM * N3_KC;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lptr_t)(wb + wave * 256), 16, vw0, sw, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lptr_t)(wb + (wave + 4) * 256), 16, vw1, sw, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lptr_t)(wb + wave * 256), 16, vw0, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lptr_t)(wb + (wave + 4) * 256), 16, vw1, 0, 0, 0);
   };
 
   f32x16 acc[2][2];  // [fn][fm]
@@ -1016,27 +1017,32 @@ __global__ __launch_bounds__(256, (MF * NF >= 10 ? 2 : MF * NF > 5 ? 3 : 4)) voi
   // (Round 2 rebuilt every piece's 64-bit address in vector registers in every
   // chunk: 184 vector instructions per 40 MFMAs -- matrix-pipe time on gfx950.)
   constexpr int NPA = (PA + 3) / 4, NPG = (PG + 3) / 4;   // pieces per wave
-  const __amdgpu_buffer_rsrc_t rsA = ep_rsrc(g.A), rsG = ep_rsrc(g.G);
+  // (bases: the split's first row of the tile's first plane / first column --
+  // 64-bit, scalar; what is left for the 32-bit offsets is the tile's TM / 32
+  // planes and the split's rows, so operands larger than 2 GB stay here)
+  const long rowA = g.a_planes ? 32 * 4 : g.lda * 4, rowG = g.ldg * 4;   // bytes per row
+  const __amdgpu_buffer_rsrc_t rsA = ep_rsrc(
+      g.a_planes ? g.A + (long)(m0 >> 5) * g.a_plane_stride + r_begin * 32
+                 : g.A + r_begin * g.lda + m0);
+  const __amdgpu_buffer_rsrc_t rsG = ep_rsrc(g.G + r_begin * g.ldg + n0);
   int voA[3], voG[4];
   static_assert(NPA <= 3 && NPG <= 4, "pieces per wave");
 #pragma unroll
   for (int k = 0; k < NPA; ++k) {
     const int e = (wave + 4 * k) * 256 + lane * 4;
     const int row = e / TM, col = e - row * TM;
-    const int m = m0 + col;
-    voA[k] = g.a_planes ? (int)(((long)(m >> 5) * g.a_plane_stride + row * 32 + (m & 31)) * 4)
-                        : (int)(((long)row * g.lda + m) * 4);
+    voA[k] = g.a_planes ? (int)(((long)(col >> 5) * g.a_plane_stride + row * 32 + (col & 31)) * 4)
+                        : (int)(((long)row * g.lda + col) * 4);
   }
 #pragma unroll
   for (int k = 0; k < NPG; ++k) {
     const int e = (wave + 4 * k) * 256 + lane * 4;
     const int row = e / TNW, col = e - row * TNW;
-    voG[k] = (int)(((long)row * g.ldg + n0 + col) * 4);
+    voG[k] = (int)(((long)row * g.ldg + col) * 4);
   }
-  const long rowA = g.a_planes ? 32 * 4 : g.lda * 4, rowG = g.ldg * 4;   // bytes per row
   auto stage = [&](int c, int st) {
     float* base = smem + st * STAGE;
-    const long r0 = r_begin + (long)c * KR;
+    const long r0 = (long)c * KR;
     const unsigned sA = (unsigned)(r0 * rowA), sG = (unsigned)(r0 * rowG);
 #pragma unroll
     for (int k = 0; k < NPA; ++k) {
@@ -1575,8 +1581,9 @@ static int gemm_nn_launch(const float* A, long lda, int a_planes, long a_plane_s
   if (wsplit && (K % N3_KC) != 0) return WN_ERR_UNSUPPORTED;
   if (wsplit && !wn_aligned16(wsplit)) return WN_ERR_MISALIGNED;
   // (gemm_nn3_kernel stages through 32-bit byte offsets of buffer resources)
-  const long a_bytes = (a_planes ? (long)((K + 31) / 32) * a_plane_stride : M * lda) * 4;
-  const bool fits32 = a_bytes < (1L << 31) && (long)K * ldw * 4 < (1L << 31);
+  // (a lane's row offset inside the A operand and inside a 16-row W chunk)
+  const long a_bytes = (a_planes ? M * 32 : M * lda) * 4;
+  const bool fits32 = a_bytes < (1L << 31) && (long)N3_KC * ldw * 4 < (1L << 31);
   if (!wsplit && ((me && me[0] == 't') || (K % N3_KC) != 0 || !fits32))
     hipLaunchKernelGGL(gemm_nn_kernel<2>, dim3((unsigned)nwg), dim3(256), 0,
                        (hipStream_t)stream, g);
@@ -1733,9 +1740,11 @@ int wn_gemm_tn(const float* A, long lda, int a_planes, long a_plane_stride,
       // (WN_TN_MODE=reg selects the register-staged kernel)
       const char* tme = getenv("WN_TN_MODE");
       // (its staging addresses are 32-bit byte offsets of a buffer resource)
-      const long a_bytes = (a_planes ? (long)a_planes * a_plane_stride : rows * lda) * 4;
+      // (per workgroup: a tile's planes -- at most five -- and a split's rows)
+      const long rps = (rows + splits - 1) / splits + 96;
+      const long a_bytes = (a_planes ? 5 * a_plane_stride + rps * 32 : rps * lda) * 4;
       const bool dma = (rows % 16 == 0) && !(tme && tme[0] == 'r') &&
-                       a_bytes < (1L << 31) && rows * ldg * 4 < (1L << 31);
+                       a_bytes < (1L << 31) && rps * ldg * 4 < (1L << 31);
 #define LAUNCH2(mf, nf)                                                          \
   do {                                                                           \
     if (dma) hipLaunchKernelGGL((gemm_tn3_kernel<mf, nf>), grid2, block2, 0, s, g); \

@@ -416,3 +416,48 @@ def test_reduce_slabs_matrix_and_tail(hip_lib, ns, n_main, n_tail, rep):
         for r in range(rep):
             assert np.abs(tt[r, :n_tail] - tot[n_main:n_main + n_tail]).max() < 1e-4
     assert np.all(tt[:, n_tail:] == 3.0)
+
+
+def test_gemm_plane_operands_beyond_2gb(hip_lib):
+    """Plane-mode operands whose planes lie more than 2 GB apart (the z planes
+    of a large batch or a wide model): the LDS-DMA kernels address a chunk /
+    a tile through 64-bit scalar bases and stay correct -- and in use (a
+    fallback to the register-staged kernels would hide a perf cliff)."""
+    from wavenet import _lib
+    lib = hip_lib
+    rng = np.random.default_rng(11)
+    M, P, N = 1600, 5, 128
+    stride = 600_000_000                     # floats between planes: 2.4 GB
+    big = torch.empty(stride * (P - 1) + M * 32, device='cuda')
+    Ap = rng.standard_normal((P, M, 32)).astype(np.float32)
+    for p in range(P):
+        big[p * stride:p * stride + M * 32] = dev(Ap[p]).reshape(-1)
+    A = Ap.transpose(1, 0, 2).reshape(M, P * 32).astype(np.float64)
+    W = rng.standard_normal((P * 32, N)).astype(np.float32)
+    dW = dev(W)
+    C = torch.empty((M, N), device='cuda')
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.call('wn_gemm_nn', big.data_ptr(), 0, P, stride, dW.data_ptr(), N, None, None, 0,
+              None, 0, C.data_ptr(), N, 0, 0, None, M, N, P * 32, 0, st)
+    assert np.abs(C.cpu().numpy() - A @ W.astype(np.float64)).max() < 1e-3
+    # TN: dW[P*32][N] = A^T G with A in the same far-apart planes
+    G = rng.standard_normal((M, N)).astype(np.float32)
+    dG = dev(G)
+    splits = 4
+    sl = lib.wn_gemm_tn_slab_floats(P * 32, N)
+    slabs = torch.zeros(splits * sl, device='cuda')
+    out = torch.empty(P * 32 * N, device='cuda')
+    _lib.call('wn_gemm_tn', big.data_ptr(), 0, P, stride, None, 0, 1, dG.data_ptr(), N,
+              slabs.data_ptr(), splits, M, P * 32, N, 0, st)
+    _lib.call('wn_reduce_slabs', slabs.data_ptr(), splits, sl, 1, 0, 0, P * 32 * N,
+              out.data_ptr(), 0, 1, 0, st)
+    ref = A.T @ G.astype(np.float64)
+    assert np.abs(out.cpu().numpy().reshape(P * 32, N) - ref).max() < 1e-3 * max(1.0, np.abs(ref).max())
+    # planes OUT that far apart
+    X = rng.standard_normal((M, 48)).astype(np.float32)
+    W2 = rng.standard_normal((48, P * 32)).astype(np.float32)
+    dX, dW2 = dev(X), dev(W2)
+    # (the epilogue reaches a lane's neighbour plane with a 32-bit offset: refused)
+    assert lib.wn_gemm_nn(dX.data_ptr(), 48, 0, 0, dW2.data_ptr(), P * 32, None, None, 0,
+                          None, 0, big.data_ptr(), 0, P, stride, None, M, P * 32, 48, 0,
+                          st) == -2

@@ -1010,7 +1010,10 @@ __global__ __launch_bounds__(256, (MF * NF >= 10 ? 2 : MF * NF > 5 ? 3 : 4)) voi
   const long r_begin = (long)split * g.rows_per_split;
   long r_end = r_begin + g.rows_per_split;
   if (r_end > g.rows) r_end = g.rows;
-  const int nchunks = r_end > r_begin ? (int)((r_end - r_begin) / KR) : 0;
+  // (the last split's last chunk may be ragged -- B * T is whatever the reader
+  // cut: its missing rows are staged as zeros)
+  const int nchunks = r_end > r_begin ? (int)((r_end - r_begin + KR - 1) / KR) : 0;
+  const int tail_rows = nchunks ? (int)(r_end - r_begin) - (nchunks - 1) * KR : KR;
 
   // Staging addresses: a buffer resource per operand (base in SGPRs), per piece
   // ONE loop-invariant 32-bit lane offset, per chunk one scalar row offset.
@@ -1044,13 +1047,41 @@ __global__ __launch_bounds__(256, (MF * NF >= 10 ? 2 : MF * NF > 5 ? 3 : 4)) voi
     float* base = smem + st * STAGE;
     const long r0 = (long)c * KR;
     const unsigned sA = (unsigned)(r0 * rowA), sG = (unsigned)(r0 * rowG);
+    float* gb = base + KR * TM;
+    if (tail_rows < KR && c == nchunks - 1) {
+      // ragged last chunk: this wave's pieces are zeroed, then only the lanes
+      // whose row exists load (a wave's DS write and its later LDS-DMA into
+      // the same bytes are ordered by the wait)
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < NPA; ++k)
+        if (wave + 4 * k < PA)
+          *reinterpret_cast<f32x4*>(base + (wave + 4 * k) * 256 + lane * 4) = zero;
+#pragma unroll
+      for (int k = 0; k < NPG; ++k)
+        if (wave + 4 * k < PG)
+          *reinterpret_cast<f32x4*>(gb + (wave + 4 * k) * 256 + lane * 4) = zero;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < NPA; ++k) {
+        const int p = wave + 4 * k;
+        if (p < PA && (p * 256 + lane * 4) / TM < tail_rows)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(base + p * 256), 16, voA[k], sA, 0, 0);
+      }
+#pragma unroll
+      for (int k = 0; k < NPG; ++k) {
+        const int p = wave + 4 * k;
+        if (p < PG && (p * 256 + lane * 4) / TNW < tail_rows)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsG, (lptr_t)(gb + p * 256), 16, voG[k], sG, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < NPA; ++k) {
       const int p = wave + 4 * k;
       if (p < PA)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(base + p * 256), 16, voA[k], sA, 0, 0);
     }
-    float* gb = base + KR * TM;
 #pragma unroll
     for (int k = 0; k < NPG; ++k) {
       const int p = wave + 4 * k;
@@ -1743,7 +1774,8 @@ int wn_gemm_tn(const float* A, long lda, int a_planes, long a_plane_stride,
       // (per workgroup: a tile's planes -- at most five -- and a split's rows)
       const long rps = (rows + splits - 1) / splits + 96;
       const long a_bytes = (a_planes ? 5 * a_plane_stride + rps * 32 : rps * lda) * 4;
-      const bool dma = (rows % 16 == 0) && !(tme && tme[0] == 'r') &&
+      // (ragged row counts: the kernel zero-fills its last chunk)
+      const bool dma = !(tme && tme[0] == 'r') &&
                        a_bytes < (1L << 31) && rps * ldg * 4 < (1L << 31);
 #define LAUNCH2(mf, nf)                                                          \
   do {                                                                           \

@@ -111,7 +111,7 @@ int wn_layer_bwd_k(const float* daf_cur, const float* dag_cur,
                    const float* dxin, float* dx_out, const float* wblock_b,
                    const float* dZ, const float* th, const float* sg,
                    const float* wblock_a, float* daf_next, float* dag_next,
-                   int B, int T, int dilation, int K, int do_b, int do_a,
+                   int B, int T, int dilation, int K, int do_b, int do_a, int blocks, long blk_stride,
                    void* stream);
 /* (k0 / Ktot: the K taps k0 .. k0 + K - 1 of a filter of Ktot taps; slab
  * layout [(2K+1) * 1024 + 96]: Wf taps, Wg taps, Wd, bf | bg | bd.  CB > 1: all

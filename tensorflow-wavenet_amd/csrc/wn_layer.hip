@@ -1264,9 +1264,15 @@ __global__ __launch_bounds__(GEN_WG) void layer_bwd_gen_kernel(
     const float* __restrict__ wblock_b, const float* __restrict__ dZ,
     const float* __restrict__ th, const float* __restrict__ sg,
     const float* __restrict__ wblock_a, float* __restrict__ daf_next,
-    float* __restrict__ dag_next, int B, int T, int d, int K) {
+    float* __restrict__ dag_next, int B, int T, int d, int K, long blk_stride) {
   constexpr int LDT = 33, MT = 32 * LDT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  // blockIdx.y (phase A only): the dilation-channel block of a channel-block
+  // layer, its planes blk_stride floats apart
+  if (DO_A) {
+    const size_t o = (size_t)blockIdx.y * blk_stride;
+    dZ += o; th += o; sg += o; daf_next += o; dag_next += o;
+  }
   float* wl = smem;                         // (2K+1) transposed matrices
   float* tiles = smem + ((2 * K + 1) * MT + 3) / 4 * 4;
   const int tid = threadIdx.x;
@@ -1794,14 +1800,16 @@ int wn_layer_bwd_k(const float* daf_cur, const float* dag_cur,
                    const float* dZ, const float* th, const float* sg,
                    const float* wblock_a, float* daf_next, float* dag_next,
                    int B, int T, int dilation, int K, int do_b, int do_a,
-                   void* stream) {
-  if (B <= 0 || T <= 0 || dilation <= 0 || K < 2) return WN_ERR_BAD_SHAPE;
+                   int blocks, long blk_stride, void* stream) {
+  if (B <= 0 || T <= 0 || dilation <= 0 || K < 2 || blocks < 1) return WN_ERR_BAD_SHAPE;
   if (K > 8) return WN_ERR_UNSUPPORTED;
   if (!do_a && !do_b) return WN_ERR_BAD_SHAPE;
+  // (several blocks per launch: the gate-gradient phase alone)
+  if (blocks > 1 && (do_b || dxin || blk_stride < (long)B * T * 32)) return WN_ERR_BAD_SHAPE;
   if (do_b && (!daf_cur || !dag_cur || !dx_out || !wblock_b)) return WN_ERR_NULL;
   if (do_a && (!dZ || !th || !sg || !wblock_a || !daf_next || !dag_next))
     return WN_ERR_NULL;
-  dim3 grid(layer_grid(B, T, GEN_WAVES)), block(GEN_WG);
+  dim3 grid(layer_grid(B, T, GEN_WAVES), blocks), block(GEN_WG);
   const size_t lds = (((size_t)(2 * K + 1) * 33 * 32 + 3) / 4 * 4 +
                       GEN_WAVES * 2048) * 4;
   hipStream_t s = (hipStream_t)stream;
@@ -1813,7 +1821,7 @@ int wn_layer_bwd_k(const float* daf_cur, const float* dag_cur,
     return WN_ERR_LAUNCH;                                                     \
   hipLaunchKernelGGL((layer_bwd_gen_kernel<DB, DA, HX>), grid, block, lds, s, \
                      daf_cur, dag_cur, dxin, dx_out, wblock_b, dZ, th, sg,    \
-                     wblock_a, daf_next, dag_next, B, T, dilation, K)
+                     wblock_a, daf_next, dag_next, B, T, dilation, K, blk_stride)
   if (do_b && do_a) { if (hx) { LAUNCH(true, true, true); } else { LAUNCH(true, true, false); } }
   else if (do_b) { if (hx) { LAUNCH(true, false, true); } else { LAUNCH(true, false, false); } }
   else { if (hx) { LAUNCH(false, true, true); } else { LAUNCH(false, true, false); } }

@@ -47,7 +47,7 @@ SIGNATURES = {
     'wn_layer_fwd_k': (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int,
                                c_int, c_int, c_int, P]),
     'wn_layer_bwd_k': (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int,
-                               c_int, c_int, c_int, c_int, P]),
+                               c_int, c_int, c_int, c_int, c_int, c_long, P]),
     'wn_layer_wgrad_k': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int,
                                  c_int, c_int, c_int, c_int, c_long, P]),
     'wn_layer_fwd_blk': (c_int, [P, c_long, c_int, P, P, P, P, P, c_int, P, P,

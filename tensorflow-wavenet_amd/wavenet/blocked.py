@@ -131,16 +131,15 @@ def backward_layers(net, ws, ids, st):
                       _lib.ptr(ws.wdT), C, None, None, 0,
                       _lib.ptr(ws.dZ[l * CB]), 0, _lib.ptr(ws.dzb[0]), 0, CB,
                       pstride, None, N, C, C, 0, st)
-        # ---- gate gradients of every dilation-channel block
+        # ---- gate gradients of every dilation-channel block (one launch,
+        # blockIdx.y = block; gate gradients only: the filter width just sizes
+        # a weight staging area this mode does not read)
+        dz0 = ws.dZ[l * CB] if dxin is None else ws.dzb[0]
+        _lib.call('wn_layer_bwd_k', None, None, None, None, None,
+                  _lib.ptr(dz0), _lib.ptr(ws.TH[l * CB]), _lib.ptr(ws.SG[l * CB]),
+                  _lib.ptr(w['all']), _lib.ptr(daf[0]), _lib.ptr(dag[0]), B, T, d,
+                  min(K, 8), 0, 1, CB, pstride, st)
         for jb in range(CB):
-            dz = ws.dZ[l * CB + jb] if dxin is None else ws.dzb[jb]
-            # (gate gradients only: the filter width just sizes a weight
-            # staging area this mode does not read)
-            _lib.call('wn_layer_bwd_k', None, None, None, None, None,
-                      _lib.ptr(dz), _lib.ptr(ws.TH[l * CB + jb]),
-                      _lib.ptr(ws.SG[l * CB + jb]), _lib.ptr(w['all']),
-                      _lib.ptr(daf[jb]), _lib.ptr(dag[jb]), B, T, d,
-                      min(K, 8), 0, 1, st)
             if ws.dsum is not None:
                 _lib.call('wn_colsum_clip', _lib.ptr(daf[jb]), _lib.ptr(dag[jb]),
                           B, T, _lib.ptr(ws.dsum_part), _lib.ptr(ws.cs_tmp), st)

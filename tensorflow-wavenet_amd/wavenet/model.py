@@ -997,7 +997,8 @@ class WaveNetModel(object):
 
         def layer_bwd(*a):           # (..., B, T, d, do_b, do_a, stream)
             if gen:
-                _lib.call('wn_layer_bwd_k', *a[:14], self.KW, *a[14:])
+                _lib.call('wn_layer_bwd_k', *a[:14], self.KW, *a[14:16], 1, 0,
+                          a[16])
             else:
                 _lib.call('wn_layer_bwd', *a)
 

@@ -392,7 +392,8 @@ __global__ __launch_bounds__(FG_THREADS, 1) void fastgen_kernel(FastGen g) {
 // Queues: layer l's ring holds d_l rows of C floats at state + roff[l] * C.
 // ===========================================================================
 #define FGW_THREADS 256
-#define FGW_MAXC 256
+#define FGW_MAXC 1024
+#define FGW_XPT (FGW_MAXC / FGW_THREADS)   // residual channels per thread
 
 struct FastGenWide {
   FastGen g;
@@ -462,13 +463,17 @@ __global__ __launch_bounds__(FGW_THREADS, 1) void fastgen_wide_kernel(FastGenWid
       }
       __syncthreads();
       // ---- 3. residual 1x1 conv and this layer's skip contribution
-      float xn = 0.f;
-      const bool has_x = tid < C;      // (C <= FGW_THREADS: one channel per thread)
-      if (has_x) {
-        const float* wd = blk + 4 * CC + tid;
-        float d0 = g.use_dense_bias ? blk[5 * CC + 2 * C + tid] : 0.f;
-        for (int k = 0; k < C; ++k) d0 = fmaf(zs[k], wd[(long)k * C], d0);
-        xn = xs[tid] + d0;
+      float xn[FGW_XPT];
+#pragma unroll
+      for (int u = 0; u < FGW_XPT; ++u) {
+        const int c = tid + u * FGW_THREADS;
+        xn[u] = 0.f;
+        if (c < C) {
+          const float* wd = blk + 4 * CC + c;
+          float d0 = g.use_dense_bias ? blk[5 * CC + 2 * C + c] : 0.f;
+          for (int k = 0; k < C; ++k) d0 = fmaf(zs[k], wd[(long)k * C], d0);
+          xn[u] = xs[c] + d0;
+        }
       }
       {
         const float* ws = g.skip_w + (long)l * C * S;
@@ -480,7 +485,9 @@ __global__ __launch_bounds__(FGW_THREADS, 1) void fastgen_wide_kernel(FastGenWid
         }
       }
       __syncthreads();
-      if (has_x) xs[tid] = xn;
+#pragma unroll
+      for (int u = 0; u < FGW_XPT; ++u)
+        if (tid + u * FGW_THREADS < C) xs[tid + u * FGW_THREADS] = xn[u];
       __syncthreads();
     }
     if (g.push) {

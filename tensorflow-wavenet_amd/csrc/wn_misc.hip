@@ -405,19 +405,21 @@ __global__ void gc_bias_kernel(const float* __restrict__ layer0, long layer_stri
                                const float* __restrict__ emb, int card,
                                const int32_t* __restrict__ ids,
                                float* __restrict__ out, int B, int ch) {
-  const int l = blockIdx.x, b = blockIdx.y, c = threadIdx.x;  // c < 2 ch
+  const int l = blockIdx.x, b = blockIdx.y;
   const float* blk = layer0 + (long)l * layer_stride;
-  float v = blk[off_bias + c];  // bf (0..ch-1) then bg (ch..2ch-1)
-  if (emb) {
-    const int id = ids[b];
-    if (id >= 0 && id < card) {
-      // Wgcf [G][ch] at off_gc, Wgcg [G][ch] at off_gc + G*ch
-      const float* w = blk + off_gc + (c >= ch ? (long)G * ch : 0) + (c % ch);
-      const float* e = emb + (long)id * G;
-      for (int g = 0; g < G; ++g) v += e[g] * w[(long)g * ch];
+  for (int c = threadIdx.x; c < 2 * ch; c += blockDim.x) {
+    float v = blk[off_bias + c];  // bf (0..ch-1) then bg (ch..2ch-1)
+    if (emb) {
+      const int id = ids[b];
+      if (id >= 0 && id < card) {
+        // Wgcf [G][ch] at off_gc, Wgcg [G][ch] at off_gc + G*ch
+        const float* w = blk + off_gc + (c >= ch ? (long)G * ch : 0) + (c % ch);
+        const float* e = emb + (long)id * G;
+        for (int g = 0; g < G; ++g) v += e[g] * w[(long)g * ch];
+      }
     }
+    out[((long)l * B + b) * 2 * ch + c] = v;
   }
-  out[((long)l * B + b) * 2 * ch + c] = v;
 }
 
 __global__ __launch_bounds__(256) void colsum_clip_kernel(
@@ -960,8 +962,8 @@ int wn_gc_bias(const float* layer0, long layer_stride, long off_bias,
                void* stream) {
   if (!layer0 || !out) return WN_ERR_NULL;
   if (emb && !ids) return WN_ERR_NULL;
-  if (L <= 0 || B <= 0 || ch < 32 || ch > 512) return WN_ERR_BAD_SHAPE;
-  hipLaunchKernelGGL(gc_bias_kernel, dim3(L, B), dim3(2 * ch), 0,
+  if (L <= 0 || B <= 0 || ch < 32) return WN_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(gc_bias_kernel, dim3(L, B), dim3(2 * ch < 1024 ? 2 * ch : 1024), 0,
                      (hipStream_t)stream, layer0, layer_stride, off_bias,
                      off_gc, G, emb, card, ids, out, B, ch);
   return wn_check_launch();

@@ -1278,7 +1278,7 @@ class WaveNetModel(object):
         return out + ws.loss_parts[0]
 
     # ---------------------------------------------------------- fast generation
-    FASTGEN_MAX_CHANNELS = 256     # wn_fastgen_run_wide: one channel per thread
+    FASTGEN_MAX_CHANNELS = 1024    # wn_fastgen_run_wide (FGW_MAXC)
 
     def _generator(self, global_condition):
         """Device-resident incremental-generation state (_create_generator,

@@ -105,10 +105,16 @@ CASES = [
     # more than 8 / K channel blocks per layer: the block kernels run in chunks
     ('r160_d136', cfg_with(TINY, batch_size=1, residual_channels=160,
                            dilation_channels=136), 70, False, None),
-    # more than 256 channels (9 / 10 blocks): training and predict_proba only
+    # more than 256 channels (9 / 10 blocks)
     ('r288_d320', cfg_with(TINY, batch_size=1, residual_channels=288,
                            dilation_channels=320, skip_channels=32,
                            quantization_channels=32), 40, False, None),
+    # the widest supported model (32 channel blocks) with biases and GC
+    ('r1024_d544_gc', cfg_with(TINY, batch_size=2, residual_channels=1024,
+                               dilation_channels=544, skip_channels=32,
+                               quantization_channels=32, dilations=[1, 2],
+                               global_condition_channels=3,
+                               global_condition_cardinality=4), 24, True, None),
     # filter widths above 8: groups of 8 taps (wavenet/blocked.py)
     ('k11', cfg_with(TINY, batch_size=2, filter_width=11), 120, False, None),
     ('k19_r64_d40', cfg_with(TINY, batch_size=1, filter_width=19,
@@ -485,12 +491,17 @@ WIDE_GEN = [
                           dilation_channels=128), None),
     ('r160_d136', cfg_with(TINY, batch_size=1, residual_channels=160,
                            dilation_channels=136), None),
+    # more channels than the generator kernel has threads
+    ('r288_d264', cfg_with(TINY, batch_size=1, residual_channels=288,
+                           dilation_channels=264), None),
+    ('r1024_d520', cfg_with(TINY, batch_size=1, residual_channels=1024,
+                            dilation_channels=520, dilations=[1, 2]), None),
 ]
 
 
 @pytest.mark.parametrize('name,cfg,gc', WIDE_GEN, ids=[c[0] for c in WIDE_GEN])
 def test_fast_generation_above_32_channels(hip_lib, name, cfg, gc):
-    """The incremental generator with 33 - 128 residual / dilation channels
+    """The incremental generator with 33 - 1024 residual / dilation channels
     (wn_fastgen_run_wide; the reference's generator has no width limit,
     model.py:444-516): every step of a teacher-forced trace longer than the
     receptive field against the float64 oracle, the no-push peek, forward-pass
@@ -548,14 +559,6 @@ def test_unsupported_configs_raise(hip_lib):
         net = WaveNetModel(**model_kwargs(cfg))
         with pytest.raises(NotImplementedError):
             net.loss(np.zeros(16, np.float32))
-    # above 256 channels the incremental generator refuses, predict_proba works
-    wide = WaveNetModel(**model_kwargs(cfg_with(
-        TINY, batch_size=1, residual_channels=288, dilation_channels=264,
-        skip_channels=32, quantization_channels=32)))
-    with pytest.raises(NotImplementedError):
-        wide.predict_proba_incremental(3)
-    p = wide.predict_proba(np.arange(20) % 32).cpu().numpy()
-    assert p.shape == (32,) and abs(float(p.sum()) - 1.0) < 1e-5
     net = WaveNetModel(**model_kwargs(cfg_with(
         TINY, batch_size=2, global_condition_channels=4,
         global_condition_cardinality=5)))

@@ -400,7 +400,10 @@ int wn_fastgen_run(const float* params_causal, const float* layer0,
  * channels (the reference's generator has no width limit, model.py:444-516):
  * layer blocks Wf[2][C][C] Wg[2][C][C] Wd[C][C] bf[C] bg[C] bd[C], causal
  * [2][Q][C], skip [L][C][S], gc_bias_fg [L][2 C], queue entries of C floats
- * (state_floats = sum(dilations) * C, C <= 1024).  One persistent workgroup,
+ * (state_floats = sum(dilations) * C).  C <= 1024, S <= 4096, Q <= 4096,
+ * L <= 1024 and 8 Q + 4 (5 C + 2 S + 3 L) <= 150 KB of LDS; C = 32 is accepted
+ * too (the host uses this entry for 32-channel models beyond the S / Q <= 512,
+ * L <= 64 of wn_fastgen_run / wn_fastgen_step).  One persistent workgroup,
  * correctness first. */
 int wn_fastgen_run_wide(const float* params_causal, const float* layer0,
                         long layer_stride, const float* skip_w,

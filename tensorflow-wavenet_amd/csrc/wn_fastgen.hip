@@ -393,7 +393,16 @@ __global__ __launch_bounds__(FG_THREADS, 1) void fastgen_kernel(FastGen g) {
 // ===========================================================================
 #define FGW_THREADS 256
 #define FGW_MAXC 1024
+#define FGW_MAXS 4096
+#define FGW_MAXQ 4096
+#define FGW_MAXL 1024
 #define FGW_XPT (FGW_MAXC / FGW_THREADS)   // residual channels per thread
+#define FGW_SPT (FGW_MAXS / FGW_THREADS)   // skip channels per thread
+
+// dynamic LDS of the wide generator: Q doubles, then 5 C + 2 S floats, 3 L ints
+static size_t fgw_lds_bytes(int C, int S, int Q, int L) {
+  return (size_t)Q * 8 + ((size_t)5 * C + 2 * (size_t)S + 3 * (size_t)L) * 4;
+}
 
 struct FastGenWide {
   FastGen g;
@@ -402,13 +411,20 @@ struct FastGenWide {
 
 __global__ __launch_bounds__(FGW_THREADS, 1) void fastgen_wide_kernel(FastGenWide a) {
   const FastGen& g = a.g;
-  __shared__ float xs[FGW_MAXC], sts[FGW_MAXC], zs[FGW_MAXC], apre[2 * FGW_MAXC];
-  __shared__ float hbuf[FG_MAXS], h2buf[FG_MAXS];
-  __shared__ double pd[FG_MAXQ];
-  __shared__ int s_code;
-  __shared__ int pos[FG_MAXL], sdil[FG_MAXL], roff[FG_MAXL];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  extern __shared__ double fgw_lds[];
   const int S = g.S, Q = g.Q, L = g.L, C = a.C;
+  double* pd = fgw_lds;                           // [Q]
+  float* xs = reinterpret_cast<float*>(pd + Q);   // [C]
+  float* sts = xs + C;                            // [C]
+  float* zs = sts + C;                            // [C]
+  float* apre = zs + C;                           // [2 C]
+  float* hbuf = apre + 2 * C;                     // [S]
+  float* h2buf = hbuf + S;                        // [S]
+  int* pos = reinterpret_cast<int*>(h2buf + S);   // [L]
+  int* sdil = pos + L;                            // [L]
+  int* roff = sdil + L;                           // [L]
+  __shared__ int s_code;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long CC = (long)C * C;
   const int steps_done = g.cursors[0];
   int prev_code = g.cursors[1];
@@ -427,9 +443,9 @@ __global__ __launch_bounds__(FGW_THREADS, 1) void fastgen_wide_kernel(FastGenWid
   for (int step = 0; step < g.n_steps; ++step) {
     const int code = s_code;
     const long tpos = (long)steps_done + step;
-    float acc[(FG_MAXS + FGW_THREADS - 1) / FGW_THREADS];
+    float acc[FGW_SPT];
 #pragma unroll
-    for (int o = 0; o < (FG_MAXS + FGW_THREADS - 1) / FGW_THREADS; ++o) acc[o] = 0.f;
+    for (int o = 0; o < FGW_SPT; ++o) acc[o] = 0.f;
     // causal layer: one-hot input = two table rows (model.py:341-346)
     for (int c = tid; c < C; c += FGW_THREADS) {
       float v = 0.f;
@@ -477,11 +493,14 @@ __global__ __launch_bounds__(FGW_THREADS, 1) void fastgen_wide_kernel(FastGenWid
       }
       {
         const float* ws = g.skip_w + (long)l * C * S;
-        int oi = 0;
-        for (int sc = tid; sc < S; sc += FGW_THREADS, ++oi) {
-          float t = acc[oi];
-          for (int k = 0; k < C; ++k) t = fmaf(zs[k], ws[(long)k * S + sc], t);
-          acc[oi] = t;
+#pragma unroll
+        for (int oi = 0; oi < FGW_SPT; ++oi) {
+          const int sc = tid + oi * FGW_THREADS;
+          if (sc < S) {
+            float t = acc[oi];
+            for (int k = 0; k < C; ++k) t = fmaf(zs[k], ws[(long)k * S + sc], t);
+            acc[oi] = t;
+          }
         }
       }
       __syncthreads();
@@ -498,9 +517,12 @@ __global__ __launch_bounds__(FGW_THREADS, 1) void fastgen_wide_kernel(FastGenWid
     }
     // ---- post-processing (model.py:505-514)
     {
-      int oi = 0;
-      for (int sc = tid; sc < S; sc += FGW_THREADS, ++oi)
-        hbuf[sc] = fmaxf(acc[oi] + (g.skip_bsum ? g.skip_bsum[sc] : 0.f), 0.f);
+#pragma unroll
+      for (int oi = 0; oi < FGW_SPT; ++oi) {
+        const int sc = tid + oi * FGW_THREADS;
+        if (sc < S)
+          hbuf[sc] = fmaxf(acc[oi] + (g.skip_bsum ? g.skip_bsum[sc] : 0.f), 0.f);
+      }
     }
     __syncthreads();
     for (int sc = tid; sc < S; sc += FGW_THREADS) {
@@ -1179,8 +1201,16 @@ int wn_fastgen_run_wide(const float* params_causal, const float* layer0,
   if (L <= 0 || S <= 0 || Q <= 0 || n_steps <= 0 || n_given < 1 || C <= 0 ||
       C % 32 != 0)
     return WN_ERR_BAD_SHAPE;
-  if (S > FG_MAXS || Q > FG_MAXQ || L > FG_MAXL || C > FGW_MAXC)
+  if (S > FGW_MAXS || Q > FGW_MAXQ || L > FGW_MAXL || C > FGW_MAXC)
     return WN_ERR_UNSUPPORTED;
+  const size_t lds = fgw_lds_bytes(C, S, Q, L);
+  if (lds > 150 * 1024) return WN_ERR_UNSUPPORTED;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(fastgen_wide_kernel),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return WN_ERR_LAUNCH;
+  }
   if (!(temperature > 0.f)) return WN_ERR_BAD_SHAPE;
   if (!push && n_steps != 1) return WN_ERR_BAD_SHAPE;
   FastGenWide a;
@@ -1196,7 +1226,7 @@ int wn_fastgen_run_wide(const float* params_causal, const float* layer0,
   g.use_dense_bias = use_biases;
   g.push = push;
   a.C = C;
-  hipLaunchKernelGGL(fastgen_wide_kernel, dim3(1), dim3(FGW_THREADS), 0,
+  hipLaunchKernelGGL(fastgen_wide_kernel, dim3(1), dim3(FGW_THREADS), lds,
                      (hipStream_t)stream, a);
   return wn_check_launch();
 }

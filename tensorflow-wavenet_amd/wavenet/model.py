@@ -1368,8 +1368,10 @@ class WaveNetModel(object):
                   self.L, self.S, self.Q, _lib.ptr(g['state']),
                   _lib.ptr(g['cursors']), _lib.ptr(samples_io))
         sd = int(seed) & (2**64 - 1)
-        if self.CB > 1:
-            # more than 32 channels: the wide single-workgroup generator
+        if self.CB > 1 or self.S > 512 or self.Q > 512 or self.L > 64:
+            # more than 32 channels, or more skip / quantization channels or
+            # layers than the tuned kernels hold in LDS (FG_MAXS / FG_MAXQ /
+            # FG_MAXL): the wide single-workgroup generator
             _lib.call('wn_fastgen_run_wide', *common[:11], self.L, self.CHn,
                       self.S, self.Q, *common[14:], int(n_given), int(n_steps),
                       float(temperature), sd, _lib.ptr(proba_out),

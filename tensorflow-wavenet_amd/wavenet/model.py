@@ -264,8 +264,13 @@ class WaveNetModel(object):
         # convs on a second, lower-priority HIP stream next to the dZ GEMM and
         # the residual-stack backward (one fork after the dtotal GEMM, one join
         # before the slab reductions): the layer kernels keep the matrix pipes
-        # about a third busy, the TN GEMMs are MFMA-bound.
-        self.overlap_tn = False
+        # about a third busy, the TN GEMMs are MFMA-bound.  None (default):
+        # on for small batches only -- at most four 32-row tiles per CU, where
+        # the backward stack is one dependent chain per tile that leaves most
+        # of the chip idle (B = 1, T = 16000: 2.03 -> 1.88 ms per step; B = 2:
+        # 2.94 -> 2.89; neutral at B = 4, 1 % SLOWER at B = 8).  True / False
+        # force it.
+        self.overlap_tn = None
         # backward of a residual block: 'bwd2' (default: one kernel per layer,
         # pre-activation gradients recomputed per tile, only dx goes through
         # HBM, tanh recovered as z / sigmoid); 'bwdw' (round-1 fused kernel:
@@ -551,6 +556,13 @@ class WaveNetModel(object):
         self._gen = None
 
     # ------------------------------------------------------------------ helpers
+    def _overlap_tn_on(self, ws):
+        if self.overlap_wgrad:
+            return False
+        if self.overlap_tn is not None:
+            return bool(self.overlap_tn)
+        return ws.B * ((ws.T + 31) // 32) <= 1024 and not self.blocked
+
     def _side_stream(self):
         if getattr(self, '_side', None) is None:
             # lower priority than the default stream: the residual-stack
@@ -865,7 +877,7 @@ class WaveNetModel(object):
         lib = _lib.load()
 
         deferred = []          # TN GEMMs postponed to the side stream
-        ovl = self.overlap_tn and not self.overlap_wgrad
+        ovl = self._overlap_tn_on(ws)
 
         def tn(*a, **kw):
             if ovl:
@@ -1091,7 +1103,7 @@ class WaveNetModel(object):
     def _backward_tail(self, ws, ids, dxin, nslab, fused):
         """After the residual stack: slab reductions of the layer-block
         gradients, causal-layer and global-conditioning gradients."""
-        if self.overlap_tn and not self.overlap_wgrad:
+        if self._overlap_tn_on(ws):
             main_s = torch.cuda.current_stream()
             _lib.call_py(lambda: main_s.wait_event(ws.ev_join))     # join
         st = _lib.stream()

@@ -246,3 +246,26 @@ def test_fused_vs_unfused_backward_many_tiles(hip_lib, B, T):
         for _ in range(3):                 # eager, recorded, replayed plan
             l3 = float(net.loss(audio, ids))
             assert l3 == l0 and torch.equal(net.grads, g0)
+
+
+@pytest.mark.parametrize('B,expect', [(1, True), (2, True), (3, False)])
+def test_small_batch_overlaps_the_weight_gradient_gemms(hip_lib, B, expect):
+    """Default stack, T = 16000: with `overlap_tn = None` the three TN GEMMs of
+    the skip / post-processing convs run on the side stream next to the
+    backward stack when the batch has at most four tiles per CU (B <= 2) --
+    same kernels, same slab order, so the gradients are the bits of the
+    one-stream order (eager, recorded and replayed launch plans)."""
+    from wavenet import WaveNetModel
+    net = WaveNetModel(seed=4, **model_kwargs(cfg_with(DEFAULT, batch_size=B)))
+    audio = synth_audio(B, 16000)
+    assert net.overlap_tn is None
+    net.overlap_tn = False
+    l0 = float(net.loss(audio))
+    g0 = net.grads.clone()
+    ws = [w for w in net._ws.values() if w.B == B][0]
+    assert not net._overlap_tn_on(ws)
+    net.overlap_tn = None
+    assert net._overlap_tn_on(ws) is expect
+    for _ in range(4):
+        l1 = float(net.loss(audio))
+        assert l1 == l0 and torch.equal(net.grads, g0)

@@ -30,7 +30,15 @@ cfg['batch_size'] = B
 net = WaveNetModel(seed=0, **model_kwargs(cfg))
 net.use_launch_plans = False
 L = net.L
-grid = min(256, (B * (T // 32) + 15) // 16)
+# the forward launch's grid, as wn_stack_fwd chooses it (the stamp buffer is
+# indexed by workgroup: it must not be smaller than the launch)
+ntiles, best, fw = B * ((T + 31) // 32), -1, 16
+for w in (16, 8, 4, 2, 1):
+    groups = (ntiles + w - 1) // w
+    cost = ((groups + 255) // 256) * max(w * 22 // 4, 70)
+    if best < 0 or cost <= best:
+        best, fw = cost, w
+grid = min(256, (ntiles + fw - 1) // fw)
 dbg = torch.zeros(grid * 16 * L * 12 + grid * 4, dtype=torch.int64, device='cuda')
 lib.wn_diag_stack_dbg.argtypes = [ctypes.c_void_p]
 lib.wn_diag_stack_dbg(dbg.data_ptr())
@@ -54,7 +62,7 @@ print('clock %.2f GHz; kernel (entry -> exit of a workgroup) median %.1f us, max
 names = ['top of layer', 'weights barrier', 'flags seen', "x[t-d] in fragments", '64 conv MFMAs',
          'tanh/sigmoid, z + sigmoid stores issued', 'dense MFMAs', "x' stored, drained, flag posted",
          'weight ring bookkeeping (+ refill by the last wave)', 'z store issued', 'sigmoid store issued']
-for wv in (0, 15):
+for wv in sorted({0, fw - 1}):
     print('--- wave %d of the workgroup: median over workgroups and layers 1..L-2, us per phase' % wv)
     tot = 0
     for i in range(1, 11):
@@ -64,7 +72,7 @@ for wv in (0, 15):
     per = (s[:, wv, 2:L - 1, 0] - s[:, wv, 1:L - 2, 0]) / clk / 1e3
     print('%-42s %6.2f   (sum of medians %.2f)' % ('layer period', np.median(per), tot))
 print('--- per wave: median us of flag wait / conv / dense / whole layer minus flag wait')
-for wv in range(16):
+for wv in range(fw):
     f = (s[:, wv, 1:L - 1, 2] - s[:, wv, 1:L - 1, 1]) / clk / 1e3
     c = (s[:, wv, 1:L - 1, 4] - s[:, wv, 1:L - 1, 3]) / clk / 1e3
     dn = (s[:, wv, 1:L - 1, 6] - s[:, wv, 1:L - 1, 5]) / clk / 1e3

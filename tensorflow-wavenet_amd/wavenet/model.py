@@ -271,6 +271,7 @@ class WaveNetModel(object):
         # 2.94 -> 2.89; neutral at B = 4, 1 % SLOWER at B = 8).  True / False
         # force it.
         self.overlap_tn = None
+        self.overlap_tn_split_frac = 0.6
         # backward of a residual block: 'bwd2' (default: one kernel per layer,
         # pre-activation gradients recomputed per tile, only dx goes through
         # HBM, tanh recovered as z / sigmoid); 'bwdw' (round-1 fused kernel:
@@ -888,6 +889,13 @@ class WaveNetModel(object):
         def tn_now(st, slabs, A, lda, a_planes, a_pstride, codes, shift, Gm,
                    ldg, key, mw, nw, dst, dst_bias, replicate=1, rep_stride=0):
             sp = ws.splits[key]
+            if ovl and 256 < ws.B * ((ws.T + 31) // 32) <= 512:
+                # beside the backward stack of a very small batch: fewer, longer
+                # workgroups disturb the stack's dependent chain less
+                # (B = 1, T = 16000 -- 500 tiles: 1.89 -> 1.80 ms per step at
+                # 0.6; 0.75 and 0.4 lose, and at B = 2 nothing changes; shapes
+                # of at most one tile per CU are too short for it to matter)
+                sp = max(1, int(sp * self.overlap_tn_split_frac))
             sl = lib.wn_gemm_tn_slab_floats(mw, nw)
             if self.gemm_mode != 'fp32' and codes is None and N % 16 == 0:
                 # opt-in split-bf16 products (fewer, larger splits)
@@ -941,6 +949,8 @@ class WaveNetModel(object):
            _lib.ptr(self._seg(Gr, 'skip_b')), replicate=L, rep_stride=S)
         if ovl:
             # fork: everything the three TN GEMMs read exists now
+            # (forking behind the dZ GEMM instead, or another order of the
+            # three, changes nothing at B = 1: 1.80 ms either way)
             main_s = torch.cuda.current_stream()
             side_s = self._side_stream()
             _lib.call_py(lambda: (ws.ev_fork.record(main_s),

@@ -253,8 +253,8 @@ def test_small_batch_overlaps_the_weight_gradient_gemms(hip_lib, B, expect):
     """Default stack, T = 16000: with `overlap_tn = None` the three TN GEMMs of
     the skip / post-processing convs run on the side stream next to the
     backward stack when the batch has at most four tiles per CU (B <= 2) --
-    same kernels, same slab order, so the gradients are the bits of the
-    one-stream order (eager, recorded and replayed launch plans)."""
+    same kernels, and at B = 2 the same slab order, so the gradients are the
+    bits of the one-stream order (eager, recorded and replayed launch plans)."""
     from wavenet import WaveNetModel
     net = WaveNetModel(seed=4, **model_kwargs(cfg_with(DEFAULT, batch_size=B)))
     audio = synth_audio(B, 16000)
@@ -266,6 +266,19 @@ def test_small_batch_overlaps_the_weight_gradient_gemms(hip_lib, B, expect):
     assert not net._overlap_tn_on(ws)
     net.overlap_tn = None
     assert net._overlap_tn_on(ws) is expect
+    lo, n = net.segments['layers']
     for _ in range(4):
         l1 = float(net.loss(audio))
-        assert l1 == l0 and torch.equal(net.grads, g0)
+        assert l1 == l0
+        if B > 1:
+            assert torch.equal(net.grads, g0)
+        else:
+            # B = 1: the TN GEMMs beside the stack use 0.6 of the splits (a
+            # different, equally fixed summation order for the skip / post-
+            # processing weights); everything else is bit-identical
+            assert torch.equal(net.grads[lo:lo + n], g0[lo:lo + n])
+            scale = g0.abs().max().item()
+            assert (net.grads - g0).abs().max().item() <= 2e-6 * scale
+    g1 = net.grads.clone()
+    net.loss(audio)
+    assert torch.equal(net.grads, g1)          # run-to-run identical

@@ -404,6 +404,34 @@ static size_t fgw_lds_bytes(int C, int S, int Q, int L) {
   return (size_t)Q * 8 + ((size_t)5 * C + 2 * (size_t)S + 3 * (size_t)L) * 4;
 }
 
+// sum_k in[k] * w[k * stride]: the weight loads in batches of sixteen (all of
+// a batch in flight before its FMAs) into four partial sums -- a plain loop
+// waits for every load before the next one is issued, and the wide generator
+// is nothing but such loops (64 channels, default stack: 3.5 ms -> 0.77 ms per
+// sample with batches of eight).
+#define FGW_BATCH 16
+__device__ __forceinline__ float fgw_dot(const float* in, const float* __restrict__ w,
+                                         long stride, int K, float init) {
+  float c[4] = {init, 0.f, 0.f, 0.f};
+  int k = 0;
+  for (; k + FGW_BATCH <= K; k += FGW_BATCH) {
+    float wv[FGW_BATCH];
+#pragma unroll
+    for (int u = 0; u < FGW_BATCH; ++u) wv[u] = w[(long)(k + u) * stride];
+#pragma unroll
+    for (int u = 0; u < FGW_BATCH; ++u) c[u & 3] = fmaf(in[k + u], wv[u], c[u & 3]);
+  }
+  for (; k + 4 <= K; k += 4) {
+    float wv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) wv[u] = w[(long)(k + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) c[u] = fmaf(in[k + u], wv[u], c[u]);
+  }
+  for (; k < K; ++k) c[0] = fmaf(in[k], w[(long)k * stride], c[0]);
+  return (c[0] + c[1]) + (c[2] + c[3]);
+}
+
 struct FastGenWide {
   FastGen g;
   int C;        // padded channels (multiple of 32, <= FGW_MAXC)
@@ -464,11 +492,8 @@ __global__ __launch_bounds__(FGW_THREADS, 1) void fastgen_wide_kernel(FastGenWid
         const int which = o / C, c = o - which * C;
         const float* w0 = blk + (long)which * 2 * CC + c;   // W_which[0][:, c]
         const float* w1 = w0 + CC;                          // W_which[1][:, c]
-        float s0 = g.bias_fg ? g.bias_fg[(long)l * 2 * C + o] : 0.f, s1 = 0.f;
-        for (int k = 0; k < C; ++k) {
-          s0 = fmaf(sts[k], w0[(long)k * C], s0);
-          s1 = fmaf(xs[k], w1[(long)k * C], s1);
-        }
+        const float s0 = fgw_dot(sts, w0, C, C, g.bias_fg ? g.bias_fg[(long)l * 2 * C + o] : 0.f);
+        const float s1 = fgw_dot(xs, w1, C, C, 0.f);
         apre[o] = s0 + s1;
       }
       __syncthreads();
@@ -486,8 +511,7 @@ __global__ __launch_bounds__(FGW_THREADS, 1) void fastgen_wide_kernel(FastGenWid
         xn[u] = 0.f;
         if (c < C) {
           const float* wd = blk + 4 * CC + c;
-          float d0 = g.use_dense_bias ? blk[5 * CC + 2 * C + c] : 0.f;
-          for (int k = 0; k < C; ++k) d0 = fmaf(zs[k], wd[(long)k * C], d0);
+          const float d0 = fgw_dot(zs, wd, C, C, g.use_dense_bias ? blk[5 * CC + 2 * C + c] : 0.f);
           xn[u] = xs[c] + d0;
         }
       }
@@ -497,9 +521,7 @@ __global__ __launch_bounds__(FGW_THREADS, 1) void fastgen_wide_kernel(FastGenWid
         for (int oi = 0; oi < FGW_SPT; ++oi) {
           const int sc = tid + oi * FGW_THREADS;
           if (sc < S) {
-            float t = acc[oi];
-            for (int k = 0; k < C; ++k) t = fmaf(zs[k], ws[(long)k * S + sc], t);
-            acc[oi] = t;
+            acc[oi] = fgw_dot(zs, ws + sc, S, C, acc[oi]);
           }
         }
       }
@@ -526,16 +548,12 @@ __global__ __launch_bounds__(FGW_THREADS, 1) void fastgen_wide_kernel(FastGenWid
     }
     __syncthreads();
     for (int sc = tid; sc < S; sc += FGW_THREADS) {
-      float c0 = g.post1_b ? g.post1_b[sc] : 0.f;
-      const float* w = g.post1_w + sc;
-      for (int k = 0; k < S; ++k) c0 = fmaf(hbuf[k], w[(long)k * S], c0);
+      const float c0 = fgw_dot(hbuf, g.post1_w + sc, S, S, g.post1_b ? g.post1_b[sc] : 0.f);
       h2buf[sc] = fmaxf(c0, 0.f);
     }
     __syncthreads();
     for (int q = tid; q < Q; q += FGW_THREADS) {
-      float c0 = g.post2_b ? g.post2_b[q] : 0.f;
-      const float* w = g.post2_w + q;
-      for (int k = 0; k < S; ++k) c0 = fmaf(h2buf[k], w[(long)k * Q], c0);
+      const float c0 = fgw_dot(h2buf, g.post2_w + q, Q, S, g.post2_b ? g.post2_b[q] : 0.f);
       pd[q] = (double)c0;
     }
     __syncthreads();

@@ -17,6 +17,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 8000
 p = json.load(open(os.path.join(ROOT, 'wavenet_params.json')))
 cfg = {k: p[k] for k in p if k != 'sample_rate'}
 cfg['batch_size'] = 1
+if os.environ.get('KB_CH'):     # more than 32 channels: the wide generator
+    cfg['residual_channels'] = cfg['dilation_channels'] = int(os.environ['KB_CH'])
 gen = WaveNetModel(seed=0, **model_kwargs(cfg))
 gen.generate(200, seed_samples=[128], seed=1)
 torch.cuda.synchronize()

@@ -440,6 +440,31 @@ __device__ __forceinline__ float fgw_dot(const float* in, const float* __restric
   return (c[0] + c[1]) + (c[2] + c[3]);
 }
 
+// two such sums at once (both batches of weight loads in flight together)
+__device__ __forceinline__ void fgw_dot2(const float* in0, const float* __restrict__ w0,
+                                         const float* in1, const float* __restrict__ w1,
+                                         long stride, int K, float& r0, float& r1) {
+  float a[4] = {r0, 0.f, 0.f, 0.f}, b[4] = {r1, 0.f, 0.f, 0.f};
+  int k = 0;
+  for (; k + 32 <= K; k += 32) {
+    float u0[32], u1[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) u0[u] = w0[(long)(k + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) u1[u] = w1[(long)(k + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) a[u & 3] = fmaf(in0[k + u], u0[u], a[u & 3]);
+#pragma unroll
+    for (int u = 0; u < 32; ++u) b[u & 3] = fmaf(in1[k + u], u1[u], b[u & 3]);
+  }
+  r0 = (a[0] + a[1]) + (a[2] + a[3]);
+  r1 = (b[0] + b[1]) + (b[2] + b[3]);
+  if (k < K) {
+    r0 = fgw_dot(in0 + k, w0 + (long)k * stride, stride, K - k, r0);
+    r1 = fgw_dot(in1 + k, w1 + (long)k * stride, stride, K - k, r1);
+  }
+}
+
 struct FastGenWide {
   FastGen g;
   int C;        // padded channels (multiple of 32, <= FGW_MAXC)
@@ -500,8 +525,8 @@ __global__ __launch_bounds__(FGW_THREADS, 1) void fastgen_wide_kernel(FastGenWid
         const int which = o / C, c = o - which * C;
         const float* w0 = blk + (long)which * 2 * CC + c;   // W_which[0][:, c]
         const float* w1 = w0 + CC;                          // W_which[1][:, c]
-        const float s0 = fgw_dot(sts, w0, C, C, g.bias_fg ? g.bias_fg[(long)l * 2 * C + o] : 0.f);
-        const float s1 = fgw_dot(xs, w1, C, C, 0.f);
+        float s0 = g.bias_fg ? g.bias_fg[(long)l * 2 * C + o] : 0.f, s1 = 0.f;
+        fgw_dot2(sts, w0, xs, w1, C, C, s0, s1);
         apre[o] = s0 + s1;
       }
       __syncthreads();
@@ -526,11 +551,12 @@ __global__ __launch_bounds__(FGW_THREADS, 1) void fastgen_wide_kernel(FastGenWid
       {
         const float* ws = g.skip_w + (long)l * C * S;
 #pragma unroll
-        for (int oi = 0; oi < FGW_SPT; ++oi) {
+        for (int oi = 0; oi < FGW_SPT; oi += 2) {
           const int sc = tid + oi * FGW_THREADS;
-          if (sc < S) {
+          if (sc + FGW_THREADS < S)             // this thread's next two columns
+            fgw_dot2(zs, ws + sc, zs, ws + sc + FGW_THREADS, S, C, acc[oi], acc[oi + 1]);
+          else if (sc < S)
             acc[oi] = fgw_dot(zs, ws + sc, S, C, acc[oi]);
-          }
         }
       }
       __syncthreads();

@@ -18,7 +18,9 @@ Extra objects on the JSON line:
                  timed live with HIP events on the launch stream in a short
                  instrumented pass of the same step right after the headline
                  loop (the headline loop itself carries no instrumentation);
-                 achieved = algorithmic FLOPs / kernel time.
+                 achieved = algorithmic FLOPs / kernel time; traffic (PMC,
+                 committed profile) next to traffic_algorithmic (operands in,
+                 outputs out, epilogue masks / pre-activations) per launch.
   step_tflops / step_frac - the WHOLE step against the fp32 MFMA peak
                  (8.804 MFLOP per audio sample).
   N > 1 only: allreduce_us_per_step (HIP events around the gradient
@@ -417,6 +419,10 @@ def main():
         2500.0 / int(args.gemm_mode[-1])
     dom = 'gemm_nn3_kernel' if args.gemm_mode == 'fp32' else \
         'gemm_nn_split_kernel'
+    Sk, Qc = int(params['skip_channels']), int(params['quantization_channels'])
+    LC = len(params['dilations']) * 32
+    algo_bytes = 4.0 * B * T * (
+        (LC + Sk) + (3 * Sk) + (Sk + Qc) + (Qc + 2 * Sk) + (3 * Sk) + (Sk + LC)) / 6
     # (the committed PMC summary was collected at the default shape only)
     traffic, traffic_src = pmc_traffic(dom) if (B, T) == (8, 16000) \
         else (None, None)
@@ -471,6 +477,12 @@ def main():
                      'frac': achieved / peak,
                      'traffic': traffic, 'traffic_source': traffic_src,
                      'traffic_unit': 'bytes per launch (rocprofv3 PMC pass)',
+                     # what the six launches of a step must move (fp32 path):
+                     # A operands in, outputs out, the pre-activation plane the
+                     # ReLU backward needs out, its two masks in; per launch
+                     'traffic_algorithmic': algo_bytes,
+                     'traffic_ratio': None if traffic is None
+                     else traffic / algo_bytes,
                      'launches_per_step': nlaunch // isteps,
                      'avg_launch_us': ktime / max(nlaunch, 1) * 1e6,
                      'flops_per_step': flops / isteps,

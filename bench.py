@@ -441,7 +441,12 @@ def main():
             'bound': 'hbm', 'traffic': by, 'traffic_source': src,
             'achieved_tb_s': None if by is None else by / us / 1e6,
             'frac_of_spec_8tb_s': None if by is None else by / us / 1e6 / 8.0,
-            'frac_of_streaming_5p3tb_s': None if by is None else by / us / 1e6 / 5.3}
+            'frac_of_streaming_5p3tb_s': None if by is None else by / us / 1e6 / 5.3,
+            # a hand-written stream with this launch's read : write plane mix
+            # (tools/ubench/hbm_stream.hip: forward 1 : 3, backward 7 : 2)
+            'mix_stream_tb_s': 4.85 if ev_name == 'wn_stack_fwd' else 5.05,
+            'frac_of_mix_stream': None if by is None else by / us / 1e6 / (
+                4.85 if ev_name == 'wn_stack_fwd' else 5.05)}
     out = {
         'metric': 'audio samples/sec (train, default wavenet_params.json)',
         'value': value, 'unit': 'audio samples/s', 'n_gpus': world,

@@ -620,3 +620,18 @@ def test_workspace_reserve_and_owner_per_kind(hip_lib):
     l1 = float(net.loss(audio))
     ref, _ = O.loss_and_grads(cfg, var, audio, dtype=np.float64)
     assert abs(l1 - ref) < TOL
+
+
+def test_random_configurations_vs_oracle(hip_lib):
+    """tools/model_fuzz.py: random constructor arguments (dilations, channel
+    counts up to 96, filter widths 2 - 9, skip / quantization channels,
+    biases, global conditioning, scalar input, residual post-processing, L2),
+    each against the float64 oracle: loss, every gradient, and a generator
+    trace where the reference's generator supports the configuration."""
+    import subprocess
+    import sys
+    from util import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'model_fuzz.py'),
+                        '24', '7'], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert '0 of 24 cases failed' in r.stdout

@@ -2,7 +2,9 @@
 quantization channels, biases, global conditioning, scalar input, residual
 post-processing, L2) against the float64 oracle: loss, every variable's
 gradient, and -- where the reference's generator supports the configuration --
-an incremental-generation trace.   python tools/model_fuzz.py [cases] [seed]"""
+an incremental-generation trace.   python tools/model_fuzz.py [cases] [seed]
+KB_BIG=1: 32 channels, filter width 2, dilations up to 512, clips of 200 - 4000
+samples (the persistent stack launches' territory)."""
 import os
 import sys
 import traceback
@@ -40,6 +42,17 @@ for case in range(n_cases):
         cfg['global_condition_cardinality'] = int(rng.choice([2, 5, 9]))
     l2 = float(rng.choice([0.0, 0.0, 1e-3])) or None
     T = int(rng.integers(8, 300))
+    if os.environ.get('KB_BIG') == '1':
+        # the default model's territory: 32 channels, width 2, dilations up to
+        # 512, clips of several tiles' length (the persistent stack launches)
+        cfg['dilations'] = [int(2 ** rng.integers(0, 10)) for _ in range(int(rng.integers(2, 13)))]
+        cfg['filter_width'] = 2
+        cfg['residual_channels'] = int(rng.choice([16, 32]))
+        cfg['dilation_channels'] = int(rng.choice([16, 32]))
+        cfg.pop('scalar_input', None)
+        cfg.pop('initial_filter_width', None)
+        T = int(rng.integers(200, 4000))
+        L = len(cfg['dilations'])
     B = cfg['batch_size']
     tag = 'L%d k%d r%d d%d s%d q%d b%d B%d T%d%s%s%s%s' % (
         L, cfg['filter_width'], cfg['residual_channels'], cfg['dilation_channels'],

@@ -18,6 +18,8 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 p = json.load(open(os.path.join(ROOT, 'wavenet_params.json')))
 cfg = {k: p[k] for k in p if k != 'sample_rate'}
 cfg['batch_size'] = B
+if os.environ.get('KB_CH'):     # more than 32 channels: the channel-block path
+    cfg['residual_channels'] = cfg['dilation_channels'] = int(os.environ['KB_CH'])
 net = WaveNetModel(seed=0, **model_kwargs(cfg))
 if os.environ.get('KB_OVERLAP_TN'):
     net.overlap_tn = os.environ['KB_OVERLAP_TN'] == '1'

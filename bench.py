@@ -51,16 +51,44 @@ STEP_FLOP_PER_SAMPLE = 8.804e6  # fwd 2.935 MFLOP x 3, default stac
 
 def synth_audio(B, T, first_clip=0, seed=1234, sample_rate=16000):
     """clip b = 0.5 sin(2 pi 110 2^(b/12) t / 16000) + 0.05 N(0,1),
-    clipped to [-1, 1]; b is the GLOBAL clip index."""
-    rng = np.random.default_rng(seed + first_clip)
+    clipped to [-1, 1], noise from ONE default_rng(1234) stream drawn clip after
+    clip; b is the GLOBAL clip index.  A rank of a data-parallel job draws (and
+    drops) the noise of the clips before its own, so that N ranks x B clips
+    hold exactly the batch one process x N B clips holds."""
+    rng = np.random.default_rng(seed)
     t = np.arange(T)
     out = np.empty((B, T), np.float32)
-    for i in range(B):
-        f = 110.0 * 2 ** ((first_clip + i) / 12.0)
-        x = 0.5 * np.sin(2 * np.pi * f * t / sample_rate) + \
-            0.05 * rng.standard_normal(T)
-        out[i] = np.clip(x, -1, 1)
+    for g in range(first_clip + B):
+        noise = rng.standard_normal(T)
+        if g < first_clip:
+            continue
+        f = 110.0 * 2 ** (g / 12.0)
+        x = 0.5 * np.sin(2 * np.pi * f * t / sample_rate) + 0.05 * noise
+        out[g - first_clip] = np.clip(x, -1, 1)
     return out
+
+
+def rank_gc_ids(rank, B):
+    """BASELINE.json configs[3]: speaker id of GLOBAL clip b is (37 b) mod 377;
+    rank r of a data-parallel job owns clips [r B, (r + 1) B)."""
+    return [(37 * (rank * B + b)) % 377 for b in range(B)]
+
+
+def collective_env():
+    """What shapes the gradient all-reduce on this run: the RCCL version and
+    every NCCL_* / RCCL_* variable found in the environment (SURVEY section 5
+    asks for ring vs tree to be comparable from the driver's line)."""
+    try:
+        ver = torch.cuda.nccl.version()
+        ver = '.'.join(str(v) for v in ver) if isinstance(ver, tuple) else str(ver)
+    except Exception as e:      # noqa: BLE001 (a CPU-only torch build)
+        ver = 'unavailable: %s' % type(e).__name__
+    env = {k: v for k, v in sorted(os.environ.items())
+           if k.startswith(('NCCL_', 'RCCL_'))}
+    return {'rccl_version': ver,
+            'NCCL_ALGO': os.environ.get('NCCL_ALGO'),
+            'NCCL_PROTO': os.environ.get('NCCL_PROTO'),
+            'env': env}
 
 
 def host_cores(cap=16):
@@ -142,6 +170,26 @@ def pmc_traffic(kernel):
         except (KeyError, ValueError, OSError):
             continue
     return None, None
+
+
+def stream_rates():
+    """({'forward stack mix': TB/s, ...}, source file) from the newest
+    committed output of tools/ubench/hbm_stream.hip (profiles/*_hbm_stream.txt:
+    a hand-written stream with the stack launches' read : write plane mixes on
+    this part) -- the denominators of `frac_of_mix_stream`."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_hbm_stream.txt')))
+    if not files:
+        return {}, None
+    rates = {}
+    with open(files[-1]) as f:
+        for line in f:
+            m = re.match(r'(.+?)\s+\d+ read : \d+ written.*?([0-9.]+) TB/s', line)
+            if m:
+                name = m.group(1).replace(', nt', '').strip()
+                rates[name] = max(rates.get(name, 0.0), float(m.group(2)))
+    return rates, os.path.relpath(files[-1], ROOT)
 
 
 def secondary(net, audio, gc_ids, kw, B, T, gen_samples=16000, opt=None):
@@ -328,8 +376,8 @@ def main():
     if args.gc:
         kw.update(global_condition_channels=32,
                   global_condition_cardinality=377)
-        gc_ids = torch.tensor([(37 * (rank * B + b)) % 377 for b in range(B)],
-                              dtype=torch.int32, device=dev)
+        gc_ids = torch.tensor(rank_gc_ids(rank, B), dtype=torch.int32,
+                              device=dev)
     net = WaveNetModel(seed=0, **kw)
     net.gemm_mode = args.gemm_mode
     if os.environ.get('WN_LAUNCH_PLANS') is not None:    # A/B knob
@@ -355,6 +403,17 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # one line per rank before the first step: which device this rank drives
+    prop = torch.cuda.get_device_properties(local)
+    bus = '%04x:%02x:%02x' % (getattr(prop, 'pci_domain_id', 0),
+                              getattr(prop, 'pci_bus_id', 0),
+                              getattr(prop, 'pci_device_id', 0))
+    sys.stderr.write('[bench] rank %d/%d (local %d): device %d = %s, PCI %s, '
+                     '%d CUs, clips [%d, %d)\n'
+                     % (rank, world, int(os.environ.get('LOCAL_RANK', 0)), local,
+                        prop.name, bus, prop.multi_processor_count,
+                        rank * B, (rank + 1) * B))
+    sys.stderr.flush()
     log('rank %d/%d: model built, warming up' % (rank, world))
     for _ in range(args.warmup):
         step()
@@ -384,7 +443,14 @@ def main():
         ar_us = sum(a.elapsed_time(b) for a, b in ar_events) / isteps * 1e3
     ranks_seen = 1
     dt_min = dt_max = dt
+    global_loss, ids_all = float(loss), None
     if world > 1:
+        gl = parallel.allreduce_mean_scalar(loss.reshape(1).float())
+        global_loss = float(gl[0])
+        if gc_ids is not None:
+            got = [torch.empty_like(gc_ids) for _ in range(world)]
+            torch.distributed.all_gather(got, gc_ids)
+            ids_all = [int(v) for t in got for v in t.cpu().tolist()]
         tt = torch.tensor([dt, -dt, ar_us or 0.0], dtype=torch.float64,
                           device=dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -414,6 +480,12 @@ def main():
     nlaunch = len(nn)
     tn_flops = sum(e[2] for e in tn)
     tn_time = sum(e[0].elapsed_time(e[1]) for e in tn) * 1e-3
+    # small batches run the TN GEMMs on a side stream beside the backward
+    # stack (net.overlap_tn): the event pairs, recorded on the main stream,
+    # then bracket nothing -- no TN figure rather than a meaningless one
+    tn_side = any(net._overlap_tn_on(w) for w in net._ws.values() if w.training)
+    if tn_side:
+        tn_time = 0.0
     step_tflops = STEP_FLOP_PER_SAMPLE * B * T / (dt / args.steps) / 1e12
     peak = FP32_MFMA_PEAK_TFLOPS if args.gemm_mode == 'fp32' else \
         2500.0 / int(args.gemm_mode[-1])
@@ -429,6 +501,7 @@ def main():
     # the two persistent residual-stack launches: HBM roofline (bytes per
     # launch from the committed PMC summary, time live)
     stacks = {}
+    rates, rates_src = stream_rates()
     for ev_name, kname in (('wn_stack_fwd', 'void stack_fwd_kernel<2, 16>'),
                            ('wn_stack_bwd', 'void stack_bwd_kernel<8, true>')):
         evs = [e for e in events if e[3] == ev_name]
@@ -444,9 +517,12 @@ def main():
             'frac_of_streaming_5p3tb_s': None if by is None else by / us / 1e6 / 5.3,
             # a hand-written stream with this launch's read : write plane mix
             # (tools/ubench/hbm_stream.hip: forward 1 : 3, backward 7 : 2)
-            'mix_stream_tb_s': 4.85 if ev_name == 'wn_stack_fwd' else 5.05,
-            'frac_of_mix_stream': None if by is None else by / us / 1e6 / (
-                4.85 if ev_name == 'wn_stack_fwd' else 5.05)}
+            'mix_stream_tb_s': rates.get('forward stack mix' if ev_name == 'wn_stack_fwd'
+                                         else 'backward stack mix'),
+            'mix_stream_source': rates_src}
+        mix = stacks[ev_name]['mix_stream_tb_s']
+        stacks[ev_name]['frac_of_mix_stream'] = None if (by is None or not mix) \
+            else by / us / 1e6 / mix
     out = {
         'metric': 'audio samples/sec (train, default wavenet_params.json)',
         'value': value, 'unit': 'audio samples/s', 'n_gpus': world,
@@ -472,7 +548,12 @@ def main():
                    'clips_per_gpu': B, 'samples_per_clip': T,
                    'global_batch': world * B,
                    'parallelism': 'dp%d' % world,
-                   'final_loss': float(loss)},
+                   'final_loss': float(loss),
+                   # mean over ranks = the loss of the global batch (equal
+                   # per-rank B*T, wavenet/parallel.py)
+                   'global_loss': global_loss,
+                   'gc_ids': ids_all if ids_all is not None else
+                   (None if gc_ids is None else gc_ids.cpu().tolist())},
         'roofline': {'bound': 'mfma',
                      'kernel': dom,
                      'achieved': achieved, 'peak': peak,
@@ -500,7 +581,10 @@ def main():
                          'frac': tn_flops / tn_time / 1e12 / peak
                          if tn_time > 0 else None,
                          'launches_per_step': len(tn) // isteps,
-                         'us_per_step': tn_time / isteps * 1e6},
+                         'us_per_step': tn_time / isteps * 1e6
+                         if tn_time > 0 else None,
+                         'note': 'on a side stream beside the backward stack '
+                                 '(small batch): not timed' if tn_side else None},
                      'stack_launches': stacks},
     }
     if world > 1:
@@ -508,6 +592,8 @@ def main():
         out['allreduce_note'] = ('max over ranks of the HIP-event time around '
                                  'the one flat-bucket gradient all-reduce '
                                  '(includes waiting for the slowest rank)')
+        out['allreduce_bytes'] = int(net.grads.numel() * net.grads.element_size())
+        out['collective'] = collective_env()
         out['step_ms_min'] = dt_min / args.steps * 1e3
         out['step_ms_max'] = dt_max / args.steps * 1e3
     if world == 1 and not args.no_secondary:

@@ -202,12 +202,18 @@ int wn_layer_bwd2(const float* x, const float* z, const float* sg,
  * handed over through memory: sc1 stores, one flag per (layer, tile), sc1
  * loads.  No grid barrier; groups are handed out by an atomic ticket in
  * dependency order, so the launch completes whatever the residency.
- *   X, Z, SG, dZ, DX : [L][B*T][32] planes, layer-major (X[0] = causal layer
+ *   X, Z, SG, dZ     : [L][B*T][32] planes, layer-major (X[0] = causal layer
  *                      output; forward writes X[1..L-1], Z, SG; backward reads
- *                      X, Z, SG, dZ and writes DX: DX[0] = dL/dx_0; for
- *                      l > 0 dL/dx_l when Q is NULL, else dL/dx_l WITHOUT the
- *                      anti-causal tap's term, which is Q[l] at the rows d_l
- *                      later)
+ *                      X, Z, SG, dZ)
+ *   DX, dx_layer_stride : the backward writes dL/dx_l at DX + l * dx_layer_stride
+ *                      floats: DX[0] = dL/dx_0; for l > 0 dL/dx_l when Q is
+ *                      NULL, else dL/dx_l WITHOUT the anti-causal tap's term,
+ *                      which is Q[l] at the rows d_l later.  dx_layer_stride =
+ *                      B*T*32 keeps every layer's plane ([L][B*T][32]); with Q
+ *                      given it may be 0: ONE [B*T][32] plane rewritten in
+ *                      place from layer to layer (a tile's own rows have no
+ *                      other reader; they stay in the L2 / Infinity Cache
+ *                      instead of travelling to HBM and back every layer)
  *   Q                : NULL, or an [L][B*T][32] scratch like DX: the backward
  *                      then runs its "push" formulation (a tile publishes
  *                      q_l[s] = da_l[s] W[0]^T, what its rows contribute to the
@@ -246,7 +252,8 @@ int wn_stack_fwd(float* X, float* Z, float* SG, const float* wimg,
                  void* stream);
 int wn_stack_bwd_slabs(int B, int T);
 int wn_stack_bwd(const float* X, const float* Z, const float* SG,
-                 const float* dZ, float* DX, float* Q, const float* wimg, float* slabs,
+                 const float* dZ, float* DX, long dx_layer_stride, float* Q,
+                 const float* wimg, float* slabs,
                  long slab_layer_stride, float* tilesum, const int* dilations,
                  unsigned* flags, unsigned* ctl, float* poison, int L, int B,
                  int T, void* stream);

@@ -473,13 +473,22 @@ __global__ __launch_bounds__(WAVES * 64) void stack_fwd_kernel(StackFwd a) {
 #ifndef SB_OWN_LD
 #define SB_OWN_LD 1
 #endif
+// cache policy of the x[t] / x[t-d] tile loads (weight-gradient operands):
+// nt (B = 8: 1621 -> 1595 us beside the in-place dx plane, whose lines are the
+// ones worth keeping in the L2; B = 1 / 2: no change)
+#ifndef SB_X_AUX
+#define SB_X_AUX 2
+#endif
 
 struct StackBwd {
   const float* X;      // [L][N][32]
   const float* Z;
   const float* SG;
   const float* dZ;
-  float* DX;           // [L][N][32]  DX[l] = dL/dx_l (PUSH: without the tap's term, l > 0)
+  float* DX;           // DX + l * dx_stride = dL/dx_l (PUSH: without the tap's term, l > 0)
+  long dx_stride;      // floats between the dx planes of two layers; PUSH: 0 = ONE plane,
+                       // rewritten in place from layer to layer (a tile's own rows
+                       // have no other reader: they stay in the L2 / Infinity Cache)
   float* Q;            // [L][N][32]  PUSH: q_l[s] = da_l[s] W[0]^T, the term row s sends to row s - d
   const float* wimg;   // [L][STACK_WBUF] backward weight images (wn_stack_pack)
   float* slabs;        // [L][>= groups][LAYER_BLOCK_FLOATS]
@@ -768,8 +777,8 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
       const wn_rsrc_t z = plane_rsrc(a.Z + (size_t)l * a.plane);
       const wn_rsrc_t sg = plane_rsrc(a.SG + (size_t)l * a.plane);
       const wn_rsrc_t dZ = plane_rsrc(a.dZ + (size_t)l * a.plane);
-      const wn_rsrc_t dxin = plane_rsrc(a.DX + (size_t)(hx ? l + 1 : l) * a.plane);
-      const wn_rsrc_t dx_out = plane_rsrc(a.DX + (size_t)l * a.plane);
+      const wn_rsrc_t dxin = plane_rsrc(a.DX + (size_t)(hx ? l + 1 : l) * a.dx_stride);
+      const wn_rsrc_t dx_out = plane_rsrc(a.DX + (size_t)l * a.dx_stride);
       const unsigned* fl_in = a.flags + (size_t)(hx ? l + 1 : l) * ntiles;
       unsigned* fl_out = a.flags + (size_t)l * ntiles;
       float* tile_colsum = a.tilesum ? a.tilesum + (size_t)l * ntiles * 64 : nullptr;
@@ -924,11 +933,11 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
         WN_WAIT_LGKM0();
         if (tile == tbase + wave) { BSTAMP(l, 15); }
         // the x tiles: in flight during the rows-t math
-        tile_dma_rs<0>(t0, x, off0, vswz, lane, 0, hi);
+        tile_dma_rs<SB_X_AUX>(t0, x, off0, vswz, lane, 0, hi);
 #ifdef SB_FAKE_ADDR
-        tile_dma_rs<0>(t1, x, off0 + 4096, vswz, lane, lo_p, hi);
+        tile_dma_rs<SB_X_AUX>(t1, x, off0 + 4096, vswz, lane, lo_p, hi);
 #else
-        tile_dma_rs<0>(t1, x, off0 - d * (WN_CH * 4), vswz, lane, lo_p, hi);
+        tile_dma_rs<SB_X_AUX>(t1, x, off0 - d * (WN_CH * 4), vswz, lane, lo_p, hi);
 #endif
         f32x16 dg;
         {
@@ -1387,7 +1396,8 @@ int wn_stack_bwd_slabs(int B, int T) {
 }
 
 int wn_stack_bwd(const float* X, const float* Z, const float* SG,
-                 const float* dZ, float* DX, float* Q, const float* wimg, float* slabs,
+                 const float* dZ, float* DX, long dx_layer_stride, float* Q,
+                 const float* wimg, float* slabs,
                  long slab_layer_stride, float* tilesum, const int* dilations,
                  unsigned* flags, unsigned* ctl, float* poison, int L, int B,
                  int T, void* stream) {
@@ -1409,6 +1419,7 @@ int wn_stack_bwd(const float* X, const float* Z, const float* SG,
   if (slab_layer_stride < groups * LAYER_BLOCK_FLOATS) return WN_ERR_BAD_SHAPE;
   StackBwd a;
   a.X = X; a.Z = Z; a.SG = SG; a.dZ = dZ; a.DX = DX; a.Q = Q; a.wimg = wimg;
+  a.dx_stride = dx_layer_stride;
   a.slabs = slabs; a.slab_layer_stride = slab_layer_stride; a.tilesum = tilesum;
   a.dil = dilations; a.flags = flags; a.ctl = ctl; a.poison = poison;
   a.L = L; a.B = B; a.T = T;
@@ -1424,6 +1435,10 @@ int wn_stack_bwd(const float* X, const float* Z, const float* SG,
   // with WN_STACK_BWD_PULL=1, for A/B) the first, "pull" one
   const char* pe = getenv("WN_STACK_BWD_PULL");
   const bool push = Q != nullptr && !(pe && pe[0] == '1');
+  // one dx plane per layer, or (push only: nobody but the owner reads a
+  // tile's dx rows) a single plane rewritten in place
+  if (dx_layer_stride != (long)B * T * WN_CH && !(push && dx_layer_stride == 0))
+    return WN_ERR_BAD_SHAPE;
 #define LAUNCH(W)                                                               \
   do {                                                                          \
     if (push) hipLaunchKernelGGL((stack_bwd_kernel<W, true>), grid, block, 0, s, a);   \

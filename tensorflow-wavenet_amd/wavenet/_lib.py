@@ -37,8 +37,8 @@ SIGNATURES = {
     'wn_stack_fwd': (c_int, [P, P, P, P, P, c_long, c_int, P, P, P, P,
                              c_int, c_int, c_int, c_int, P]),
     'wn_stack_bwd_slabs': (c_int, [c_int, c_int]),
-    'wn_stack_bwd': (c_int, [P, P, P, P, P, P, P, P, c_long, P, P, P, P, P,
-                             c_int, c_int, c_int, P]),
+    'wn_stack_bwd': (c_int, [P, P, P, P, P, c_long, P, P, P, c_long, P, P, P,
+                             P, P, c_int, c_int, c_int, P]),
     'wn_layer_bwd': (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int,
                              c_int, c_int, c_int, P]),
     'wn_layer_wgrad_slab_floats': (c_int, []),

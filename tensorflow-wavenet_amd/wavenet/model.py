@@ -130,15 +130,23 @@ class _Workspace(object):
         self.c1 = alloc('c1', (N, S)) if net.residual_postproc else None
         self.da = alloc('da', (2, 2 * CB, N, CH)) if self.legacy else None
         alloc('dx', (2, CB, N, CH))
-        # persistent backward (wn_stack_bwd): dL/dx_l of EVERY layer (waves
-        # of different workgroups are up to a few layers apart, so two
-        # ping-pong planes are not enough), its flags and control block
-        # (allocated whenever the option could apply, so that switching
-        # `layer_bwd` / `fused_bwd` back and forth keeps one behaviour)
+        # persistent backward (wn_stack_bwd), "push" formulation: a tile's
+        # own dx rows have no reader but the wave that wrote them, so ONE
+        # plane is rewritten in place from layer to layer (it stays in the L2
+        # / Infinity Cache; DX[0] ends up as dL/dx_0).  The "pull"
+        # formulation (WN_STACK_BWD_PULL=1, A/B) and the per-layer checks of
+        # tests/test_gpu_stack.py (`net.stack_bwd_keep_dx`) keep dL/dx_l of
+        # EVERY layer.  Plus the q planes, flags and control block (allocated
+        # whenever the option could apply, so that switching `layer_bwd` /
+        # `fused_bwd` back and forth keeps one behaviour)
         self.stack_bwd = (net.stack_bwd and not net.blocked and not net.generic_layers
                           and L <= 256 and N * CH * 4 < 2 ** 31)
         if self.stack_bwd:
-            alloc('DX', (L, N, CH))
+            self.keep_dx = bool(net.stack_bwd_keep_dx) or \
+                os.environ.get('WN_STACK_BWD_PULL') == '1'
+            if parent is not None and getattr(parent, 'DX', None) is not None:
+                self.keep_dx = parent.keep_dx
+            alloc('DX', (L if self.keep_dx else 1, N, CH))
             # q_l planes of the "push" formulation: what a tile's rows send to
             # the rows d earlier (csrc/wn_stack.hip)
             alloc('DQ', (L, N, CH))
@@ -161,6 +169,13 @@ class _Workspace(object):
         alloc('wst', (S, L * CHn))
         ntiles = B * ((T + 31) // 32)
         self.nslab = max(1, min(512, ntiles // 4))
+        if net.blocked:
+            # the pair-slab scratch of the channel-block path grows with the
+            # SQUARE of the block count (CB^2 x nslab x up to 17.5 K floats:
+            # 36 GB at 1024 channels and 8 taps with 512 slabs): fewer, longer
+            # row splits beyond 8 GB instead of an opaque allocation failure
+            per = CB * CB * ((2 * min(net.KW, 8) + 1) * 1024 + 96) * 4
+            self.nslab = max(1, min(self.nslab, (8 << 30) // per))
         self.nslab_f = lib.wn_layer_bwdw_slabs(B, T)      # fused kernel
         self.nslab_2 = lib.wn_layer_bwd2_slabs(B, T)
         self.nslab_s = lib.wn_stack_bwd_slabs(B, T) if self.stack_bwd else 0
@@ -287,6 +302,9 @@ class WaveNetModel(object):
         # the same for the backward of the stack (wn_stack_bwd instead of one
         # wn_layer_bwd2 per layer); read when a workspace is created
         self.stack_bwd = os.environ.get('WN_STACK_BWD', '1') != '0'
+        # diagnostic: keep dL/dx_l of every layer instead of one plane
+        # rewritten in place (read when a workspace is created)
+        self.stack_bwd_keep_dx = False
         # generate(): four kernels per sample over many CUs, replayed from a
         # hipGraph, instead of the single-workgroup persistent kernel
         self.fastgen_multi_cu = True
@@ -733,7 +751,8 @@ class WaveNetModel(object):
     # ------------------------------------------------------------ launch plans
     def _plan_key(self, tag, ws, ids, extra):
         return (tag, extra, ids is not None, self.generic_layers,
-                self.fused_bwd, self.layer_bwd, self.overlap_tn, self.stack_fwd, self.stack_bwd, self.gemm_mode, self.causal_wgrad_segsum, self.tf_xent_zero_label_quirk,
+                self.fused_bwd, self.layer_bwd, self.overlap_tn,
+                self.overlap_tn_split_frac, self.stack_fwd, self.stack_bwd, self.gemm_mode, self.causal_wgrad_segsum, self.tf_xent_zero_label_quirk,
                 _lib.stream(), self.params.data_ptr(), self.grads.data_ptr())
 
     def _stage_ids(self, ws, ids):
@@ -987,6 +1006,7 @@ class WaveNetModel(object):
                 _lib.call_timed('wn_stack_bwd', (
                     _lib.ptr(ws.X), _lib.ptr(ws.Z),
                     _lib.ptr(ws.SG), _lib.ptr(ws.dZ), _lib.ptr(ws.DX),
+                    ws.N * CH if ws.keep_dx else 0,
                     _lib.ptr(ws.DQ), _lib.ptr(ws.wimg_b), _lib.ptr(ws.lslabs),
                     ws.lslabs.shape[1] * self.LAYER_BLOCK,
                     None if tsum is None else _lib.ptr(tsum),

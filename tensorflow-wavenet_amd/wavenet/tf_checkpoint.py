@@ -251,7 +251,9 @@ def _extents(buf):
 
 
 def _tensor_proto(buf):
-    """TensorProto -> (dtype code, shape, flat numpy array)."""
+    """TensorProto -> (dtype code, shape, flat numpy array), or None for a
+    dtype that cannot be a model weight (strings, resources ...: skipped, as
+    read_v2 skips them)."""
     dtype, shape, content = 0, [], None
     vals = {5: [], 6: [], 7: [], 10: [], 11: []}   # float, double, int, int64, bool
     for no, wt, v in _fields(buf):
@@ -264,7 +266,7 @@ def _tensor_proto(buf):
         elif no in vals:
             vals[no].append((wt, v))
     if dtype not in _DTYPES:
-        raise ValueError('unsupported checkpoint dtype %d' % dtype)
+        return None
     np_dt = np.dtype(_DTYPES[dtype])
     if content is not None and len(content):
         return dtype, shape, np.frombuffer(content, dtype=np_dt.newbyteorder('<')).astype(np_dt)
@@ -317,7 +319,7 @@ def read_v1(path, verify_checksums=True):
                         ext = _extents(v2)
                     elif n2 == 3 and w2 == 2:
                         tensor = _tensor_proto(v2)
-                if name is not None and tensor is not None:
+                if name is not None and tensor is not None:   # (None: not a weight dtype)
                     pieces.setdefault(name, []).append((ext, tensor))
     out = {}
     for name, plist in pieces.items():
@@ -333,7 +335,16 @@ def read_v1(path, verify_checksums=True):
                 length = size - start if length is None else length
                 idx.append(slice(start, start + length))
                 sub.append(length)
-            if flat.size != int(np.prod(sub, dtype=np.int64)):
+            want = int(np.prod(sub, dtype=np.int64))
+            if 0 < flat.size < want:
+                # TensorProto's typed value lists may be shorter than the
+                # tensor: the LAST value stands for the rest (a constant
+                # tensor is stored as one value)
+                flat = np.concatenate([flat, np.full(want - flat.size, flat[-1],
+                                                     dtype=flat.dtype)])
+            elif flat.size == 0 and want:
+                flat = np.zeros(want, dtype=np_dt)     # (no value at all: zeros)
+            if flat.size != want:
                 raise ValueError('checkpoint slice of %r: %d values for extents %s'
                                  % (name, flat.size, sub))
             full[tuple(idx)] = flat.reshape(sub)

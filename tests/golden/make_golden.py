@@ -106,7 +106,105 @@ def incremental_case(cfg, n, seed=0):
     return out
 
 
+def _relu_masks(c):
+    return dict(total=c['total'] > 0, c1=c['c1'] > 0)
+
+
+def fp32_error(cfg, var, audio, ids=None):
+    """Per variable: max |g32 - g64| / max |g64| where g32 is THIS oracle run
+    in float32 on the same inputs, taking float64's side at the ReLU kinks (so
+    that only rounding is measured, not which subgradient a value that rounds
+    across 0 picks).  It is what a straightforward float32 evaluation of the
+    reference's graph loses on this case: the yardstick for how close a
+    float32 device path can be asked to come (tests bound the device by
+    max(2e-5, 4 x this))."""
+    l64, g64, c = O.loss_and_grads(cfg, var, audio, ids, dtype=np.float64,
+                                   return_cache=True)
+    l32, g32 = O.loss_and_grads(cfg, var, audio, ids, dtype=np.float32,
+                                relu_masks=_relu_masks(c))
+    names, err = [], []
+    for (n, a), (_, b) in zip(O.flatten_variables(g32), O.flatten_variables(g64)):
+        names.append(n)
+        sc = np.abs(b).max()
+        err.append(np.abs(a.astype(np.float64) - b).max() / sc if sc > 0 else 0.0)
+    return names, np.asarray(err), l64, g64, c, abs(float(l32) - float(l64))
+
+
+def fp32_error_cases():
+    """Deep narrow stacks are ill-conditioned: the float32
+    oracle's own error for the cases of tests/test_gpu_model.py whose device
+    error sits near the fixed 2e-5 bar.  Same weights (seed 0, biases
+    N(0, 0.1)) and audio (default_rng(7)) as the test."""
+    out = {}
+    for name, cfg, T in (
+            ('L70', cfg_with(TINY, batch_size=1, dilations=[1, 2, 4, 8, 16] * 14), 200),):
+        var = O.create_variables(cfg, seed=0, dtype=np.float64, bias_scale=0.1)
+        audio = np.random.default_rng(7).uniform(-1, 1, (1, T)).astype(np.float32)
+        names, err, l64, _, _, dl = fp32_error(cfg, var, audio)
+        out[name + '/names'] = np.array(names)
+        out[name + '/err32'] = err
+        out[name + '/loss'] = np.float64(l64)
+        out[name + '/loss_err32'] = np.float64(dl)
+        print(name, 'float32 oracle vs float64: worst %.3e (%s)' % (
+            err.max(), names[int(err.argmax())]))
+    return out
+
+
+N_SAMPLED = 32
+
+
+def sample_index(n_elems, var_index):
+    """The N_SAMPLED flat positions of a variable that the full-size fixture
+    holds (seeded by the variable's index; shared with the tests)."""
+    rng = np.random.default_rng(9000 + var_index)
+    return rng.integers(0, n_elems, N_SAMPLED)
+
+
+def config1_fullsize():
+    """BASELINE.json configs[0] at FULL length: the default stack, one clip of
+    16000 samples (BASELINE.md's synthetic clip 0), weights of
+    create_variables(seed 0) with N(0, 0.1) biases, float64 oracle.  The
+    gradient tensors are 6 MB; committed are per variable sum, abs-sum, max
+    abs and 32 sampled entries, the float32 oracle's own error (fp32_error),
+    and how many post-processing pre-activations sit within 2e-5 of the ReLU
+    kink (where a float32 device may legitimately take the other side)."""
+    from util import DEFAULT, synth_audio
+    cfg = cfg_with(DEFAULT, batch_size=1)
+    var = O.create_variables(cfg, seed=0, dtype=np.float64, bias_scale=0.1)
+    audio = synth_audio(1, 16000)
+    names, err, l64, g64, c, dl = fp32_error(cfg, var, audio)
+    flat = O.flatten_variables(g64)
+    out = {'names': np.array(names), 'err32': err, 'loss': np.float64(l64),
+           'loss_err32': np.float64(dl),
+           'sum': np.array([a.sum() for _, a in flat]),
+           'abssum': np.array([np.abs(a).sum() for _, a in flat]),
+           'absmax': np.array([np.abs(a).max() for _, a in flat]),
+           # (float32: 6e-8 relative, three hundred times below the 2e-5 bar)
+           'samples': np.stack([a.reshape(-1)[sample_index(a.size, i)]
+                                for i, (_, a) in enumerate(flat)]).astype(np.float32),
+           'near_kink': np.array([int((np.abs(c[k]) < 2e-5).sum())
+                                  for k in ('total', 'c1')]),
+           'logits_first_last': np.stack([c['logits'][0, 0], c['logits'][0, -1]]),
+           'audio_crc': np.array([audio.sum(dtype=np.float64),
+                                  np.abs(audio).sum(dtype=np.float64)])}
+    print('config1 T=16000: loss %.9f, float32 oracle worst %.3e (%s), near-kink %s'
+          % (l64, err.max(), names[int(err.argmax())], out['near_kink']))
+    return {'config1/' + k: v for k, v in out.items()}
+
+
 def main():
+    if '--fullsize-only' not in sys.argv:
+        small()
+    np.savez_compressed(os.path.join(HERE, 'fp32_oracle_error.npz'),
+                        **fp32_error_cases())
+    np.savez_compressed(os.path.join(HERE, 'config1_fullsize.npz'),
+                        **config1_fullsize())
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith('.npz'):
+            print(f, os.path.getsize(os.path.join(HERE, f)))
+
+
+def small():
     np.savez_compressed(os.path.join(HERE, 'reference_literals.npz'),
                         **literal())
     np.savez_compressed(os.path.join(HERE, 'mulaw_families.npz'),
@@ -126,9 +224,6 @@ def main():
     # receptive field of TINY = 2*(1+2+4+8)+2 = 32 -> 80 steps > RF
     np.savez_compressed(os.path.join(HERE, 'incremental.npz'),
                         **incremental_case(cfg_with(TINY, batch_size=1), 80))
-    for f in sorted(os.listdir(HERE)):
-        if f.endswith('.npz'):
-            print(f, os.path.getsize(os.path.join(HERE, f)))
 
 
 if __name__ == '__main__':

@@ -81,16 +81,22 @@ def test_stack_entries_validate_without_gpu(hip_lib):
                                 2, 1, 64, 1, None) == -3
     assert hip_lib.wn_stack_fwd(a, a, a, a, None, 0, 0, a, a, a, None,
                                 257, 1, 64, 1, None) == -2        # L > 256
-    assert hip_lib.wn_stack_bwd(a, a, a, a, None, a, a, a, 5216, None, a, a, a,
+    pl = 1 * 64 * 32
+    assert hip_lib.wn_stack_bwd(a, a, a, a, None, pl, a, a, a, 5216, None, a, a, a,
                                 None, 2, 1, 64, None) == -5
-    assert hip_lib.wn_stack_bwd(a, a, a, a, a, a, a, a, 5216, None, a, a, a,
+    assert hip_lib.wn_stack_bwd(a, a, a, a, a, pl, a, a, a, 5216, None, a, a, a,
                                 None, 2, 0, 64, None) == -1
-    assert hip_lib.wn_stack_bwd(a, a, a, a, a, None, a, a, 100, None, a, a, a,
+    assert hip_lib.wn_stack_bwd(a, a, a, a, a, pl, None, a, a, 100, None, a, a, a,
                                 None, 2, 1, 64, None) == -1       # slab stride too small
-    assert hip_lib.wn_stack_bwd(a, a + 4, a, a, a, a, a, a, 5216, None, a, a, a,
+    assert hip_lib.wn_stack_bwd(a, a + 4, a, a, a, pl, a, a, a, 5216, None, a, a, a,
                                 None, 2, 1, 64, None) == -3
-    assert hip_lib.wn_stack_bwd(a, a, a, a, a, a + 4, a, a, 5216, None, a, a, a,
+    assert hip_lib.wn_stack_bwd(a, a, a, a, a, pl, a + 4, a, a, 5216, None, a, a, a,
                                 None, 2, 1, 64, None) == -3       # Q misaligned
+    # one dx plane rewritten in place (stride 0) needs the push formulation's Q
+    assert hip_lib.wn_stack_bwd(a, a, a, a, a, 0, None, a, a, 5216, None, a, a, a,
+                                None, 2, 1, 64, None) == -1
+    assert hip_lib.wn_stack_bwd(a, a, a, a, a, 77, a, a, a, 5216, None, a, a, a,
+                                None, 2, 1, 64, None) == -1       # neither 0 nor a plane
 
 
 @pytest.mark.parametrize('q', [2, 16, 123, 128, 256])

@@ -49,6 +49,21 @@ def test_checkpoint_naming(tmp_path):
     assert train.latest_checkpoint(str(tmp_path)).endswith('model.ckpt-20')
 
 
+def test_latest_checkpoint_ignores_v2_data_shards_and_meta(tmp_path):
+    """A logdir holding only a step-0 TensorFlow V2 checkpoint and no
+    `checkpoint` marker: the prefix is the checkpoint, not the data shard
+    (whose name also ends in digits) nor the .meta graph."""
+    d = str(tmp_path)
+    for name in ('model.ckpt-0.index', 'model.ckpt-0.data-00000-of-00001',
+                 'model.ckpt-0.meta', 'model.ckpt-7.data-00000-of-00002',
+                 'model.ckpt-7.data-00001-of-00002', 'model.ckpt-7.index',
+                 'model.ckpt-best'):
+        open(os.path.join(d, name), 'w').close()
+    assert train.latest_checkpoint(d) == os.path.join(d, 'model.ckpt-7')
+    os.remove(os.path.join(d, 'model.ckpt-7.index'))
+    assert train.latest_checkpoint(d) == os.path.join(d, 'model.ckpt-0')
+
+
 def test_generate_flags():
     a = generate.get_arguments(['ck'])
     assert (a.samples, a.temperature, a.window) == (16000, 1.0, 8000)

@@ -22,19 +22,35 @@ GRAD_REL = 2e-5     # fp32 MFMA path vs float64 oracle, per variable, relative
 _ERRLOG = {}
 
 
+def _fp32_oracle_error(tag):
+    """{variable: error of the float32 ORACLE against float64, relative to the
+    variable's largest entry} for the cases tests/golden/make_golden.py
+    (fp32_error_cases) holds -- the ill-conditioned deep stacks -- else {}."""
+    fx = np.load(os.path.join(GOLD, 'fp32_oracle_error.npz'))
+    if tag is None or tag + '/names' not in fx.files:
+        return {}
+    return dict(zip([str(n) for n in fx[tag + '/names']], fx[tag + '/err32']))
+
+
 def check_grads(net, ref_g, tol=TOL, rel=GRAD_REL, tag=None):
     """Every variable's gradient against the float64 oracle: <= GRAD_REL of
     the variable's largest entry (exact-fp32 MFMA accumulation over <= a few
     10^4 rows observes ~1e-6; a missing small term would be orders above).
+    Where a float32 evaluation of the ORACLE itself is further than a quarter
+    of that from float64 (the 70-layer 8-channel stack: 1.1e-5; committed in
+    tests/golden/fp32_oracle_error.npz) the bound is 4 x the oracle's own
+    float32 error instead: conditioning of the network, not a missing term.
     The observed ratios are logged to gpurun_out/grad_errors.json."""
     got = tree_to_numpy(net.gradients)
+    e32 = _fp32_oracle_error(tag)
     bad = []
     for (n, a), (_, b) in zip(flat_named(got), flat_named(ref_g)):
         err = np.abs(a - b).max()
         scale = np.abs(b).max()
+        rel_v = max(rel, 4.0 * float(e32.get(n, 0.0)))
         if tag is not None:
             _ERRLOG.setdefault(tag, {})[n] = (float(err), float(scale))
-        if not (err <= rel * scale + 1e-9 and err <= tol * max(1.0, scale)):
+        if not (err <= rel_v * scale + 1e-9 and err <= tol * max(1.0, scale)):
             bad.append((n, float(err), float(scale)))
     assert not bad, bad[:6]
 

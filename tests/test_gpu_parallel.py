@@ -68,6 +68,73 @@ def test_two_ranks_real_model_equal_single_process(hip_lib, tmp_path, opt, gc):
     assert np.abs(a['params'] - b['params']).max() <= 1e-6
 
 
+# The GPU box admits at most 6 processes on its card (this pytest process is
+# one of them), so the many-rank rehearsals below run FOUR ranks on the one
+# GPU over gloo; the 8-rank arithmetic (shard ranges, 1/N, gc ids of 64 clips,
+# broadcast, step agreement) is covered on CPU by tests/test_parallel_gloo.py.
+REHEARSAL_RANKS = int(os.environ.get('WN_REHEARSE_RANKS', 4))
+
+
+def test_many_ranks_real_model_equal_single_process(hip_lib, tmp_path):
+    """REHEARSAL_RANKS ranks x 1 clip == 1 process x that many clips after two
+    full training steps (parameters and per-step global losses <= 1e-6)."""
+    n = REHEARSAL_RANKS
+    spec = dict(mode='dp', B=n, T=300, steps=2, opt='adam', lr=1e-3,
+                cfg=dict(global_condition_channels=4,
+                         global_condition_cardinality=5))
+    spec['out'] = str(tmp_path / 'dpn.npz')
+    _run_ranks(spec, n, dict(WN_SHARE_GPU='1', WN_DIST_BACKEND='gloo'))
+    one = dict(spec, out=str(tmp_path / 'dp1.npz'))
+    _run_ranks(one, 1)
+    a = np.load(spec['out'])
+    b = np.load(one['out'])
+    assert np.abs(a['losses'] - b['losses']).max() < 1e-6
+    assert np.abs(a['params'] - b['params']).max() <= 1e-6
+
+
+def _bench_json(args, env, timeout=900):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args
+                       + ['--no-secondary', '--no-cpu-baseline'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=timeout)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    line = [l for l in p.stdout.decode().splitlines() if l.startswith('{')][-1]
+    return json.loads(line), p.stderr.decode()
+
+
+@pytest.mark.parametrize('gc', [False, True], ids=['plain', 'gc'])
+def test_bench_many_ranks_rehearsal(hip_lib, gc):
+    """`python bench.py --gpus N [--gc]` (configs[2] / configs[3] with N ranks
+    of one clip each, sharing this box's GPU over gloo): every rank is seen,
+    the global batch and the per-rank speaker ids are what the 8-GPU run will
+    use, every rank names its device before the first step, the JSON says
+    which collective library / settings ran -- and the loss of the global
+    batch after the same number of steps equals ONE process with N clips."""
+    n = REHEARSAL_RANKS
+    env = dict(os.environ, WN_SHARE_GPU='1', WN_DIST_BACKEND='gloo')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    common = ['--steps', '2', '--warmup', '1', '--samples', '4000'] + \
+        (['--gc'] if gc else [])
+    r, err = _bench_json(['--gpus', str(n), '--batch', '1'] + common, env)
+    assert r['n_gpus'] == n and r['ranks_seen'] == n
+    assert r['config']['global_batch'] == n
+    assert r['allreduce_bytes'] == 4 * (1630432 if gc else 1515968)
+    assert r['collective']['rccl_version'] and 'NCCL_ALGO' in r['collective']
+    assert r['allreduce_us_per_step'] > 0
+    for k in range(n):
+        assert '[bench] rank %d/%d' % (k, n) in err and 'PCI' in err
+    if gc:
+        assert r['config']['gc_ids'] == [(37 * b) % 377 for b in range(n)]
+        assert len(set(r['config']['gc_ids'])) == n
+    env1 = {k: v for k, v in env.items() if k not in ('WN_SHARE_GPU', 'WN_DIST_BACKEND')}
+    one, _ = _bench_json(['--gpus', '1', '--batch', str(n)] + common, env1)
+    assert one['config']['global_batch'] == n
+    assert abs(one['config']['global_loss'] - r['config']['global_loss']) <= 1e-6
+    if gc:
+        assert one['config']['gc_ids'] == r['config']['gc_ids']
+
+
 def test_rccl_world_one_allreduces_the_gradient_bucket(hip_lib, tmp_path):
     """backend "nccl" (RCCL) comes up on the device and all-reduces /
     broadcasts the flat fp32 buckets of the real model."""

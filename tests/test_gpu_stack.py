@@ -179,11 +179,16 @@ def test_stack_backward_equals_per_layer(hip_lib, name, mk, B, T, kind):
     """wn_stack_bwd vs one wn_layer_bwd2 per layer: dL/dx_0 and the weight
     gradients to rounding (the persistent launch sums a tile's own rows before
     the anti-causal tap, and the tiles of a slab in another order), repeated
-    runs bitwise."""
+    runs bitwise.  `a` keeps dL/dx_l of every layer (the per-layer float64
+    check needs them); `c` is the product configuration -- ONE dx plane
+    rewritten in place from layer to layer -- and must give the same bits."""
     cfg = mk()
     a, _ = build_pair(cfg)
     b, _ = build_pair(cfg)
+    c, _ = build_pair(cfg)
     a.stack_bwd, b.stack_bwd = True, False
+    a.stack_bwd_keep_dx = True
+    assert c.stack_bwd and not c.stack_bwd_keep_dx
     audio = synth_audio(B, T)
     gc = np.array([(37 * i) % 377 for i in range(B)], np.int32) if kind == 'gc' else None
     prev = None
@@ -195,6 +200,14 @@ def test_stack_backward_equals_per_layer(hip_lib, name, mk, B, T, kind):
         if not wa.stack_bwd:
             pytest.skip('configuration runs the generic backward kernels')
         assert float(la) == float(lb)
+        lc = c.loss(audio, global_condition_batch=gc) if gc is not None else c.loss(audio)
+        torch.cuda.synchronize()
+        wc = list(c._ws.values())[0]
+        assert wc.DX.shape[0] == 1 and wa.DX.shape[0] == a.L
+        assert float(lc) == float(la)
+        assert torch.equal(wc.DX[0], wa.DX[0])
+        assert torch.equal(c.grads, a.grads)
+        assert int(wc.stack_ctl_b[3]) == 0
         # (same terms, another order of summation: the persistent launch adds
         # the tile's own rows first and the anti-causal tap last)
         dxb = wb.dx[0][0] if torch.equal(wa.DX[0] != 0, wb.dx[0][0] != 0) and \
@@ -252,6 +265,7 @@ def test_child_workspace_owns_fresh_backward_control_block(hip_lib):
     a.loss(audio)
     b.loss(audio)
     a.stack_bwd = True                     # read when a workspace is created
+    a.stack_bwd_keep_dx = True             # (_check_layer_grads reads every layer's dx)
     short = audio[:, :4500]
     la, lb = a.loss(short), b.loss(short)
     torch.cuda.synchronize()

@@ -4,7 +4,7 @@ import os
 
 import numpy as np
 
-from util import O
+from util import O, ROOT
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
@@ -125,3 +125,33 @@ def test_thresholds_reproduce_encode():
                             np.float32([-1, 1, 0, -0.0])])
         assert np.array_equal(O.mu_law_encode(x, q),
                               np.searchsorted(thr, x, side='right'))
+
+
+def test_config1_fullsize_fixture_is_the_oracle_at_full_length():
+    """tests/golden/config1_fullsize.npz (BASELINE.json configs[0]: default
+    stack, ONE clip of 16000 samples, float64) is what this oracle computes:
+    loss, and every variable's gradient through its sum / abs-sum / max and 32
+    sampled entries.  (The GPU test of the same name pins the device to it.)"""
+    import sys
+    gold = os.path.join(ROOT, 'tests', 'golden')
+    if gold not in sys.path:
+        sys.path.insert(0, gold)
+    from make_golden import sample_index
+    from util import DEFAULT, cfg_with, synth_audio
+    fx = np.load(os.path.join(gold, 'config1_fullsize.npz'))
+    cfg = cfg_with(DEFAULT, batch_size=1)
+    var = O.create_variables(cfg, seed=0, dtype=np.float64, bias_scale=0.1)
+    audio = synth_audio(1, 16000)
+    loss, g = O.loss_and_grads(cfg, var, audio, dtype=np.float64)
+    assert abs(loss - float(fx['config1/loss'])) < 1e-12
+    flat = O.flatten_variables(g)
+    assert [n for n, _ in flat] == [str(n) for n in fx['config1/names']]
+    assert len(flat) == 405
+    for i, (n, a) in enumerate(flat):
+        sc = float(fx['config1/absmax'][i])
+        assert abs(np.abs(a).max() - sc) <= 1e-9 * sc + 1e-300, n
+        assert abs(a.sum() - fx['config1/sum'][i]) <= 1e-9 * fx['config1/abssum'][i] + 1e-300, n
+        got = a.reshape(-1)[sample_index(a.size, i)]
+        assert np.abs(got - fx['config1/samples'][i]).max() <= 2e-7 * sc + 1e-300, n
+    # the float32 oracle's own error on this case is the tests' yardstick
+    assert 0 < fx['config1/err32'].max() < 2e-5

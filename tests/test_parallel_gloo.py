@@ -42,11 +42,12 @@ def _worker(rank, world, port, out_dir):
     from wavenet import parallel
     r, w, _ = parallel.init_from_env(backend='gloo')
     assert (r, w) == (rank, world) and parallel.is_distributed()
-    B, T = 4, 21
+    B, T = 2 * world, 21
     cfg = cfg_with(TINY, batch_size=B // world)
     var = O.create_variables(cfg, seed=0, dtype=np.float64, bias_scale=0.1)
     audio = np.random.default_rng(5).uniform(-1, 1, (B, T)).astype(np.float32)
     lo, hi = parallel.shard_range(B, rank, world)
+    assert (lo, hi) == (2 * rank, 2 * rank + 2)
     loss, g = O.loss_and_grads(cfg, var, audio[lo:hi], dtype=np.float64)
     bucket = _Bucket(torch.from_numpy(O.pack(g)))
     # rank 1 starts from garbage weights: broadcast must fix that
@@ -59,7 +60,7 @@ def _worker(rank, world, port, out_dir):
     mloss = parallel.allreduce_mean_scalar(torch.tensor(loss))
     # per-step agreement (train.py): rank 1 holds a shorter tail piece, and
     # in the second call its reader "failed"
-    t_common, ok = parallel.agree_step(100 if rank == 0 else 37, True)
+    t_common, ok = parallel.agree_step(37 if rank == 1 else 100 + rank, True)
     assert (t_common, ok) == (37, True)
     t_common, ok = parallel.agree_step(64, rank == 0)
     assert ok is False
@@ -73,12 +74,15 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_dp_two_ranks_equal_full_batch(tmp_path):
-    world = 2
+@pytest.mark.parametrize('world', [2, 8])
+def test_dp_ranks_equal_full_batch(tmp_path, world):
+    """world = 8 is the rank count of BASELINE.json configs[2] / [3]: shard
+    ranges, the 1/N of the flat bucket, broadcast, the per-step agreement and
+    the abort decision at the size the driver's first 8-GPU run has."""
     port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world,
              join=True)
-    B, T = 4, 21
+    B, T = 2 * world, 21
     cfg = cfg_with(TINY, batch_size=B)
     var = O.create_variables(cfg, seed=0, dtype=np.float64, bias_scale=0.1)
     audio = np.random.default_rng(5).uniform(-1, 1, (B, T)).astype(np.float32)
@@ -89,6 +93,19 @@ def test_dp_two_ranks_equal_full_batch(tmp_path):
         assert np.abs(got - full).max() < 1e-12
         assert abs(float(np.load(os.path.join(str(tmp_path),
                                               'l%d.npy' % r))) - loss) < 1e-12
+
+
+def test_bench_gc_ids_of_eight_ranks():
+    """configs[3] at 8 GPUs: rank r owns global clips [8 r, 8 r + 8) with
+    speaker id (37 b) mod 377 -- 64 distinct ids, every one a valid row."""
+    sys.path.insert(0, ROOT)
+    import bench
+    ids = [bench.rank_gc_ids(r, 8) for r in range(8)]
+    flat = [i for row in ids for i in row]
+    assert flat == [(37 * b) % 377 for b in range(64)]
+    assert len(set(flat)) == 64 and min(flat) >= 0 and max(flat) < 377
+    env = bench.collective_env()
+    assert set(env) >= {'rccl_version', 'NCCL_ALGO', 'NCCL_PROTO', 'env'}
 
 
 def test_world_size_one_is_identity():

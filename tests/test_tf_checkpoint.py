@@ -44,6 +44,27 @@ def test_reader_round_trip(tmp_path, fmt, snappy):
         np.testing.assert_array_equal(got[k], want[k])
 
 
+def test_v1_short_value_lists_and_foreign_dtypes(tmp_path):
+    """TensorProto semantics a real Saver file may use: a typed value list
+    shorter than the tensor repeats its LAST value (a constant is stored as one
+    value), an empty one means zeros; a tensor of a dtype that cannot be a
+    model weight (DT_STRING = 7) is skipped in V1 as it is in V2."""
+    import struct
+    path = str(tmp_path / 'model.ckpt-3')
+    raw = {'const': (1, (2, 3), W.field(5, 2, struct.pack('<f', 0.25))),
+           'ramp_then_flat': (1, (5,), W.field(5, 2, struct.pack('<2f', 1.0, 2.0))),
+           'empty': (1, (4,), b''),
+           'label': (7, (1,), W.field(8, 2, b'hello'))}
+    W.write_v1(path, {'w': np.arange(6, dtype=np.float32).reshape(2, 3)},
+               raw_tensors=raw)
+    got = C.read_checkpoint(path)
+    assert sorted(got) == ['const', 'empty', 'ramp_then_flat', 'w']
+    np.testing.assert_array_equal(got['const'], np.full((2, 3), 0.25, np.float32))
+    np.testing.assert_array_equal(got['ramp_then_flat'],
+                                  np.array([1, 2, 2, 2, 2], np.float32))
+    np.testing.assert_array_equal(got['empty'], np.zeros(4, np.float32))
+
+
 def test_known_answers():
     assert C.crc32c(b'123456789') == 0xe3069283           # the CRC-32C check value
     assert C.crc32c(b'\0' * 32) == 0x8a9136aa             # RFC 3720 B.4

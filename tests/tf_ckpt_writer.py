@@ -130,11 +130,20 @@ def shape_proto(shape):
     return b''.join(field(2, 2, field(1, 0, int(d))) for d in shape)
 
 
-def write_v1(path, tensors, **kw):
+def write_v1(path, tensors, raw_tensors=None, **kw):
     """tensors: {name: ndarray}; one full slice per tensor, typed repeated
-    values (float_val / double_val / int_val / int64_val), as TF <= 0.11."""
+    values (float_val / double_val / int_val / int64_val), as TF <= 0.11.
+    raw_tensors: {name: (dtype code, shape, value-field bytes)} written as
+    given (a constant stored as ONE value, a string tensor ...)."""
     meta = b''
     entries = []
+    for name, (dt, shape, vals) in sorted((raw_tensors or {}).items()):
+        full = b''.join(field(1, 2, b'') for _ in shape)
+        meta += field(1, 2, field(1, 2, name.encode()) + field(2, 2, shape_proto(shape)) +
+                      field(3, 0, dt) + field(4, 2, full))
+        tensor = field(1, 0, dt) + field(2, 2, shape_proto(shape)) + vals
+        data = field(1, 2, name.encode()) + field(2, 2, full) + field(3, 2, tensor)
+        entries.append((b'\x00' + name.encode() + b'\x00\x01', field(2, 2, data)))
     for name, a in sorted(tensors.items()):
         a = np.require(a, requirements='C')
         dt = DT[a.dtype]

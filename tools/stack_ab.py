@@ -5,6 +5,9 @@
     KB_B=1 python tools/stack_ab.py ...                  (clips per batch)
     KB_PULL=1 python tools/stack_ab.py lib.so            (one library: the "pull" and the
                                                           "push" formulation of wn_stack_bwd)
+    KB_DX=1 python tools/stack_ab.py lib.so              (one library: a dx plane per layer
+                                                          vs one plane rewritten in place)
+    KB_SAVE_SG=0                                         (forward without the sigmoid planes)
 
 The planes the kernels read are produced once by the default library's own
 training step; every variant then runs pack + launch on the same inputs
@@ -46,6 +49,7 @@ def main():
     cfg['batch_size'] = B
     net = WaveNetModel(seed=0, **model_kwargs(cfg))
     net.use_launch_plans = False
+    net.stack_bwd_keep_dx = True
     audio = synth_audio(B, T)
     net.loss(audio)
     torch.cuda.synchronize()
@@ -60,6 +64,9 @@ def main():
         # reads WN_STACK_BWD_PULL): "pull" first = the reference of the diffs
         lib = libs[0][1]
         libs = [('pull', lib), ('push', lib)]
+    if os.environ.get('KB_DX'):
+        lib = libs[0][1]
+        libs = [('dx_per_layer', lib), ('dx_in_place', lib)]
     nslab = max(l.wn_stack_bwd_slabs(B, T) for _, l in libs)
     slabs = torch.zeros(L, nslab, net.LAYER_BLOCK, device='cuda')
     wimg = torch.zeros(L, max(l.wn_stack_wimg_floats() for _, l in libs), device='cuda')
@@ -71,7 +78,8 @@ def main():
         lib.wn_stack_pack(ptr(net._layer_block(P, 0)), net.layer_stride, None,
                           ptr(wimg), L, st)
         code = lib.wn_stack_bwd(ptr(ws.X), ptr(ws.Z), ptr(ws.SG), ptr(ws.dZ),
-                                ptr(ws.DX), ptr(ws.DQ), ptr(wimg), ptr(slabs),
+                                ptr(ws.DX), 0 if name == 'dx_in_place' or os.environ.get('KB_INPLACE') == '1' else ws.N * 32,
+                                ptr(ws.DQ), ptr(wimg), ptr(slabs),
                                 slabs.shape[1] * net.LAYER_BLOCK, None,
                                 ptr(net._dil_dev), ptr(ws.stack_flags_b),
                                 ptr(ws.stack_ctl_b), ptr(ws.loss_parts[1:]),
@@ -87,7 +95,7 @@ def main():
                                 bias.stride(1) if bias is not None else 0,
                                 ptr(net._dil_dev), ptr(ws.stack_flags),
                                 ptr(ws.stack_ctl), ptr(ws.loss_parts), L, B, T,
-                                1, st)
+                                int(os.environ.get('KB_SAVE_SG', 1)), st)
         assert code == 0, code
 
     for what, run in (('bwd', run_bwd), ('fwd', run_fwd)):

@@ -75,6 +75,10 @@ int main() {
   run<1, 3, true>("forward stack mix, nt", src, dst, n4);
   run<7, 2, false>("backward stack mix", src, dst, n4);
   run<7, 2, true>("backward stack mix, nt", src, dst, n4);
+  // round 4: the backward's own dx rows are ONE plane rewritten in place (cache
+  // resident): what still streams is 6 planes read, 1 written
+  run<6, 1, false>("backward stack mix r4", src, dst, n4);
+  run<6, 1, true>("backward stack mix r4, nt", src, dst, n4);
   CK(hipFree(src));
   CK(hipFree(dst));
   return 0;

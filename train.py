@@ -18,6 +18,7 @@ import argparse
 import glob
 import json
 import os
+import re
 import sys
 import time
 from datetime import datetime
@@ -114,11 +115,16 @@ def latest_checkpoint(logdir):
         # (a TensorFlow V2 checkpoint is a prefix: model.ckpt-N.index / .data-*)
         if os.path.exists(path) or tf_checkpoint.checkpoint_format(path):
             return path
-    found = glob.glob(os.path.join(logdir, 'model.ckpt-*'))
-    found = sorted({f[:-len('.index')] if f.endswith('.index') else f for f in found})
-    found = [f for f in found if f.rsplit('-', 1)[-1].isdigit()]
-    return max(found, key=lambda f: int(f.rsplit('-', 1)[-1])) if found \
-        else None
+    # only `model.ckpt-<step>` itself or a V2 prefix's `.index`: a V2 data
+    # shard (`model.ckpt-N.data-00000-of-00001`) and `.meta` also end in
+    # digits / start with the prefix, and must not be taken for a checkpoint
+    found = {}
+    for f in glob.glob(os.path.join(logdir, 'model.ckpt-*')):
+        base = f[:-len('.index')] if f.endswith('.index') else f
+        m = re.match(r'model\.ckpt-(\d+)$', os.path.basename(base))
+        if m:
+            found[base] = int(m.group(1))
+    return max(found, key=found.get) if found else None
 
 
 def load(net, logdir):

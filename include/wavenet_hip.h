@@ -270,6 +270,37 @@ int wn_gemm_nn(const float* A, long lda, int a_planes, long a_plane_stride,
                long ld_mask, const float* addend, long ld_add, float* C,
                long ldc, int c_planes, long c_plane_stride, float* Cpre,
                long M, int N, int K, int relu, void* stream);
+
+/* ---- a CHAIN of row-wise dependent NN GEMMs in one persistent launch
+ * (csrc/wn_gemm.hip, gemm_nn_chain_kernel): the skip sum -> postprocess1 ->
+ * postprocess2 of wavenet/model.py:430-440 as ONE launch, and their data
+ * gradients (dlogits W2^T -> . W1^T -> . Ws^T) as another.  Problem p + 1 may
+ * read, as A operand / addend / mask, what problem p writes (C, Cpre) -- row
+ * block by row block: a 128-row block of p + 1 starts as soon as every column
+ * tile of that row block of p is stored, so one problem's ragged end overlaps
+ * the next one's start.  Bitwise the results of nprob wn_gemm_nn calls.
+ *   wn_nn_problem : the arguments of wn_gemm_nn; all problems the same M,
+ *                   K % 16 == 0, operands < 2 GB (else WN_ERR_UNSUPPORTED:
+ *                   issue the single calls)
+ *   nx            : XCD work queues, the value wn_gemm_nn_chain_probe returned
+ *                   (8: whole MI355X; 1: single-XCD partition; 0: do not call)
+ *   ctl           : wn_gemm_nn_chain_ctl_words(M) uint32, zero before first
+ *                   use, re-armed by the kernel; ctl[9] != 0 after a launch: a
+ *                   bounded dependency wait (2 s) expired or tiles were left
+ *                   uncomputed -- results invalid (sticky; the caller clears it)
+ *   poison        : NULL, or one float that is set to NaN in that case
+ * wn_gemm_nn_chain_probe launches a tiny kernel and SYNCHRONISES the stream:
+ * call it once per process / device; scratch = 1024 uint32 of device memory. */
+typedef struct wn_nn_problem {
+  const float* A; long lda; int a_planes; long a_plane_stride;
+  const float* W; int ldw; const float* bias; const float* mask; long ld_mask;
+  const float* addend; long ld_add; float* C; long ldc; int c_planes;
+  long c_plane_stride; float* Cpre; long M; int N, K, relu;
+} wn_nn_problem;
+long wn_gemm_nn_chain_ctl_words(long M);
+int wn_gemm_nn_chain_probe(unsigned* scratch, void* stream);
+int wn_gemm_nn_chain(const wn_nn_problem* probs, int nprob, int nx, unsigned* ctl,
+                     float* poison, void* stream);
 /* opt-in: same contraction with fp32 accuracy rebuilt from bf16 matrix
  * instructions (every operand split exactly into three bf16 pieces, nprod =
  * 3 / 6 / 9 piece products; 6 is as accurate as the fp32 MFMA path).

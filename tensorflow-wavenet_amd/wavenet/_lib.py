@@ -127,6 +127,34 @@ SIGNATURES = {
     'wn_fastgen_pack': (c_int, [P, c_long, P, c_int, P]),
 }
 
+
+
+class NNProblem(ctypes.Structure):
+    """wn_nn_problem (include/wavenet_hip.h): the arguments of wn_gemm_nn."""
+    _fields_ = [('A', P), ('lda', c_long), ('a_planes', c_int),
+                ('a_plane_stride', c_long), ('W', P), ('ldw', c_int),
+                ('bias', P), ('mask', P), ('ld_mask', c_long), ('addend', P),
+                ('ld_add', c_long), ('C', P), ('ldc', c_long),
+                ('c_planes', c_int), ('c_plane_stride', c_long), ('Cpre', P),
+                ('M', c_long), ('N', c_int), ('K', c_int), ('relu', c_int)]
+
+
+def nn_problems(arg_tuples):
+    """ctypes array of wn_nn_problem from wn_gemm_nn argument tuples (without
+    the trailing stream)."""
+    arr = (NNProblem * len(arg_tuples))()
+    for q, a in zip(arr, arg_tuples):
+        for (name, _), v in zip(NNProblem._fields_, a):
+            setattr(q, name, v)
+    return arr
+
+
+SIGNATURES.update({
+    'wn_gemm_nn_chain_ctl_words': (c_long, [c_long]),
+    'wn_gemm_nn_chain_probe': (c_int, [P, P]),
+    'wn_gemm_nn_chain': (c_int, [ctypes.POINTER(NNProblem), c_int, c_int, P, P, P]),
+})
+
 _lib = None
 
 

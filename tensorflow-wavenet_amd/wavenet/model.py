@@ -102,6 +102,12 @@ class _Workspace(object):
         if 'stack_ctl' in fresh:         # (a view shares the owner's epoch)
             self.stack_ctl[2] = 1
         alloc('bsum', (S,))
+        # control blocks of the chained NN GEMM launches (wn_gemm_nn_chain):
+        # forward (skip sum -> post1 -> post2) and backward (their data
+        # gradients) each own one
+        nw = lib.wn_gemm_nn_chain_ctl_words(N)
+        alloc('nnc_ctl_f', (nw,), torch.int32, fill=0)
+        alloc('nnc_ctl_b', (nw,), torch.int32, fill=0)
         self.total = alloc('total', (N, S)) if net.residual_postproc else None
         self.nparts = lib.wn_xent_partials(N)
         # (the first 2 words: the NaN "poison" of wn_stack_fwd / wn_stack_bwd,
@@ -305,6 +311,17 @@ class WaveNetModel(object):
         # diagnostic: keep dL/dx_l of every layer instead of one plane
         # rewritten in place (read when a workspace is created)
         self.stack_bwd_keep_dx = False
+        # OPT-IN (WN_NN_CHAIN=1; default off): the three NN GEMMs of the skip
+        # sum / post-processing (and the three of their data gradients) as ONE
+        # persistent launch each (wn_gemm_nn_chain: a problem's ragged end
+        # overlaps the next one's start; bitwise the results of the six
+        # wn_gemm_nn launches).  Measured on MI355X:
+        # what the overlap returns at B = 8 (the K = 256 / 512 launches lose
+        # 8 - 14 % to their ragged ends) a persistent workgroup pays back per
+        # tile -- its next tile's first chunk waits behind its own epilogue
+        # stores -- 4736 vs 4728 us per step; at B = 1 / 2 it loses 10 - 20 %.
+        self.nn_chain = os.environ.get('WN_NN_CHAIN', '0') == '1'
+        self._nn_chain_nx = None      # XCD queues (probed on first use)
         # generate(): four kernels per sample over many CUs, replayed from a
         # hipGraph, instead of the single-workgroup persistent kernel
         self.fastgen_multi_cu = True
@@ -607,6 +624,14 @@ class WaveNetModel(object):
                         'stack launch expired (2 s); the results of that step '
                         'are invalid.  WN_STACK_FWD=0 / WN_STACK_BWD=0 select '
                         'the one-launch-per-layer kernels.' % name)
+            for name in ('nnc_ctl_f', 'nnc_ctl_b'):
+                ctl = getattr(ws, name, None)
+                if ctl is not None and int(ctl[9]) != 0:
+                    raise _lib.WaveNetHipError(
+                        '%s: the chained NN GEMM launch left tiles uncomputed '
+                        'or a dependency wait expired (2 s); the results of '
+                        'that step are invalid.  WN_NN_CHAIN=0 selects one '
+                        'launch per GEMM.' % name)
 
     def reset_device_errors(self):
         """Clear the expired-wait record (control word 3 and the NaN poison
@@ -617,6 +642,10 @@ class WaveNetModel(object):
                 ctl = getattr(ws, name, None)
                 if ctl is not None:
                     ctl[3] = 0
+            for name in ('nnc_ctl_f', 'nnc_ctl_b'):
+                ctl = getattr(ws, name, None)
+                if ctl is not None:
+                    ctl.zero_()
             ws.loss_parts[:2] = 0.0
 
     def _bwd_image_with_fwd(self, ws):
@@ -724,6 +753,37 @@ class WaveNetModel(object):
                   self.L, nb, self.CHn, _lib.stream())
         return out, (W2 if ids is not None else 0)
 
+    def _nn_chain_queues(self):
+        """XCD work queues of wn_gemm_nn_chain on this device (0: not usable).
+        Probed once (a tiny launch + one stream synchronisation)."""
+        if self._nn_chain_nx is None:
+            scratch = torch.zeros(1024, dtype=torch.int32, device=self.device)
+            self._nn_chain_nx = int(_lib.load().wn_gemm_nn_chain_probe(
+                _lib.ptr(scratch), _lib.stream()))
+        return self._nn_chain_nx
+
+    def _nn_seq(self, ws, ctl, poison, calls):
+        """A sequence of row-wise dependent wn_gemm_nn calls (argument tuples
+        without the stream): ONE chained persistent launch when the option is
+        on and the shapes allow it (fp32 mode, K % 16 == 0, operands below
+        2 GB, a validated XCD topology), else one launch per call."""
+        st = _lib.stream()
+        ok = (self.nn_chain and self.gemm_mode == 'fp32' and len(calls) <= 3
+              and all(c[18] % 16 == 0 and c[17] % 4 == 0 and
+                      c[16] * max(c[1], 32) * 4 < 2 ** 31 and
+                      16 * c[5] * 4 < 2 ** 31 for c in calls)
+              and self._nn_chain_queues() > 0)
+        if not ok:
+            for c in calls:
+                self._nn(*(c + (st,)))
+            return
+        probs = _lib.nn_problems(calls)
+        flops = sum(2.0 * c[16] * c[17] * c[18] for c in calls)
+        _lib.call_timed('wn_gemm_nn_chain',
+                        (probs, len(calls), self._nn_chain_nx, _lib.ptr(ctl),
+                         _lib.ptr(poison), st), flops,
+                        getattr(self, '_gemm_events', None))
+
     def _nn(self, *args):
         """wn_gemm_nn (or, when `gemm_mode` asks for it, wn_gemm_nn_split),
         optionally bracketed by HIP events on the launch stream (bench.py's
@@ -752,7 +812,7 @@ class WaveNetModel(object):
     def _plan_key(self, tag, ws, ids, extra):
         return (tag, extra, ids is not None, self.generic_layers,
                 self.fused_bwd, self.layer_bwd, self.overlap_tn,
-                self.overlap_tn_split_frac, self.stack_fwd, self.stack_bwd, self.gemm_mode, self.causal_wgrad_segsum, self.tf_xent_zero_label_quirk,
+                self.overlap_tn_split_frac, self.nn_chain, self.stack_fwd, self.stack_bwd, self.gemm_mode, self.causal_wgrad_segsum, self.tf_xent_zero_label_quirk,
                 _lib.stream(), self.params.data_ptr(), self.grads.data_ptr())
 
     def _stage_ids(self, ws, ids):
@@ -867,22 +927,23 @@ class WaveNetModel(object):
             bsum = ws.bsum
         # total = sum_l z_l * Ws_l (+ sum_l bs_l); h1 = relu(total)
         LP, C = L * self.CB, self.CHn      # planes, padded channels
-        self._nn(_lib.ptr(ws.Z), 0, LP, N * CH,
-                  _lib.ptr(self._seg(P, 'skip_w')), S, _lib.ptr(bsum), None, 0,
-                  None, 0, _lib.ptr(ws.h1), S, 0, 0,
-                  _lib.ptr(ws.total) if self.residual_postproc else None,
-                  N, S, L * C, 1, st)
         b1 = self._seg(P, 'post1_b') if self.use_biases else None
         b2 = self._seg(P, 'post2_b') if self.use_biases else None
         rp = self.residual_postproc
-        self._nn(_lib.ptr(ws.h1), S, 0, 0,
-                  _lib.ptr(self._seg(P, 'post1_w')), S, _lib.ptr(b1), None, 0,
-                  _lib.ptr(ws.total) if rp else None, S, _lib.ptr(ws.h2), S, 0,
-                  0, _lib.ptr(ws.c1) if (rp and ws.training) else None,
-                  N, S, S, 1, st)
-        self._nn(_lib.ptr(ws.h2), S, 0, 0,
-                  _lib.ptr(self._seg(P, 'post2_w')), Q, _lib.ptr(b2), None, 0,
-                  None, 0, _lib.ptr(ws.logits), Q, 0, 0, None, N, Q, S, 0, st)
+        self._nn_seq(ws, ws.nnc_ctl_f, ws.loss_parts, [
+            (_lib.ptr(ws.Z), 0, LP, N * CH,
+             _lib.ptr(self._seg(P, 'skip_w')), S, _lib.ptr(bsum), None, 0,
+             None, 0, _lib.ptr(ws.h1), S, 0, 0,
+             _lib.ptr(ws.total) if self.residual_postproc else None,
+             N, S, L * C, 1),
+            (_lib.ptr(ws.h1), S, 0, 0,
+             _lib.ptr(self._seg(P, 'post1_w')), S, _lib.ptr(b1), None, 0,
+             _lib.ptr(ws.total) if rp else None, S, _lib.ptr(ws.h2), S, 0,
+             0, _lib.ptr(ws.c1) if (rp and ws.training) else None,
+             N, S, S, 1),
+            (_lib.ptr(ws.h2), S, 0, 0,
+             _lib.ptr(self._seg(P, 'post2_w')), Q, _lib.ptr(b2), None, 0,
+             None, 0, _lib.ptr(ws.logits), Q, 0, 0, None, N, Q, S, 0)])
 
     # ------------------------------------------------------------------ backward
     def _backward_eager(self, ws, ids):
@@ -940,29 +1001,42 @@ class WaveNetModel(object):
                 _lib.call('wn_reduce_slabs', _lib.ptr(slabs), sp, sl, 1, 0,
                           mw * nw, nw, dst_bias, 0, replicate, rep_stride, st)
 
-        # postprocess2:  dW2 = h2^T dlogits ; dh2 = dlogits W2^T
+        # The data gradients first -- dc1 = (dlogits W2^T) * [c1 > 0],
+        # dtotal = (dc1 W1^T) * [total > 0] (+ dh2 when residual_postproc),
+        # dZ planes = dtotal Ws_all^T -- as ONE chained launch (a 128-row block
+        # of a GEMM starts when that row block of the previous one is stored),
+        # then the three weight-gradient (TN) GEMMs, whose operands all exist
+        # by then: dW2 = h2^T dlogits, dW1 = h1^T dc1, dWs_all = Z^T dtotal
+        # (+ column sums = the bias gradients).
+        LP, C = L * self.CB, self.CHn      # planes, padded channels
+        _lib.call('wn_transpose', _lib.ptr(self._seg(P, 'post2_w')), S, Q, Q,
+                  _lib.ptr(ws.w2t), S, st)
+        _lib.call('wn_transpose', _lib.ptr(self._seg(P, 'post1_w')), S, S, S,
+                  _lib.ptr(ws.w1t), S, st)
+        _lib.call('wn_transpose', _lib.ptr(self._seg(P, 'skip_w')), L * C, S,
+                  S, _lib.ptr(ws.wst), L * C, st)
+        nn_dc1 = (_lib.ptr(dlog), Q, 0, 0, _lib.ptr(ws.w2t), S,
+                  None, _lib.ptr(ws.c1 if rp else ws.h2), S, None, 0,
+                  _lib.ptr(ws.dc1), S, 0, 0, _lib.ptr(ws.dh2) if rp else None,
+                  N, S, Q, 0)
+        nn_dtotal = (_lib.ptr(ws.dc1), S, 0, 0, _lib.ptr(ws.w1t), S,
+                     None, _lib.ptr(ws.h1), S, _lib.ptr(ws.dh2) if rp else None,
+                     S, _lib.ptr(ws.dtotal), S, 0, 0, None, N, S, S, 0)
+        nn_dz = (_lib.ptr(ws.dtotal), S, 0, 0, _lib.ptr(ws.wst),
+                 L * C, None, None, 0, None, 0, _lib.ptr(ws.dZ), 0, LP,
+                 N * CH, None, N, L * C, S, 0)
+        # (small batches: the TN GEMMs run on a side stream beside the dZ GEMM
+        # and the backward stack, so the dZ GEMM stays a launch of its own
+        # behind the fork)
+        self._nn_seq(ws, ws.nnc_ctl_b, ws.loss_parts[1:],
+                     [nn_dc1, nn_dtotal] if ovl else [nn_dc1, nn_dtotal, nn_dz])
         tn(_lib.ptr(ws.h2), S, 0, 0, None, 0, _lib.ptr(dlog), Q, 'post2', S, Q,
            _lib.ptr(self._seg(Gr, 'post2_w')),
            _lib.ptr(self._seg(Gr, 'post2_b')))
-        _lib.call('wn_transpose', _lib.ptr(self._seg(P, 'post2_w')), S, Q, Q,
-                  _lib.ptr(ws.w2t), S, st)
-        # dc1 = dh2 * [c1 > 0]   (h2 = relu(c1) (+ total))
-        self._nn(_lib.ptr(dlog), Q, 0, 0, _lib.ptr(ws.w2t), S,
-                  None, _lib.ptr(ws.c1 if rp else ws.h2), S, None, 0,
-                  _lib.ptr(ws.dc1), S, 0, 0, _lib.ptr(ws.dh2) if rp else None,
-                  N, S, Q, 0, st)
-        # postprocess1
         tn(_lib.ptr(ws.h1), S, 0, 0, None, 0, _lib.ptr(ws.dc1), S, 'post1', S,
            S, _lib.ptr(self._seg(Gr, 'post1_w')),
            _lib.ptr(self._seg(Gr, 'post1_b')))
-        _lib.call('wn_transpose', _lib.ptr(self._seg(P, 'post1_w')), S, S, S,
-                  _lib.ptr(ws.w1t), S, st)
-        # dtotal = (dc1 W1^T) * [total > 0] (+ dh2 when residual_postproc)
-        self._nn(_lib.ptr(ws.dc1), S, 0, 0, _lib.ptr(ws.w1t), S,
-                  None, _lib.ptr(ws.h1), S, _lib.ptr(ws.dh2) if rp else None,
-                  S, _lib.ptr(ws.dtotal), S, 0, 0, None, N, S, S, 0, st)
-        # skip convs: dWs_all = Z^T dtotal ; dbs_l = colsum(dtotal) for every l
-        LP, C = L * self.CB, self.CHn      # planes, padded channels
+        # skip convs: dbs_l = colsum(dtotal) for every l
         tn(_lib.ptr(ws.Z), 0, LP, N * CH, None, 0, _lib.ptr(ws.dtotal), S,
            'skip', L * C, S, _lib.ptr(self._seg(Gr, 'skip_w')),
            _lib.ptr(self._seg(Gr, 'skip_b')), replicate=L, rep_stride=S)
@@ -977,12 +1051,7 @@ class WaveNetModel(object):
             for a, kw in deferred:
                 tn_now(side_s.cuda_stream, ws.slabs_tn, *a, **kw)
             _lib.call_py(lambda: ws.ev_join.record(side_s))
-        # dZ planes = dtotal Ws_all^T
-        _lib.call('wn_transpose', _lib.ptr(self._seg(P, 'skip_w')), L * C, S,
-                  S, _lib.ptr(ws.wst), L * C, st)
-        self._nn(_lib.ptr(ws.dtotal), S, 0, 0, _lib.ptr(ws.wst),
-                  L * C, None, None, 0, None, 0, _lib.ptr(ws.dZ), 0, LP,
-                  N * CH, None, N, L * C, S, 0, st)
+            self._nn_seq(ws, ws.nnc_ctl_b, ws.loss_parts[1:], [nn_dz])
         if self.blocked:
             # channel-block path: residual stack, causal layer and global
             # conditioning gradients (wavenet/blocked.py)

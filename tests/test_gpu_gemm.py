@@ -461,3 +461,146 @@ def test_gemm_plane_operands_beyond_2gb(hip_lib):
     assert lib.wn_gemm_nn(dX.data_ptr(), 48, 0, 0, dW2.data_ptr(), P * 32, None, None, 0,
                           None, 0, big.data_ptr(), 0, P, stride, None, M, P * 32, 48, 0,
                           st) == -2
+
+
+def _chain_case(M, P_in, S, Q, P_out, rp, seed):
+    """The two chains of a training step in miniature: forward skip sum (plane
+    operand) -> post1 -> post2, backward dc1 -> dtotal -> dZ (plane output,
+    N % 128 == 32 or 64: a wave half beyond N), with biases, ReLU, masks, the
+    pre-activation copy and (rp) the addend a previous problem wrote."""
+    rng = np.random.default_rng(seed)
+    r = lambda *s: dev(rng.standard_normal(s).astype(np.float32))
+    t = dict(Z=r(P_in, M, 32), Ws=r(P_in * 32, S), bs=r(S), W1=r(S, S), b1=r(S),
+             W2=r(S, Q), b2=r(Q), dlog=r(M, Q), W2t=r(Q, S), W1t=r(S, S),
+             Wst=r(S, P_out * 32))
+    return t
+
+
+def _chain_problems(t, o, M, P_in, S, Q, P_out, rp):
+    p = lambda x: None if x is None else x.data_ptr()
+    fwd = [
+        (p(t['Z']), 0, P_in, M * 32, p(t['Ws']), S, p(t['bs']), None, 0, None, 0,
+         p(o['h1']), S, 0, 0, p(o['total']) if rp else None, M, S, P_in * 32, 1),
+        (p(o['h1']), S, 0, 0, p(t['W1']), S, p(t['b1']), None, 0,
+         p(o['total']) if rp else None, S, p(o['h2']), S, 0, 0,
+         p(o['c1']) if rp else None, M, S, S, 1),
+        (p(o['h2']), S, 0, 0, p(t['W2']), Q, p(t['b2']), None, 0, None, 0,
+         p(o['logits']), Q, 0, 0, None, M, Q, S, 0)]
+    bwd = [
+        (p(t['dlog']), Q, 0, 0, p(t['W2t']), S, None, p(o['c1'] if rp else o['h2']), S,
+         None, 0, p(o['dc1']), S, 0, 0, p(o['dh2']) if rp else None, M, S, Q, 0),
+        (p(o['dc1']), S, 0, 0, p(t['W1t']), S, None, p(o['h1']), S,
+         p(o['dh2']) if rp else None, S, p(o['dtotal']), S, 0, 0, None, M, S, S, 0),
+        (p(o['dtotal']), S, 0, 0, p(t['Wst']), P_out * 32, None, None, 0, None, 0,
+         p(o['dZ']), 0, P_out, M * 32, None, M, P_out * 32, S, 0)]
+    return fwd, bwd
+
+
+def _chain_outputs(M, S, Q, P_out):
+    e = lambda *s: torch.full(s, float('nan'), device='cuda')
+    return dict(h1=e(M, S), total=e(M, S), h2=e(M, S), c1=e(M, S), logits=e(M, Q),
+                dc1=e(M, S), dh2=e(M, S), dtotal=e(M, S), dZ=e(P_out, M, 32))
+
+
+@pytest.mark.parametrize('M,P_in,S,Q,P_out,rp', [
+    (128000 // 8 + 77, 6, 256, 128, 5, False),   # ragged M, dZ N = 160 (32 columns in the last tile)
+    (3000, 4, 512, 256, 6, True),                # N = 192: a dead wave half; residual_postproc
+    (300, 2, 64, 32, 2, False),                  # fewer row blocks than XCD queues
+    (1, 1, 16, 16, 1, True),
+])
+def test_gemm_nn_chain_bitwise_equals_single_launches(hip_lib, M, P_in, S, Q, P_out, rp):
+    """wn_gemm_nn_chain (one persistent launch, row-block dependencies inside
+    the launch) against the same problems as single wn_gemm_nn launches: every
+    output bitwise equal, also on a re-used control block (the kernel re-arms
+    it), and the single launches against float64."""
+    from wavenet import _lib
+    lib = hip_lib
+    st = torch.cuda.current_stream().cuda_stream
+    scratch = torch.zeros(1024, dtype=torch.int32, device='cuda')
+    nx = lib.wn_gemm_nn_chain_probe(scratch.data_ptr(), st)
+    if nx == 0:
+        pytest.skip('XCD topology not validated on this device: single launches are used')
+    t = _chain_case(M, P_in, S, Q, P_out, rp, seed=M + S)
+    ref_o, got_o = _chain_outputs(M, S, Q, P_out), _chain_outputs(M, S, Q, P_out)
+    fr, br = _chain_problems(t, ref_o, M, P_in, S, Q, P_out, rp)
+    for c in fr + br:
+        _lib.call('wn_gemm_nn', *(c + (st,)))
+    fg, bg = _chain_problems(t, got_o, M, P_in, S, Q, P_out, rp)
+    ctl = torch.zeros(lib.wn_gemm_nn_chain_ctl_words(M), dtype=torch.int32, device='cuda')
+    poison = torch.zeros(1, device='cuda')
+    for rep in range(3):
+        for k in got_o.values():
+            k.fill_(float('nan'))
+        for chain in (fg, bg):
+            _lib.call('wn_gemm_nn_chain', _lib.nn_problems(chain), 3, nx, ctl.data_ptr(),
+                      poison.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert int(ctl[9]) == 0 and float(poison) == 0.0
+        assert int(ctl.abs().sum()) == 0          # re-armed
+        for name in ref_o:
+            if not rp and name in ('total', 'c1', 'dh2'):
+                continue
+            assert torch.equal(ref_o[name], got_o[name]), (name, rep)
+    # a chain of two, and of one
+    for k in ('dc1', 'dtotal'):
+        got_o[k].fill_(float('nan'))
+    _lib.call('wn_gemm_nn_chain', _lib.nn_problems(bg[:2]), 2, nx, ctl.data_ptr(),
+              poison.data_ptr(), st)
+    got_o['dZ'].fill_(float('nan'))
+    _lib.call('wn_gemm_nn_chain', _lib.nn_problems(bg[2:]), 1, nx, ctl.data_ptr(),
+              poison.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert int(ctl[9]) == 0 and float(poison) == 0.0
+    for k in ('dc1', 'dtotal', 'dZ'):
+        assert torch.equal(ref_o[k], got_o[k]), k
+    # the single launches themselves against float64
+    Z = t['Z'].cpu().numpy().transpose(1, 0, 2).reshape(M, P_in * 32).astype(np.float64)
+    total = Z @ t['Ws'].cpu().numpy().astype(np.float64) + t['bs'].cpu().numpy()
+    assert np.abs(ref_o['h1'].cpu().numpy() - np.maximum(total, 0)).max() < \
+        1e-4 * max(1.0, np.abs(total).max())
+
+
+def test_gemm_nn_chain_argument_checks(hip_lib):
+    from wavenet import _lib
+    lib = hip_lib
+    st = torch.cuda.current_stream().cuda_stream
+    a = torch.zeros(64, 16, device='cuda')
+    ctl = torch.zeros(lib.wn_gemm_nn_chain_ctl_words(64), dtype=torch.int32, device='cuda')
+    ok = (a.data_ptr(), 16, 0, 0, a.data_ptr(), 16, None, None, 0, None, 0,
+          a.data_ptr(), 16, 0, 0, None, 64, 16, 16, 0)
+    assert lib.wn_gemm_nn_chain(_lib.nn_problems([ok]), 0, 8, ctl.data_ptr(), None, st) == -1
+    assert lib.wn_gemm_nn_chain(_lib.nn_problems([ok] * 3), 3, 3, ctl.data_ptr(), None, st) == -1
+    assert lib.wn_gemm_nn_chain(_lib.nn_problems([ok]), 1, 8, None, None, st) == -5
+    k12 = ok[:18] + (12, 0)          # K % 16 != 0: the single launch takes another kernel
+    assert lib.wn_gemm_nn_chain(_lib.nn_problems([k12]), 1, 8, ctl.data_ptr(), None, st) == -2
+    m2 = ok[:16] + (32,) + ok[17:]   # another M in the same chain
+    assert lib.wn_gemm_nn_chain(_lib.nn_problems([ok, m2]), 2, 8, ctl.data_ptr(), None, st) == -1
+
+
+@pytest.mark.parametrize('rp', [False, True])
+def test_model_with_chained_nn_gemms_bitwise_equals_default(hip_lib, rp):
+    """`net.nn_chain = True` (opt-in: the skip-sum / post-processing GEMMs and
+    their data gradients as two chained persistent launches): loss, logits and
+    every gradient bitwise equal to the default six launches, over three steps
+    on one workspace (eager, recorded and replayed launch plan)."""
+    import json
+    import os
+    from util import ROOT, build_pair, synth_audio
+    p = json.load(open(os.path.join(ROOT, 'wavenet_params.json')))
+    cfg = {k: p[k] for k in p if k != 'sample_rate'}
+    cfg.update(batch_size=3, residual_postproc=rp)
+    a, _ = build_pair(cfg)
+    b, _ = build_pair(cfg)
+    a.nn_chain = True
+    if a._nn_chain_queues() == 0:
+        pytest.skip('XCD topology not validated on this device')
+    assert not b.nn_chain
+    audio = synth_audio(3, 4100)
+    for rep in range(3):
+        la, lb = a.loss(audio), b.loss(audio)
+        torch.cuda.synchronize()
+        assert float(la) == float(lb)
+        assert torch.equal(a.grads, b.grads), rep
+    wa = list(a._ws.values())[0]
+    assert int(wa.nnc_ctl_f[9]) == 0 and int(wa.nnc_ctl_b[9]) == 0
+    a.check_device_errors()

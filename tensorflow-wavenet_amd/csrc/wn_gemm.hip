@@ -611,6 +611,14 @@ struct GemmNNChain {
 };
 
 __global__ __launch_bounds__(256, 4) void gemm_nn_chain_kernel(GemmNNChain a) {
+#ifdef NNC_STAMPS   // diagnostic build: a.poison carries a stamp buffer [grid][32 tiles][8]
+  unsigned long long* cdbg = reinterpret_cast<unsigned long long*>(a.poison) + (size_t)blockIdx.x * 256;
+  a.poison = nullptr;
+  int ctile = 0;
+#define CSTAMP(i) if (threadIdx.x == 0 && ctile < 32) cdbg[ctile * 8 + (i)] = __builtin_amdgcn_s_memrealtime()
+#else
+#define CSTAMP(i)
+#endif
   __shared__ __attribute__((aligned(1024))) float smem[NN3_LDSF];
   __shared__ int s_ticket, s_flag;
   const int tid = threadIdx.x;
@@ -639,9 +647,22 @@ __global__ __launch_bounds__(256, 4) void gemm_nn_chain_kernel(GemmNNChain a) {
     __hip_atomic_store(a.ctl + 9, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (a.poison) *a.poison = __builtin_nanf("");
   }
-  int next = -1;
-  if (tid == 0 && !lost)
-    next = (int)__hip_atomic_fetch_add(a.ctl + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // Tickets: a RETURNING atomic performed at the memory side, 3 - 5 us away
+  // (p90 12 us under load).  Written with the compiler's atomic the wave waits
+  // for the value on the spot (LLVM turns it into a wave reduction +
+  // s_waitcnt vmcnt(0) + v_readfirstlane) -- per tile: 50 - 100 us per chain at
+  // B = 8.  So thread 0 issues the instruction itself and reads the register
+  // only behind the next tile-top wait; between the two the register is
+  // "pending" and must not be copied or spilled by the compiler: it is an
+  // early-clobber asm output whose only use is the asm that waits
+  // (checked in the generated code; a broken ticket shows as a wrong tile
+  // count in ctl[10] -> error + poison, and in tests/test_gpu_gemm.py).
+  unsigned tick = (unsigned)c3;          // thread 0: the next ticket (pending after NNC_TICKET_ISSUE)
+  unsigned* const tickp = a.ctl + xcc;
+#define NNC_TICKET_ISSUE()                                                                   \
+  asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=&v"(tick) : "v"(tickp), "v"(1u) : "memory")
+#define NNC_TICKET_WAIT() asm volatile("s_waitcnt vmcnt(0)" : "+v"(tick) : : "memory")
+  if (tid == 0 && !lost) NNC_TICKET_ISSUE();
   unsigned my_tiles = 0;
   // the tile whose "stored" counter is still to be raised: a tile is published
   // behind the NEXT tile's first chunk barrier (which waits for every older
@@ -652,14 +673,17 @@ __global__ __launch_bounds__(256, 4) void gemm_nn_chain_kernel(GemmNNChain a) {
   // (raw barriers: __syncthreads() waits for vmcnt(0) as well)
 #define NNC_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
   for (;;) {
-    if (tid == 0) { s_ticket = lost ? c3 : next; s_flag = 0; }
+    if (tid == 0) {
+      NNC_TICKET_WAIT();
+      s_ticket = lost ? c3 : (int)tick;
+      s_flag = 0;
+    }
     NNC_BARRIER();       // (also: every wave is through the previous tile's epilogue LDS reads)
     const int t = __builtin_amdgcn_readfirstlane(s_ticket);
     if (t >= c3) break;
-    // the NEXT ticket: requested now, used after this tile (the atomic is
-    // performed at the memory side, a microsecond away)
-    if (tid == 0)
-      next = (int)__hip_atomic_fetch_add(a.ctl + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    CSTAMP(0);
+    // the NEXT ticket: requested now, read at the top of the next tile
+    if (tid == 0) NNC_TICKET_ISSUE();
     const int p = t < c1 ? 0 : t < c2 ? 1 : 2;
     const int i = t - (p == 0 ? 0 : p == 1 ? c1 : c2);
     const int tn = p == 0 ? tn0 : p == 1 ? tn1 : tn2;
@@ -716,6 +740,7 @@ __global__ __launch_bounds__(256, 4) void gemm_nn_chain_kernel(GemmNNChain a) {
         NNC_BARRIER();
       }
     }
+    CSTAMP(1);
     const long m0 = (long)mb * NN_TM;
     {
       GemmNN g;
@@ -730,10 +755,17 @@ __global__ __launch_bounds__(256, 4) void gemm_nn_chain_kernel(GemmNNChain a) {
       // one's operand comes from an earlier launch, where it makes no
       // difference -- one copy of the tile body)
       unsigned* const pub_now = pub;
+      CSTAMP(2);
       nn3_tile<NNC_A_AUX, false>(g, smem, tile_n, m0, m_end, nullptr, [&]() {
+        CSTAMP(3);
         if (pub_now != nullptr && tid == 0)
           __hip_atomic_fetch_add(pub_now, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       });
+      CSTAMP(4);
+#ifdef NNC_STAMPS
+      if (threadIdx.x == 0 && ctile < 32) cdbg[ctile * 8 + 6] = (unsigned long long)t;
+      ++ctile;
+#endif
     }
     pub = p + 1 < a.np ? done + (size_t)p * a.tiles_m + mb : nullptr;
     if (tid == 0) ++my_tiles;
@@ -744,6 +776,8 @@ __global__ __launch_bounds__(256, 4) void gemm_nn_chain_kernel(GemmNNChain a) {
       __hip_atomic_fetch_add(pub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 #undef NNC_BARRIER
+#undef NNC_TICKET_ISSUE
+#undef NNC_TICKET_WAIT
   // the last workgroup out: every tile computed?  re-arm the control block
   if (tid == 0) {
     if (my_tiles)

@@ -474,10 +474,11 @@ __global__ __launch_bounds__(WAVES * 64) void stack_fwd_kernel(StackFwd a) {
 #define SB_OWN_LD 1
 #endif
 // cache policy of the x[t] / x[t-d] tile loads (weight-gradient operands):
-// nt (B = 8: 1621 -> 1595 us beside the in-place dx plane, whose lines are the
-// ones worth keeping in the L2; B = 1 / 2: no change)
+// 2 = nt measured 1621 -> 1595 us in the isolated launch A/B (tools/stack_ab.py)
+// and 1493 -> 1502 us inside the training step (three interleaved bench.py
+// runs per build on one box): not kept
 #ifndef SB_X_AUX
-#define SB_X_AUX 2
+#define SB_X_AUX 0
 #endif
 
 struct StackBwd {

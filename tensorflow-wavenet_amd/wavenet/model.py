@@ -310,7 +310,7 @@ class WaveNetModel(object):
         self.stack_bwd = os.environ.get('WN_STACK_BWD', '1') != '0'
         # diagnostic: keep dL/dx_l of every layer instead of one plane
         # rewritten in place (read when a workspace is created)
-        self.stack_bwd_keep_dx = False
+        self.stack_bwd_keep_dx = os.environ.get('WN_STACK_KEEP_DX') == '1'   # (A/B knob)
         # OPT-IN (WN_NN_CHAIN=1; default off): the three NN GEMMs of the skip
         # sum / post-processing (and the three of their data gradients) as ONE
         # persistent launch each (wn_gemm_nn_chain: a problem's ragged end

@@ -804,6 +804,16 @@ __global__ __launch_bounds__(256, 4) void gemm_nn_chain_kernel(GemmNNChain a) {
   }
 }
 
+// (Round 4 also built the chain WITHOUT the persistent loop: one tile per
+// workgroup, all problems in one grid whose linear order is the dependency
+// order, the hardware's in-order dispatch as the queue, workgroup -> XCD taken
+// as bid & 7.  It measured what the overlap is worth without any per-tile
+// loop cost -- forward chain 2176 vs 2201 us, backward 2295 vs 2290 us, the
+// step 9.39 - 9.40 vs 9.40 - 9.44 ms -- and it is not safe: which XCD
+// workgroup 0 of a launch lands on depends on what was dispatched before
+// (the in-kernel HW_REG_XCC_ID check fired behind small grids and beside
+// another stream's kernels), so same-XCD coherence cannot be taken from the
+// workgroup index.  Removed.)
 // the XCD a workgroup runs on, for wn_gemm_nn_chain_probe
 __global__ void xcc_probe_kernel(unsigned* out) {
   unsigned x;

@@ -1051,7 +1051,7 @@ class WaveNetModel(object):
             for a, kw in deferred:
                 tn_now(side_s.cuda_stream, ws.slabs_tn, *a, **kw)
             _lib.call_py(lambda: ws.ev_join.record(side_s))
-            self._nn_seq(ws, ws.nnc_ctl_b, ws.loss_parts[1:], [nn_dz])
+            self._nn(*(nn_dz + (st,)))
         if self.blocked:
             # channel-block path: residual stack, causal layer and global
             # conditioning gradients (wavenet/blocked.py)

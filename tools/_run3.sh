@@ -1,3 +1,3 @@
 cd /root/repo
-timeout -k 10 1150 python -m pytest tests -x -q -m gpu > gpurun_out/t_all.log 2>&1
-tail -n 6 gpurun_out/t_all.log
+timeout -k 10 600 python -m pytest tests/test_gpu_gemm.py -x -q -k "chain" > gpurun_out/t4.log 2>&1
+tail -n 3 gpurun_out/t4.log

@@ -481,6 +481,31 @@ int wn_fastgen_step(const float* params_causal, const float* layer0,
 int wn_fastgen_finish(int Q, int32_t* cursors, int32_t* samples_io,
                       const int32_t* ctl, float* proba_out, const float* logits,
                       void* stream);
+
+/* ONE persistent multi-CU launch for n_steps samples (csrc/wn_fastgen.hip,
+ * fg_persist_kernel): the same inputs, state and results as n_steps x
+ * wn_fastgen_step + wn_fastgen_finish, without a kernel boundary per stage and
+ * with every workgroup's weights resident for the run (chain segments of ~10
+ * layers in LDS, skip / post-processing slices in LDS; the stages hand over
+ * through sc1 payloads + relaxed agent-scope flags).  cursors[2] must be 0 on
+ * entry.  sync: 16 uint32 (zeroed by the call; sync[12] != 0 afterwards = a
+ * bounded wait expired, results invalid); ll: wn_fastgen_persist_ll_words(L, S,
+ * Q) 8-byte hand-over words (payload + step in one store; zeroed by the call).
+ * Needs wn_fastgen_persist_workgroups(L, S, Q) <= CUs (all resident at once),
+ * else WN_ERR_UNSUPPORTED: use wn_fastgen_step. */
+int wn_fastgen_persist_workgroups(int L, int S, int Q);
+long wn_fastgen_persist_ll_words(int L, int S, int Q);
+int wn_fastgen_persist(const float* params_causal, const float* layer0,
+                       long layer_stride, const float* skip_w,
+                       const float* skip_bsum, const float* post1_w,
+                       const float* post1_b, const float* post2_w,
+                       const float* post2_b, const float* gc_bias_fg,
+                       const int32_t* dilations_dev, int L, int S, int Q,
+                       float* state, int32_t* cursors, int32_t* samples_io,
+                       const int32_t* ctl, float* proba_out, int use_biases,
+                       const float* cw_img, float* pre, float* z_all, float* h1,
+                       float* h2, float* logits, unsigned* sync,
+                       unsigned long long* ll, int n_steps, void* stream);
 int wn_fastgen_pre(const float* layer0, long layer_stride,
                    const float* gc_bias_fg, const int32_t* dilations_dev,
                    int L, const float* state, const int32_t* cursors,

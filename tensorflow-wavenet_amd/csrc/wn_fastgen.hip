@@ -792,7 +792,7 @@ __global__ __launch_bounds__(256) void fg_pre_kernel(FgStep g, int ahead) {
 }
 
 __device__ __forceinline__ int fg_draw_wave(const FgStep& g, double* pd, int lane,
-                                            int steps_done);
+                                            int steps_done, const float* lg = nullptr);
 
 #ifdef FG_STAMPS   // diagnostic build: per-layer phase stamps of the chain wave
 __device__ unsigned long long fg_dbg[8 + FG_MAXL * 8];
@@ -1083,8 +1083,9 @@ __global__ __launch_bounds__(256) void fg_logits_kernel(FgStep g) {
 // It runs at the START of the next step's chain kernel instead, next to that
 // kernel's weight / table prologue.)
 __device__ __forceinline__ int fg_draw_wave(const FgStep& g, double* pd, int lane,
-                                            int steps_done) {
+                                            int steps_done, const float* lg) {
   const int Q = g.Q;
+  if (!lg) lg = g.logits;      // (the persistent kernel hands in its own coherent copy)
   const int local = steps_done - g.ctl[FGCTL_BASE];
   const int code = g.samples[local];
   const int n_given = g.ctl[FGCTL_NGIVEN];
@@ -1092,7 +1093,7 @@ __device__ __forceinline__ int fg_draw_wave(const FgStep& g, double* pd, int lan
   const float temperature = __int_as_float(g.ctl[FGCTL_TEMP]);
   const uint64_t seed = (uint64_t)(uint32_t)g.ctl[FGCTL_SEED] |
                         ((uint64_t)(uint32_t)g.ctl[FGCTL_SEED + 1] << 32);
-  for (int q = lane; q < Q; q += 64) pd[q] = (double)g.logits[q];
+  for (int q = lane; q < Q; q += 64) pd[q] = (double)lg[q];
   __builtin_amdgcn_wave_barrier();
   double m = -1e300;
   for (int q = lane; q < Q; q += 64) m = fmax(m, pd[q]);
@@ -1171,6 +1172,408 @@ __global__ __launch_bounds__(64) void fg_draw_kernel(FgStep g) {
   __shared__ double pd[FG_MAXQ];
   if (g.cursors[2]) fg_draw_wave(g, pd, threadIdx.x, g.cursors[0]);
 }
+
+
+// ===========================================================================
+// Round 4: ONE persistent multi-CU launch for a whole run of samples
+// (wn_fastgen_persist).  The step kernels above pay four kernel boundaries per
+// sample (1.65 us each inside a replayed graph, tools/ubench/hop_vs_boundary)
+// and stream the 600 KB of chain weights through one CU's LDS ring again for
+// every sample, with a workgroup barrier per layer between the chain wave and
+// its loaders.  Here every workgroup stays resident for the run and owns its
+// weights:
+//   chain segments  nseg workgroups, L / nseg consecutive layers each, their
+//                   Wf[1] | Wg[1] | Wd images resident in LDS (12 KB a layer);
+//                   wave 0 is the serial chain (no barrier inside a segment),
+//                   waves 1..4 compute the NEXT step's past-tap
+//                   pre-activations of the segment's layers meanwhile;
+//   skip            S / 16 workgroups, 16 skip channels each, their [L*32][16]
+//                   slice of Ws resident in LDS; they take in a segment's z as
+//                   soon as its flag is up, so only the last segment's share
+//                   is left after the chain;
+//   post1, logits   S / 16 and Q / 16 workgroups with resident weight slices;
+//   draw            one wave: float64 softmax, temperature, inverse-CDF draw.
+// Hand-overs inside the launch (0.65 - 0.8 us a hop on an idle chip): the
+// payload with sc1 (write-through) stores, s_waitcnt vmcnt(0), then a relaxed
+// agent-scope flag / counter holding the 1-based step; consumers poll it and
+// read the payload with sc1 loads.  Every wait is bounded (2 s): on expiry the
+// error word is set, the waiter goes on without waiting, and the grid drains.
+// All nseg + S/16 + S/16 + Q/16 + 1 workgroups must be resident together (86
+// for the default stack on 256 CUs); the host refuses shapes that cannot be.
+// ===========================================================================
+#define FGP_THREADS 320
+#define FGP_MAXSEG 8
+#define FGP_SEGL 16            // most layers per chain segment (12.25 KB of LDS each)
+// sync words (uint32): [0..7] segment flags, [8] h1 counter, [9] h2 counter,
+// [10] logits counter, [11] draw flag, [12] error
+#define FGP_SEG 0
+#define FGP_H1 8
+#define FGP_H2 9
+#define FGP_LG 10
+#define FGP_DRAW 11
+#define FGP_ERR 12
+#define FGP_WORDS 16
+
+struct FgPersist {
+  FgStep g;
+  unsigned* sync;        // FGP_WORDS words, zero before the launch ([12]: error)
+  unsigned long long* ll;   // hand-over words (wn_fastgen_persist_ll_words), zero before the launch
+  int n_steps, nseg;
+  unsigned long long* dbg;   // diagnostic stamps or null
+};
+
+__device__ __forceinline__ float fgp_ld(const float* p) {          // sc1 (device-scope) load
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void fgp_st(float* p, float v) {        // sc1 (write-through) store
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// a tail mat-vec role: OUT16 = 16 outputs of  out = act(in[K] * W[:, col0 .. col0+15] + b)
+// with the weight slice resident in LDS as [K][16]
+__device__ __forceinline__ float fgp_mv16(const float* in_s, const float* w_s, int K, int o,
+                                          int part, int parts) {
+  const int per = (K + parts - 1) / parts;
+  const int k0 = part * per, k1 = min(K, k0 + per);
+  float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+  int k = k0;
+  for (; k + 4 <= k1; k += 4) {
+    c0 = fmaf(in_s[k], w_s[k * 16 + o], c0);
+    c1 = fmaf(in_s[k + 1], w_s[(k + 1) * 16 + o], c1);
+    c2 = fmaf(in_s[k + 2], w_s[(k + 2) * 16 + o], c2);
+    c3 = fmaf(in_s[k + 3], w_s[(k + 3) * 16 + o], c3);
+  }
+  for (; k < k1; ++k) c0 = fmaf(in_s[k], w_s[k * 16 + o], c0);
+  return (c0 + c1) + (c2 + c3);
+}
+
+// Hand-over words ("LL" style): a 32-bit payload and the 1-based step it
+// belongs to in ONE 8-byte write-through store; the consumer polls the word
+// itself until the step matches.  One memory round trip per hop instead of
+// three (payload drain + flag, then poll + load): the first version of this
+// kernel (counters + sc1 payloads) spent 2.3 / 4.6 / 3.8 / 1.6 us in its four
+// tail hand-overs and ran at 49 us per sample.  A location is rewritten once
+// per step, and no producer can run a step ahead of a consumer of the same
+// word (every word's next write waits, through the draw, for this step's
+// reads), so a reader never sees a later step's value.
+typedef unsigned long long fgp_ll_t;
+__device__ __forceinline__ void fgp_put(fgp_ll_t* p, float v, unsigned step) {
+  __hip_atomic_store(p, ((fgp_ll_t)step << 32) | (fgp_ll_t)__float_as_uint(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+// poll until the word carries `step` (bounded: 2 s; `dead` = some wait expired)
+__device__ __forceinline__ float fgp_get(const fgp_ll_t* p, unsigned step, unsigned* sync,
+                                         bool& dead) {
+  fgp_ll_t w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned spins = 0;
+  unsigned long long t_start = 0;
+  while (!dead && (unsigned)(w >> 32) != step) {
+    __builtin_amdgcn_s_sleep(1);
+    w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((++spins & 255u) == 0) {
+      const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+      if (t_start == 0) t_start = now;
+      if (now - t_start > 200000000ull ||
+          __hip_atomic_load(sync + FGP_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        __hip_atomic_store(sync + FGP_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        dead = true;
+      }
+    }
+  }
+  return __uint_as_float((unsigned)w);
+}
+
+__global__ __launch_bounds__(FGP_THREADS) void fg_persist_kernel(FgPersist a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const FgStep& g = a.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int L = g.L, S = g.S, Q = g.Q, nseg = a.nseg, n_steps = a.n_steps;
+  const int nsk = (S + 15) / 16, nlg = (Q + 15) / 16;
+  const int base = g.ctl[FGCTL_BASE];
+  unsigned* sync = a.sync;
+  // hand-over words: z [L][32] | h1 [S] | h2 [S] | logits [Q] | x [nseg][32] | code
+  fgp_ll_t* zll = a.ll;
+  fgp_ll_t* h1ll = zll + L * 32;
+  fgp_ll_t* h2ll = h1ll + S;
+  fgp_ll_t* lgll = h2ll + S;
+  fgp_ll_t* xll = lgll + Q;
+  fgp_ll_t* codell = xll + FGP_MAXSEG * 32;
+  bool dead = false;
+  int role = blockIdx.x;
+#ifdef FGP_STAMPS
+#define PSTAMP(slot) if (a.dbg && (tid & 63) == 0) a.dbg[(size_t)(slot)] = __builtin_amdgcn_s_memrealtime()
+#else
+#define PSTAMP(slot)
+#endif
+
+  if (role < nseg) {
+    // ------------------------------------------------------------ chain segment
+    const int seg = role;
+    const int l0 = (int)((long)seg * L / nseg), l1 = (int)((long)(seg + 1) * L / nseg);
+    const int nl = l1 - l0;
+    float* wres = lds;                                 // [nl][FGC_CW]
+    float* pre_s = wres + (size_t)nl * FGC_CW;         // [nl][64] this step's past-tap pre-activations
+    float* bd_s = pre_s + nl * 64;                     // [nl][32] dense biases
+    float* inv = bd_s + nl * 32;                       // [32] x broadcast
+    float* zv = inv + 32;                              // [32]
+    int* meta = reinterpret_cast<int*>(zv + 32);       // [nl] ring offset (rows), [nl] dilation
+    int* flags = meta + 2 * FGP_SEGL;                  // [0] pre ready for step, [1] chain done with step
+    for (int i = tid; i < nl * FGC_CW / 4; i += FGP_THREADS)
+      reinterpret_cast<f32x4*>(wres)[i] =
+          reinterpret_cast<const f32x4*>(g.cw_img + (size_t)l0 * FGC_CW)[i];
+    for (int i = tid; i < nl * 64; i += FGP_THREADS) pre_s[i] = g.pre[(size_t)l0 * 64 + i];
+    for (int i = tid; i < nl * 32; i += FGP_THREADS)
+      bd_s[i] = g.use_dense_bias
+                    ? g.layer0[(size_t)(l0 + (i >> 5)) * g.layer_stride + LAYER_OFF_BD + (i & 31)]
+                    : 0.f;
+    if (tid < nl) {
+      int ro = 0;
+      for (int q = 0; q < l0 + tid; ++q) ro += g.dil[q];
+      meta[tid] = ro;
+      meta[FGP_SEGL + tid] = g.dil[l0 + tid];
+    }
+    if (tid == 0) { flags[0] = 1; flags[1] = 0; flags[2] = 0; flags[3] = 0; }
+    __syncthreads();
+    const int nn = lane & 31, gsel = lane >> 5;
+    if (wave == 0) {
+      // ---- the serial chain of this segment (body of fg_chain_kernel, no
+      // workgroup barrier, weights resident)
+      int prev_code = g.cursors[1];
+      for (int i = 0; i < n_steps; ++i) {
+        const unsigned step = (unsigned)(i + 1);
+        float x = 0.f;
+        if (seg == 0) {
+          int code = g.samples[0];
+          if (i > 0) code = __float_as_int(fgp_get(codell, (unsigned)i, sync, dead));
+          PSTAMP(i * 16 + 0);
+          if (lane < 32) {
+            float v = 0.f;
+            if (prev_code >= 0 && prev_code < Q) v = g.causal[(long)prev_code * 32 + lane];
+            if (code >= 0 && code < Q) v += g.causal[((long)Q + code) * 32 + lane];
+            x = v;
+          }
+          prev_code = code;
+        } else {
+          x = fgp_get(xll + (seg - 1) * 32 + (lane & 31), step, sync, dead);
+        }
+        // this step's past-tap pre-activations are in LDS (helper waves)
+        while (!dead && __hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < i + 1)
+          __builtin_amdgcn_s_sleep(1);
+        PSTAMP(i * 16 + 1 + seg);
+        const int tpos = base + i;
+        for (int ll = 0; ll < nl; ++ll) {
+          const float* wl = wres + (size_t)ll * FGC_CW;
+          const float* w1 = wl + gsel * 1024 + nn * 32;
+          const float* wd = wl + 2 * 1024 + nn * 32;
+          f32x4 qw[8], pw[4];
+#pragma unroll
+          for (int c = 0; c < 8; ++c)
+            qw[c] = *reinterpret_cast<const f32x4*>(w1 + ((c ^ (nn & 7)) << 2));
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc)
+            pw[cc] = *reinterpret_cast<const f32x4*>(wd + (((gsel * 4 + cc) ^ (nn & 7)) << 2));
+          float a0 = pre_s[ll * 64 + lane], a1 = 0.f, a2 = 0.f, a3 = 0.f;
+          const float bdl = bd_s[ll * 32 + (lane & 31)];
+          const int d = meta[FGP_SEGL + ll];
+          if (lane < 32) {
+            fgp_st(g.state + ((long)meta[ll] + tpos % d) * 32 + lane, x);   // enqueue x_l[t]
+            inv[lane] = x;
+          }
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(inv + 4 * c);
+            const f32x4 q = qw[c];
+            a0 = fmaf(xv[0], q[0], a0); a1 = fmaf(xv[1], q[1], a1);
+            a2 = fmaf(xv[2], q[2], a2); a3 = fmaf(xv[3], q[3], a3);
+          }
+          const float av = (a0 + a1) + (a2 + a3);
+          const float sg = wn_sigmoid(gsel ? av : 2.f * av);
+          const float act = gsel ? sg : fmaf(2.f, sg, -1.f);
+          const auto pr = __builtin_amdgcn_permlane32_swap(
+              __float_as_uint(act), __float_as_uint(act), false, false);
+          const float z = __uint_as_float(pr[0]) * __uint_as_float(pr[1]);
+          if (lane < 32) {
+            fgp_put(zll + (l0 + ll) * 32 + lane, z, step);
+            zv[lane] = z;
+          }
+          if (l0 + ll + 1 < L) {
+            __builtin_amdgcn_wave_barrier();
+            float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+              const int c = gsel * 4 + cc;
+              const f32x4 zz = *reinterpret_cast<const f32x4*>(zv + 4 * c);
+              const f32x4 pq = pw[cc];
+              d0 = fmaf(zz[0], pq[0], d0); d1 = fmaf(zz[1], pq[1], d1);
+              d2 = fmaf(zz[2], pq[2], d2); d3 = fmaf(zz[3], pq[3], d3);
+            }
+            const float dh = (d0 + d1) + (d2 + d3);
+            const auto pd2 = __builtin_amdgcn_permlane32_swap(
+                __float_as_uint(dh), __float_as_uint(dh), false, false);
+            if (lane < 32)
+              x += bdl + (__uint_as_float(pd2[0]) + __uint_as_float(pd2[1]));
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+        // x to the next segment at once; the queue entries this segment wrote
+        // are for its own helper waves: drained behind the hand-over
+        if (seg + 1 < nseg && lane < 32) fgp_put(xll + seg * 32 + lane, x, step);
+        PSTAMP(i * 16 + 6 + seg);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0)
+          __hip_atomic_store(flags + 1, i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    } else {
+      // ---- helper waves: the NEXT step's past-tap pre-activations of this
+      // segment's layers (model.py:335-338, the `state` half of the conv):
+      // pre[l][n] = bias_fg[l][n] + sum_k x_l[t + 1 - d_l][k] * W[0][k][n],
+      // one wave per layer, lane = output n (filter | gate); the queue entry
+      // is read with device-scope loads after the chain wave's flag (its
+      // write-through stores were acknowledged before it set the flag)
+      const int hw = wave - 1;                          // 0..3
+      for (int i = 0; i + 1 < n_steps; ++i) {
+        while (!dead && __hip_atomic_load(flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < i + 1) {
+          __builtin_amdgcn_s_sleep(4);
+          if (__hip_atomic_load(sync + FGP_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) dead = true;
+        }
+        const int tpos = base + i + 1;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int ll = hw; ll < nl; ll += 4) {
+          const int l = l0 + ll, d = meta[FGP_SEGL + ll];
+          const float xv = lane < 32 ? fgp_ld(g.state + ((long)meta[ll] + tpos % d) * 32 + lane) : 0.f;
+          const float* W = g.layer0 + (long)l * g.layer_stride + (lane < 32 ? 0 : 2 * 1024) + (lane & 31);
+          float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            p0 = fmaf(__shfl(xv, k), W[k * 32], p0);
+            p1 = fmaf(__shfl(xv, 8 + k), W[(8 + k) * 32], p1);
+            p2 = fmaf(__shfl(xv, 16 + k), W[(16 + k) * 32], p2);
+            p3 = fmaf(__shfl(xv, 24 + k), W[(24 + k) * 32], p3);
+          }
+          acc[(ll - hw) >> 2] = (g.bias_fg ? g.bias_fg[l * 64 + lane] : 0.f) + ((p0 + p1) + (p2 + p3));
+        }
+        // (the chain wave is past this segment's layers of step i: pre_s is free)
+        for (int ll = hw; ll < nl; ll += 4) pre_s[ll * 64 + lane] = acc[(ll - hw) >> 2];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // four helper waves: the last one to finish raises the step
+        if (lane == 0) {
+          const int old = __hip_atomic_fetch_add(flags + 2, 1, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (old == 3) {
+            __hip_atomic_store(flags + 2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(flags, i + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+      }
+    }
+    return;
+  }
+  role -= nseg;
+  if (tid >= 256) return;          // the tail roles are 256-thread workgroups
+  float* in_s = lds;               // staged input vector
+  const int o = tid & 15, part = tid >> 4;
+  if (role < nsk) {
+    // ------------------------------------------------------------------- skip
+    const int KK = L * 32, col0 = role * 16;
+    float* w_s = lds + ((KK + 3) & ~3);               // [KK][16]
+    float* red = w_s + (size_t)KK * 16;               // [16][16]
+    for (int i = tid; i < KK * 16; i += 256) {
+      const int k = i >> 4, c = i & 15;
+      w_s[i] = col0 + c < S ? g.skip_w[(size_t)k * S + col0 + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = 0; i < n_steps; ++i) {
+      const unsigned step = (unsigned)(i + 1);
+      float accv = 0.f;
+      for (int sg = 0; sg < nseg; ++sg) {
+        const int l0 = (int)((long)sg * L / nseg), l1 = (int)((long)(sg + 1) * L / nseg);
+        const int n = (l1 - l0) * 32;
+        for (int k = tid; k < n; k += 256)
+          in_s[l0 * 32 + k] = fgp_get(zll + l0 * 32 + k, step, sync, dead);
+        __syncthreads();
+        accv += fgp_mv16(in_s + l0 * 32, w_s + (size_t)l0 * 32 * 16, n, o, part, 16);
+      }
+      red[part * 16 + o] = accv;
+      __syncthreads();
+      if (part == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) t += red[p * 16 + o];
+        if (col0 + o < S)
+          fgp_put(h1ll + col0 + o, fmaxf((g.skip_bsum ? g.skip_bsum[col0 + o] : 0.f) + t, 0.f), step);
+      }
+      if (role == 0) { PSTAMP(i * 16 + 11); }
+      __syncthreads();             // (red is rewritten in the next step)
+    }
+    return;
+  }
+  role -= nsk;
+  if (role < nsk + nlg) {
+    // ------------------------------------------------------- post1 / logits
+    const bool lg = role >= nsk;
+    const int col0 = (lg ? role - nsk : role) * 16, N = lg ? Q : S;
+    const float* W = lg ? g.post2_w : g.post1_w;
+    const float* bias = lg ? g.post2_b : g.post1_b;
+    float* w_s = lds + ((S + 3) & ~3);                // [S][16]
+    float* red = w_s + (size_t)S * 16;
+    for (int i = tid; i < S * 16; i += 256) {
+      const int k = i >> 4, c = i & 15;
+      w_s[i] = col0 + c < N ? W[(size_t)k * N + col0 + c] : 0.f;
+    }
+    __syncthreads();
+    const fgp_ll_t* src = lg ? h2ll : h1ll;
+    fgp_ll_t* dst = lg ? lgll : h2ll;
+    for (int i = 0; i < n_steps; ++i) {
+      const unsigned step = (unsigned)(i + 1);
+      for (int k = tid; k < S; k += 256) in_s[k] = fgp_get(src + k, step, sync, dead);
+      __syncthreads();
+      red[part * 16 + o] = fgp_mv16(in_s, w_s, S, o, part, 16);
+      __syncthreads();
+      if (part == 0 && col0 + o < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) t += red[p * 16 + o];
+        t += bias ? bias[col0 + o] : 0.f;
+        fgp_put(dst + col0 + o, lg ? t : fmaxf(t, 0.f), step);
+      }
+      if (role == 0) { PSTAMP(i * 16 + 12); }
+      if (role == nsk) { PSTAMP(i * 16 + 13); }
+      __syncthreads();
+    }
+    return;
+  }
+  // ---------------------------------------------------------------------- draw
+  if (wave != 0) return;
+  double* pd = reinterpret_cast<double*>(lds);        // [Q]
+  float* lgs = reinterpret_cast<float*>(pd + ((Q + 1) & ~1));   // [Q] the step's logits
+  int cur_code = g.samples[0];     // the code step i consumed (kept in a register: this CU's
+                                   // L1 may hold an older copy of the samples line)
+  for (int i = 0; i < n_steps; ++i) {
+    const unsigned step = (unsigned)(i + 1);
+    for (int q = lane; q < Q; q += 64) lgs[q] = fgp_get(lgll + q, step, sync, dead);
+    PSTAMP(i * 16 + 14);
+    __builtin_amdgcn_wave_barrier();
+    const int next = fg_draw_wave(g, pd, lane, base + i, lgs);
+    // the code of step i + 1 for segment 0
+    if (lane == 0 && i + 1 < n_steps) fgp_put(codell, __int_as_float(next), step);
+    PSTAMP(i * 16 + 15);
+    if (i + 1 < n_steps) cur_code = next;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // cursors as wn_fastgen_finish leaves them: {steps done, the last code consumed, nothing pending}
+  if (lane == 0) {
+    g.cursors[0] = base + n_steps;
+    g.cursors[1] = cur_code;
+    g.cursors[2] = 0;
+  }
+#undef PSTAMP
+}
+
+#ifdef FGP_STAMPS
+static unsigned long long* g_fgp_dbg = nullptr;   // [n_steps][16] (diagnostic build only)
+extern "C" int wn_diag_fgp_dbg(unsigned long long* p) { g_fgp_dbg = p; return WN_OK; }
+#endif
 
 extern "C" {
 
@@ -1338,6 +1741,86 @@ int wn_fastgen_finish(int Q, int32_t* cursors, int32_t* samples_io,
   g.Q = Q; g.cursors = cursors; g.samples = samples_io; g.ctl = ctl;
   g.proba_out = proba_out; g.logits = const_cast<float*>(logits);
   hipLaunchKernelGGL(fg_draw_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, g);
+  return wn_check_launch();
+}
+
+// ONE persistent launch for n_steps samples (see fg_persist_kernel): same
+// inputs, state and results as n_steps x wn_fastgen_step + wn_fastgen_finish
+// (cursors[2] must be 0 on entry: no draw pending).  `sync`: 16 uint32 (zeroed
+// by this call), `xhand`: 8 x 32 floats of scratch.  After the launch
+// sync[12] != 0 means a bounded wait (2 s) expired: the samples are invalid.
+// Needs every workgroup resident at once: nseg + 2 * ceil(S / 16) +
+// ceil(Q / 16) + 1 <= CUs, else WN_ERR_UNSUPPORTED (use wn_fastgen_step).
+// 8-byte hand-over words of wn_fastgen_persist (z, h1, h2, logits, x, code)
+long wn_fastgen_persist_ll_words(int L, int S, int Q) {
+  if (L <= 0 || S <= 0 || Q <= 0) return 0;
+  return (long)L * 32 + 2L * S + Q + FGP_MAXSEG * 32 + 8;
+}
+
+int wn_fastgen_persist_workgroups(int L, int S, int Q) {
+  if (L <= 0 || S <= 0 || Q <= 0) return 0;
+  int nseg = (L + 9) / 10;
+  if (nseg > FGP_MAXSEG) nseg = FGP_MAXSEG;
+  return nseg + 2 * ((S + 15) / 16) + (Q + 15) / 16 + 1;
+}
+
+int wn_fastgen_persist(const float* params_causal, const float* layer0,
+                       long layer_stride, const float* skip_w,
+                       const float* skip_bsum, const float* post1_w,
+                       const float* post1_b, const float* post2_w,
+                       const float* post2_b, const float* gc_bias_fg,
+                       const int32_t* dilations_dev, int L, int S, int Q,
+                       float* state, int32_t* cursors, int32_t* samples_io,
+                       const int32_t* ctl, float* proba_out, int use_biases,
+                       const float* cw_img, float* pre, float* z_all, float* h1,
+                       float* h2, float* logits, unsigned* sync,
+                       unsigned long long* ll, int n_steps, void* stream) {
+  if (!cw_img || !logits || !ctl || !pre || !sync || !ll) return WN_ERR_NULL;
+  if (!params_causal || !layer0 || !skip_w || !post1_w || !post2_w ||
+      !dilations_dev || !state || !cursors || !samples_io || !z_all || !h1 ||
+      !h2)
+    return WN_ERR_NULL;
+  if (L <= 0 || S <= 0 || Q <= 0 || n_steps <= 0) return WN_ERR_BAD_SHAPE;
+  if (S > FG_MAXS || Q > FG_MAXQ || L > FG_MAXL) return WN_ERR_UNSUPPORTED;
+  FgPersist a;
+  FgStep& g = a.g;
+  g.causal = params_causal; g.layer0 = layer0; g.layer_stride = layer_stride;
+  g.skip_w = skip_w; g.skip_bsum = skip_bsum; g.post1_w = post1_w;
+  g.post1_b = post1_b; g.post2_w = post2_w; g.post2_b = post2_b;
+  g.bias_fg = gc_bias_fg; g.dil = dilations_dev; g.L = L; g.S = S; g.Q = Q;
+  g.state = state; g.cursors = cursors; g.samples = samples_io; g.ctl = ctl;
+  g.proba_out = proba_out;
+  g.use_dense_bias = use_biases; g.cw_img = cw_img; g.pre = pre;
+  g.z_all = z_all; g.h1 = h1; g.h2 = h2; g.logits = logits;
+  int nseg = (L + 9) / 10;
+  if (nseg > FGP_MAXSEG) nseg = FGP_MAXSEG;
+  const int per = (L + nseg - 1) / nseg;
+  if (per > FGP_SEGL) return WN_ERR_UNSUPPORTED;
+  a.sync = sync; a.ll = ll; a.n_steps = n_steps; a.nseg = nseg; a.dbg = nullptr;
+#ifdef FGP_STAMPS
+  a.dbg = g_fgp_dbg;
+#endif
+  const int wgs = wn_fastgen_persist_workgroups(L, S, Q);
+  if (wgs > wn_device_cus()) return WN_ERR_UNSUPPORTED;
+  // dynamic LDS: the largest role
+  size_t chain = (size_t)per * FGC_CW + per * 64 + per * 32 + 64 + 2 * FGP_SEGL + 8;
+  size_t skip = (size_t)((L * 32 + 3) & ~3) + (size_t)L * 32 * 16 + 256;
+  size_t post = (size_t)((S + 3) & ~3) + (size_t)S * 16 + 256;
+  size_t draw = (size_t)(((Q + 1) & ~1) * 2 + Q);
+  size_t fl = chain;
+  if (skip > fl) fl = skip;
+  if (post > fl) fl = post;
+  if (draw > fl) fl = draw;
+  const size_t bytes = fl * 4;
+  if (bytes > 160 * 1024 - 512) return WN_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipFuncSetAttribute((const void*)fg_persist_kernel,
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+    return WN_ERR_LAUNCH;
+  if (hipMemsetAsync(sync, 0, FGP_WORDS * sizeof(unsigned), s) != hipSuccess ||
+      hipMemsetAsync(ll, 0, (size_t)wn_fastgen_persist_ll_words(L, S, Q) * 8, s) != hipSuccess)
+    return WN_ERR_LAUNCH;
+  hipLaunchKernelGGL(fg_persist_kernel, dim3(wgs), dim3(FGP_THREADS), bytes, s, a);
   return wn_check_launch();
 }
 

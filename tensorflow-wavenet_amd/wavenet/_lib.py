@@ -122,6 +122,11 @@ SIGNATURES = {
     'wn_fastgen_step': (c_int, [P, P, c_long, P, P, P, P, P, P, P, P, c_int,
                                 c_int, c_int, P, P, P, P, P, c_int, P, P, P,
                                 P, P, P, P]),
+    'wn_fastgen_persist_workgroups': (c_int, [c_int, c_int, c_int]),
+    'wn_fastgen_persist_ll_words': (c_long, [c_int, c_int, c_int]),
+    'wn_fastgen_persist': (c_int, [P, P, c_long, P, P, P, P, P, P, P, P, c_int,
+                                   c_int, c_int, P, P, P, P, P, c_int, P, P, P,
+                                   P, P, P, P, P, c_int, P]),
     'wn_fastgen_pre': (c_int, [P, c_long, P, P, c_int, P, P, P, P]),
     'wn_fastgen_finish': (c_int, [c_int, P, P, P, P, P, P]),
     'wn_fastgen_pack': (c_int, [P, c_long, P, c_int, P]),

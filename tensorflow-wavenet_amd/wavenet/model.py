@@ -326,6 +326,12 @@ class WaveNetModel(object):
         # hipGraph, instead of the single-workgroup persistent kernel
         self.fastgen_multi_cu = True
         self.fastgen_graph_steps = 200
+        # the multi-CU path as ONE persistent launch per generate() call
+        # (wn_fastgen_persist: chain segments / skip / post-processing / draw
+        # workgroups resident for the whole run, weights resident in LDS,
+        # in-launch hand-overs instead of four kernel boundaries per sample);
+        # WN_FASTGEN_PERSIST=0: the step kernels replayed from a hipGraph
+        self.fastgen_persistent = os.environ.get('WN_FASTGEN_PERSIST', '1') != '0'
         # 'fp32' (default): fp32 MFMA GEMMs.  'bf16x6' / 'bf16x9' / 'bf16x3':
         # opt-in split-bf16 products for the six NN GEMMs (wn_gemm_nn_split;
         # x6 measures the same error vs float64 as the fp32 MFMA path)
@@ -1530,6 +1536,26 @@ class WaveNetModel(object):
         tail = (_lib.ptr(g['ctl']), _lib.ptr(pb), 1 if ub else 0,
                 _lib.ptr(g['cw_img']), _lib.ptr(g['pre']), _lib.ptr(g['z_all']),
                 _lib.ptr(g['h1']), _lib.ptr(g['h2']), _lib.ptr(g['logits']))
+
+        lib = _lib.load()
+        if self.fastgen_persistent and lib.wn_fastgen_persist_workgroups(
+                self.L, self.S, self.Q) <= torch.cuda.get_device_properties(
+                    self.device).multi_processor_count:
+            sync = self._gen_buf('fgp_sync', 16, torch.int32)
+            ll = self._gen_buf('fgp_ll', int(lib.wn_fastgen_persist_ll_words(
+                self.L, self.S, self.Q)), torch.int64)
+            _lib.call('wn_fastgen_persist', *common, *tail, _lib.ptr(sync),
+                      _lib.ptr(ll), int(n_steps), _lib.stream())
+            g['steps'] += int(n_steps)
+            samples_io[:n_io].copy_(io[:n_io])
+            if proba_out is not None:
+                proba_out.view(-1).copy_(pb[:proba_out.numel()])
+            if int(sync[12]) != 0:       # (synchronises; a generation call ends on the host anyway)
+                raise _lib.WaveNetHipError(
+                    'wn_fastgen_persist: a hand-over wait inside the persistent '
+                    'generation launch expired (2 s); the samples are invalid. '
+                    'WN_FASTGEN_PERSIST=0 selects the step kernels.')
+            return
 
         def one():
             _lib.call('wn_fastgen_step', *common, *tail, _lib.stream())

@@ -57,13 +57,15 @@ def traced(request, hip_lib):
     return net, cfg, var, wave, gid, probs, gen
 
 
-@pytest.mark.parametrize('multi', [False, True], ids=['one_wg', 'multi_cu'])
-def test_default_stack_teacher_forced_trace(traced, multi):
-    """Every one of N_TRACE next-sample distributions of both device paths
-    (persistent single-workgroup kernel; multi-CU step kernels replayed from a
-    hipGraph) equals the oracle's."""
+@pytest.mark.parametrize('multi,persist', [(False, False), (True, False), (True, True)],
+                         ids=['one_wg', 'multi_cu_graph', 'multi_cu_persistent'])
+def test_default_stack_teacher_forced_trace(traced, multi, persist):
+    """Every one of N_TRACE next-sample distributions of the three device paths
+    (single-workgroup kernel; multi-CU step kernels replayed from a hipGraph;
+    ONE persistent multi-CU launch for the whole run) equals the oracle's."""
     net, cfg, var, wave, gid, probs, _ = traced
     net.fastgen_multi_cu = multi
+    net.fastgen_persistent = persist
     net.fastgen_graph_steps = 200              # 1199 steps -> 4 graph replays
     seed = wave[:N_TRACE]
     out, pr = net.generate(0, seed_samples=seed, return_proba_every=1,
@@ -109,8 +111,9 @@ def test_default_stack_prime_from_6000_sample_seed(traced):
     # generate() from the long seed: the first drawn sample's distribution is
     # probs[N_SEED-1]; teacher-force the drawn continuation through the oracle
     # and require it to be likely under the oracle's distributions
-    for multi in (False, True):
+    for multi, persist in ((False, False), (True, False), (True, True)):
         net.fastgen_multi_cu = multi
+        net.fastgen_persistent = persist
         net.fastgen_graph_steps = 50
         out = net.generate(120, seed_samples=wave, seed=5,
                            global_condition=gid).cpu().numpy()

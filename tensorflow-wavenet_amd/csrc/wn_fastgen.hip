@@ -1283,6 +1283,128 @@ __device__ __forceinline__ float fgp_get(const fgp_ll_t* p, unsigned step, unsig
   return __uint_as_float((unsigned)w);
 }
 
+// up to two words per thread, both polled in ONE loop (two dependent polls
+// cost two memory round trips): words k0 and k0 + 256 of `src` into `dst`
+__device__ __forceinline__ void fgp_get2(float* dst, const fgp_ll_t* src, int k0, int n,
+                                         unsigned step, unsigned* sync, bool& dead) {
+  const bool h0 = k0 < n, h1 = k0 + 256 < n;
+  if (!h0) return;
+  fgp_ll_t w0 = __hip_atomic_load(src + k0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  fgp_ll_t w1 = h1 ? __hip_atomic_load(src + k0 + 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                   : ((fgp_ll_t)step << 32);
+  unsigned spins = 0;
+  unsigned long long t_start = 0;
+  while (!dead && ((unsigned)(w0 >> 32) != step || (unsigned)(w1 >> 32) != step)) {
+    __builtin_amdgcn_s_sleep(1);
+    if ((unsigned)(w0 >> 32) != step)
+      w0 = __hip_atomic_load(src + k0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned)(w1 >> 32) != step)
+      w1 = __hip_atomic_load(src + k0 + 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((++spins & 255u) == 0) {
+      const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+      if (t_start == 0) t_start = now;
+      if (now - t_start > 200000000ull ||
+          __hip_atomic_load(sync + FGP_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        __hip_atomic_store(sync + FGP_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        dead = true;
+      }
+    }
+  }
+  dst[k0] = __uint_as_float((unsigned)w0);
+  if (h1) dst[k0 + 256] = __uint_as_float((unsigned)w1);
+}
+
+// The draw of fg_draw_wave by a 256-thread workgroup (the persistent
+// kernel's draw role): float64 softmax of Q logits in LDS `lgs`, temperature,
+// inverse-CDF draw with the same random number -- one exp / log / division per
+// thread instead of Q / 64 per lane, reductions and the prefix sum by wave
+// shuffles + four partials in LDS.  Returns the code the next step consumes.
+// red: 16 doubles + 4 ints of LDS.
+__device__ __forceinline__ int fg_draw_wg256(const FgStep& g, const float* lgs, double* red,
+                                             int tid, int steps_done) {
+  const int Q = g.Q, lane = tid & 63, wave = tid >> 6;
+  int* ired = reinterpret_cast<int*>(red + 16);
+  const int local = steps_done - g.ctl[FGCTL_BASE];
+  const int n_given = g.ctl[FGCTL_NGIVEN];
+  const int proba_every = g.ctl[FGCTL_PEVERY] > 0 ? g.ctl[FGCTL_PEVERY] : 1;
+  const float temperature = __int_as_float(g.ctl[FGCTL_TEMP]);
+  const uint64_t seed = (uint64_t)(uint32_t)g.ctl[FGCTL_SEED] |
+                        ((uint64_t)(uint32_t)g.ctl[FGCTL_SEED + 1] << 32);
+  // contiguous segment of this thread (Q <= 512: at most two values)
+  const int per = (Q + 255) / 256;
+  const int q0 = min(Q, tid * per), q1 = min(Q, q0 + per);
+  double v[2] = {-1e300, -1e300};
+  for (int q = q0; q < q1; ++q) v[q - q0] = (double)lgs[q];
+  auto wg_max = [&](double x, int slot) {
+    for (int o = 32; o >= 1; o >>= 1) x = fmax(x, __shfl_xor(x, o));
+    if (lane == 0) red[slot * 4 + wave] = x;
+    __syncthreads();
+    return fmax(fmax(red[slot * 4], red[slot * 4 + 1]), fmax(red[slot * 4 + 2], red[slot * 4 + 3]));
+  };
+  auto wg_sum = [&](double x, int slot) {
+    for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o);
+    if (lane == 0) red[slot * 4 + wave] = x;
+    __syncthreads();
+    return (red[slot * 4] + red[slot * 4 + 1]) + (red[slot * 4 + 2] + red[slot * 4 + 3]);
+  };
+  const double m = wg_max(fmax(v[0], v[1]), 0);
+  double e[2] = {0.0, 0.0};
+  for (int q = q0; q < q1; ++q) e[q - q0] = exp(v[q - q0] - m);
+  const double se = wg_sum(e[0] + e[1], 1);
+  const bool want_p = g.proba_out && (local % proba_every == 0);
+  float* po = want_p ? g.proba_out + (long)(local / proba_every) * Q : nullptr;
+  double pq[2] = {0.0, 0.0};
+  for (int q = q0; q < q1; ++q) {
+    const float p32 = (float)(e[q - q0] / se);
+    if (po) po[q] = p32;
+    pq[q - q0] = (double)p32;
+  }
+  int next;
+  if (local + 1 >= n_given) {
+    if (temperature != 1.0f) {
+      const double tau = (double)temperature;
+      double lp[2] = {-1e300, -1e300};
+      for (int q = q0; q < q1; ++q)
+        lp[q - q0] = log(pq[q - q0] > 0.0 ? pq[q - q0] : 1e-300) / tau;
+      const double mx = wg_max(fmax(lp[0], lp[1]), 2);
+      for (int q = q0; q < q1; ++q) pq[q - q0] = exp(lp[q - q0] - mx);
+    }
+    const double seg = pq[0] + pq[1];
+    double incl = seg;
+    for (int o = 1; o < 64; o <<= 1) {
+      const double t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) red[12 + wave] = incl;
+    if (tid == 0) ired[0] = -1;
+    __syncthreads();
+    double offs = 0.0;
+    for (int w = 0; w < wave; ++w) offs += red[12 + w];
+    const double total = (red[12] + red[13]) + (red[14] + red[15]);
+    incl += offs;
+    const uint64_t r = splitmix64(seed ^ splitmix64((uint64_t)steps_done));
+    const double u = (double)(r >> 11) * (1.0 / 9007199254740992.0) * total;
+    const double excl = incl - seg;
+    if (q1 > q0 && u >= excl && u < incl) {
+      double c = excl;
+      int pick = q1 - 1;
+      for (int q = q0; q < q1; ++q) {
+        c += pq[q - q0];
+        if (u < c) { pick = q; break; }
+      }
+      atomicMax(ired, pick);
+    }
+    __syncthreads();
+    next = ired[0];
+    if (next < 0) next = Q - 1;
+    if (tid == 0) g.samples[local + 1] = next;
+  } else {
+    next = g.samples[local + 1];           // still inside the given samples
+  }
+  __syncthreads();                          // (red / ired are reused by the next step)
+  return next;
+}
+
 __global__ __launch_bounds__(FGP_THREADS) void fg_persist_kernel(FgPersist a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const FgStep& g = a.g;
@@ -1318,6 +1440,8 @@ __global__ __launch_bounds__(FGP_THREADS) void fg_persist_kernel(FgPersist a) {
     float* zv = inv + 32;                              // [32]
     int* meta = reinterpret_cast<int*>(zv + 32);       // [nl] ring offset (rows), [nl] dilation
     int* flags = meta + 2 * FGP_SEGL;                  // [0] pre ready for step, [1] chain done with step
+    int* rowoff = flags + 8;                           // [2][FGP_SEGL] float offset of the ring row of
+                                                       // the step (parity): no modulo on the chain
     for (int i = tid; i < nl * FGC_CW / 4; i += FGP_THREADS)
       reinterpret_cast<f32x4*>(wres)[i] =
           reinterpret_cast<const f32x4*>(g.cw_img + (size_t)l0 * FGC_CW)[i];
@@ -1331,6 +1455,7 @@ __global__ __launch_bounds__(FGP_THREADS) void fg_persist_kernel(FgPersist a) {
       for (int q = 0; q < l0 + tid; ++q) ro += g.dil[q];
       meta[tid] = ro;
       meta[FGP_SEGL + tid] = g.dil[l0 + tid];
+      rowoff[tid] = (ro + base % g.dil[l0 + tid]) * 32;
     }
     if (tid == 0) { flags[0] = 1; flags[1] = 0; flags[2] = 0; flags[3] = 0; }
     __syncthreads();
@@ -1360,7 +1485,6 @@ __global__ __launch_bounds__(FGP_THREADS) void fg_persist_kernel(FgPersist a) {
         while (!dead && __hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < i + 1)
           __builtin_amdgcn_s_sleep(1);
         PSTAMP(i * 16 + 1 + seg);
-        const int tpos = base + i;
         for (int ll = 0; ll < nl; ++ll) {
           const float* wl = wres + (size_t)ll * FGC_CW;
           const float* w1 = wl + gsel * 1024 + nn * 32;
@@ -1374,9 +1498,8 @@ __global__ __launch_bounds__(FGP_THREADS) void fg_persist_kernel(FgPersist a) {
             pw[cc] = *reinterpret_cast<const f32x4*>(wd + (((gsel * 4 + cc) ^ (nn & 7)) << 2));
           float a0 = pre_s[ll * 64 + lane], a1 = 0.f, a2 = 0.f, a3 = 0.f;
           const float bdl = bd_s[ll * 32 + (lane & 31)];
-          const int d = meta[FGP_SEGL + ll];
           if (lane < 32) {
-            fgp_st(g.state + ((long)meta[ll] + tpos % d) * 32 + lane, x);   // enqueue x_l[t]
+            fgp_st(g.state + rowoff[(i & 1) * FGP_SEGL + ll] + lane, x);   // enqueue x_l[t]
             inv[lane] = x;
           }
           __builtin_amdgcn_wave_barrier();
@@ -1455,6 +1578,9 @@ __global__ __launch_bounds__(FGP_THREADS) void fg_persist_kernel(FgPersist a) {
         }
         // (the chain wave is past this segment's layers of step i: pre_s is free)
         for (int ll = hw; ll < nl; ll += 4) pre_s[ll * 64 + lane] = acc[(ll - hw) >> 2];
+        if (hw == 0 && lane < nl)
+          rowoff[((i + 1) & 1) * FGP_SEGL + lane] =
+              (meta[lane] + tpos % meta[FGP_SEGL + lane]) * 32;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // four helper waves: the last one to finish raises the step
         if (lane == 0) {
@@ -1489,8 +1615,7 @@ __global__ __launch_bounds__(FGP_THREADS) void fg_persist_kernel(FgPersist a) {
       for (int sg = 0; sg < nseg; ++sg) {
         const int l0 = (int)((long)sg * L / nseg), l1 = (int)((long)(sg + 1) * L / nseg);
         const int n = (l1 - l0) * 32;
-        for (int k = tid; k < n; k += 256)
-          in_s[l0 * 32 + k] = fgp_get(zll + l0 * 32 + k, step, sync, dead);
+        fgp_get2(in_s + l0 * 32, zll + l0 * 32, tid, n, step, sync, dead);
         __syncthreads();
         accv += fgp_mv16(in_s + l0 * 32, w_s + (size_t)l0 * 32 * 16, n, o, part, 16);
       }
@@ -1526,7 +1651,7 @@ __global__ __launch_bounds__(FGP_THREADS) void fg_persist_kernel(FgPersist a) {
     fgp_ll_t* dst = lg ? lgll : h2ll;
     for (int i = 0; i < n_steps; ++i) {
       const unsigned step = (unsigned)(i + 1);
-      for (int k = tid; k < S; k += 256) in_s[k] = fgp_get(src + k, step, sync, dead);
+      fgp_get2(in_s, src, tid, S, step, sync, dead);
       __syncthreads();
       red[part * 16 + o] = fgp_mv16(in_s, w_s, S, o, part, 16);
       __syncthreads();
@@ -1544,25 +1669,25 @@ __global__ __launch_bounds__(FGP_THREADS) void fg_persist_kernel(FgPersist a) {
     return;
   }
   // ---------------------------------------------------------------------- draw
-  if (wave != 0) return;
-  double* pd = reinterpret_cast<double*>(lds);        // [Q]
-  float* lgs = reinterpret_cast<float*>(pd + ((Q + 1) & ~1));   // [Q] the step's logits
+  // (256 threads: one logit per thread for Q <= 256)
+  float* lgs = lds;                                             // [Q] the step's logits
+  double* dred = reinterpret_cast<double*>(lds + ((Q + 3) & ~3));   // 16 doubles + 4 ints
   int cur_code = g.samples[0];     // the code step i consumed (kept in a register: this CU's
                                    // L1 may hold an older copy of the samples line)
   for (int i = 0; i < n_steps; ++i) {
     const unsigned step = (unsigned)(i + 1);
-    for (int q = lane; q < Q; q += 64) lgs[q] = fgp_get(lgll + q, step, sync, dead);
+    fgp_get2(lgs, lgll, tid, Q, step, sync, dead);
     PSTAMP(i * 16 + 14);
-    __builtin_amdgcn_wave_barrier();
-    const int next = fg_draw_wave(g, pd, lane, base + i, lgs);
+    __syncthreads();
+    const int next = fg_draw_wg256(g, lgs, dred, tid, base + i);
     // the code of step i + 1 for segment 0
-    if (lane == 0 && i + 1 < n_steps) fgp_put(codell, __int_as_float(next), step);
+    if (tid == 0 && i + 1 < n_steps) fgp_put(codell, __int_as_float(next), step);
     PSTAMP(i * 16 + 15);
     if (i + 1 < n_steps) cur_code = next;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   // cursors as wn_fastgen_finish leaves them: {steps done, the last code consumed, nothing pending}
-  if (lane == 0) {
+  if (tid == 0) {
     g.cursors[0] = base + n_steps;
     g.cursors[1] = cur_code;
     g.cursors[2] = 0;
@@ -1803,10 +1928,10 @@ int wn_fastgen_persist(const float* params_causal, const float* layer0,
   const int wgs = wn_fastgen_persist_workgroups(L, S, Q);
   if (wgs > wn_device_cus()) return WN_ERR_UNSUPPORTED;
   // dynamic LDS: the largest role
-  size_t chain = (size_t)per * FGC_CW + per * 64 + per * 32 + 64 + 2 * FGP_SEGL + 8;
+  size_t chain = (size_t)per * FGC_CW + per * 64 + per * 32 + 64 + 2 * FGP_SEGL + 8 + 2 * FGP_SEGL;
   size_t skip = (size_t)((L * 32 + 3) & ~3) + (size_t)L * 32 * 16 + 256;
   size_t post = (size_t)((S + 3) & ~3) + (size_t)S * 16 + 256;
-  size_t draw = (size_t)(((Q + 1) & ~1) * 2 + Q);
+  size_t draw = (size_t)((Q + 3) & ~3) + 40;
   size_t fl = chain;
   if (skip > fl) fl = skip;
   if (post > fl) fl = post;

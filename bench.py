@@ -275,6 +275,10 @@ def secondary(net, audio, gc_ids, kw, B, T, gen_samples=16000, opt=None):
             'fastgen_samples_per_s': gen_samples / dt,
             'fastgen_us_per_sample': dt / gen_samples * 1e6,
             'fastgen_samples': gen_samples,
+            # one persistent multi-CU launch for the run (wn_fastgen_persist) or
+            # four step kernels per sample replayed from a hipGraph
+            'fastgen_path': 'persistent launch' if gen.fastgen_persistent
+            else 'step kernels in a hipGraph',
             'gc_ms_per_step': gc_ms,
             'gc_samples_per_s': None if gc_ms is None else B * T / gc_ms * 1e3,
             'b1_ms_per_step': b1_ms,
@@ -523,6 +527,13 @@ def main():
         mix = stacks[ev_name]['mix_stream_tb_s']
         stacks[ev_name]['frac_of_mix_stream'] = None if (by is None or not mix) \
             else by / us / 1e6 / mix
+        if ev_name == 'wn_stack_bwd':
+            # the PMC bytes are L2 <-> fabric requests: they include the own dx
+            # rows (one plane rewritten in place, served by the Infinity Cache)
+            # and the stream rate moves +-10 % between boxes, so this ratio can
+            # pass 1; the launch is bound by its issue slots
+            stacks[ev_name]['note'] = ('traffic counts Infinity-Cache hits; '
+                                       'indicative, not an HBM fraction')
     out = {
         'metric': 'audio samples/sec (train, default wavenet_params.json)',
         'value': value, 'unit': 'audio samples/s', 'n_gpus': world,

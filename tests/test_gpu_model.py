@@ -403,20 +403,25 @@ def test_incremental_vs_oracle_and_naive(hip_lib):
     naive = net.predict_proba(wave).cpu().numpy()
     assert np.abs(naive - z['inc/naive_last']).max() < 1e-5
     assert np.abs(naive - p).max() < 1e-5
-    # teacher-forced generate() gives the same trace on both device paths:
-    # the single-workgroup persistent kernel and the multi-CU step kernels
-    for multi in (False, True):
+    # teacher-forced generate() gives the same trace on the three device paths:
+    # the single-workgroup kernel, the multi-CU step kernels (hipGraph) and
+    # the persistent multi-CU launch (here: one chain segment, one workgroup
+    # per tail stage)
+    for multi, persist in ((False, False), (True, False), (True, True)):
         net.fastgen_multi_cu = multi
+        net.fastgen_persistent = persist
         out, pr = net.generate(0, seed_samples=wave, return_proba_every=1)
         assert np.array_equal(out.cpu().numpy(), wave)
         assert np.abs(pr.cpu().numpy() - probs[:len(wave) - 1]).max() < 1e-5
 
 
-@pytest.mark.parametrize('multi', [False, True])
-def test_generate_sampling(hip_lib, multi):
+@pytest.mark.parametrize('multi,persist', [(False, False), (True, False), (True, True)],
+                         ids=['one_wg', 'multi_cu_graph', 'multi_cu_persistent'])
+def test_generate_sampling(hip_lib, multi, persist):
     cfg = cfg_with(MID, batch_size=1)
     net, var = build_pair(cfg)
     net.fastgen_multi_cu = multi
+    net.fastgen_persistent = persist
     net.fastgen_graph_steps = 50          # exercise graph capture + replay
     a = net.generate(300, seed_samples=[128], seed=11).cpu().numpy()
     b = net.generate(300, seed_samples=[128], seed=11).cpu().numpy()
@@ -424,6 +429,19 @@ def test_generate_sampling(hip_lib, multi):
     assert a.shape == (301,) and a[0] == 128
     assert np.array_equal(a, b) and not np.array_equal(a, c)
     assert a.min() >= 0 and a.max() < 256
+    if multi:
+        # the persistent launch and the step kernels draw the SAME samples, also
+        # with a temperature and with probabilities returned every third step
+        net.fastgen_persistent = not persist
+        a2 = net.generate(300, seed_samples=[128], seed=11).cpu().numpy()
+        t1, p1 = net.generate(90, seed_samples=[3, 200, 17], temperature=0.7, seed=4,
+                              return_proba_every=3)
+        net.fastgen_persistent = persist
+        t2, p2 = net.generate(90, seed_samples=[3, 200, 17], temperature=0.7, seed=4,
+                              return_proba_every=3)
+        assert np.array_equal(a, a2)
+        assert torch.equal(t1, t2) and p1.shape == p2.shape
+        assert float((p1 - p2).abs().max()) < 1e-6
     # drawn samples follow the predicted distribution: teacher-force the drawn
     # sequence through the oracle and compare empirical log-likelihood ranks
     gen = O.IncrementalGenerator(cfg, var, dtype=np.float64)

@@ -258,9 +258,17 @@ def secondary(net, audio, gc_ids, kw, B, T, gen_samples=16000, opt=None):
     net1 = WaveNetModel(seed=0, **kw1)
     ids1 = None if gc_ids is None else gc_ids[:1]
     b1_ms = timed_steps(net1, audio[:1], ids1)
+    log('B=1: %.2f ms/step' % b1_ms)
+    # the reference's own training shape: one piece of `--sample_size` 100 000
+    # samples (train.py:30; SURVEY 8d asks for it as a secondary figure)
+    t100k_ms = None
+    if T != 100000:
+        a100 = torch.from_numpy(synth_audio(1, 100000)).to(audio.device)
+        t100k_ms = timed_steps(net1, a100, ids1, n=5, warm=2)
+        del a100
+        log('B=1, T=100000: %.2f ms/step' % t100k_ms)
     del net1
     torch.cuda.empty_cache()
-    log('B=1: %.2f ms/step' % b1_ms)
     gen = WaveNetModel(seed=0, **kw1)
     gc = 5 if kw.get('global_condition_channels') else None
     gen.generate(200, seed_samples=[128], seed=1, global_condition=gc)  # warm-up
@@ -283,6 +291,8 @@ def secondary(net, audio, gc_ids, kw, B, T, gen_samples=16000, opt=None):
             'gc_samples_per_s': None if gc_ms is None else B * T / gc_ms * 1e3,
             'b1_ms_per_step': b1_ms,
             'b1_samples_per_s': T / b1_ms * 1e3,
+            't100k_ms_per_step': t100k_ms,
+            't100k_samples_per_s': None if t100k_ms is None else 100000 / t100k_ms * 1e3,
             'optin_bf16x6_ms_per_step': optin}
 
 

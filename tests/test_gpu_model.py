@@ -669,3 +669,32 @@ def test_random_configurations_vs_oracle(hip_lib):
                         '24', '7'], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert '0 of 24 cases failed' in r.stdout
+
+
+def test_persistent_generator_short_runs_and_state_continuity(hip_lib):
+    """wn_fastgen_persist at the edges: runs of 1, 2, 3 and 17 steps (the helper
+    waves' look-ahead loop is empty at 1), with global conditioning, a
+    temperature and probabilities every step, draw the samples of the step
+    kernels; and the queues / cursors it leaves continue on either path."""
+    cfg = cfg_with(MID, batch_size=1, global_condition_channels=4,
+                   global_condition_cardinality=5)
+    net, var = build_pair(cfg)
+    for n in (1, 2, 3, 17):
+        outs = []
+        for persist in (0, 1):
+            net.fastgen_persistent = persist
+            o, p = net.generate(n, seed_samples=[5, 9], seed=3, temperature=0.9,
+                                global_condition=2, return_proba_every=1)
+            outs.append((o.cpu().numpy(), p.cpu().numpy()))
+        assert np.array_equal(outs[0][0], outs[1][0]), n
+        assert np.abs(outs[0][1] - outs[1][1]).max() < 1e-6
+    res = []
+    for first, then in ((1, 0), (0, 0), (0, 1), (1, 1)):
+        net.reset_generator()
+        net.fastgen_persistent = first
+        a = net.generate(40, seed_samples=[7], seed=1, global_condition=1).cpu().numpy()
+        net.fastgen_persistent = then
+        b = net.continue_generation(40, int(a[-1]), 1.0, 1, 2).cpu().numpy()
+        res.append(np.concatenate([a, b]))
+    for r in res[1:]:
+        assert np.array_equal(res[0], r)

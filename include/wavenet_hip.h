@@ -123,6 +123,18 @@ int wn_layer_wgrad_k(const float* x, const float* daf, const float* dag,
                      int num_slabs, int B, int T, int dilation, int K, int k0,
                      int Ktot, int CB, long plane_stride, void* stream);
 
+/* out planes = addend planes + in planes * W (+ bias): the 1x1 residual conv
+ * x_{l+1} = x_l + z_l Wd (+ bd) of wavenet/model.py:294-300, 330 for the
+ * channel-block models (C = 32, 64, 96 or 128 padded channels = C / 32 planes of
+ * [rows][32]) and its data gradient dz = dZ + dx_{l+1} Wd^T, as one streaming
+ * launch per layer (a wave per 32-row tile) instead of a K = N = C plane-mode
+ * wn_gemm_nn.  W [C][C] row-major ([Cin][Cout]); bias [C] or NULL; addend in
+ * the planes' layout or NULL.  Other widths: WN_ERR_UNSUPPORTED (use wn_gemm_nn). */
+int wn_dense_planes(const float* in, long in_plane_stride, const float* W,
+                    const float* bias, const float* addend, long add_plane_stride,
+                    float* out, long out_plane_stride, long rows, int C,
+                    void* stream);
+
 /* more than 32 residual / dilation channels: channels are cut into 32-wide
  * blocks, each block of an activation is its own [B*T][32] plane, and one
  * launch computes ONE output block from all input blocks (weights in the

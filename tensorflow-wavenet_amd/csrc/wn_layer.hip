@@ -1706,6 +1706,76 @@ static int layer_grid(int B, int T, int waves = LAYER_WAVES, bool spread = false
   return (int)(g < 1 ? 1 : g);
 }
 
+// ---------------------------------------------------------------------------
+// The 1x1 convs of the channel-block models (33 - 128 channels) as a streaming
+// kernel: out planes = addend planes + in planes * W (+ bias), W [C][C] in the
+// reference's [Cin][Cout] order, C = 32 * CB.  Forward: x_{l+1} = x_l + z_l Wd
+// (+ bd) (model.py:294-300, 330); backward: dz = dZ + dx_{l+1} Wd^T.  As
+// plane-mode wn_gemm_nn launches these are K = N = C <= 128 GEMMs: four K chunks
+// between a tile's first load and its epilogue, half of every 128-column tile
+// masked at C = 64 -- 54 us a launch at 8 x 16000 x 64 channels against an HBM
+// floor of 20, 98 of them per step.  Here a wave takes a 32-row tile: the CB
+// input planes' rows in one batch of coalesced loads (8 full rows per
+// instruction), fragments through the wave's LDS tile, CB x CB x 16 MFMAs with
+// the weights in LDS in their own layout, the addend rows loaded meanwhile.
+// ---------------------------------------------------------------------------
+template <int CB>
+__global__ __launch_bounds__(256) void dense_planes_kernel(
+    const float* __restrict__ in, long in_pstride, const float* __restrict__ W,
+    const float* __restrict__ bias, const float* __restrict__ addend, long add_pstride,
+    float* __restrict__ out, long out_pstride, long rows) {
+  constexpr int C = 32 * CB;
+  __shared__ __attribute__((aligned(16))) float wl[C * C];
+  __shared__ __attribute__((aligned(16))) float tiles[4 * 1024];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  for (int p = wave; p < C * C / 256; p += 4)
+    __builtin_amdgcn_global_load_lds((wn_gptr_t)(W + p * 256 + lane * 4),
+                                     (wn_lptr_t)(wl + p * 256), 16, 0, 0);
+  float* ta = tiles + wave * 1024;
+  const long ntiles = (rows + 31) / 32;
+  const long tile = (long)blockIdx.x * 4 + wave;
+  const bool any = tile < ntiles;
+  const long r0 = any ? tile * 32 : 0;
+  const int hi = any ? (int)(rows - r0 < 32 ? rows - r0 : 32) : 0;
+  RowRegs rin[CB], radd[CB];
+#pragma unroll
+  for (int b = 0; b < CB; ++b) rin[b] = rows_load(in + b * in_pstride + r0 * 32, lane, 0, hi);
+#pragma unroll
+  for (int b = 0; b < CB; ++b)
+    if (addend) radd[b] = rows_load(addend + b * add_pstride + r0 * 32, lane, 0, hi);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                 // the weights are in LDS
+  f32x16 fr[CB];
+#pragma unroll
+  for (int b = 0; b < CB; ++b) {
+    __builtin_amdgcn_wave_barrier();
+    rows_to_lds(ta, lane, rin[b]);
+    __builtin_amdgcn_wave_barrier();
+    fr[b] = frag_from_lds(ta, j, h);
+  }
+#pragma unroll
+  for (int ob = 0; ob < CB; ++ob) {
+    f32x16 acc = frag_zero();
+#pragma unroll
+    for (int ib = 0; ib < CB; ++ib)
+      mma32<C>(acc, fr[ib], wl + (ib * 32 + 4 * h) * C + ob * 32 + j);
+    __builtin_amdgcn_wave_barrier();
+    frag_to_lds(ta, j, h, acc);
+    __builtin_amdgcn_wave_barrier();
+    RowRegs ro = rows_from_lds(ta, lane);
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (bias) b4 = *reinterpret_cast<const f32x4*>(bias + ob * 32 + (lane & 7) * 4);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      ro.v[c] += b4;
+      if (addend) ro.v[c] += radd[ob].v[c];
+    }
+    rows_store(out + ob * out_pstride + r0 * 32, lane, hi, ro);
+  }
+}
+
 extern "C" {
 
 int wn_layer_fwd(const float* x, float* x_out, float* z, float* th, float* sg,
@@ -1930,6 +2000,38 @@ int wn_layer_wgrad_k(const float* x, const float* daf, const float* dag,
 }
 
 // number of slabs (workgroups) wn_layer_bwdw writes for this shape
+// out planes = addend planes + in planes * W (+ bias): the 1x1 residual conv of
+// the channel-block models and its data gradient as a streaming kernel (see
+// dense_planes_kernel).  CB = C / 32 planes of [rows][32] each way, 1 <= CB <= 4;
+// W [C][C] row-major ([Cin][Cout]); bias [C] or NULL; addend planes or NULL.
+int wn_dense_planes(const float* in, long in_plane_stride, const float* W,
+                    const float* bias, const float* addend, long add_plane_stride,
+                    float* out, long out_plane_stride, long rows, int C,
+                    void* stream) {
+  if (!in || !W || !out) return WN_ERR_NULL;
+  if (rows <= 0) return WN_ERR_BAD_SHAPE;
+  if (C != 32 && C != 64 && C != 96 && C != 128) return WN_ERR_UNSUPPORTED;
+  const void* ptrs[] = {in, W, bias, addend, out};
+  for (const void* p : ptrs)
+    if (p && !wn_aligned16(p)) return WN_ERR_MISALIGNED;
+  if ((in_plane_stride & 3) || (add_plane_stride & 3) || (out_plane_stride & 3))
+    return WN_ERR_MISALIGNED;
+  const long ntiles = (rows + 31) / 32;
+  const long wgs = (ntiles + 3) / 4;
+  if (wgs > 0x7fffffffL) return WN_ERR_BAD_SHAPE;
+  dim3 grid((unsigned)wgs), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(CBV)                                                              \
+  hipLaunchKernelGGL((dense_planes_kernel<CBV>), grid, block, 0, s, in, in_plane_stride, \
+                     W, bias, addend, add_plane_stride, out, out_plane_stride, rows)
+  if (C == 32) LAUNCH(1);
+  else if (C == 64) LAUNCH(2);
+  else if (C == 96) LAUNCH(3);
+  else LAUNCH(4);
+#undef LAUNCH
+  return wn_check_launch();
+}
+
 int wn_layer_bwdw_slabs(int B, int T) { return layer_grid(B, T, BW_WAVES); }
 
 int wn_layer_bwdw(const float* x, const float* z, const float* daf_cur,

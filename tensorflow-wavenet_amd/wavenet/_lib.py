@@ -44,6 +44,8 @@ SIGNATURES = {
     'wn_layer_wgrad_slab_floats': (c_int, []),
     'wn_layer_wgrad': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int,
                                P]),
+    'wn_dense_planes': (c_int, [P, c_long, P, P, P, c_long, P, c_long, c_long, c_int,
+                                P]),
     'wn_layer_fwd_k': (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int,
                                c_int, c_int, c_int, P]),
     'wn_layer_bwd_k': (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int,

@@ -92,6 +92,16 @@ def forward_layers(net, ws, bias, bstride, save_ts, st):
         # x_{l+1} = x_l + z_l Wd (+ bd)   model.py:294-300,330 -- ONE plane-mode
         # GEMM for all residual-channel blocks (planes in, planes out, the
         # addend x_l in the output's plane layout: ld_add = 0)
+        if CB <= 4:
+            # (up to 128 channels: a streaming kernel, a wave per 32-row tile,
+            # instead of a K = N = C GEMM launch that is all prologue and
+            # epilogue: 54 -> see DESIGN section 8)
+            _lib.call('wn_dense_planes', _lib.ptr(ws.Z[l * CB]), pstride,
+                      _lib.ptr(w['wd']),
+                      _lib.ptr(w['bd']) if net.use_biases else None,
+                      _lib.ptr(ws.X[l * CB]), pstride,
+                      _lib.ptr(ws.X[(l + 1) * CB]), pstride, N, C, st)
+            continue
         _lib.call('wn_gemm_nn', _lib.ptr(ws.Z[l * CB]), 0, CB, pstride,
                   _lib.ptr(w['wd']), C,
                   _lib.ptr(w['bd']) if net.use_biases else None,
@@ -127,10 +137,15 @@ def backward_layers(net, ws, ids, st):
         if dxin is not None:
             # dz = dZ + dx' Wd^T for all dilation-channel blocks in one
             # plane-mode GEMM (Wd^T as [res][dil]; addend dZ in plane layout)
-            _lib.call('wn_gemm_nn', _lib.ptr(dxin[0]), 0, CB, pstride,
-                      _lib.ptr(ws.wdT), C, None, None, 0,
-                      _lib.ptr(ws.dZ[l * CB]), 0, _lib.ptr(ws.dzb[0]), 0, CB,
-                      pstride, None, N, C, C, 0, st)
+            if CB <= 4:
+                _lib.call('wn_dense_planes', _lib.ptr(dxin[0]), pstride,
+                          _lib.ptr(ws.wdT), None, _lib.ptr(ws.dZ[l * CB]),
+                          pstride, _lib.ptr(ws.dzb[0]), pstride, N, C, st)
+            else:
+                _lib.call('wn_gemm_nn', _lib.ptr(dxin[0]), 0, CB, pstride,
+                          _lib.ptr(ws.wdT), C, None, None, 0,
+                          _lib.ptr(ws.dZ[l * CB]), 0, _lib.ptr(ws.dzb[0]), 0, CB,
+                          pstride, None, N, C, C, 0, st)
         # ---- gate gradients of every dilation-channel block (one launch,
         # blockIdx.y = block; gate gradients only: the filter width just sizes
         # a weight staging area this mode does not read)

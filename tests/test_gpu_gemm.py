@@ -604,3 +604,40 @@ def test_model_with_chained_nn_gemms_bitwise_equals_default(hip_lib, rp):
     wa = list(a._ws.values())[0]
     assert int(wa.nnc_ctl_f[9]) == 0 and int(wa.nnc_ctl_b[9]) == 0
     a.check_device_errors()
+
+
+@pytest.mark.parametrize('C', [64, 96, 128])
+@pytest.mark.parametrize('rows', [1, 77, 4000 * 3 + 5])
+def test_dense_planes_vs_float64(hip_lib, C, rows):
+    """wn_dense_planes: out planes = addend planes + in planes * W (+ bias), the
+    1x1 residual conv of the channel-block models, against float64 and against
+    the plane-mode wn_gemm_nn it replaces."""
+    from wavenet import _lib
+    rng = np.random.default_rng(C + rows)
+    CB = C // 32
+    x = rng.standard_normal((CB, rows, 32)).astype(np.float32)
+    add = rng.standard_normal((CB, rows, 32)).astype(np.float32)
+    W = rng.standard_normal((C, C)).astype(np.float32)
+    b = rng.standard_normal(C).astype(np.float32)
+    dx, da, dW, db = dev(x), dev(add), dev(W), dev(b)
+    st = torch.cuda.current_stream().cuda_stream
+    X = x.transpose(1, 0, 2).reshape(rows, C).astype(np.float64)
+    A = add.transpose(1, 0, 2).reshape(rows, C).astype(np.float64)
+    for use_b, use_a in ((1, 1), (0, 1), (1, 0), (0, 0)):
+        out = torch.full((CB, rows, 32), float('nan'), device='cuda')
+        _lib.call('wn_dense_planes', dx.data_ptr(), rows * 32, dW.data_ptr(),
+                  db.data_ptr() if use_b else None, da.data_ptr() if use_a else None,
+                  rows * 32, out.data_ptr(), rows * 32, rows, C, st)
+        ref = X @ W.astype(np.float64) + (b if use_b else 0) + (A if use_a else 0)
+        got = out.cpu().numpy().transpose(1, 0, 2).reshape(rows, C)
+        assert np.abs(got - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+    ref_g = torch.empty((CB, rows, 32), device='cuda')
+    _lib.call('wn_gemm_nn', dx.data_ptr(), 0, CB, rows * 32, dW.data_ptr(), C,
+              db.data_ptr(), None, 0, da.data_ptr(), 0, ref_g.data_ptr(), 0, CB,
+              rows * 32, None, rows, C, C, 0, st)
+    out = torch.empty((CB, rows, 32), device='cuda')
+    _lib.call('wn_dense_planes', dx.data_ptr(), rows * 32, dW.data_ptr(), db.data_ptr(),
+              da.data_ptr(), rows * 32, out.data_ptr(), rows * 32, rows, C, st)
+    assert float((out - ref_g).abs().max()) < 1e-4 * max(1.0, float(ref_g.abs().max()))
+    assert hip_lib.wn_dense_planes(dx.data_ptr(), rows * 32, dW.data_ptr(), None, None, 0,
+                                   out.data_ptr(), rows * 32, rows, 160, st) == -2

@@ -319,10 +319,23 @@ __global__ __launch_bounds__(256) void layer_wgrad_kernel(
     const float* __restrict__ x, const float* __restrict__ daf,
     const float* __restrict__ dag, const float* __restrict__ z,
     const float* __restrict__ dxin, float* __restrict__ slabs, int B, int T,
-    int d) {
+    int d, int CB, long plane_stride) {
   __shared__ __attribute__((aligned(16))) float lds[4 * 4 * WG_TILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
+  // blockIdx.y: the (input block a, output block b) pair of a channel-block
+  // layer with two taps (wn_layer_wgrad_k: every plane of the pair read ONCE
+  // for all five products; the generic-tap kernel makes a pass per tap)
+  {
+    const int pair = blockIdx.y, pa = pair / CB, pb = pair - pa * CB;
+    x += (size_t)pa * plane_stride;
+    daf += (size_t)pb * plane_stride;
+    dag += (size_t)pb * plane_stride;
+    if (HAS_DENSE) {
+      z += (size_t)pa * plane_stride;
+      dxin += (size_t)pb * plane_stride;
+    }
+  }
   float* t_xp = lds + wave * 4 * WG_TILE;
   float* t_xc = t_xp + WG_TILE;
   float* t_f = t_xc + WG_TILE;
@@ -425,7 +438,7 @@ __global__ __launch_bounds__(256) void layer_wgrad_kernel(
     }
     __syncthreads();
   }
-  float* out = slabs + (size_t)blockIdx.x * LAYER_BLOCK_FLOATS;
+  float* out = slabs + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * LAYER_BLOCK_FLOATS;
   for (int e = tid; e < LAYER_BLOCK_FLOATS; e += 256) out[e] = red[e];
 }
 
@@ -1988,6 +2001,17 @@ int wn_layer_wgrad_k(const float* x, const float* daf, const float* dag,
   if ((dxin != nullptr) != (z != nullptr)) return WN_ERR_NULL;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(num_slabs, CB * CB), block(256);
+  if (K == 2 && k0 == 0 && Ktot == 2) {
+    // two taps: the one-pass kernel of the 32-channel models per block pair
+    // (same slab layout; 24 instead of 32 plane reads per layer at 64 channels)
+    if (dxin)
+      hipLaunchKernelGGL((layer_wgrad_kernel<true>), grid, block, 0, s, x, daf, dag, z,
+                         dxin, slabs, B, T, dilation, CB, plane_stride);
+    else
+      hipLaunchKernelGGL((layer_wgrad_kernel<false>), grid, block, 0, s, x, daf, dag, z,
+                         dxin, slabs, B, T, dilation, CB, plane_stride);
+    return wn_check_launch();
+  }
   if (dxin)
     hipLaunchKernelGGL((layer_wgrad_gen_kernel<true>), grid, block, 0, s, x,
                        daf, dag, z, dxin, slabs, B, T, dilation, K, k0, Ktot, CB,
@@ -2124,10 +2148,10 @@ int wn_layer_wgrad(const float* x, const float* daf, const float* dag,
   dim3 grid(num_slabs), block(256);
   if (dxin)
     hipLaunchKernelGGL((layer_wgrad_kernel<true>), grid, block, 0, s, x, daf,
-                       dag, z, dxin, slabs, B, T, dilation);
+                       dag, z, dxin, slabs, B, T, dilation, 1, 0L);
   else
     hipLaunchKernelGGL((layer_wgrad_kernel<false>), grid, block, 0, s, x, daf,
-                       dag, z, dxin, slabs, B, T, dilation);
+                       dag, z, dxin, slabs, B, T, dilation, 1, 0L);
   return wn_check_launch();
 }
 

@@ -326,7 +326,10 @@ int wn_gemm_nn_split(const float* A, long lda, int a_planes,
                      int c_planes, long c_plane_stride, float* Cpre, long M,
                      int N, int K, int relu, void* w_scratch, int nprod,
                      void* stream);
+/* floats per slab of wn_gemm_tn: the Mw x Nw matrix and
+ * wn_gemm_tn_tail_rows(Mw, Nw) rows of column sums behind it */
 long wn_gemm_tn_slab_floats(int Mw, int Nw);
+int wn_gemm_tn_tail_rows(int Mw, int Nw);
 /* recommended `splits` for wn_gemm_tn (grid = one resident wave of
  * workgroups); kind: 0 dense A, 1 one-hot A, 2 wn_gemm_tn_split */
 int wn_gemm_tn_splits(long rows, int Mw, int Nw, int kind);
@@ -336,6 +339,11 @@ int wn_gemm_tn_split(const float* A, long lda, int a_planes,
                      long a_plane_stride, const float* G, long ldg,
                      float* slabs, int splits, long rows, int Mw, int Nw,
                      int want_colsum, int nprod, void* stream);
+/* want_colsum: 0 none; 1 the column sums of G (the bias gradient) in the first
+ * tail row of every slab; 2 ("spread", shapes with wn_gemm_tn_tail_rows > 1
+ * only): every tile row of a split sums its share of the rows into its own
+ * tail row -- no workgroup carries all the extra adds, none falls behind and
+ * re-fetches its chunks -- and wn_reduce_slabs_mt(tail_rows) adds the rows up */
 int wn_gemm_tn(const float* A, long lda, int a_planes, long a_plane_stride,
                const int32_t* codes, int shift, int T, const float* G,
                long ldg, float* slabs, int splits, long rows, int Mw, int Nw,
@@ -346,11 +354,12 @@ int wn_reduce_slabs(const float* slabs, int num_slabs, long slab_stride,
                     long rep_stride, void* stream);
 /* the slabs of one wn_gemm_tn in ONE launch: elements [0, n_main) of every
  * slab (the matrix) -> dst_main, the n_tail elements behind them (column sums
- * = bias gradient) -> dst_tail, `replicate` copies rep_stride floats apart.
+ * = bias gradient; tail_rows partial rows of n_tail each, summed) -> dst_tail,
+ * `replicate` copies rep_stride floats apart.
  * All counts / strides multiples of 4 floats, pointers 16-byte aligned. */
 int wn_reduce_slabs_mt(const float* slabs, int num_slabs, long slab_stride,
                        long n_main, float* dst_main, long n_tail, float* dst_tail,
-                       int replicate, long rep_stride, void* stream);
+                       int replicate, long rep_stride, int tail_rows, void* stream);
 /* channel-block models (more than 32 residual / dilation channels,
  * model.py:46-60 puts no limit on them): the wn_layer_wgrad_k slabs of the
  * CB x CB block pairs of one layer, slabs[pair = a * CB + b][num_slabs]

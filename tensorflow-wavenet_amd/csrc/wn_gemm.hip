@@ -1256,12 +1256,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn2_kernel(GemmTN g) {
         slab[(long)m * g.Nw + n] = acc[a][b][rr];
       }
     }
-  if (g.want_colsum && tm == 0) {
+  if (g.want_colsum && (tm == 0 || g.want_colsum == 2)) {
+    // (spread tail layout: this kernel sums in tile row 0 only; the other tile
+    // rows' partial rows are zero)
 #pragma unroll
     for (int b = 0; b < NF; ++b) {
       float v = cs[b] + __shfl_xor(cs[b], 32);
       const int n = n0 + wave * (NF * 32) + b * 32 + i;
-      if (h == 0) slab[(long)g.Mw * g.Nw + n] = v;
+      if (h == 0) slab[(long)g.Mw * g.Nw + (long)tm * g.Nw + n] = tm == 0 ? v : 0.f;
     }
   }
 }
@@ -1401,9 +1403,9 @@ __global__ __launch_bounds__(256, (MF * NF >= 10 ? 2 : MF * NF > 5 ? 3 : 4)) voi
   // loop the adds stayed in every workgroup's loop as add + select, and on
   // gfx950 they are matrix-pipe time; a branch per chunk sends the
   // accumulators through memory.)
-  auto kloop = [&](auto cs_tag) {
+  auto kloop = [&](auto cs_tag, int c_begin, int c_end) {
     constexpr bool SUM = decltype(cs_tag)::value;
-    for (int c = 0; c < nchunks; ++c) {
+    for (int c = c_begin; c < c_end; ++c) {
       const int st = c & 1;
       // chunk c landed for every wave; all reads of the other stage retired
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1475,9 +1477,32 @@ __global__ __launch_bounds__(256, (MF * NF >= 10 ? 2 : MF * NF > 5 ? 3 : 4)) voi
   // (which row of tiles sums the columns rotates with the split and the column
   // tile: with tm == 0 the workgroups that carry the extra adds have
   // consecutive ids, share CUs and set the time of a one-round launch)
-  const bool do_cs = g.want_colsum && tm == (split + 3 * tn) % g.tiles_m;
-  if (do_cs) kloop(wn_true{});
-  else kloop(wn_false{});
+  // want_colsum == 2 ("spread", the host's default): EVERY tile row sums the
+  // columns of its share of the split's chunks -- chunk c when c % tiles_m ==
+  // its residue -- into its own partial row of the slab's tail (tiles_m rows;
+  // the slab reduction adds them up).  With ONE owner tile row per (split,
+  // column tile) the four owners of a split were the slowest workgroups of a
+  // one-round launch (2258 vs 2220 us per step without sums) and, falling
+  // behind the other 36, re-fetched their chunks from beyond the L2 (2.5 GB of
+  // traffic per dWs launch against 1.08 GB of operands).  The K loop stays
+  // free of per-chunk branches: per group of tiles_m chunks three plain
+  // loops (before / the summed chunk / after).
+  const bool spread = g.want_colsum == 2;
+  const bool do_cs = spread ? true : (g.want_colsum && tm == (split + 3 * tn) % g.tiles_m);
+  if (spread) {
+    const int own = (tm + split + 3 * tn) % g.tiles_m;
+    for (int c0 = 0; c0 < nchunks; c0 += g.tiles_m) {
+      const int ce = min(nchunks, c0 + g.tiles_m);
+      const int cs_at = min(ce, c0 + own);
+      kloop(wn_false{}, c0, cs_at);
+      kloop(wn_true{}, cs_at, min(ce, cs_at + 1));
+      kloop(wn_false{}, min(ce, cs_at + 1), ce);
+    }
+  } else if (do_cs) {
+    kloop(wn_true{}, 0, nchunks);
+  } else {
+    kloop(wn_false{}, 0, nchunks);
+  }
 
   float* slab = g.slabs + (long)split * g.slab_stride;
 #pragma unroll
@@ -1499,7 +1524,7 @@ __global__ __launch_bounds__(256, (MF * NF >= 10 ? 2 : MF * NF > 5 ? 3 : 4)) voi
       cs[b] += cs2[b].x + cs2[b].y;
       float v = cs[b] + __shfl_xor(cs[b], 32);
       const int n = n0 + wave * (NF * 32) + b * 32 + i;
-      if (h == 0) slab[(long)g.Mw * g.Nw + n] = v;
+      if (h == 0) slab[(long)g.Mw * g.Nw + (spread ? (long)tm * g.Nw : 0) + n] = v;
     }
   }
 }
@@ -1700,7 +1725,7 @@ __global__ void reduce_slabs4_kernel(const float* __restrict__ slabs,
 __global__ __launch_bounds__(256) void reduce_slabs_mt_kernel(
     const float* __restrict__ slabs, int num_slabs, long slab_stride, long n_main4,
     float* __restrict__ dst_main, long n_tail4, float* __restrict__ dst_tail,
-    int replicate, long rep_stride) {
+    int replicate, long rep_stride, int tail_rows) {
   __shared__ f32x4 part[4][64];
   const int col = threadIdx.x & 63, pt = threadIdx.x >> 6;
   const long e = (long)blockIdx.x * 64 + col;
@@ -1724,6 +1749,26 @@ __global__ __launch_bounds__(256) void reduce_slabs_mt_kernel(
 #pragma unroll
     for (int k = 0; k < 7; ++k)
       if (s + k < s1) acc[k] += p[(long)(s + k) * st];
+    // the further partial rows of a spread column-sum tail: (slab, row) pairs
+    // in batches of eight loads, like the slabs themselves
+    if (e >= n_main4 && tail_rows > 1) {
+      const int nv = (s1 - s0) * (tail_rows - 1);
+      int v = 0;
+      for (; v + 7 < nv; v += 8) {
+        f32x4 w[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int q = s0 + (v + k) / (tail_rows - 1), t = 1 + (v + k) % (tail_rows - 1);
+          w[k] = p[(long)q * st + (long)t * n_tail4];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += w[k];
+      }
+      for (; v < nv; ++v) {
+        const int q = s0 + v / (tail_rows - 1), t = 1 + v % (tail_rows - 1);
+        acc[v & 7] += p[(long)q * st + (long)t * n_tail4];
+      }
+    }
   }
   part[pt][col] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   __syncthreads();
@@ -2062,11 +2107,28 @@ int wn_gemm_nn_split(const float* A, long lda, int a_planes, long a_plane_stride
 }
 
 // Number of floats one slab needs for wn_gemm_tn.
-long wn_gemm_tn_slab_floats(int Mw, int Nw) { return (long)Mw * Nw + Nw; }
+
 
 static int tn_device_cus() { return wn_device_cus(); }
 
 // Workgroup-tile shape of the LDS-staged TN kernels for an output, or false.
+static bool tn_wg_tile(int Mw, int Nw, int* mf, int* nf);
+
+// Rows of column sums in a slab's tail: the tile rows of the workgroup-tile
+// kernels (every tile row sums its share of a split's chunks, want_colsum = 2),
+// 1 for the shapes of the LDS-free kernel.
+int wn_gemm_tn_tail_rows(int Mw, int Nw) {
+  int mf = 0, nf = 0;
+  if (Mw <= 0 || Nw <= 0 || !tn_wg_tile(Mw, Nw, &mf, &nf)) return 1;
+  return Mw / (mf * 32);
+}
+
+// Number of floats one slab needs for wn_gemm_tn: the matrix and
+// wn_gemm_tn_tail_rows rows of column sums (want_colsum = 1 uses the first).
+long wn_gemm_tn_slab_floats(int Mw, int Nw) {
+  return (long)Mw * Nw + (long)wn_gemm_tn_tail_rows(Mw, Nw) * Nw;
+}
+
 static bool tn_wg_tile(int Mw, int Nw, int* mf, int* nf) {
   int m = 0, n = 0;
   if (Nw % 256 == 0) n = 2; else if (Nw % 128 == 0) n = 1;
@@ -2185,6 +2247,8 @@ int wn_gemm_tn(const float* A, long lda, int a_planes, long a_plane_stride,
       return wn_check_launch();
     }
   }
+  // (the LDS-free kernel knows the single-row tail only)
+  if (want_colsum == 2) return WN_ERR_UNSUPPORTED;
   // wave-tile shape: least padding waste, then largest tile
   const int m32 = (Mw + 31) / 32, n32 = (Nw + 31) / 32;
   int NF = (n32 % 2 == 0) ? 2 : 1;
@@ -2274,10 +2338,10 @@ int wn_reduce_slabs(const float* slabs, int num_slabs, long slab_stride,
 
 int wn_reduce_slabs_mt(const float* slabs, int num_slabs, long slab_stride,
                        long n_main, float* dst_main, long n_tail, float* dst_tail,
-                       int replicate, long rep_stride, void* stream) {
+                       int replicate, long rep_stride, int tail_rows, void* stream) {
   if (!slabs || !dst_main || (n_tail > 0 && !dst_tail)) return WN_ERR_NULL;
-  if (num_slabs <= 0 || n_main <= 0 || n_tail < 0 || replicate < 1 ||
-      slab_stride < n_main + n_tail)
+  if (num_slabs <= 0 || n_main <= 0 || n_tail < 0 || replicate < 1 || tail_rows < 1 ||
+      slab_stride < n_main + (long)tail_rows * n_tail)
     return WN_ERR_BAD_SHAPE;
   if (((n_main | n_tail | slab_stride | rep_stride) & 3) != 0) return WN_ERR_UNSUPPORTED;
   if (!wn_aligned16(slabs) || !wn_aligned16(dst_main) || (dst_tail && !wn_aligned16(dst_tail)))
@@ -2285,7 +2349,7 @@ int wn_reduce_slabs_mt(const float* slabs, int num_slabs, long slab_stride,
   const long n4 = (n_main + n_tail) / 4;
   hipLaunchKernelGGL(reduce_slabs_mt_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0,
                      (hipStream_t)stream, slabs, num_slabs, slab_stride, n_main / 4, dst_main,
-                     n_tail / 4, dst_tail, replicate, rep_stride);
+                     n_tail / 4, dst_tail, replicate, rep_stride, tail_rows);
   return wn_check_launch();
 }
 

@@ -74,6 +74,7 @@ SIGNATURES = {
     'wn_gemm_nn_split': (c_int, [P, c_long, c_int, c_long, P, c_int, P, P,
                                  c_long, P, c_long, P, c_long, c_int, c_long,
                                  P, c_long, c_int, c_int, c_int, P, c_int, P]),
+    'wn_gemm_tn_tail_rows': (c_int, [c_int, c_int]),
     'wn_gemm_tn_slab_floats': (c_long, [c_int, c_int]),
     'wn_gemm_tn_splits': (c_int, [c_long, c_int, c_int, c_int]),
     'wn_gemm_tn_split': (c_int, [P, c_long, c_int, c_long, P, c_long, P, c_int,
@@ -83,7 +84,7 @@ SIGNATURES = {
     'wn_reduce_slabs': (c_int, [P, c_int, c_long, c_int, c_long, c_long,
                                 c_long, P, c_long, c_int, c_long, P]),
     'wn_reduce_slabs_mt': (c_int, [P, c_int, c_long, c_long, P, c_long, P, c_int,
-                                   c_long, P]),
+                                   c_long, c_int, P]),
     'wn_reduce_pair_slabs': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P,
                                      c_int, c_long, c_int, c_int, P]),
     'wn_transpose': (c_int, [P, c_int, c_int, c_long, P, c_long, P]),

@@ -293,6 +293,9 @@ class WaveNetModel(object):
         # force it.
         self.overlap_tn = None
         self.overlap_tn_split_frac = 0.6
+        # column sums (bias gradients) of the weight-gradient GEMMs spread over
+        # all tile rows of a split (WN_TN_SPREAD=0: one owner tile row, A/B)
+        self.tn_spread_colsum = os.environ.get('WN_TN_SPREAD', '1') != '0'
         # backward of a residual block: 'bwd2' (default: one kernel per layer,
         # pre-activation gradients recomputed per tile, only dx goes through
         # HBM, tanh recovered as z / sigmoid); 'bwdw' (round-1 fused kernel:
@@ -818,7 +821,7 @@ class WaveNetModel(object):
     def _plan_key(self, tag, ws, ids, extra):
         return (tag, extra, ids is not None, self.generic_layers,
                 self.fused_bwd, self.layer_bwd, self.overlap_tn,
-                self.overlap_tn_split_frac, self.nn_chain, self.stack_fwd, self.stack_bwd, self.gemm_mode, self.causal_wgrad_segsum, self.tf_xent_zero_label_quirk,
+                self.overlap_tn_split_frac, self.tn_spread_colsum, self.nn_chain, self.stack_fwd, self.stack_bwd, self.gemm_mode, self.causal_wgrad_segsum, self.tf_xent_zero_label_quirk,
                 _lib.stream(), self.params.data_ptr(), self.grads.data_ptr())
 
     def _stage_ids(self, ws, ids):
@@ -983,6 +986,16 @@ class WaveNetModel(object):
                 # of at most one tile per CU are too short for it to matter)
                 sp = max(1, int(sp * self.overlap_tn_split_frac))
             sl = lib.wn_gemm_tn_slab_floats(mw, nw)
+            # the slabs' matrix and column sums go through ONE reduction launch
+            # when the shapes allow; then the column sums are "spread" too:
+            # every tile row of a split sums its share (wn_gemm_tn,
+            # want_colsum = 2)
+            mt = bool(ub and dst_bias is not None and (mw * nw) % 4 == 0 and
+                      nw % 4 == 0 and sl % 4 == 0 and rep_stride % 4 == 0)
+            tr = 1
+            if mt and self.gemm_mode == 'fp32' and codes is None and \
+                    self.tn_spread_colsum:
+                tr = int(lib.wn_gemm_tn_tail_rows(mw, nw))
             if self.gemm_mode != 'fp32' and codes is None and N % 16 == 0:
                 # opt-in split-bf16 products (fewer, larger splits)
                 sp = min(sp, lib.wn_gemm_tn_splits(N, mw, nw, 2))
@@ -992,14 +1005,15 @@ class WaveNetModel(object):
             else:
                 _lib.call_timed('wn_gemm_tn',
                                 (A, lda, a_planes, a_pstride, codes, shift, T,
-                                 Gm, ldg, _lib.ptr(slabs), sp, N, mw, nw, ub,
+                                 Gm, ldg, _lib.ptr(slabs), sp, N, mw, nw,
+                                 2 if tr > 1 else ub,
                                  st), 2.0 * N * mw * nw,
                                 getattr(self, '_gemm_events', None))
-            if ub and dst_bias is not None and (mw * nw) % 4 == 0 and \
-                    nw % 4 == 0 and sl % 4 == 0 and rep_stride % 4 == 0:
+            if mt:
                 # matrix and column sums (bias gradient) in one launch
                 _lib.call('wn_reduce_slabs_mt', _lib.ptr(slabs), sp, sl,
-                          mw * nw, dst, nw, dst_bias, replicate, rep_stride, st)
+                          mw * nw, dst, nw, dst_bias, replicate, rep_stride,
+                          tr, st)
                 return
             _lib.call('wn_reduce_slabs', _lib.ptr(slabs), sp, sl, 1, 0, 0,
                       mw * nw, dst, 0, 1, 0, st)

@@ -406,7 +406,7 @@ def test_reduce_slabs_matrix_and_tail(hip_lib, ns, n_main, n_tail, rep):
         m = torch.full((n_main,), 3.0, device='cuda')
         t = torch.full((rep, n_tail + 4), 3.0, device='cuda')
         _lib.call('wn_reduce_slabs_mt', d.data_ptr(), ns, stride, n_main, m.data_ptr(),
-                  n_tail, t.data_ptr() if n_tail else None, rep, n_tail + 4, st)
+                  n_tail, t.data_ptr() if n_tail else None, rep, n_tail + 4, 1, st)
         outs.append((m, t))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     tot = slabs.astype(np.float64).sum(0)
@@ -641,3 +641,39 @@ def test_dense_planes_vs_float64(hip_lib, C, rows):
     assert float((out - ref_g).abs().max()) < 1e-4 * max(1.0, float(ref_g.abs().max()))
     assert hip_lib.wn_dense_planes(dx.data_ptr(), rows * 32, dW.data_ptr(), None, None, 0,
                                    out.data_ptr(), rows * 32, rows, 160, st) == -2
+
+
+@pytest.mark.parametrize('rows,Mw,Nw,splits', [(4800, 160, 128, 9), (128000 // 8, 1600, 512, 25),
+                                               (3333, 512, 256, 5), (2048, 512, 512, 3)])
+def test_gemm_tn_spread_column_sums(hip_lib, rows, Mw, Nw, splits):
+    """want_colsum = 2: every tile row of a split sums the columns of its share
+    of the chunks into its own tail row; wn_reduce_slabs_mt(tail_rows) adds
+    them up.  Matrix bitwise what want_colsum = 1 gives, column sums equal to
+    float64 (ragged row counts: the register-staged kernel's zero rows)."""
+    from wavenet import _lib
+    lib = hip_lib
+    rng = np.random.default_rng(rows + Mw)
+    A = rng.standard_normal((rows, Mw)).astype(np.float32)
+    G = rng.standard_normal((rows, Nw)).astype(np.float32)
+    tr = lib.wn_gemm_tn_tail_rows(Mw, Nw)
+    assert tr == Mw // (160 if Mw % 160 == 0 else 128)
+    sl = lib.wn_gemm_tn_slab_floats(Mw, Nw)
+    assert sl == Mw * Nw + tr * Nw
+    dA, dG = dev(A), dev(G)
+    st = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for want in (1, 2):
+        slabs = torch.full((splits * sl,), float('nan'), device='cuda')
+        out = torch.empty(Mw * Nw, device='cuda')
+        cs = torch.empty(Nw, device='cuda')
+        _lib.call('wn_gemm_tn', dA.data_ptr(), Mw, 0, 0, None, 0, 1, dG.data_ptr(), Nw,
+                  slabs.data_ptr(), splits, rows, Mw, Nw, want, st)
+        _lib.call('wn_reduce_slabs_mt', slabs.data_ptr(), splits, sl, Mw * Nw, out.data_ptr(),
+                  Nw, cs.data_ptr(), 1, Nw, tr if want == 2 else 1, st)
+        outs.append((out, cs))
+    assert torch.equal(outs[0][0], outs[1][0])
+    ref = G.astype(np.float64).sum(0)
+    for _, cs in outs:
+        assert np.abs(cs.cpu().numpy() - ref).max() < 2e-3
+    assert lib.wn_gemm_tn(dA.data_ptr(), 100, 0, 0, None, 0, 1, dG.data_ptr(), 36,
+                          slabs.data_ptr(), 2, 64, 100, 36, 2, st) == -2    # no tile rows to spread over

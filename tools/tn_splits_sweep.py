@@ -34,7 +34,7 @@ for name, Mw, Nw, pa in (('dWs', 1600, 512, 50), ('dW1', 512, 512, 0), ('dW2', 5
                                       G.data_ptr(), Nw, slabs.data_ptr(), sp, N, Mw, Nw, 1, st)
                 assert code == 0, code
                 code = lib.wn_reduce_slabs_mt(slabs.data_ptr(), sp, sl, Mw * Nw, dst.data_ptr(), Nw,
-                                              dstb.data_ptr(), 1, 0, st)
+                                              dstb.data_ptr(), 1, 0, 1, st)
                 assert code == 0, code
             e1.record()
             torch.cuda.synchronize()

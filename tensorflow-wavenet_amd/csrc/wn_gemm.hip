@@ -1722,16 +1722,20 @@ __global__ void reduce_slabs4_kernel(const float* __restrict__ slabs,
 // sums = bias gradient) to dst_tail, `replicate` copies rep_stride apart (the
 // skip convs' bias gradients are the same row for every layer).  Same fixed
 // order as reduce_slabs4<4>.
-__global__ __launch_bounds__(256) void reduce_slabs_mt_kernel(
+// (sixteen waves per workgroup, each a sixteenth of the slabs -- and of the
+// (slab, row) pairs of a spread column-sum tail: with four the two tail
+// workgroups of a dWs reduction took 34 us, the others 19)
+#define RMT_PARTS 16
+__global__ __launch_bounds__(64 * RMT_PARTS) void reduce_slabs_mt_kernel(
     const float* __restrict__ slabs, int num_slabs, long slab_stride, long n_main4,
     float* __restrict__ dst_main, long n_tail4, float* __restrict__ dst_tail,
     int replicate, long rep_stride, int tail_rows) {
-  __shared__ f32x4 part[4][64];
+  __shared__ f32x4 part[RMT_PARTS][64];
   const int col = threadIdx.x & 63, pt = threadIdx.x >> 6;
   const long e = (long)blockIdx.x * 64 + col;
   const long n4 = n_main4 + n_tail4;
-  const int per = (num_slabs + 3) / 4;
-  const int s0 = pt * per, s1 = min(num_slabs, s0 + per);
+  const int per = (num_slabs + RMT_PARTS - 1) / RMT_PARTS;
+  const int s0 = min(num_slabs, pt * per), s1 = min(num_slabs, s0 + per);
   f32x4 acc[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1773,7 +1777,10 @@ __global__ __launch_bounds__(256) void reduce_slabs_mt_kernel(
   part[pt][col] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   __syncthreads();
   if (pt != 0 || e >= n4) return;
-  const f32x4 v = (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
+  f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < RMT_PARTS; q += 4)
+    v += (part[q][col] + part[q + 1][col]) + (part[q + 2][col] + part[q + 3][col]);
   if (e < n_main4) {
     reinterpret_cast<f32x4*>(dst_main)[e] = v;
   } else {
@@ -2347,7 +2354,7 @@ int wn_reduce_slabs_mt(const float* slabs, int num_slabs, long slab_stride,
   if (!wn_aligned16(slabs) || !wn_aligned16(dst_main) || (dst_tail && !wn_aligned16(dst_tail)))
     return WN_ERR_MISALIGNED;
   const long n4 = (n_main + n_tail) / 4;
-  hipLaunchKernelGGL(reduce_slabs_mt_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0,
+  hipLaunchKernelGGL(reduce_slabs_mt_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(64 * RMT_PARTS), 0,
                      (hipStream_t)stream, slabs, num_slabs, slab_stride, n_main / 4, dst_main,
                      n_tail / 4, dst_tail, replicate, rep_stride, tail_rows);
   return wn_check_launch();

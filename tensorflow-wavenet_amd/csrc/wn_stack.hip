@@ -66,6 +66,8 @@ struct StackFwd {
   float* poison;       // set to NaN when a bounded wait expires (or null)
   int L, B, T;
   long plane;          // N * 32 floats
+  // 16-row launch: [L][N][32] hand-over words {value, epoch} (or null: flags)
+  unsigned long long* ll;
 #ifdef STACK_STAMPS
   unsigned long long* dbg;   // diagnostic build: [grid][16][L][12] s_memtime stamps
 #endif
@@ -1266,6 +1268,842 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// Small batches: the same two launches on 16-ROW tiles.
+// With at most a tile or two per SIMD the launches above are bound by ONE
+// wave's dependent path through a layer (B = 1, T = 16000: 500 tiles on 1024
+// SIMDs; stamps: forward 5.4 us, backward 12.9 us per layer, of which the
+// wave's own MFMAs 2.1 / 4.4 us and its gate math and LDS transits most of the
+// rest).  A 16-row tile halves all of that and doubles the waves:
+//   * time-major products on v_mfma_f32_16x16x4_f32 (32 cycles): lane (jr =
+//     lane & 15, g = lane >> 4) holds, of a [16 rows][32 channels] operand, the
+//     two 16-byte pieces  [row jr][16 blk + 4 g .. + 3], blk = 0, 1  (F16).  A
+//     K-step (blk, e) contracts the channels 16 blk + 4 g' + e, g' = 0..3, and
+//     the accumulator of output block mb holds [row jr][16 mb + 4 g + e]: the
+//     output IS the next product's B operand, as in the 32-row kernels.  A
+//     lane's four A operands of (mb, blk) are one ds_read_b128 of the SAME
+//     weight images (wn_stack_pack);
+//   * that layout is also what a lane reads from / writes to a [N][32] plane
+//     with one 16-byte access per piece (64 contiguous bytes per row and
+//     instruction): time-major operands go registers <-> memory directly, no
+//     LDS transit; LDS tiles only where an operand is needed with the CHANNEL
+//     on the lane (the weight-gradient products of the backward, which stay on
+//     v_mfma_f32_32x32x2_f32 over K = 16 rows, so that accumulators, ordered
+//     accumulation and slabs are the 32-row kernel's);
+//   * same hand-over scheme, flags per 16-row tile.
+// The products sum their 32 terms in another grouping than the 32-row kernels
+// (4 + 4 + ... instead of 2 + 2 + ...): results agree to rounding, not bitwise
+// (tests/test_gpu_stack.py).
+// ---------------------------------------------------------------------------
+struct F16 {
+  f32x4 v[2];
+};
+#ifdef STACK_STAMPS
+// diagnostic build: [grid][8][L][16] s_memtime stamps + [grid][4] clock calibration
+#define S16STAMP(l, i)                                                       \
+  if (lane == 0)                                                             \
+    a.dbg[(((size_t)blockIdx.x * 8 + wave) * L + (l)) * 16 + (i)] =          \
+        __builtin_amdgcn_s_memtime()
+#define S16CAL(k)                                                                        \
+  if (tid == 0) {                                                                        \
+    unsigned long long* cal_ = a.dbg + (size_t)gridDim.x * 8 * L * 16 + (size_t)blockIdx.x * 4; \
+    cal_[k] = __builtin_amdgcn_s_memrealtime();                                          \
+    cal_[k + 1] = __builtin_amdgcn_s_memtime();                                          \
+  }
+#else
+#define S16STAMP(l, i)
+#define S16CAL(k)
+#endif
+#define wn_mfma16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
+
+__device__ __forceinline__ F16 f16_zero() {
+  F16 f;
+  f.v[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f.v[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  return f;
+}
+
+// pieces of plane row `row_bytes / 128` (`voff` = row_bytes + 16 g: the lane's
+// byte offset of piece 0; < 2^31, host check), zero when !valid
+template <int AUX>
+__device__ __forceinline__ F16 f16_ld(wn_rsrc_t rs, int voff, bool valid) {
+  F16 f = f16_zero();
+  if (valid) {
+    f.v[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, AUX));
+    f.v[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 64, 0, AUX));
+  }
+  return f;
+}
+template <int AUX>
+__device__ __forceinline__ void f16_st(wn_rsrc_t rs, int voff, bool valid, const F16& f) {
+  if (valid) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f.v[0]), rs, voff, 0, AUX);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f.v[1]), rs, voff + 64, 0, AUX);
+  }
+}
+
+// accA^T += WA^T frag, accB^T += WB^T frag from the FORWARD image (rows
+// padded to SF_LD): `wa` / `wb` = matrix + jr * SF_LD + 4 g.  Four independent
+// accumulation chains, the eight operand reads up front.
+__device__ __forceinline__ void mma16t2(F16& accA, F16& accB, const F16& frag,
+                                        const float* wa, const float* wb) {
+  f32x4 a[2][2], b[2][2];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      a[mb][blk] = *reinterpret_cast<const f32x4*>(wa + mb * 16 * SF_LD + blk * 16);
+      b[mb][blk] = *reinterpret_cast<const f32x4*>(wb + mb * 16 * SF_LD + blk * 16);
+    }
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      accA.v[0] = wn_mfma16(a[0][blk][e], frag.v[blk][e], accA.v[0]);
+      accA.v[1] = wn_mfma16(a[1][blk][e], frag.v[blk][e], accA.v[1]);
+      accB.v[0] = wn_mfma16(b[0][blk][e], frag.v[blk][e], accB.v[0]);
+      accB.v[1] = wn_mfma16(b[1][blk][e], frag.v[blk][e], accB.v[1]);
+    }
+}
+__device__ __forceinline__ void mma16t(F16& acc, const F16& frag, const float* wa) {
+  f32x4 a[2][2];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+      a[mb][blk] = *reinterpret_cast<const f32x4*>(wa + mb * 16 * SF_LD + blk * 16);
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc.v[0] = wn_mfma16(a[0][blk][e], frag.v[blk][e], acc.v[0]);
+      acc.v[1] = wn_mfma16(a[1][blk][e], frag.v[blk][e], acc.v[1]);
+    }
+}
+
+// time-major pieces <-> a swizzled [16][32] LDS tile (chunk c of row r at
+// c ^ (r & 7)): `lt` = tile + jr * 32, `sw` = jr & 7
+__device__ __forceinline__ F16 f16_from_lds(const float* lt, int g, int sw) {
+  F16 f;
+  f.v[0] = *reinterpret_cast<const f32x4*>(lt + ((g ^ sw) << 2));
+  f.v[1] = *reinterpret_cast<const f32x4*>(lt + (((4 + g) ^ sw) << 2));
+  return f;
+}
+__device__ __forceinline__ void f16_to_lds(float* lt, int g, int sw, const F16& f) {
+  *reinterpret_cast<f32x4*>(lt + ((g ^ sw) << 2)) = f.v[0];
+  *reinterpret_cast<f32x4*>(lt + (((4 + g) ^ sw) << 2)) = f.v[1];
+}
+
+// Hand-over words (LL = true): the dilated tap of a 16-row tile costs two
+// dependent memory round trips per layer with flags -- the producer drains its
+// x' stores, then posts the flag; the consumer reads the flag, then the rows --
+// and on a path this short that is most of it.  With `ll` every float of x_l
+// (l > 0) also goes out as ONE 8-byte word {value, epoch} (RCCL's LL idea, as
+// in the persistent generator of wn_fastgen.hip): the producer stores and goes
+// on without waiting, the consumer polls the words themselves -- one round
+// trip, the validity in the data.  Twice the bytes on the hand-over; at these
+// sizes nobody is short of bandwidth.  Rows of the wave's own tile (d < 16)
+// come back from a wave-private LDS tile.  The X planes are still written
+// (plain stores: the backward reads them after the launch).
+template <int AUX>
+__device__ __forceinline__ void ll16_put(wn_rsrc_t rs, int voff2, bool valid, const F16& f,
+                                         unsigned epoch) {
+  if (!valid) return;
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      u32x4 w;
+      w[0] = __float_as_uint(f.v[blk][2 * p]);
+      w[1] = epoch;
+      w[2] = __float_as_uint(f.v[blk][2 * p + 1]);
+      w[3] = epoch;
+      __builtin_amdgcn_raw_buffer_store_b128(w, rs, voff2 + (2 * blk + p) * 64, 0, AUX);
+    }
+}
+struct LL16 {
+  u32x4 w[4];
+};
+__device__ __forceinline__ LL16 ll16_request(wn_rsrc_t rs, int voff2) {
+  LL16 r;
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+      r.w[2 * blk + p] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff2 + (2 * blk + p) * 64, 0, 16);
+  return r;
+}
+__device__ __forceinline__ bool ll16_ready(const LL16& r, unsigned epoch) {
+  bool ok = true;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ok = ok && r.w[i][1] == epoch && r.w[i][3] == epoch;
+  return ok;
+}
+__device__ __forceinline__ F16 ll16_value(const LL16& r) {
+  F16 f;
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      f.v[blk][2 * p] = __uint_as_float(r.w[2 * blk + p][0]);
+      f.v[blk][2 * p + 1] = __uint_as_float(r.w[2 * blk + p][2]);
+    }
+  return f;
+}
+
+template <int SAVE, int WAVES, bool LL>
+__global__ __launch_bounds__(WAVES * 64) void stack_fwd16_kernel(StackFwd a) {
+  __shared__ __attribute__((aligned(1024))) float wl[2 * STACK_WBUF];
+  __shared__ __attribute__((aligned(16))) float own[LL ? WAVES * 512 : 4];
+  __shared__ int s_group;
+  __shared__ int s_done[STACK_MAXL], s_ready[STACK_MAXL];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int jr = lane & 15, g = lane >> 4;
+  const int T = a.T, L = a.L;
+  const int tiles_per_clip = (T + 15) >> 4;
+  const int ntiles = tiles_per_clip * a.B;
+  const int ngroups = (ntiles + WAVES - 1) / WAVES;
+  const unsigned epoch =
+      __hip_atomic_load(a.ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  float* town = own + (LL ? wave * 512 : 0);
+  bool dead = false;
+  S16CAL(0);
+
+  auto issue_weights = [&](int l, int p0, int step) {
+    const float* wb = a.wimg + (size_t)l * STACK_WBUF;
+    float* dst = wl + (l & 1) * STACK_WBUF;
+    for (int p = p0; p < STACK_WBUF / 256; p += step)
+      __builtin_amdgcn_global_load_lds((wn_gptr_t)(wb + p * 256 + lane * 4),
+                                       (wn_lptr_t)(dst + p * 256), 16, 0, 0);
+  };
+
+  for (;;) {
+    if (tid == 0) s_group = (int)atomicAdd(a.ctl, 1u);
+    __syncthreads();
+    const int gi = __builtin_amdgcn_readfirstlane(s_group);
+    __syncthreads();
+    if (gi >= ngroups) break;
+    const int tile = gi * WAVES + wave;
+    const int nactive = min(WAVES, ntiles - gi * WAVES);
+    const bool any = tile < ntiles;
+    const int b = any ? tile / tiles_per_clip : 0;
+    const int tt = any ? tile - b * tiles_per_clip : 0;
+    const int t0 = tt * 16;
+    const int hi = any ? min(16, T - t0) : 0;
+    const bool mine = jr < hi;                       // this lane's row exists
+    // the lane's byte offset of piece 0 of ITS row in a plane (x 2: in a
+    // layer of hand-over words)
+    const int voff = ((b * T + t0 + jr) * WN_CH + 4 * g) * 4;
+    // ... of its first pair of hand-over words (a row's 32 words: [pair k =
+    // 2 blk + p][g][2], so that one instruction moves 64 contiguous bytes a row)
+    const int voff2 = (b * T + t0 + jr) * (WN_CH * 8) + 16 * g;
+
+    for (int i = tid; i < L; i += WAVES * 64) {
+      s_done[i] = 0;
+      s_ready[i] = i < 2;
+    }
+    issue_weights(0, wave, WAVES);
+    if (L > 1) issue_weights(1, wave, WAVES);
+    F16 xc = f16_ld<16>(plane_rsrc(a.X), voff, mine);
+    // filter | gate bias of the first layer (the next layer's is requested a
+    // layer ahead)
+    F16 bf = f16_zero(), bg = f16_zero();
+    auto bias_request = [&](int l) {
+      if (!a.bias) return;
+      const float* bp = a.bias + (size_t)l * a.bias_layer_stride +
+                        (size_t)b * a.bias_clip_stride + 4 * g;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        bf.v[mb] = *reinterpret_cast<const f32x4*>(bp + 16 * mb);
+        bg.v[mb] = *reinterpret_cast<const f32x4*>(bp + 32 + 16 * mb);
+      }
+    };
+    bias_request(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();        // weights of layers 0 and 1 are in LDS
+    int publish = 0;
+
+    for (int l = 0; any && l < L; ++l) {
+      const int d = a.dil[l];
+      S16STAMP(l, 0);
+      wait_lds(s_ready + l, dead, a.ctl, a.poison, lane);
+      S16STAMP(l, 1);
+      const wn_rsrc_t xl = plane_rsrc(a.X + (size_t)l * a.plane);
+      int woff = jr * SF_LD + 4 * g + (l & 1) * STACK_WBUF;
+      asm volatile("" : "+v"(woff));
+      const float* wlane = wl + woff;
+      F16 af = bf, ag = bg;
+      if (l + 1 < L) bias_request(l + 1);
+      // the dilated tap: rows t0-d .. t0-d+15 of x_l, owned by at most two
+      // other tiles of this clip (and, d < 16, by this one)
+      const int lo_row = t0 - d;
+      const bool tap = mine && t0 + jr - d >= 0;          // this lane's tap row exists
+      const bool tap_own = LL && l > 0 && jr >= d;          // ... in the wave's own tile
+      int fidx = -1;
+      unsigned fval = epoch;
+      LL16 req;
+      const wn_rsrc_t hl = plane_rsrc(LL ? reinterpret_cast<const float*>(a.ll) + (size_t)l * a.plane * 2
+                                         : a.X);
+      const bool via_ll = LL && l > 0 && tap && !tap_own;
+      if (LL) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) req.w[i] = u32x4{0u, epoch, 0u, epoch};
+        if (via_ll) req = ll16_request(hl, voff2 - d * (WN_CH * 8));
+      } else if (l > 0 && lo_row + 15 >= 0) {
+        // flags requested first, looked at after the current-tap products
+        const int first = max(lo_row, 0) >> 4, last = (lo_row + 15) >> 4;
+        if (lane == 0 && first != tt) fidx = b * tiles_per_clip + first;
+        if (lane == 1 && last != first && last != tt) fidx = b * tiles_per_clip + last;
+        if (fidx >= 0)
+          fval = __hip_atomic_load(a.flags + (size_t)l * ntiles + fidx, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+      }
+      mma16t2(af, ag, xc, wlane + 1 * SF_MT, wlane + 3 * SF_MT);   // Wf[1], Wg[1]: current tap
+      S16STAMP(l, 2);
+      F16 xp;
+      if (LL && l > 0) {
+        // poll the words themselves (bounded like a flag wait)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned spins = 0;
+        unsigned long long t_start = 0;
+        while (!dead && __builtin_amdgcn_ballot_w64(!ll16_ready(req, epoch)) != 0) {
+          __builtin_amdgcn_s_sleep(1);
+          if (via_ll && !ll16_ready(req, epoch)) req = ll16_request(hl, voff2 - d * (WN_CH * 8));
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if ((++spins & 63u) == 0) {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (t_start == 0) t_start = now;
+            if (now - t_start > 200000000ull) {   // 2 s at 100 MHz
+              if (lane == 0) {
+                __hip_atomic_store(a.ctl + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a.poison) *a.poison = __builtin_nanf("");
+              }
+              dead = true;
+            }
+          }
+        }
+        xp = ll16_value(req);
+        if (tap_own && mine) xp = f16_from_lds(town + (jr - d) * 32, g, (jr - d) & 7);
+        if (!tap) xp = f16_zero();
+      } else {
+        if (__builtin_amdgcn_ballot_w64(fval != epoch) != 0)
+          wait_flags(a.flags + (size_t)l * ntiles, fidx, epoch, a.ctl, a.poison, dead, lane);
+        xp = f16_ld<16>(xl, voff - d * (WN_CH * 4), tap);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      S16STAMP(l, 3);
+      if (publish) {
+        // (the weight pieces issued at the end of the previous layer are older
+        // than the loads just waited for)
+        if (lane == 0)
+          __hip_atomic_store(s_ready + publish, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        publish = 0;
+      }
+      mma16t2(af, ag, xp, wlane + 0 * SF_MT, wlane + 2 * SF_MT);   // Wf[0], Wg[0]: past tap
+      S16STAMP(l, 4);
+      F16 zz;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          af.v[mb][e] = wn_tanh(af.v[mb][e]);
+          ag.v[mb][e] = wn_sigmoid(ag.v[mb][e]);
+          zz.v[mb][e] = af.v[mb][e] * ag.v[mb][e];
+        }
+      S16STAMP(l, 5);
+      if (l + 1 < L) {
+        const float* bd = wl + (l & 1) * STACK_WBUF + SF_OFF_BD + 4 * g;
+        xc.v[0] += *reinterpret_cast<const f32x4*>(bd);
+        xc.v[1] += *reinterpret_cast<const f32x4*>(bd + 16);
+        mma16t(xc, zz, wlane + 4 * SF_MT);                          // Wd
+        S16STAMP(l, 6);
+        if (LL) {
+          // x' first as hand-over words: what other waves wait for; no drain
+          ll16_put<16>(plane_rsrc(reinterpret_cast<const float*>(a.ll) + (size_t)(l + 1) * a.plane * 2),
+                       voff2, mine, xc, epoch);
+          f16_to_lds(town + jr * 32, g, jr & 7, xc);
+          f16_st<0>(plane_rsrc(a.X + (size_t)(l + 1) * a.plane), voff, mine, xc);
+        } else {
+          f16_st<16>(plane_rsrc(a.X + (size_t)(l + 1) * a.plane), voff, mine, xc);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lane == 0)
+            __hip_atomic_store(a.flags + (size_t)(l + 1) * ntiles + tile, epoch,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      S16STAMP(l, 7);
+      f16_st<0>(plane_rsrc(a.Z + (size_t)l * a.plane), voff, mine, zz);
+      if (SAVE == 2) f16_st<0>(plane_rsrc(a.SG + (size_t)l * a.plane), voff, mine, ag);
+      {
+        int old = 0;
+        if (lane == 0)
+          old = __hip_atomic_fetch_add(s_done + l, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old == nactive - 1 && l + 2 < L) {
+          // (every wave's reads of this half have returned: each waited for
+          // its LDS reads before the MFMAs that used them)
+          issue_weights(l + 2, 0, 1);
+          publish = l + 2;
+        }
+      }
+      S16STAMP(l, 8);
+    }
+    __syncthreads();
+  }
+  S16CAL(2);
+  if (tid == 0) {
+    const unsigned done = atomicAdd(a.ctl + 1, 1u);
+    if (done == gridDim.x - 1) {
+      __hip_atomic_store(a.ctl + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.ctl + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.ctl + 2, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// LDS-DMA of a [16][32] tile into the swizzled layout of rows_to_lds (see
+// tile_dma_rs; two 1-KiB pieces)
+template <int AUX>
+__device__ __forceinline__ void tile_dma16_rs(float* lds_tile, wn_rsrc_t rs, int soff,
+                                              int vswz, int lane, int lo, int hi) {
+  if (lo <= 0 && hi >= 16) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (wn_lptr_t)(lds_tile + c * 256), 16,
+                                               vswz, soff + c * 1024, 0, AUX);
+  } else {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+      *reinterpret_cast<f32x4*>(lds_tile + c * 256 + lane * 4) = zero;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int r = 8 * c + (lane >> 3);
+      const int sc = soff + c * 1024;     // (a negative start goes into the lanes' offsets)
+      if (r >= lo && r < hi)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (wn_lptr_t)(lds_tile + c * 256), 16,
+                                                 vswz + min(sc, 0), max(sc, 0), 0, AUX);
+    }
+  }
+}
+
+// accA^T[cin] += A[cin][cout] frag[cout], accB likewise with matrix B, from the
+// dense swizzled BACKWARD image: `off0` = jr * 32 + ((g ^ ((jr >> 1) & 7)) << 2)
+// (chunk g of row jr; chunk 4 + g sits at off0 ^ 16, rows 16 + jr 512 floats on)
+__device__ __forceinline__ void mma16s2(F16& accA, F16& accB, const F16& frag,
+                                        const float* ma, const float* mb_, int off0) {
+  f32x4 a[2][2], b[2][2];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      a[mb][blk] = *reinterpret_cast<const f32x4*>(ma + mb * 512 + (off0 ^ (blk << 4)));
+      b[mb][blk] = *reinterpret_cast<const f32x4*>(mb_ + mb * 512 + (off0 ^ (blk << 4)));
+    }
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      accA.v[0] = wn_mfma16(a[0][blk][e], frag.v[blk][e], accA.v[0]);
+      accA.v[1] = wn_mfma16(a[1][blk][e], frag.v[blk][e], accA.v[1]);
+      accB.v[0] = wn_mfma16(b[0][blk][e], frag.v[blk][e], accB.v[0]);
+      accB.v[1] = wn_mfma16(b[1][blk][e], frag.v[blk][e], accB.v[1]);
+    }
+}
+__device__ __forceinline__ void mma16s(F16& acc, const F16& frag, const float* ma, int off0) {
+  f32x4 a[2][2];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+      a[mb][blk] = *reinterpret_cast<const f32x4*>(ma + mb * 512 + (off0 ^ (blk << 4)));
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc.v[0] = wn_mfma16(a[0][blk][e], frag.v[blk][e], acc.v[0]);
+      acc.v[1] = wn_mfma16(a[1][blk][e], frag.v[blk][e], acc.v[1]);
+    }
+}
+
+// The backward on 16-row tiles ("push" formulation, one tile per wave and
+// layer).  Three 2-KiB LDS tiles per wave for the operands that are needed with
+// the channel on the lane (weight-gradient products), used in the 32-row
+// kernel's order: z | dx_{l+1} (dWd), then x[t] | x[t-d] | da_f, then da_g
+// through the third tile.  108 KiB per 8-wave workgroup: a weight-gradient GEMM
+// workgroup of the side stream still fits beside it on the CU (six tiles per
+// wave, everything requested at the layer's top, filled the CU's LDS and the
+// GEMMs beside a B = 1 backward took 934 instead of 731 us).  Weight ring,
+// ordered accumulation, slabs, tickets, flags, bounded waits: as
+// stack_bwd_kernel.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void stack_bwd16_kernel(StackBwd a) {
+  constexpr int SLAB = WAVES > 1 ? LAYER_BLOCK_FLOATS : 16;
+  __shared__ __attribute__((aligned(1024))) float wl[2 * SB_WIMG];
+  __shared__ __attribute__((aligned(1024))) float tiles[WAVES * 1536];
+  __shared__ __attribute__((aligned(16))) float slab[SLAB];
+  __shared__ int s_group;
+  __shared__ int s_done[STACK_MAXL], s_ready[STACK_MAXL];
+  __shared__ int s_tok[2][8];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;        // 32 x 32 products: channel, row parity
+  const int jr = lane & 15, g = lane >> 4;       // 16 x 16 products: row, piece
+  const int sw = jr & 7;
+  const int vswz = ((lane >> 3) * 32 + (((lane & 7) ^ ((lane >> 3) & 7)) << 2)) * 4;
+  float* t0 = tiles + wave * 1536;               // z[t], then x[t]
+  float* t1 = t0 + 512;                          // dx_{l+1}[t] (complete), then x[t - d]
+  float* t2 = t0 + 1024;                         // da_f[t], then da_g[t]
+  const TileElemPtr te = tile_elem_ptrs(t0, j, h);   // [row 2 s + h][channel j] of tile n: te.p[s & 3][n * 512 + 64 s]
+  const int T = a.T, L = a.L;
+  const int tiles_per_clip = (T + 15) >> 4;
+  const int ntiles = tiles_per_clip * a.B;
+  const int ngroups = (ntiles + WAVES - 1) / WAVES;
+  const unsigned epoch =
+      __hip_atomic_load(a.ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  bool dead = false;
+  S16CAL(0);
+
+  auto issue_wimg = [&](int l, int p0, int step) {
+    const float* src = a.wimg + (size_t)l * STACK_WBUF;
+    float* dst = wl + (l & 1) * SB_WIMG;
+    for (int p = p0; p < SB_WIMG / 256; p += step)
+      __builtin_amdgcn_global_load_lds((wn_gptr_t)(src + p * 256 + lane * 4),
+                                       (wn_lptr_t)(dst + p * 256), 16, 0, 0);
+  };
+
+  for (;;) {
+    if (tid == 0) s_group = (int)atomicAdd(a.ctl, 1u);
+    __syncthreads();
+    const int ticket = __builtin_amdgcn_readfirstlane(s_group);
+    __syncthreads();
+    if (ticket >= ngroups) break;
+    const int gi = ngroups - 1 - ticket;
+    const int tile = gi * WAVES + wave;
+    const bool any = tile < ntiles;
+    const int b = any ? tile / tiles_per_clip : 0;
+    const int tt = any ? tile - b * tiles_per_clip : 0;
+    const int tt0 = tt * 16;
+    const int hi = any ? min(16, T - tt0) : 0;
+    const bool mine = jr < hi;
+    const int off0 = (b * T + tt0) * (WN_CH * 4);            // bytes (< 2^31: host check)
+    const int voff = off0 + (jr * WN_CH + 4 * g) * 4;        // the lane's piece 0 of its row
+    for (int i = tid; i < L; i += WAVES * 64) {
+      s_done[i] = 0;
+      s_ready[i] = i >= L - 2;
+    }
+    if (tid < 16) s_tok[tid >> 3][tid & 7] = 0;
+    issue_wimg(L - 1, wave, WAVES);
+    if (L > 1) issue_wimg(L - 2, wave, WAVES);
+    WN_WAIT_VM0();
+    __syncthreads();
+
+    // lanes 0 / 1: index of the (at most two) flags the rows t + dd of this
+    // tile wait for, -1 on the other lanes / when there is nothing to wait for
+    auto flag_idx2 = [&](int dd) -> int {
+      if (!any) return -1;
+      const int hif = min(hi, T - dd - tt0);
+      if (hif <= 0) return -1;
+      const int first = (tt0 + dd) >> 4, last = (tt0 + dd + hif - 1) >> 4;
+      int idx = -1;
+      if (lane == 0 && first != tt) idx = b * tiles_per_clip + first;
+      if (lane == 1 && last != first && last != tt) idx = b * tiles_per_clip + last;
+      return idx;
+    };
+    unsigned nfv_push = epoch;    // flag value(s) requested ahead for the next layer
+    for (int l = L - 1; l >= 0; --l) {
+      const int d = a.dil[l];
+      const bool hx = l + 1 < L;
+      const int dn = hx ? a.dil[l + 1] : 0;
+      const wn_rsrc_t qin = plane_rsrc(a.Q + (size_t)(hx ? l + 1 : l) * a.plane);
+      const wn_rsrc_t q_out = plane_rsrc(a.Q + (size_t)l * a.plane);
+      const wn_rsrc_t x = plane_rsrc(a.X + (size_t)l * a.plane);
+      const wn_rsrc_t z = plane_rsrc(a.Z + (size_t)l * a.plane);
+      const wn_rsrc_t sg = plane_rsrc(a.SG + (size_t)l * a.plane);
+      const wn_rsrc_t dZ = plane_rsrc(a.dZ + (size_t)l * a.plane);
+      const wn_rsrc_t dxin = plane_rsrc(a.DX + (size_t)(hx ? l + 1 : l) * a.dx_stride);
+      const wn_rsrc_t dx_out = plane_rsrc(a.DX + (size_t)l * a.dx_stride);
+      const unsigned* fl_in = a.flags + (size_t)(hx ? l + 1 : l) * ntiles;
+      unsigned* fl_out = a.flags + (size_t)l * ntiles;
+      float* tile_colsum = a.tilesum ? a.tilesum + (size_t)l * ntiles * 64 : nullptr;
+      S16STAMP(l, 0);
+      wait_lds_ge(s_ready + l, 1, dead, a.ctl, a.poison, lane);
+      S16STAMP(l, 1);
+      f32x16 cf0 = frag_zero(), cf1 = frag_zero(), cg0 = frag_zero(),
+             cg1 = frag_zero(), cd = frag_zero();
+      float sf = 0.f, sgs = 0.f, sd = 0.f;
+      int woff = jr * 32 + ((g ^ ((jr >> 1) & 7)) << 2) + (l & 1) * SB_WIMG;
+      asm volatile("" : "+v"(woff));
+      const float* const wm = wl;
+      if (any) {
+        const int lo_p = max(0, d - tt0);
+        // ---- rows t: z through LDS (needed both ways), the others time-major
+        tile_dma16_rs<SB_STREAM>(t0, z, off0, vswz, lane, 0, hi);
+        F16 dz = f16_ld<SB_STREAM>(dZ, voff, mine);
+        const F16 ss = f16_ld<SB_STREAM>(sg, voff, mine);
+        F16 di = f16_zero();
+        if (hx) {
+          // dx_{l+1}[t] = own rows (this wave's store of the layer above: same
+          // CU, past the vector L1) + q_{l+1}[t + dn] of the tiles dn rows later
+          di = f16_ld<SB_OWN_LD>(dxin, voff, mine);
+          const int hi_q = min(hi, T - dn - tt0);
+          F16 qv = f16_zero();
+          if (hi_q > 0) {
+            const int idx = flag_idx2(dn);
+            if (__builtin_amdgcn_ballot_w64(idx >= 0 && nfv_push != epoch) != 0)
+              wait_flags(fl_in, idx, epoch, a.ctl, a.poison, dead, lane);
+            qv = f16_ld<16>(qin, voff + dn * (WN_CH * 4), jr < hi_q);
+          }
+          S16STAMP(l, 2);
+          WN_WAIT_VM0();
+          S16STAMP(l, 3);
+          di.v[0] += qv.v[0];
+          di.v[1] += qv.v[1];
+          f16_to_lds(t1 + jr * 32, g, sw, di);
+          __builtin_amdgcn_wave_barrier();
+          // dWd += z^T dx_{l+1} over the 16 rows (8 steps of two rows; operands
+          // of step s + 1 requested before the MFMA of step s)
+          float ez = te.p[0][0 * 512], ei = te.p[0][1 * 512];
+#pragma unroll
+          for (int s = 0; s < 8; ++s) {
+            const int sn = (s + 1) & 7, o = 64 * sn;
+            const float nz = te.p[sn & 3][0 * 512 + o], ni = te.p[sn & 3][1 * 512 + o];
+            __builtin_amdgcn_sched_barrier(0);
+            cd = sb_mfma(ez, ei, cd);
+            sd += ei;
+            __builtin_amdgcn_sched_barrier(0);
+            ez = nz;
+            ei = ni;
+          }
+        } else {
+          WN_WAIT_VM0();
+        }
+        const F16 zz = f16_from_lds(t0 + jr * 32, g, sw);
+        WN_WAIT_LGKM0();
+        S16STAMP(l, 4);
+        __builtin_amdgcn_wave_barrier();
+        // the x tiles: in flight during the rows-t math
+        tile_dma16_rs<SB_X_AUX>(t0, x, off0, vswz, lane, 0, hi);
+        tile_dma16_rs<SB_X_AUX>(t1, x, off0 - d * (WN_CH * 4), vswz, lane, lo_p, hi);
+        if (hx) mma16s(dz, di, wm + 4 * 1024, woff);            // + dx_{l+1}[t] Wd^T
+        F16 df, dg;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            // (gate_grad of wn_common.h on this layout)
+            const float sgm = ss.v[mb][e], zv = zz.v[mb][e];
+            const float th = zv * __builtin_amdgcn_rcpf(sgm + 1e-30f);
+            df.v[mb][e] = dz.v[mb][e] * __builtin_fmaf(-zv, th, sgm);
+            dg.v[mb][e] = dz.v[mb][e] * __builtin_fmaf(-zv, sgm, zv);
+          }
+        f16_to_lds(t2 + jr * 32, g, sw, df);
+        S16STAMP(l, 5);
+        // own_l[t] = dx_{l+1}[t] + da[t] W[1]^T,  q_l[t] = da[t] W[0]^T
+        F16 dx = di, qf = f16_zero();
+        mma16s2(dx, qf, df, wm + 1 * 1024, wm + 0 * 1024, woff);   // da_f: Wf[1], Wf[0]
+        mma16s2(dx, qf, dg, wm + 3 * 1024, wm + 2 * 1024, woff);   // da_g: Wg[1], Wg[0]
+        S16STAMP(l, 6);
+        if (dead) { qf.v[0][0] = __builtin_nanf(""); dx.v[0][0] = __builtin_nanf(""); }
+        f16_st<16>(q_out, voff, mine, qf);
+        f16_st<SB_OWN_ST>(dx_out, voff, mine, dx);
+        WN_WAIT_VM0();                               // x tiles in, q and own rows stored
+        if (lane == 0)
+          __hip_atomic_store(fl_out + tile, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the flags this tile will look at in the layer below: requested now
+        // (after layer 0: by the completion of dx_0 below)
+        nfv_push = epoch;
+        {
+          const int nidx = flag_idx2(d);
+          if (nidx >= 0)
+            nfv_push = __hip_atomic_load(fl_out + nidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        S16STAMP(l, 7);
+        __builtin_amdgcn_wave_barrier();
+        // ---- c1 += x[t]^T da, c0 += x[t-d]^T da, ts += column sums of da
+        auto wgrad2 = [&](f32x16& c1, f32x16& c0, float& ts) {
+          float exc = te.p[0][0 * 512], exp_ = te.p[0][1 * 512], eb = te.p[0][2 * 512];
+#pragma unroll
+          for (int s = 0; s < 8; ++s) {
+            const int sn = (s + 1) & 7, o = 64 * sn;
+            const float nxc = te.p[sn & 3][0 * 512 + o], nxp = te.p[sn & 3][1 * 512 + o],
+                        nb = te.p[sn & 3][2 * 512 + o];
+            __builtin_amdgcn_sched_barrier(0);
+            c1 = sb_mfma(exc, eb, c1);
+            c0 = sb_mfma(exp_, eb, c0);
+            ts += eb;
+            __builtin_amdgcn_sched_barrier(0);
+            exc = nxc;
+            exp_ = nxp;
+            eb = nb;
+          }
+        };
+        float tsf = 0.f, tsg = 0.f;
+        wgrad2(cf1, cf0, tsf);
+        __builtin_amdgcn_wave_barrier();
+        f16_to_lds(t2 + jr * 32, g, sw, dg);   // ... then da_g[t] through the same tile
+        __builtin_amdgcn_wave_barrier();
+        wgrad2(cg1, cg0, tsg);
+        sf += tsf;
+        sgs += tsg;
+        if (tile_colsum) {
+          const float ca = tsf + __shfl_xor(tsf, 32), cb = tsg + __shfl_xor(tsg, 32);
+          if (h == 0) {
+            tile_colsum[(size_t)tile * 64 + j] = ca;
+            tile_colsum[(size_t)tile * 64 + 32 + j] = cb;
+          }
+        }
+        WN_WAIT_LGKM0();                     // the tiles are free for the next layer's DMA
+        S16STAMP(l, 8);
+      }
+      // ---- this wave no longer reads layer l's weights; the last one to say
+      // so refills their ring half with layer l - 2
+      bool refill = false;
+      {
+        int old = 0;
+        if (lane == 0)
+          old = __hip_atomic_fetch_add(s_done + l, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old == WAVES - 1 && l >= 2) {
+          issue_wimg(l - 2, 0, 1);
+          refill = true;
+        }
+      }
+      // ---- ordered accumulation of the weight-gradient slab over the waves
+      // (as stack_bwd_kernel)
+      sf += __shfl_xor(sf, 32);
+      sgs += __shfl_xor(sgs, 32);
+      sd += __shfl_xor(sd, 32);
+      float* out = a.slabs + (size_t)l * a.slab_layer_stride +
+                   (size_t)gi * LAYER_BLOCK_FLOATS;
+      const int tbase_l = (L - l) * 16;
+      int* tok = s_tok[l & 1];
+      const int* tok_up = s_tok[(l + 1) & 1];
+      const int e0 = 4 * h * 32 + j;
+      __builtin_amdgcn_s_setprio(2);
+      S16STAMP(l, 9);
+      const f32x4* slab4 = reinterpret_cast<const f32x4*>(slab) + lane;
+      auto slab_out = [&](float* dst, int m) {
+        f32x16 p;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = slab4[(m * 4 + q) * 64];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) p[4 * q + e] = v[e];
+        }
+        float pb = 0.f;
+        if (m >= 2 && h == 0) pb = slab[LAYER_W_FLOATS + (m - 2) * 32 + j];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          dst[m * 1024 + e0 + (8 * (r >> 2) + (r & 3)) * 32] = p[r];
+        if (m >= 2 && h == 0) dst[LAYER_W_FLOATS + (m - 2) * 32 + j] = pb;
+      };
+      auto chain = [&](f32x16& c, int m, float& bsum) {
+        if (WAVES > 1) {
+          if (wave == 0) {
+            if (hx) {
+              wait_lds_ge(tok_up + m, tbase_l - 16 + WAVES, dead, a.ctl, a.poison, lane);
+              slab_out(out + a.slab_layer_stride, m);
+            }
+          } else {
+            wait_lds_ge(tok + m, tbase_l + wave, dead, a.ctl, a.poison, lane);
+            f32x4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = slab4[(m * 4 + q) * 64];
+            if (m >= 2 && h == 0) bsum += slab[LAYER_W_FLOATS + (m - 2) * 32 + j];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) c[4 * q + e] += v[q][e];
+          }
+        }
+        if (WAVES == 1) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            out[m * 1024 + e0 + (8 * (r >> 2) + (r & 3)) * 32] = c[r];
+          if (m >= 2 && h == 0) out[LAYER_W_FLOATS + (m - 2) * 32 + j] = bsum;
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            reinterpret_cast<f32x4*>(slab)[(m * 4 + q) * 64 + lane] =
+                f32x4{c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]};
+          if (m >= 2 && h == 0) slab[LAYER_W_FLOATS + (m - 2) * 32 + j] = bsum;
+          WN_WAIT_LGKM0();
+          if (lane == 0)
+            __hip_atomic_store(tok + m, tbase_l + wave + 1, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      };
+      float nosum = 0.f;
+      chain(cf0, 0, nosum);
+      chain(cf1, 1, nosum);
+      chain(cg0, 2, sf);
+      chain(cg1, 3, sgs);
+      chain(cd, 4, sd);
+      __builtin_amdgcn_s_setprio(0);
+      S16STAMP(l, 10);
+      if (refill) {
+        WN_WAIT_VM0();
+        if (lane == 0)
+          __hip_atomic_store(s_ready + l - 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    // dx_0[t] = own_0[t] + q_0[t + d_0], completed in place
+    if (any) {
+      const int d0 = a.dil[0];
+      const wn_rsrc_t dx0 = plane_rsrc(a.DX), q0 = plane_rsrc(a.Q);
+      F16 ro = f16_ld<SB_OWN_LD>(dx0, voff, mine);
+      const int hi_q = min(hi, T - d0 - tt0);
+      if (hi_q > 0) {
+        const int idx = flag_idx2(d0);
+        if (__builtin_amdgcn_ballot_w64(idx >= 0 && nfv_push != epoch) != 0)
+          wait_flags(a.flags, idx, epoch, a.ctl, a.poison, dead, lane);
+        const F16 rq = f16_ld<16>(q0, voff + d0 * (WN_CH * 4), jr < hi_q);
+        WN_WAIT_VM0();
+        ro.v[0] += rq.v[0];
+        ro.v[1] += rq.v[1];
+      }
+      WN_WAIT_VM0();
+      if (dead) ro.v[0][0] = __builtin_nanf("");
+      f16_st<0>(dx0, voff, mine, ro);
+    }
+    if (WAVES > 1 && wave == 0) {          // the bottom layer's finished slab
+      const int e0 = 4 * h * 32 + j;
+      float* dst = a.slabs + (size_t)gi * LAYER_BLOCK_FLOATS;
+      for (int m = 0; m < 5; ++m) {
+        wait_lds_ge(s_tok[0] + m, L * 16 + WAVES, dead, a.ctl, a.poison, lane);
+        f32x16 p;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = reinterpret_cast<const f32x4*>(slab)[(m * 4 + q) * 64 + lane];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) p[4 * q + e] = v[e];
+        }
+        float pb = 0.f;
+        if (m >= 2 && h == 0) pb = slab[LAYER_W_FLOATS + (m - 2) * 32 + j];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          dst[m * 1024 + e0 + (8 * (r >> 2) + (r & 3)) * 32] = p[r];
+        if (m >= 2 && h == 0) dst[LAYER_W_FLOATS + (m - 2) * 32 + j] = pb;
+      }
+    }
+    __syncthreads();
+  }
+  S16CAL(2);
+  if (tid == 0) {
+    const unsigned done = atomicAdd(a.ctl + 1, 1u);
+    if (done == gridDim.x - 1) {
+      __hip_atomic_store(a.ctl + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.ctl + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.ctl + 2, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 #ifdef STACK_STAMPS
 static unsigned long long* g_stack_dbg = nullptr;
 static unsigned long long* g_stack_dbg_b = nullptr;
@@ -1276,9 +2114,34 @@ extern "C" int wn_diag_stack_dbg_b(unsigned long long* p) { g_stack_dbg_b = p; r
 extern "C" {
 
 // unsigned ints of `flags` for a (B, T, L) problem
+// (one word per 16-row tile: enough for either tile height)
 long wn_stack_flag_count(int B, int T, int L) {
   if (B <= 0 || T <= 0 || L <= 0) return 0;
-  return (long)L * B * ((T + 31) / 32);
+  return (long)L * B * ((T + 15) / 16);
+}
+
+// Rows of a tile in wn_stack_fwd / wn_stack_bwd for a shape: 16 while the
+// batch has at most two 32-row tiles per CU (every wave then runs alone on its
+// dependent path: halve the path), else 32.  WN_STACK_ROWS=16 / 32 forces it
+// (A/B, tests).
+int wn_stack_tile_rows(int B, int T) {
+  if (B <= 0 || T <= 0) return 32;
+  if (const char* e = getenv("WN_STACK_ROWS")) {
+    const int r = atoi(e);
+    if (r == 16 || r == 32) return r;
+  }
+  const long ntiles = (long)B * ((T + 31) / 32);
+  return ntiles <= 2L * wn_device_cus() ? 16 : 32;
+}
+
+// waves per workgroup of the 16-row launches: WN_STACK16_WAVES_F / _B = 4 / 8
+// force it for the forward / backward launch (A/B, tests)
+static int stack16_waves(const char* name, int dflt) {
+  if (const char* e = getenv(name)) {
+    const int w = atoi(e);
+    if (w == 4 || w == 8) return w;
+  }
+  return dflt;
 }
 
 int wn_stack_wimg_floats(void) { return STACK_WBUF; }
@@ -1294,11 +2157,18 @@ int wn_stack_pack(const float* layer0, long layer_stride, float* wimg_fwd,
   return wn_check_launch();
 }
 
+// 8-byte hand-over words of the 16-row forward launch (0: the shape runs the
+// 32-row launch, which hands over through flags)
+long wn_stack_ll_words(int B, int T, int L) {
+  if (B <= 0 || T <= 0 || L <= 0 || wn_stack_tile_rows(B, T) != 16) return 0;
+  return (long)L * B * T * WN_CH;
+}
+
 int wn_stack_fwd(float* X, float* Z, float* SG, const float* wimg,
                  const float* bias, long bias_layer_stride,
                  int bias_clip_stride, const int* dilations, unsigned* flags,
-                 unsigned* ctl, float* poison, int L, int B, int T, int save_sg,
-                 void* stream) {
+                 unsigned* ctl, float* poison, unsigned long long* ll, int L, int B,
+                 int T, int save_sg, void* stream) {
   if (!X || !Z || !wimg || !dilations || !flags || !ctl) return WN_ERR_NULL;
   if (save_sg && !SG) return WN_ERR_NULL;
   if (L <= 0 || B <= 0 || T <= 0) return WN_ERR_BAD_SHAPE;
@@ -1311,11 +2181,39 @@ int wn_stack_fwd(float* X, float* Z, float* SG, const float* wimg,
   a.bias_clip_stride = bias_clip_stride; a.dil = dilations; a.flags = flags;
   a.ctl = ctl; a.poison = poison; a.L = L; a.B = B; a.T = T;
   a.plane = (long)B * T * WN_CH;
+  a.ll = ll;
 #ifdef STACK_STAMPS
   if (!g_stack_dbg) return WN_ERR_NULL;
   a.dbg = g_stack_dbg;
 #endif
   if (L > STACK_MAXL) return WN_ERR_UNSUPPORTED;
+  if (wn_stack_tile_rows(B, T) == 16) {
+    // (32-bit byte offsets into a plane, and into a layer of hand-over words)
+    if ((long)B * T * WN_CH * 8 >= (1L << 31)) return WN_ERR_UNSUPPORTED;
+    if (ll && (reinterpret_cast<uintptr_t>(ll) & 15u)) return WN_ERR_MISALIGNED;
+    const long nt16 = (long)B * ((T + 15) / 16);
+    const int cus16 = wn_device_cus();
+    // one wave per SIMD while that covers the batch in one pass, else two
+    const int w16 = stack16_waves("WN_STACK16_WAVES_F", (nt16 + 3) / 4 <= cus16 ? 4 : 8);
+    long g16 = (nt16 + w16 - 1) / w16;
+    if (g16 > cus16) g16 = cus16;
+    dim3 grid16((unsigned)g16), block16(w16 * 64);
+    hipStream_t s16 = (hipStream_t)stream;
+#define LAUNCH16(W, H)                                                              \
+  do {                                                                              \
+    if (save_sg)                                                                    \
+      hipLaunchKernelGGL((stack_fwd16_kernel<2, W, H>), grid16, block16, 0, s16, a);  \
+    else                                                                            \
+      hipLaunchKernelGGL((stack_fwd16_kernel<0, W, H>), grid16, block16, 0, s16, a);  \
+  } while (0)
+    if (ll) {
+      if (w16 == 8) LAUNCH16(8, true); else LAUNCH16(4, true);
+    } else {
+      if (w16 == 8) LAUNCH16(8, false); else LAUNCH16(4, false);
+    }
+#undef LAUNCH16
+    return wn_check_launch();
+  }
   // waves (= tiles) per workgroup: 16 when that fills every CU, fewer for
   // small batches so that the tiles still spread over the whole chip
   const long ntiles = (long)B * ((T + 31) / 32);
@@ -1358,6 +2256,11 @@ int wn_stack_fwd(float* X, float* Z, float* SG, const float* wimg,
 // at most one group per CU covers the batch; small batches use fewer waves so
 // that the tiles spread over the whole chip
 static void stack_bwd_shape(int B, int T, int* waves_out, int* tpw_out) {
+  if (wn_stack_tile_rows(B, T) == 16) {     // 16-row tiles: one per wave
+    *waves_out = stack16_waves("WN_STACK16_WAVES_B", 8);
+    *tpw_out = 1;
+    return;
+  }
   const long ntiles = (long)B * ((T + 31) / 32);
   const int cus = wn_device_cus();
   // experiments (A/B of co-residency with a side-stream GEMM, stamps):
@@ -1392,7 +2295,8 @@ int wn_stack_bwd_slabs(int B, int T) {
   if (B <= 0 || T <= 0) return 0;
   int w, t;
   stack_bwd_shape(B, T, &w, &t);
-  const long ntiles = (long)B * ((T + 31) / 32);
+  const int rows = wn_stack_tile_rows(B, T);
+  const long ntiles = (long)B * ((T + rows - 1) / rows);
   return (int)((ntiles + (long)w * t - 1) / ((long)w * t));
 }
 
@@ -1415,7 +2319,8 @@ int wn_stack_bwd(const float* X, const float* Z, const float* SG,
   if (Q && !wn_aligned16(Q)) return WN_ERR_MISALIGNED;
   int waves, tpw;
   stack_bwd_shape(B, T, &waves, &tpw);
-  const long ntiles = (long)B * ((T + 31) / 32);
+  const int rows = wn_stack_tile_rows(B, T);
+  const long ntiles = (long)B * ((T + rows - 1) / rows);
   const long groups = (ntiles + (long)waves * tpw - 1) / ((long)waves * tpw);
   if (slab_layer_stride < groups * LAYER_BLOCK_FLOATS) return WN_ERR_BAD_SHAPE;
   StackBwd a;
@@ -1440,6 +2345,12 @@ int wn_stack_bwd(const float* X, const float* Z, const float* SG,
   // tile's dx rows) a single plane rewritten in place
   if (dx_layer_stride != (long)B * T * WN_CH && !(push && dx_layer_stride == 0))
     return WN_ERR_BAD_SHAPE;
+  if (rows == 16) {
+    if (!push) return WN_ERR_UNSUPPORTED;     // (the 16-row launch is "push" only)
+    if (waves == 8) hipLaunchKernelGGL((stack_bwd16_kernel<8>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((stack_bwd16_kernel<4>), grid, block, 0, s, a);
+    return wn_check_launch();
+  }
 #define LAUNCH(W)                                                               \
   do {                                                                          \
     if (push) hipLaunchKernelGGL((stack_bwd_kernel<W, true>), grid, block, 0, s, a);   \

@@ -98,6 +98,12 @@ class _Workspace(object):
         alloc('stack_flags', (lib.wn_stack_flag_count(B, T, L),), torch.int32,
               fill=0)
         alloc('wimg_f', (L, lib.wn_stack_wimg_floats()))
+        # 16-row forward launch (small batches): the rows a tile hands to its
+        # dilated-tap readers as {value, epoch} words the readers poll
+        # (0 words when the shape runs 32-row tiles; WN_STACK_LL=0: flags, A/B)
+        nll = lib.wn_stack_ll_words(B, T, L) \
+            if os.environ.get('WN_STACK_LL', '1') != '0' else 0
+        self.stack_ll = alloc('stack_ll', (nll,), torch.int64, fill=0) if nll else None
         alloc('stack_ctl', (4,), torch.int32, fill=0)
         if 'stack_ctl' in fresh:         # (a view shares the owner's epoch)
             self.stack_ctl[2] = 1
@@ -215,7 +221,17 @@ class _Workspace(object):
         self.ev_join = torch.cuda.Event() if dev.type == 'cuda' else None
         self.dsum = alloc('dsum', (L, B, 2 * CHn)) if net.G else None
         self.gc_part = alloc('gc_part', (L, B, net.G)) if net.G else None
-        self.tilesum = alloc('tilesum', (L, ntiles, 64)) if net.G else None
+        # per-tile column sums of da: [L][tiles][64] for 32-row tiles (the
+        # per-layer kernels, wn_stack_bwd on big batches) or 16-row tiles
+        # (wn_stack_bwd on small ones, wn_stack_tile_rows): two views of one buffer
+        self.stack_rows = lib.wn_stack_tile_rows(B, T)
+        nt16 = B * ((T + 15) // 16)
+        if net.G:
+            buf = alloc('tilesum_buf', (L * nt16 * 64,))
+            self.tilesum = buf[:L * ntiles * 64].view(L, ntiles, 64)
+            self.tilesum16 = buf.view(L, nt16, 64)
+        else:
+            self.tilesum = self.tilesum16 = None
         self.dsum_part = alloc(
             'dsum_part', (B * lib.wn_colsum_clip_chunks(T) * 64,)) \
             if net.G else None
@@ -909,7 +925,7 @@ class WaveNetModel(object):
                       0 if bias is None else bias.shape[1] * bias.shape[2],
                       bstride, _lib.ptr(self._dil_dev),
                       _lib.ptr(ws.stack_flags), _lib.ptr(ws.stack_ctl),
-                      _lib.ptr(ws.loss_parts),
+                      _lib.ptr(ws.loss_parts), _lib.ptr(ws.stack_ll),
                       L, B, T, 1 if save_ts else 0, st), 0.0,
                       getattr(self, '_gemm_events', None))
         for l, d in enumerate(self.dilations if not self.blocked and not stack
@@ -1088,6 +1104,8 @@ class WaveNetModel(object):
             dxin, xp = None, 0
             tsum = None if ws.dsum is None else ws.tilesum
             if self._stack_bwd_ok() and getattr(ws, 'stack_bwd', False):
+                if ws.stack_rows == 16 and tsum is not None:
+                    tsum = ws.tilesum16
                 # all L layers in one persistent launch (csrc/wn_stack.hip)
                 if not self._bwd_image_with_fwd(ws):
                     _lib.call('wn_stack_pack', _lib.ptr(self._layer_block(P, 0)),
@@ -1103,7 +1121,8 @@ class WaveNetModel(object):
                     _lib.ptr(ws.stack_ctl_b),
                     _lib.ptr(ws.loss_parts[1:]), L, B, T, st), 0.0,
                     getattr(self, '_gemm_events', None))
-                self._backward_tail(ws, ids, ws.DX[0], ws.nslab_s, True)
+                self._backward_tail(ws, ids, ws.DX[0], ws.nslab_s, True,
+                                    tile_rows=ws.stack_rows)
                 return
             # transposed weight images of all layers (the kernels DMA them
             # into LDS): one small launch per step
@@ -1219,7 +1238,7 @@ class WaveNetModel(object):
             main.wait_event(ws.ev_done[0])
         self._backward_tail(ws, ids, dxin, nslab, fused)
 
-    def _backward_tail(self, ws, ids, dxin, nslab, fused):
+    def _backward_tail(self, ws, ids, dxin, nslab, fused, tile_rows=32):
         """After the residual stack: slab reductions of the layer-block
         gradients, causal-layer and global-conditioning gradients."""
         if self._overlap_tn_on(ws):
@@ -1233,7 +1252,7 @@ class WaveNetModel(object):
         if fused and ws.dsum is not None:
             # per-clip sums of da_l for every layer from the per-tile sums the
             # fused kernel wrote (fixed order over a clip's tiles)
-            tpc = (T + 31) // 32
+            tpc = (T + tile_rows - 1) // tile_rows
             _lib.call('wn_reduce_slabs', _lib.ptr(ws.tilesum), tpc, 64, L * B,
                       tpc * 64, 0, 64, _lib.ptr(ws.dsum), 64, 1, 0, st)
         # layer-block gradients: fixed-order sum of the per-workgroup slabs

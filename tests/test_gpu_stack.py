@@ -59,6 +59,14 @@ CASES = [
 ]
 
 
+@pytest.fixture(autouse=True)
+def _tile_rows_32(monkeypatch):
+    """The bitwise statements of this file are about the 32-row launches; small
+    batches would otherwise run the 16-row ones (wn_stack_tile_rows), which sum
+    in another grouping -- they have their own tests below."""
+    monkeypatch.setenv('WN_STACK_ROWS', '32')
+
+
 @pytest.mark.parametrize('name,mk,B,T,kind', CASES, ids=[c[0] for c in CASES])
 def test_stack_forward_bitwise_equals_per_layer(hip_lib, name, mk, B, T, kind):
     cfg = mk()
@@ -82,6 +90,46 @@ def test_stack_forward_bitwise_equals_per_layer(hip_lib, name, mk, B, T, kind):
         ctl = wa.stack_ctl.cpu().tolist()
         assert ctl[0] == 0 and ctl[1] == 0 and ctl[3] == 0, ctl
         assert ctl[2] == 2 + rep, ctl
+
+
+@pytest.mark.parametrize('waves', ['4', '8'])
+@pytest.mark.parametrize('name,mk,B,T,kind', CASES, ids=[c[0] for c in CASES])
+def test_stack_forward_16_row_tiles(hip_lib, monkeypatch, name, mk, B, T, kind, waves):
+    """The small-batch launch (16-row tiles on v_mfma_f32_16x16x4_f32) against
+    one launch per layer: the same products summed in another grouping, so
+    every plane agrees to rounding (2e-5 of the plane's largest entry after up
+    to 50 layers), run to run bitwise."""
+    monkeypatch.setenv('WN_STACK_ROWS', '16')
+    monkeypatch.setenv('WN_STACK16_WAVES_F', waves)
+    cfg = mk()
+    a, b = _pair(cfg)
+    assert hip_lib.wn_stack_tile_rows(B, T) == 16
+    audio = synth_audio(B, T)
+    gc = np.array([(37 * i) % 377 for i in range(B)], np.int32) if kind == 'gc' else None
+    prev = None
+    worst = {'X': 0.0, 'Z': 0.0, 'SG': 0.0}
+    for rep in range(3):
+        la = a.loss(audio, global_condition_batch=gc) if gc is not None else a.loss(audio)
+        lb = b.loss(audio, global_condition_batch=gc) if gc is not None else b.loss(audio)
+        torch.cuda.synchronize()
+        wa, wb = list(a._ws.values())[0], list(b._ws.values())[0]
+        for pl in ('X', 'Z', 'SG'):
+            pa, pb = getattr(wa, pl), getattr(wb, pl)
+            for l in range(pa.shape[0]):
+                sc = float(pb[l].abs().max())
+                err = float((pa[l] - pb[l]).abs().max())
+                worst[pl] = max(worst[pl], err / (sc + 1e-30))
+                assert err <= (2e-5 if pl == 'X' else 1e-4) * sc + 1e-30, (pl, l, err, sc, rep)
+        assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(lb))
+        scale = float(b.grads.abs().max())
+        assert float((a.grads - b.grads).abs().max()) <= 2e-3 * scale
+        ctl = wa.stack_ctl.cpu().tolist()
+        assert ctl[0] == 0 and ctl[1] == 0 and ctl[3] == 0 and ctl[2] == 2 + rep, ctl
+        cur = (wa.X.clone(), wa.Z.clone(), wa.SG.clone(), float(la))
+        if prev is not None:
+            assert all(torch.equal(x, y) for x, y in zip(prev[:3], cur[:3])) and prev[3] == cur[3]
+        prev = cur
+    print('16-row forward %s waves %s: worst plane errors %s' % (name, waves, worst))
 
 
 def test_stack_inference_forward(hip_lib):
@@ -174,14 +222,21 @@ def _check_layer_grads(a, b, wa, name):
     assert float((ga - gb).abs().max()) <= 2e-6 * max(scale, 1e-30)
 
 
+@pytest.mark.parametrize('rows,waves', [(32, '8'), (16, '8'), (16, '4')])
 @pytest.mark.parametrize('name,mk,B,T,kind', CASES, ids=[c[0] for c in CASES])
-def test_stack_backward_equals_per_layer(hip_lib, name, mk, B, T, kind):
+def test_stack_backward_equals_per_layer(hip_lib, monkeypatch, name, mk, B, T, kind, rows, waves):
     """wn_stack_bwd vs one wn_layer_bwd2 per layer: dL/dx_0 and the weight
     gradients to rounding (the persistent launch sums a tile's own rows before
     the anti-causal tap, and the tiles of a slab in another order), repeated
     runs bitwise.  `a` keeps dL/dx_l of every layer (the per-layer float64
     check needs them); `c` is the product configuration -- ONE dx plane
-    rewritten in place from layer to layer -- and must give the same bits."""
+    rewritten in place from layer to layer -- and must give the same bits.
+    rows = 16: the small-batch launch (16-row tiles), forced on every shape
+    here; all three models then run the 16-row FORWARD too, so the planes the
+    backward paths read are bitwise the same."""
+    monkeypatch.setenv('WN_STACK_ROWS', str(rows))
+    monkeypatch.setenv('WN_STACK16_WAVES_B', waves)
+    assert hip_lib.wn_stack_tile_rows(B, T) == rows
     cfg = mk()
     a, _ = build_pair(cfg)
     b, _ = build_pair(cfg)

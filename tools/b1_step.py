@@ -21,6 +21,8 @@ cfg['batch_size'] = B
 if os.environ.get('KB_CH'):     # more than 32 channels: the channel-block path
     cfg['residual_channels'] = cfg['dilation_channels'] = int(os.environ['KB_CH'])
 net = WaveNetModel(seed=0, **model_kwargs(cfg))
+if os.environ.get('KB_SPLIT_FRAC'):
+    net.overlap_tn_split_frac = float(os.environ['KB_SPLIT_FRAC'])
 if os.environ.get('KB_OVERLAP_TN'):
     net.overlap_tn = os.environ['KB_OVERLAP_TN'] == '1'
 opt = optimizer_factory['adam'](learning_rate=1e-3, momentum=0.9)

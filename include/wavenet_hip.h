@@ -253,30 +253,23 @@ int wn_layer_bwd2(const float* x, const float* z, const float* sg,
  *                      l * slab_layer_stride + g * 5216, g < wn_stack_bwd_slabs(B, T)
  *   tilesum          : as wn_layer_bwd2 ([L][tiles][64] or NULL), tiles =
  *                      B * ceil(T / wn_stack_tile_rows(B, T))
- * Tile height: 32 rows; 16 for small batches (wn_stack_tile_rows: at most two
- * 32-row tiles per CU -- every wave is then alone on its dependent path
- * through a layer, and a 16-row tile on v_mfma_f32_16x16x4_f32 halves that
- * path).  Both launches of a shape use the same height; it sets the slab count
+ * Tile height: 32 rows; 16 for small batches (wn_stack_tile_rows: at most four
+ * 32-row tiles per CU -- the launches are then bound by one wave's dependent
+ * path through a layer, and a 16-row tile on v_mfma_f32_16x16x4_f32 halves
+ * that path).  Both launches of a shape use the same height; it sets the slab count
  * (wn_stack_bwd_slabs) and the tilesum layout.  The 16-row results agree with
  * the 32-row ones to rounding (another summation grouping), not bitwise.
  * L <= 256. */
 long wn_stack_flag_count(int B, int T, int L);
 int wn_stack_tile_rows(int B, int T);
-/* wn_stack_fwd, 16-row tiles: `ll` = wn_stack_ll_words(B, T, L) 8-byte words
- * (16-byte aligned, zero before first use; 0 words: the shape runs 32-row
- * tiles), or NULL.  With it the rows a tile hands to its dilated-tap readers
- * travel as {value, epoch} words that the reader polls directly -- one memory
- * round trip per layer instead of two (store drain + flag, then flag read +
- * row read); NULL: flags, as the 32-row launch. */
-long wn_stack_ll_words(int B, int T, int L);
 int wn_stack_wimg_floats(void);
 int wn_stack_pack(const float* layer0, long layer_stride, float* wimg_fwd,
                   float* wimg_bwd, int L, void* stream);
 int wn_stack_fwd(float* X, float* Z, float* SG, const float* wimg,
                  const float* bias, long bias_layer_stride,
                  int bias_clip_stride, const int* dilations, unsigned* flags,
-                 unsigned* ctl, float* poison, unsigned long long* ll, int L,
-                 int B, int T, int save_sg, void* stream);
+                 unsigned* ctl, float* poison, int L, int B, int T, int save_sg,
+                 void* stream);
 int wn_stack_bwd_slabs(int B, int T);
 int wn_stack_bwd(const float* X, const float* Z, const float* SG,
                  const float* dZ, float* DX, long dx_layer_stride, float* Q,

@@ -1725,7 +1725,9 @@ __global__ void reduce_slabs4_kernel(const float* __restrict__ slabs,
 // (sixteen waves per workgroup, each a sixteenth of the slabs -- and of the
 // (slab, row) pairs of a spread column-sum tail: with four the two tail
 // workgroups of a dWs reduction took 34 us, the others 19)
+#ifndef RMT_PARTS
 #define RMT_PARTS 16
+#endif
 __global__ __launch_bounds__(64 * RMT_PARTS) void reduce_slabs_mt_kernel(
     const float* __restrict__ slabs, int num_slabs, long slab_stride, long n_main4,
     float* __restrict__ dst_main, long n_tail4, float* __restrict__ dst_tail,

@@ -66,8 +66,6 @@ struct StackFwd {
   float* poison;       // set to NaN when a bounded wait expires (or null)
   int L, B, T;
   long plane;          // N * 32 floats
-  // 16-row launch: [L][N][32] hand-over words {value, epoch} (or null: flags)
-  unsigned long long* ll;
 #ifdef STACK_STAMPS
   unsigned long long* dbg;   // diagnostic build: [grid][16][L][12] s_memtime stamps
 #endif
@@ -1299,14 +1297,14 @@ struct F16 {
   f32x4 v[2];
 };
 #ifdef STACK_STAMPS
-// diagnostic build: [grid][8][L][16] s_memtime stamps + [grid][4] clock calibration
+// diagnostic build: [grid][16][L][16] s_memtime stamps + [grid][4] clock calibration
 #define S16STAMP(l, i)                                                       \
   if (lane == 0)                                                             \
-    a.dbg[(((size_t)blockIdx.x * 8 + wave) * L + (l)) * 16 + (i)] =          \
+    a.dbg[(((size_t)blockIdx.x * 16 + wave) * L + (l)) * 16 + (i)] =         \
         __builtin_amdgcn_s_memtime()
 #define S16CAL(k)                                                                        \
   if (tid == 0) {                                                                        \
-    unsigned long long* cal_ = a.dbg + (size_t)gridDim.x * 8 * L * 16 + (size_t)blockIdx.x * 4; \
+    unsigned long long* cal_ = a.dbg + (size_t)gridDim.x * 16 * L * 16 + (size_t)blockIdx.x * 4; \
     cal_[k] = __builtin_amdgcn_s_memrealtime();                                          \
     cal_[k + 1] = __builtin_amdgcn_s_memtime();                                          \
   }
@@ -1324,22 +1322,24 @@ __device__ __forceinline__ F16 f16_zero() {
 }
 
 // pieces of plane row `row_bytes / 128` (`voff` = row_bytes + 16 g: the lane's
-// byte offset of piece 0; < 2^31, host check), zero when !valid
+// byte offset of piece 0; < 2^31, host check), zero when !valid.  An invalid
+// lane asks for an offset past the resource's 2^31 - 1 bytes: the buffer unit
+// answers 0 (drops the store) -- no branch around the access, so the
+// compiler's count of outstanding loads stays exact.
+#define WN_BUF_OOB ((int)0x80000000u)
 template <int AUX>
 __device__ __forceinline__ F16 f16_ld(wn_rsrc_t rs, int voff, bool valid) {
-  F16 f = f16_zero();
-  if (valid) {
-    f.v[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, AUX));
-    f.v[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 64, 0, AUX));
-  }
+  const int o = valid ? voff : WN_BUF_OOB;
+  F16 f;
+  f.v[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, AUX));
+  f.v[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o + 64, 0, AUX));
   return f;
 }
 template <int AUX>
 __device__ __forceinline__ void f16_st(wn_rsrc_t rs, int voff, bool valid, const F16& f) {
-  if (valid) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f.v[0]), rs, voff, 0, AUX);
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f.v[1]), rs, voff + 64, 0, AUX);
-  }
+  const int o = valid ? voff : WN_BUF_OOB;
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f.v[0]), rs, o, 0, AUX);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f.v[1]), rs, o + 64, 0, AUX);
 }
 
 // accA^T += WA^T frag, accB^T += WB^T frag from the FORWARD image (rows
@@ -1394,67 +1394,19 @@ __device__ __forceinline__ void f16_to_lds(float* lt, int g, int sw, const F16& 
   *reinterpret_cast<f32x4*>(lt + (((4 + g) ^ sw) << 2)) = f.v[1];
 }
 
-// Hand-over words (LL = true): the dilated tap of a 16-row tile costs two
-// dependent memory round trips per layer with flags -- the producer drains its
-// x' stores, then posts the flag; the consumer reads the flag, then the rows --
-// and on a path this short that is most of it.  With `ll` every float of x_l
-// (l > 0) also goes out as ONE 8-byte word {value, epoch} (RCCL's LL idea, as
-// in the persistent generator of wn_fastgen.hip): the producer stores and goes
-// on without waiting, the consumer polls the words themselves -- one round
-// trip, the validity in the data.  Twice the bytes on the hand-over; at these
-// sizes nobody is short of bandwidth.  Rows of the wave's own tile (d < 16)
-// come back from a wave-private LDS tile.  The X planes are still written
-// (plain stores: the backward reads them after the launch).
-template <int AUX>
-__device__ __forceinline__ void ll16_put(wn_rsrc_t rs, int voff2, bool valid, const F16& f,
-                                         unsigned epoch) {
-  if (!valid) return;
-#pragma unroll
-  for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      u32x4 w;
-      w[0] = __float_as_uint(f.v[blk][2 * p]);
-      w[1] = epoch;
-      w[2] = __float_as_uint(f.v[blk][2 * p + 1]);
-      w[3] = epoch;
-      __builtin_amdgcn_raw_buffer_store_b128(w, rs, voff2 + (2 * blk + p) * 64, 0, AUX);
-    }
-}
-struct LL16 {
-  u32x4 w[4];
-};
-__device__ __forceinline__ LL16 ll16_request(wn_rsrc_t rs, int voff2) {
-  LL16 r;
-#pragma unroll
-  for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-      r.w[2 * blk + p] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff2 + (2 * blk + p) * 64, 0, 16);
-  return r;
-}
-__device__ __forceinline__ bool ll16_ready(const LL16& r, unsigned epoch) {
-  bool ok = true;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) ok = ok && r.w[i][1] == epoch && r.w[i][3] == epoch;
-  return ok;
-}
-__device__ __forceinline__ F16 ll16_value(const LL16& r) {
-  F16 f;
-#pragma unroll
-  for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      f.v[blk][2 * p] = __uint_as_float(r.w[2 * blk + p][0]);
-      f.v[blk][2 * p + 1] = __uint_as_float(r.w[2 * blk + p][2]);
-    }
-  return f;
-}
-
-template <int SAVE, int WAVES, bool LL>
+// (Built, measured, removed: the rows a tile hands to its tap readers as
+// 8-byte {value, epoch} words that the readers poll directly -- RCCL's LL idea,
+// what took the persistent generator of wn_fastgen.hip from 43.6 to 34.4 us --
+// instead of "drain the stores, post a flag" / "read the flag, read the rows".
+// Here it is neutral: 234 vs 229 us at B = 1 (260 before a row's words were
+// laid out so that one instruction moves 64 contiguous bytes per row).  Stamps:
+// the tap's wait shrinks from 0.50 to 0.43 us and the x' hand-off from 0.47 to
+// 0.35, but 4 KiB of words per tile and layer on top of the planes make every
+// other memory phase slower (weight ring 0.17 -> 0.47 us, z / sigmoid stores
+// 0.21 -> 0.48).)
+template <int SAVE, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void stack_fwd16_kernel(StackFwd a) {
   __shared__ __attribute__((aligned(1024))) float wl[2 * STACK_WBUF];
-  __shared__ __attribute__((aligned(16))) float own[LL ? WAVES * 512 : 4];
   __shared__ int s_group;
   __shared__ int s_done[STACK_MAXL], s_ready[STACK_MAXL];
   const int tid = threadIdx.x;
@@ -1467,7 +1419,6 @@ __global__ __launch_bounds__(WAVES * 64) void stack_fwd16_kernel(StackFwd a) {
   const int ngroups = (ntiles + WAVES - 1) / WAVES;
   const unsigned epoch =
       __hip_atomic_load(a.ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  float* town = own + (LL ? wave * 512 : 0);
   bool dead = false;
   S16CAL(0);
 
@@ -1493,12 +1444,8 @@ __global__ __launch_bounds__(WAVES * 64) void stack_fwd16_kernel(StackFwd a) {
     const int t0 = tt * 16;
     const int hi = any ? min(16, T - t0) : 0;
     const bool mine = jr < hi;                       // this lane's row exists
-    // the lane's byte offset of piece 0 of ITS row in a plane (x 2: in a
-    // layer of hand-over words)
+    // the lane's byte offset of piece 0 of ITS row in a plane
     const int voff = ((b * T + t0 + jr) * WN_CH + 4 * g) * 4;
-    // ... of its first pair of hand-over words (a row's 32 words: [pair k =
-    // 2 blk + p][g][2], so that one instruction moves 64 contiguous bytes a row)
-    const int voff2 = (b * T + t0 + jr) * (WN_CH * 8) + 16 * g;
 
     for (int i = tid; i < L; i += WAVES * 64) {
       s_done[i] = 0;
@@ -1537,22 +1484,14 @@ __global__ __launch_bounds__(WAVES * 64) void stack_fwd16_kernel(StackFwd a) {
       F16 af = bf, ag = bg;
       if (l + 1 < L) bias_request(l + 1);
       // the dilated tap: rows t0-d .. t0-d+15 of x_l, owned by at most two
-      // other tiles of this clip (and, d < 16, by this one)
+      // other tiles of this clip (d < 16: and by this one -- its own stores of
+      // the layer before, read back like the others'); flags requested first,
+      // looked at after the current-tap products
       const int lo_row = t0 - d;
       const bool tap = mine && t0 + jr - d >= 0;          // this lane's tap row exists
-      const bool tap_own = LL && l > 0 && jr >= d;          // ... in the wave's own tile
       int fidx = -1;
       unsigned fval = epoch;
-      LL16 req;
-      const wn_rsrc_t hl = plane_rsrc(LL ? reinterpret_cast<const float*>(a.ll) + (size_t)l * a.plane * 2
-                                         : a.X);
-      const bool via_ll = LL && l > 0 && tap && !tap_own;
-      if (LL) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) req.w[i] = u32x4{0u, epoch, 0u, epoch};
-        if (via_ll) req = ll16_request(hl, voff2 - d * (WN_CH * 8));
-      } else if (l > 0 && lo_row + 15 >= 0) {
-        // flags requested first, looked at after the current-tap products
+      if (l > 0 && lo_row + 15 >= 0) {
         const int first = max(lo_row, 0) >> 4, last = (lo_row + 15) >> 4;
         if (lane == 0 && first != tt) fidx = b * tiles_per_clip + first;
         if (lane == 1 && last != first && last != tt) fidx = b * tiles_per_clip + last;
@@ -1562,37 +1501,10 @@ __global__ __launch_bounds__(WAVES * 64) void stack_fwd16_kernel(StackFwd a) {
       }
       mma16t2(af, ag, xc, wlane + 1 * SF_MT, wlane + 3 * SF_MT);   // Wf[1], Wg[1]: current tap
       S16STAMP(l, 2);
-      F16 xp;
-      if (LL && l > 0) {
-        // poll the words themselves (bounded like a flag wait)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned spins = 0;
-        unsigned long long t_start = 0;
-        while (!dead && __builtin_amdgcn_ballot_w64(!ll16_ready(req, epoch)) != 0) {
-          __builtin_amdgcn_s_sleep(1);
-          if (via_ll && !ll16_ready(req, epoch)) req = ll16_request(hl, voff2 - d * (WN_CH * 8));
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          if ((++spins & 63u) == 0) {
-            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-            if (t_start == 0) t_start = now;
-            if (now - t_start > 200000000ull) {   // 2 s at 100 MHz
-              if (lane == 0) {
-                __hip_atomic_store(a.ctl + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (a.poison) *a.poison = __builtin_nanf("");
-              }
-              dead = true;
-            }
-          }
-        }
-        xp = ll16_value(req);
-        if (tap_own && mine) xp = f16_from_lds(town + (jr - d) * 32, g, (jr - d) & 7);
-        if (!tap) xp = f16_zero();
-      } else {
-        if (__builtin_amdgcn_ballot_w64(fval != epoch) != 0)
-          wait_flags(a.flags + (size_t)l * ntiles, fidx, epoch, a.ctl, a.poison, dead, lane);
-        xp = f16_ld<16>(xl, voff - d * (WN_CH * 4), tap);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
+      if (__builtin_amdgcn_ballot_w64(fval != epoch) != 0)
+        wait_flags(a.flags + (size_t)l * ntiles, fidx, epoch, a.ctl, a.poison, dead, lane);
+      const F16 xp = f16_ld<16>(xl, voff - d * (WN_CH * 4), tap);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       S16STAMP(l, 3);
       if (publish) {
         // (the weight pieces issued at the end of the previous layer are older
@@ -1619,19 +1531,12 @@ __global__ __launch_bounds__(WAVES * 64) void stack_fwd16_kernel(StackFwd a) {
         xc.v[1] += *reinterpret_cast<const f32x4*>(bd + 16);
         mma16t(xc, zz, wlane + 4 * SF_MT);                          // Wd
         S16STAMP(l, 6);
-        if (LL) {
-          // x' first as hand-over words: what other waves wait for; no drain
-          ll16_put<16>(plane_rsrc(reinterpret_cast<const float*>(a.ll) + (size_t)(l + 1) * a.plane * 2),
-                       voff2, mine, xc, epoch);
-          f16_to_lds(town + jr * 32, g, jr & 7, xc);
-          f16_st<0>(plane_rsrc(a.X + (size_t)(l + 1) * a.plane), voff, mine, xc);
-        } else {
-          f16_st<16>(plane_rsrc(a.X + (size_t)(l + 1) * a.plane), voff, mine, xc);
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          if (lane == 0)
-            __hip_atomic_store(a.flags + (size_t)(l + 1) * ntiles + tile, epoch,
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        // x' first: it is what other waves wait for
+        f16_st<16>(plane_rsrc(a.X + (size_t)(l + 1) * a.plane), voff, mine, xc);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0)
+          __hip_atomic_store(a.flags + (size_t)(l + 1) * ntiles + tile, epoch,
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       S16STAMP(l, 7);
       f16_st<0>(plane_rsrc(a.Z + (size_t)l * a.plane), voff, mine, zz);
@@ -1695,16 +1600,24 @@ __device__ __forceinline__ void tile_dma16_rs(float* lds_tile, wn_rsrc_t rs, int
 // (chunk g of row jr; chunk 4 + g sits at off0 ^ 16, rows 16 + jr 512 floats on)
 __device__ __forceinline__ void mma16s2(F16& accA, F16& accB, const F16& frag,
                                         const float* ma, const float* mb_, int off0) {
+  // (the operands of K-half blk + 1 requested before the MFMAs of half blk:
+  // 16 + 16 registers in flight instead of 32 up front)
   f32x4 a[2][2], b[2][2];
 #pragma unroll
-  for (int mb = 0; mb < 2; ++mb)
+  for (int mb = 0; mb < 2; ++mb) {
+    a[mb][0] = *reinterpret_cast<const f32x4*>(ma + mb * 512 + off0);
+    b[mb][0] = *reinterpret_cast<const f32x4*>(mb_ + mb * 512 + off0);
+  }
 #pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-      a[mb][blk] = *reinterpret_cast<const f32x4*>(ma + mb * 512 + (off0 ^ (blk << 4)));
-      b[mb][blk] = *reinterpret_cast<const f32x4*>(mb_ + mb * 512 + (off0 ^ (blk << 4)));
+  for (int blk = 0; blk < 2; ++blk) {
+    if (blk == 0) {
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        a[mb][1] = *reinterpret_cast<const f32x4*>(ma + mb * 512 + (off0 ^ 16));
+        b[mb][1] = *reinterpret_cast<const f32x4*>(mb_ + mb * 512 + (off0 ^ 16));
+      }
     }
-#pragma unroll
-  for (int blk = 0; blk < 2; ++blk)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       accA.v[0] = wn_mfma16(a[0][blk][e], frag.v[blk][e], accA.v[0]);
@@ -1712,6 +1625,8 @@ __device__ __forceinline__ void mma16s2(F16& accA, F16& accB, const F16& frag,
       accB.v[0] = wn_mfma16(b[0][blk][e], frag.v[blk][e], accB.v[0]);
       accB.v[1] = wn_mfma16(b[1][blk][e], frag.v[blk][e], accB.v[1]);
     }
+    __builtin_amdgcn_sched_barrier(0);
+  }
 }
 __device__ __forceinline__ void mma16s(F16& acc, const F16& frag, const float* ma, int off0) {
   f32x4 a[2][2];
@@ -2104,6 +2019,373 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd16_kernel(StackBwd a) {
   }
 }
 
+// The 16-row backward with the weight gradients on waves of their own.
+// Stamps of stack_bwd16_kernel at B = 1 (tools/stack16_stamps.py): of a layer's
+// 11.3 us, 4.3 are wave 0 in the ordered accumulation (it copies the finished
+// slab of the layer above to memory, matrix by matrix, before it starts the
+// chain -- and every other wave's sums queue behind it), and a wave's own
+// weight-gradient MFMAs are as long as its whole dx path.  Here a workgroup is
+// RW "row" waves and three "matrix" waves:
+//   * a row wave walks its tile through the dx path only (80 16x16x4 MFMAs) and
+//     leaves dx_{l+1}[t], da_f[t], da_g[t] in three LDS tiles, channel-on-lane
+//     readable, then signals;
+//   * a matrix wave owns the weight-gradient matrices of ONE left operand for
+//     the whole group -- x[t]: dWf[1], dWg[1]; x[t-d]: dWf[0], dWg[0]; z[t]:
+//     dWd -- and accumulates  A^T B  over the RW tiles in turn (A read straight
+//     from memory with the channel on the lane: a step's two rows are 256
+//     contiguous bytes; B = the row waves' tiles), holds the group's complete
+//     sums in registers and stores them into the slab: no accumulation across
+//     waves, no chain, no slab in LDS.  Fixed order over the tiles: bitwise
+//     reproducible.
+// Row waves and matrix waves are coupled by LDS counters ("written" per tile,
+// "read" per pass; bounded waits like every other one).
+template <int RW>
+__global__ __launch_bounds__((RW + 3) * 64) __attribute__((amdgpu_waves_per_eu(RW == 4 ? 4 : 1)))
+void stack_bwd16s_kernel(StackBwd a) {
+  constexpr int NW = RW + 3;
+  __shared__ __attribute__((aligned(1024))) float wl[2 * SB_WIMG];
+  __shared__ __attribute__((aligned(1024))) float tiles[RW * 1536];
+  __shared__ int s_group;
+  __shared__ int s_done[STACK_MAXL], s_ready[STACK_MAXL];
+  // layers whose tiles row wave w has written / matrix-wave passes over the
+  // group's tiles (three a layer)
+  __shared__ int s_prod[RW], s_cons;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;        // 32 x 32 products: channel, row parity
+  const int jr = lane & 15, g = lane >> 4;       // 16 x 16 products: row, piece
+  const int sw = jr & 7;
+  const int T = a.T, L = a.L;
+  const int tiles_per_clip = (T + 15) >> 4;
+  const int ntiles = tiles_per_clip * a.B;
+  const int ngroups = (ntiles + RW - 1) / RW;
+  const unsigned epoch =
+      __hip_atomic_load(a.ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  bool dead = false;
+  S16CAL(0);
+
+  auto issue_wimg = [&](int l, int p0, int step) {
+    const float* src = a.wimg + (size_t)l * STACK_WBUF;
+    float* dst = wl + (l & 1) * SB_WIMG;
+    for (int p = p0; p < SB_WIMG / 256; p += step)
+      __builtin_amdgcn_global_load_lds((wn_gptr_t)(src + p * 256 + lane * 4),
+                                       (wn_lptr_t)(dst + p * 256), 16, 0, 0);
+  };
+
+  for (;;) {
+    if (tid == 0) s_group = (int)atomicAdd(a.ctl, 1u);
+    __syncthreads();
+    const int ticket = __builtin_amdgcn_readfirstlane(s_group);
+    __syncthreads();
+    if (ticket >= ngroups) break;
+    const int gi = ngroups - 1 - ticket;
+    const int nactive = min(RW, ntiles - gi * RW);
+    for (int i = tid; i < L; i += NW * 64) {
+      s_done[i] = 0;
+      s_ready[i] = i >= L - 2;
+    }
+    if (tid < RW) s_prod[tid] = 0;
+    if (tid == 0) s_cons = 0;
+    if (wave < RW) {
+      issue_wimg(L - 1, wave, RW);
+      if (L > 1) issue_wimg(L - 2, wave, RW);
+      WN_WAIT_VM0();
+    }
+    __syncthreads();
+
+    if (wave < RW) {
+      // ================================================= a row wave: the dx path
+      const int tile = gi * RW + wave;
+      const bool any = tile < ntiles;
+      const int b = any ? tile / tiles_per_clip : 0;
+      const int tt = any ? tile - b * tiles_per_clip : 0;
+      const int tt0 = tt * 16;
+      const int hi = any ? min(16, T - tt0) : 0;
+      const bool mine = jr < hi;
+      const int off0 = (b * T + tt0) * (WN_CH * 4);            // bytes (< 2^31: host check)
+      const int voff = off0 + (jr * WN_CH + 4 * g) * 4;        // the lane's piece 0 of its row
+      float* t_di = tiles + wave * 1536;
+      float* t_f = t_di + 512;
+      float* t_g = t_di + 1024;
+      auto flag_idx2 = [&](int dd) -> int {
+        if (!any) return -1;
+        const int hif = min(hi, T - dd - tt0);
+        if (hif <= 0) return -1;
+        const int first = (tt0 + dd) >> 4, last = (tt0 + dd + hif - 1) >> 4;
+        int idx = -1;
+        if (lane == 0 && first != tt) idx = b * tiles_per_clip + first;
+        if (lane == 1 && last != first && last != tt) idx = b * tiles_per_clip + last;
+        return idx;
+      };
+      unsigned nfv_push = epoch;
+      for (int l = L - 1; any && l >= 0; --l) {
+        const int d = a.dil[l];
+        const bool hx = l + 1 < L;
+        const int dn = hx ? a.dil[l + 1] : 0;
+        const wn_rsrc_t qin = plane_rsrc(a.Q + (size_t)(hx ? l + 1 : l) * a.plane);
+        const wn_rsrc_t q_out = plane_rsrc(a.Q + (size_t)l * a.plane);
+        const wn_rsrc_t z = plane_rsrc(a.Z + (size_t)l * a.plane);
+        const wn_rsrc_t sg = plane_rsrc(a.SG + (size_t)l * a.plane);
+        const wn_rsrc_t dZ = plane_rsrc(a.dZ + (size_t)l * a.plane);
+        const wn_rsrc_t dxin = plane_rsrc(a.DX + (size_t)(hx ? l + 1 : l) * a.dx_stride);
+        const wn_rsrc_t dx_out = plane_rsrc(a.DX + (size_t)l * a.dx_stride);
+        const unsigned* fl_in = a.flags + (size_t)(hx ? l + 1 : l) * ntiles;
+        unsigned* fl_out = a.flags + (size_t)l * ntiles;
+        S16STAMP(l, 0);
+        wait_lds_ge(s_ready + l, 1, dead, a.ctl, a.poison, lane);
+        S16STAMP(l, 1);
+        int woff = jr * 32 + ((g ^ ((jr >> 1) & 7)) << 2) + (l & 1) * SB_WIMG;
+        asm volatile("" : "+v"(woff));
+        const float* const wm = wl;
+        // ---- rows t, all time-major, straight into registers
+        F16 dz = f16_ld<SB_STREAM>(dZ, voff, mine);
+        const F16 ss = f16_ld<SB_STREAM>(sg, voff, mine);
+        const F16 zz = f16_ld<SB_STREAM>(z, voff, mine);
+        F16 di = f16_zero();
+        if (hx) {
+          di = f16_ld<SB_OWN_LD>(dxin, voff, mine);
+          const int hi_q = min(hi, T - dn - tt0);
+          F16 qv = f16_zero();
+          if (hi_q > 0) {
+            const int idx = flag_idx2(dn);
+            if (__builtin_amdgcn_ballot_w64(idx >= 0 && nfv_push != epoch) != 0)
+              wait_flags(fl_in, idx, epoch, a.ctl, a.poison, dead, lane);
+            qv = f16_ld<16>(qin, voff + dn * (WN_CH * 4), jr < hi_q);
+          }
+          S16STAMP(l, 2);
+          WN_WAIT_VM0();
+          di.v[0] += qv.v[0];
+          di.v[1] += qv.v[1];
+        } else {
+          S16STAMP(l, 2);
+          WN_WAIT_VM0();
+        }
+        S16STAMP(l, 3);
+        // the matrix waves are through this wave's tiles of the layer above
+#ifndef S16_NOFREEWAIT   // (timing-only ablation: results meaningless)
+        wait_lds_ge(&s_cons, 3 * (L - 1 - l), dead, a.ctl, a.poison, lane);
+#endif
+        f16_to_lds(t_di + jr * 32, g, sw, di);
+        if (hx) mma16s(dz, di, wm + 4 * 1024, woff);            // + dx_{l+1}[t] Wd^T
+        F16 df, dg;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            // (gate_grad of wn_common.h on this layout)
+            const float sgm = ss.v[mb][e], zv = zz.v[mb][e];
+            const float th = zv * __builtin_amdgcn_rcpf(sgm + 1e-30f);
+            df.v[mb][e] = dz.v[mb][e] * __builtin_fmaf(-zv, th, sgm);
+            dg.v[mb][e] = dz.v[mb][e] * __builtin_fmaf(-zv, sgm, zv);
+          }
+        f16_to_lds(t_f + jr * 32, g, sw, df);
+        f16_to_lds(t_g + jr * 32, g, sw, dg);
+        WN_WAIT_LGKM0();
+        if (lane == 0)
+          __hip_atomic_store(s_prod + wave, L - l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        S16STAMP(l, 4);
+        // own_l[t] = dx_{l+1}[t] + da[t] W[1]^T,  q_l[t] = da[t] W[0]^T
+        F16 dx = di, qf = f16_zero();
+        mma16s2(dx, qf, df, wm + 1 * 1024, wm + 0 * 1024, woff);   // da_f: Wf[1], Wf[0]
+        mma16s2(dx, qf, dg, wm + 3 * 1024, wm + 2 * 1024, woff);   // da_g: Wg[1], Wg[0]
+        S16STAMP(l, 5);
+        if (dead) { qf.v[0][0] = __builtin_nanf(""); dx.v[0][0] = __builtin_nanf(""); }
+        f16_st<16>(q_out, voff, mine, qf);
+        f16_st<SB_OWN_ST>(dx_out, voff, mine, dx);
+        // this wave no longer reads layer l's weights; the last one to say so
+        // refills their ring half with layer l - 2
+        bool refill = false;
+        {
+          int old = 0;
+          if (lane == 0)
+            old = __hip_atomic_fetch_add(s_done + l, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          old = __builtin_amdgcn_readfirstlane(old);
+          if (old == nactive - 1 && l >= 2) {
+            issue_wimg(l - 2, 0, 1);
+            refill = true;
+          }
+        }
+        WN_WAIT_VM0();                               // q and own rows stored (and the refill landed)
+        if (lane == 0)
+          __hip_atomic_store(fl_out + tile, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (refill && lane == 0)
+          __hip_atomic_store(s_ready + l - 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // the flags this tile will look at in the layer below: requested now
+        // (after layer 0: by the completion of dx_0 below)
+        nfv_push = epoch;
+        {
+          const int nidx = flag_idx2(d);
+          if (nidx >= 0)
+            nfv_push = __hip_atomic_load(fl_out + nidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        S16STAMP(l, 6);
+      }
+      // dx_0[t] = own_0[t] + q_0[t + d_0], completed in place
+      if (any) {
+        const int d0 = a.dil[0];
+        const wn_rsrc_t dx0 = plane_rsrc(a.DX), q0 = plane_rsrc(a.Q);
+        F16 ro = f16_ld<SB_OWN_LD>(dx0, voff, mine);
+        const int hi_q = min(hi, T - d0 - tt0);
+        if (hi_q > 0) {
+          const int idx = flag_idx2(d0);
+          if (__builtin_amdgcn_ballot_w64(idx >= 0 && nfv_push != epoch) != 0)
+            wait_flags(a.flags, idx, epoch, a.ctl, a.poison, dead, lane);
+          const F16 rq = f16_ld<16>(q0, voff + d0 * (WN_CH * 4), jr < hi_q);
+          WN_WAIT_VM0();
+          ro.v[0] += rq.v[0];
+          ro.v[1] += rq.v[1];
+        }
+        WN_WAIT_VM0();
+        if (dead) ro.v[0][0] = __builtin_nanf("");
+        f16_st<0>(dx0, voff, mine, ro);
+      }
+    } else {
+      // ============ a matrix wave: the weight gradients of one left operand
+      const int mw = wave - RW;       // 0: x[t] (Wf[1], Wg[1])  1: x[t-d] (Wf[0], Wg[0])  2: z[t] (Wd)
+      const bool past = mw == 1, two = mw < 2;
+      // element [row 2 s + h][channel j] of row wave n's tile k (0: dx_{l+1},
+      // 1: da_f, 2: da_g):  te.p[s & 3][n * 1536 + k * 512 + 64 * s]
+      const TileElemPtr te = tile_elem_ptrs(tiles, j, h);
+      const int e0 = 4 * h * 32 + j;
+      // the group's tiles: first row in its clip, byte offset in a plane
+      int g_tt0[RW], g_off[RW];
+#pragma unroll
+      for (int n = 0; n < RW; ++n) {
+        const int tile = gi * RW + n;
+        const int b = tile / tiles_per_clip;
+        g_tt0[n] = (tile - b * tiles_per_clip) * 16;
+        g_off[n] = (b * T + g_tt0[n]) * (WN_CH * 4);
+      }
+      const int lane4 = lane * 4;
+      for (int l = L - 1; l >= 0; --l) {
+        const int d = a.dil[l];
+        const bool hx = l + 1 < L;
+        const wn_rsrc_t ap = plane_rsrc((mw == 2 ? a.Z : a.X) + (size_t)l * a.plane);
+        float* tile_colsum = a.tilesum ? a.tilesum + (size_t)l * ntiles * 64 : nullptr;
+        float* out = a.slabs + (size_t)l * a.slab_layer_stride + (size_t)gi * LAYER_BLOCK_FLOATS;
+        S16STAMP(l, 0);
+        f32x16 acc0 = frag_zero(), acc1 = frag_zero();
+        float bs0 = 0.f, bs1 = 0.f;
+        const bool work = two || hx;    // (top layer: no gradient flows into x_L)
+        // A operands, element [row 2 s + h][channel j] of a tile, straight from
+        // memory, four tiles ahead of their use (a row outside the tile asks
+        // for an offset past the resource and reads as 0)
+        float ax[4][8];
+        auto request = [&](int n, float (&dst)[8]) {
+          const int hi = n < nactive && work ? min(16, T - g_tt0[n]) : 0;
+          const int lo = past ? max(0, d - g_tt0[n]) : 0;
+          const int soff = g_off[n] - (past ? d * (WN_CH * 4) : 0);   // (>= 0 when lo == 0)
+#ifdef S16_NOLOAD   // (timing-only ablation: results meaningless)
+          if (true) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) dst[s] = 1.f + soff;
+          } else
+#endif
+          if (lo == 0 && hi == 16) {       // a whole tile: one lane offset, scalar tile offsets
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+              dst[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                     ap, lane4 + s * 256, soff, SB_X_AUX));
+          } else {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+              const int r = 2 * s + h;
+              dst[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                  ap, r >= lo && r < hi ? soff + lane4 + s * 256 : WN_BUF_OOB, 0, SB_X_AUX));
+            }
+          }
+        };
+#pragma unroll
+        for (int n = 0; n < 4; ++n) request(n, ax[n]);
+        S16STAMP(l, 1);
+        // every row wave of the group has written its tiles of this layer
+        for (int n = 0; n < nactive; ++n)
+          wait_lds_ge(s_prod + n, L - l, dead, a.ctl, a.poison, lane);
+        S16STAMP(l, 2);
+        // B operands (the row waves' tiles); an idle row wave's tile reads as 0
+        float bv[16];
+        auto tile_read = [&](int n, float (&dst)[16]) {
+#pragma unroll
+          for (int s = 0; s < 8; ++s) {
+            const float v0 = te.p[s & 3][n * 1536 + (two ? 512 : 0) + 64 * s];
+            dst[s] = n < nactive ? v0 : 0.f;
+            if (two) {
+              const float v1 = te.p[s & 3][n * 1536 + 1024 + 64 * s];
+              dst[8 + s] = n < nactive ? v1 : 0.f;
+            }
+          }
+        };
+#pragma unroll
+        for (int n = 0; n < RW; ++n) {
+          tile_read(n, bv);
+          __builtin_amdgcn_sched_barrier(0);
+          float ts0 = 0.f, ts1 = 0.f;
+#pragma unroll
+          for (int s = 0; s < 8; ++s) {
+#ifdef S16_NOMMA    // (timing-only ablation: results meaningless)
+            acc0[s] += ax[n & 3][s] * bv[s];
+            if (two) acc1[s] += ax[n & 3][s] * bv[8 + s];
+#else
+            acc0 = sb_mfma(ax[n & 3][s], bv[s], acc0);
+            if (two) acc1 = sb_mfma(ax[n & 3][s], bv[8 + s], acc1);
+#endif
+            ts0 += bv[s];
+            if (two) ts1 += bv[8 + s];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (n + 4 < RW) request(n + 4, ax[n & 3]);
+          bs0 += ts0;
+          bs1 += ts1;
+          if (tile_colsum && n < nactive && mw == 0) {
+            const float c0 = ts0 + __shfl_xor(ts0, 32), c1 = ts1 + __shfl_xor(ts1, 32);
+            if (h == 0) {
+              tile_colsum[(size_t)(gi * RW + n) * 64 + j] = c0;
+              tile_colsum[(size_t)(gi * RW + n) * 64 + 32 + j] = c1;
+            }
+          }
+        }
+        // (every LDS read above has returned: its MFMA has been issued)
+        if (lane == 0)
+          __hip_atomic_fetch_add(&s_cons, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        S16STAMP(l, 3);
+        if (!work) { acc0 = frag_zero(); bs0 = 0.f; }
+        if (dead) acc0[0] = __builtin_nanf("");
+        // slab: Wf[0] | Wf[1] | Wg[0] | Wg[1] | Wd | bf | bg | bd
+        const int m0 = mw == 0 ? 1 : mw == 1 ? 0 : 4;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          out[m0 * 1024 + e0 + (8 * (r >> 2) + (r & 3)) * 32] = acc0[r];
+        if (two) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            out[(m0 + 2) * 1024 + e0 + (8 * (r >> 2) + (r & 3)) * 32] = acc1[r];
+        }
+        // bias sums: column sums of da_f, da_g (with x[t]'s wave) and of
+        // dx_{l+1} (with z's) over the group's rows
+        bs0 += __shfl_xor(bs0, 32);
+        bs1 += __shfl_xor(bs1, 32);
+        if (h == 0 && mw == 0) {
+          out[LAYER_W_FLOATS + j] = bs0;
+          out[LAYER_W_FLOATS + 32 + j] = bs1;
+        }
+        if (h == 0 && mw == 2) out[LAYER_W_FLOATS + 64 + j] = bs0;
+        S16STAMP(l, 4);
+      }
+    }
+    __syncthreads();
+  }
+  S16CAL(2);
+  if (tid == 0) {
+    const unsigned done = atomicAdd(a.ctl + 1, 1u);
+    if (done == gridDim.x - 1) {
+      __hip_atomic_store(a.ctl + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.ctl + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.ctl + 2, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 #ifdef STACK_STAMPS
 static unsigned long long* g_stack_dbg = nullptr;
 static unsigned long long* g_stack_dbg_b = nullptr;
@@ -2121,9 +2403,11 @@ long wn_stack_flag_count(int B, int T, int L) {
 }
 
 // Rows of a tile in wn_stack_fwd / wn_stack_bwd for a shape: 16 while the
-// batch has at most two 32-row tiles per CU (every wave then runs alone on its
-// dependent path: halve the path), else 32.  WN_STACK_ROWS=16 / 32 forces it
-// (A/B, tests).
+// batch has at most four 32-row tiles per CU (the launches are then bound by
+// one wave's dependent path through a layer: halve the path), else 32.
+// Measured, T = 16000, ms per training step at 32 / 16 rows: B = 1 1.780 /
+// 1.683, B = 2 2.999 / 2.947, B = 3 4.14 / 4.60, B = 4 5.01 / 5.56.
+// WN_STACK_ROWS=16 / 32 forces it (A/B, tests).
 int wn_stack_tile_rows(int B, int T) {
   if (B <= 0 || T <= 0) return 32;
   if (const char* e = getenv("WN_STACK_ROWS")) {
@@ -2131,7 +2415,7 @@ int wn_stack_tile_rows(int B, int T) {
     if (r == 16 || r == 32) return r;
   }
   const long ntiles = (long)B * ((T + 31) / 32);
-  return ntiles <= 2L * wn_device_cus() ? 16 : 32;
+  return ntiles <= 4L * wn_device_cus() ? 16 : 32;
 }
 
 // waves per workgroup of the 16-row launches: WN_STACK16_WAVES_F / _B = 4 / 8
@@ -2157,18 +2441,11 @@ int wn_stack_pack(const float* layer0, long layer_stride, float* wimg_fwd,
   return wn_check_launch();
 }
 
-// 8-byte hand-over words of the 16-row forward launch (0: the shape runs the
-// 32-row launch, which hands over through flags)
-long wn_stack_ll_words(int B, int T, int L) {
-  if (B <= 0 || T <= 0 || L <= 0 || wn_stack_tile_rows(B, T) != 16) return 0;
-  return (long)L * B * T * WN_CH;
-}
-
 int wn_stack_fwd(float* X, float* Z, float* SG, const float* wimg,
                  const float* bias, long bias_layer_stride,
                  int bias_clip_stride, const int* dilations, unsigned* flags,
-                 unsigned* ctl, float* poison, unsigned long long* ll, int L, int B,
-                 int T, int save_sg, void* stream) {
+                 unsigned* ctl, float* poison, int L, int B, int T, int save_sg,
+                 void* stream) {
   if (!X || !Z || !wimg || !dilations || !flags || !ctl) return WN_ERR_NULL;
   if (save_sg && !SG) return WN_ERR_NULL;
   if (L <= 0 || B <= 0 || T <= 0) return WN_ERR_BAD_SHAPE;
@@ -2181,16 +2458,14 @@ int wn_stack_fwd(float* X, float* Z, float* SG, const float* wimg,
   a.bias_clip_stride = bias_clip_stride; a.dil = dilations; a.flags = flags;
   a.ctl = ctl; a.poison = poison; a.L = L; a.B = B; a.T = T;
   a.plane = (long)B * T * WN_CH;
-  a.ll = ll;
 #ifdef STACK_STAMPS
   if (!g_stack_dbg) return WN_ERR_NULL;
   a.dbg = g_stack_dbg;
 #endif
   if (L > STACK_MAXL) return WN_ERR_UNSUPPORTED;
   if (wn_stack_tile_rows(B, T) == 16) {
-    // (32-bit byte offsets into a plane, and into a layer of hand-over words)
-    if ((long)B * T * WN_CH * 8 >= (1L << 31)) return WN_ERR_UNSUPPORTED;
-    if (ll && (reinterpret_cast<uintptr_t>(ll) & 15u)) return WN_ERR_MISALIGNED;
+    // (tile offsets inside a plane are 32-bit byte offsets of a buffer resource)
+    if ((long)B * T * WN_CH * 4 >= (1L << 31)) return WN_ERR_UNSUPPORTED;
     const long nt16 = (long)B * ((T + 15) / 16);
     const int cus16 = wn_device_cus();
     // one wave per SIMD while that covers the batch in one pass, else two
@@ -2199,18 +2474,14 @@ int wn_stack_fwd(float* X, float* Z, float* SG, const float* wimg,
     if (g16 > cus16) g16 = cus16;
     dim3 grid16((unsigned)g16), block16(w16 * 64);
     hipStream_t s16 = (hipStream_t)stream;
-#define LAUNCH16(W, H)                                                              \
-  do {                                                                              \
-    if (save_sg)                                                                    \
-      hipLaunchKernelGGL((stack_fwd16_kernel<2, W, H>), grid16, block16, 0, s16, a);  \
-    else                                                                            \
-      hipLaunchKernelGGL((stack_fwd16_kernel<0, W, H>), grid16, block16, 0, s16, a);  \
+#define LAUNCH16(W)                                                              \
+  do {                                                                           \
+    if (save_sg)                                                                 \
+      hipLaunchKernelGGL((stack_fwd16_kernel<2, W>), grid16, block16, 0, s16, a);  \
+    else                                                                         \
+      hipLaunchKernelGGL((stack_fwd16_kernel<0, W>), grid16, block16, 0, s16, a);  \
   } while (0)
-    if (ll) {
-      if (w16 == 8) LAUNCH16(8, true); else LAUNCH16(4, true);
-    } else {
-      if (w16 == 8) LAUNCH16(8, false); else LAUNCH16(4, false);
-    }
+    if (w16 == 8) LAUNCH16(8); else LAUNCH16(4);
 #undef LAUNCH16
     return wn_check_launch();
   }
@@ -2347,8 +2618,19 @@ int wn_stack_bwd(const float* X, const float* Z, const float* SG,
     return WN_ERR_BAD_SHAPE;
   if (rows == 16) {
     if (!push) return WN_ERR_UNSUPPORTED;     // (the 16-row launch is "push" only)
-    if (waves == 8) hipLaunchKernelGGL((stack_bwd16_kernel<8>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((stack_bwd16_kernel<4>), grid, block, 0, s, a);
+    // WN_STACK16_SPLIT=1: the weight gradients on waves of their own
+    // (stack_bwd16s_kernel: 347 instead of 573 us alone at B = 1, but the side
+    // stream's weight-gradient GEMMs no longer fit beside it -- DESIGN.md)
+    const char* se = getenv("WN_STACK16_SPLIT");
+    if (!(se && se[0] == '1')) {
+      if (waves == 8) hipLaunchKernelGGL((stack_bwd16_kernel<8>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((stack_bwd16_kernel<4>), grid, block, 0, s, a);
+    } else {
+      if (waves == 8)
+        hipLaunchKernelGGL((stack_bwd16s_kernel<8>), grid, dim3(11 * 64), 0, s, a);
+      else
+        hipLaunchKernelGGL((stack_bwd16s_kernel<4>), grid, dim3(7 * 64), 0, s, a);
+    }
     return wn_check_launch();
   }
 #define LAUNCH(W)                                                               \

@@ -35,9 +35,8 @@ SIGNATURES = {
     'wn_stack_wimg_floats': (c_int, []),
     'wn_stack_tile_rows': (c_int, [c_int, c_int]),
     'wn_stack_pack': (c_int, [P, c_long, P, P, c_int, P]),
-    'wn_stack_fwd': (c_int, [P, P, P, P, P, c_long, c_int, P, P, P, P, P,
+    'wn_stack_fwd': (c_int, [P, P, P, P, P, c_long, c_int, P, P, P, P,
                              c_int, c_int, c_int, c_int, P]),
-    'wn_stack_ll_words': (c_long, [c_int, c_int, c_int]),
     'wn_stack_bwd_slabs': (c_int, [c_int, c_int]),
     'wn_stack_bwd': (c_int, [P, P, P, P, P, c_long, P, P, P, c_long, P, P, P,
                              P, P, c_int, c_int, c_int, P]),

@@ -98,12 +98,6 @@ class _Workspace(object):
         alloc('stack_flags', (lib.wn_stack_flag_count(B, T, L),), torch.int32,
               fill=0)
         alloc('wimg_f', (L, lib.wn_stack_wimg_floats()))
-        # 16-row forward launch (small batches): the rows a tile hands to its
-        # dilated-tap readers as {value, epoch} words the readers poll
-        # (0 words when the shape runs 32-row tiles; WN_STACK_LL=0: flags, A/B)
-        nll = lib.wn_stack_ll_words(B, T, L) \
-            if os.environ.get('WN_STACK_LL', '1') != '0' else 0
-        self.stack_ll = alloc('stack_ll', (nll,), torch.int64, fill=0) if nll else None
         alloc('stack_ctl', (4,), torch.int32, fill=0)
         if 'stack_ctl' in fresh:         # (a view shares the owner's epoch)
             self.stack_ctl[2] = 1
@@ -925,7 +919,7 @@ class WaveNetModel(object):
                       0 if bias is None else bias.shape[1] * bias.shape[2],
                       bstride, _lib.ptr(self._dil_dev),
                       _lib.ptr(ws.stack_flags), _lib.ptr(ws.stack_ctl),
-                      _lib.ptr(ws.loss_parts), _lib.ptr(ws.stack_ll),
+                      _lib.ptr(ws.loss_parts),
                       L, B, T, 1 if save_ts else 0, st), 0.0,
                       getattr(self, '_gemm_events', None))
         for l, d in enumerate(self.dilations if not self.blocked and not stack

@@ -65,34 +65,31 @@ def test_stack_entries_validate_without_gpu(hip_lib):
     assert hip_lib.wn_stack_flag_count(8, 16000, 50) == 50 * 8 * 1000
     assert hip_lib.wn_stack_flag_count(2, 33, 3) == 3 * 2 * 3     # ragged tile counts
     assert hip_lib.wn_stack_flag_count(0, 33, 3) == 0
-    # tile height: 16 rows while the batch has at most two 32-row tiles per CU
+    # tile height: 16 rows while the batch has at most four 32-row tiles per CU
     # (256 CUs assumed without a device)
     assert hip_lib.wn_stack_tile_rows(8, 16000) == 32
-    assert hip_lib.wn_stack_tile_rows(2, 16000) == 32
+    assert hip_lib.wn_stack_tile_rows(3, 16000) == 32
+    assert hip_lib.wn_stack_tile_rows(2, 16000) == 16
     assert hip_lib.wn_stack_tile_rows(1, 16000) == 16
     assert hip_lib.wn_stack_tile_rows(0, 16000) == 32
     assert hip_lib.wn_stack_bwd_slabs(8, 16000) == 250           # 16 tiles per group
     assert hip_lib.wn_stack_bwd_slabs(1, 16000) == 125           # 8 waves x one 16-row tile
-    assert hip_lib.wn_stack_ll_words(1, 16000, 50) == 50 * 16000 * 32
-    assert hip_lib.wn_stack_ll_words(8, 16000, 50) == 0          # 32-row tiles: flags
     assert hip_lib.wn_stack_bwd_slabs(0, 16000) == 0
     buf = (ctypes.c_float * 64)()
     a = ctypes.addressof(buf)
-    assert hip_lib.wn_stack_fwd(None, a, a, a, None, 0, 0, a, a, a, None, None,
+    assert hip_lib.wn_stack_fwd(None, a, a, a, None, 0, 0, a, a, a, None,
                                 2, 1, 64, 1, None) == -5
-    assert hip_lib.wn_stack_fwd(a, a, None, a, None, 0, 0, a, a, a, None, None,
+    assert hip_lib.wn_stack_fwd(a, a, None, a, None, 0, 0, a, a, a, None,
                                 2, 1, 64, 1, None) == -5          # save_sg without SG
-    assert hip_lib.wn_stack_fwd(a, a, a, a, None, 0, 0, a, a, a, None, None,
+    assert hip_lib.wn_stack_fwd(a, a, a, a, None, 0, 0, a, a, a, None,
                                 0, 1, 64, 1, None) == -1          # L <= 0
     assert hip_lib.wn_stack_pack(a, 100, a, a, 2, None) == -1     # stride < block
     assert hip_lib.wn_stack_pack(a, 5216, None, None, 2, None) == -5
     assert hip_lib.wn_stack_wimg_floats() % 256 == 0
-    assert hip_lib.wn_stack_fwd(a + 4, a, a, a, None, 0, 0, a, a, a, None, None,
+    assert hip_lib.wn_stack_fwd(a + 4, a, a, a, None, 0, 0, a, a, a, None,
                                 2, 1, 64, 1, None) == -3
-    assert hip_lib.wn_stack_fwd(a, a, a, a, None, 0, 0, a, a, a, None, None,
+    assert hip_lib.wn_stack_fwd(a, a, a, a, None, 0, 0, a, a, a, None,
                                 257, 1, 64, 1, None) == -2        # L > 256
-    assert hip_lib.wn_stack_fwd(a, a, a, a, None, 0, 0, a, a, a, None, a + 8,
-                                2, 1, 64, 1, None) == -3          # hand-over words misaligned
     pl = 1 * 64 * 32
     assert hip_lib.wn_stack_bwd(a, a, a, a, None, pl, a, a, a, 5216, None, a, a, a,
                                 None, 2, 1, 64, None) == -5

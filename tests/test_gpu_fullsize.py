@@ -51,12 +51,21 @@ def _log(tag, payload):
     json.dump(cur, open(path, 'w'), indent=1)
 
 
-def test_full_size_dp_identity_and_determinism(hip_lib):
+def test_full_size_dp_identity_and_determinism(hip_lib, monkeypatch):
     """grad(B=8) == mean of the eight single-clip gradients, loss
     likewise -- EVERY variable within max(2e-5, 4 x the float32 oracle's own
     error) of that variable's largest entry; two runs are bitwise identical
     (slab reductions, no float atomics).  Clip 0 of the batch is the clip
-    test_config1_full_length_vs_oracle pins against the float64 oracle."""
+    test_config1_full_length_vs_oracle pins against the float64 oracle.
+    Both sides on 32-row tiles: a single clip would by default run the 16-row
+    stack launches, whose activations differ from the 32-row ones in the last
+    bits -- enough to put a handful of the 16000 x 512 post-processing ReLUs on
+    the other side of their kink (test_config1_full_length_vs_oracle counts 7
+    against 11 such positions for the two tile heights), and a gradient is not
+    continuous there: the two heights agree with the float64 oracle to 3e-6 of
+    a variable EACH, taking their own side at those kinks, and with each other
+    only to 1.7e-3.  The identity under test is the sharding's."""
+    monkeypatch.setenv('WN_STACK_ROWS', '32')
     from wavenet import WaveNetModel
     T = 16000
     audio = synth_audio(8, T)

@@ -130,7 +130,10 @@ def test_bench_many_ranks_rehearsal(hip_lib, gc):
     env1 = {k: v for k, v in env.items() if k not in ('WN_SHARE_GPU', 'WN_DIST_BACKEND')}
     one, _ = _bench_json(['--gpus', '1', '--batch', str(n)] + common, env1)
     assert one['config']['global_batch'] == n
-    assert abs(one['config']['global_loss'] - r['config']['global_loss']) <= 1e-6
+    # (the weight-gradient slabs of N x 1 clip and 1 x N clips group the tiles
+    # differently: after three optimizer steps the float32 losses, ~5.3, may
+    # differ by a few units in the last place, 4.8e-7 each)
+    assert abs(one['config']['global_loss'] - r['config']['global_loss']) <= 5e-6
     if gc:
         assert one['config']['gc_ids'] == r['config']['gc_ids']
 

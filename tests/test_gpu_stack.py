@@ -222,7 +222,7 @@ def _check_layer_grads(a, b, wa, name):
     assert float((ga - gb).abs().max()) <= 2e-6 * max(scale, 1e-30)
 
 
-@pytest.mark.parametrize('rows,waves', [(32, '8'), (16, '8'), (16, '4')])
+@pytest.mark.parametrize('rows,waves', [(32, '8'), (16, '8'), (16, '4'), (16, 'split8'), (16, 'split4')])
 @pytest.mark.parametrize('name,mk,B,T,kind', CASES, ids=[c[0] for c in CASES])
 def test_stack_backward_equals_per_layer(hip_lib, monkeypatch, name, mk, B, T, kind, rows, waves):
     """wn_stack_bwd vs one wn_layer_bwd2 per layer: dL/dx_0 and the weight
@@ -235,6 +235,10 @@ def test_stack_backward_equals_per_layer(hip_lib, monkeypatch, name, mk, B, T, k
     here; all three models then run the 16-row FORWARD too, so the planes the
     backward paths read are bitwise the same."""
     monkeypatch.setenv('WN_STACK_ROWS', str(rows))
+    # ('splitN': the opt-in launch with the weight gradients on waves of their
+    # own, N row waves per workgroup)
+    monkeypatch.setenv('WN_STACK16_SPLIT', '1' if waves.startswith('split') else '0')
+    waves = waves.replace('split', '')
     monkeypatch.setenv('WN_STACK16_WAVES_B', waves)
     assert hip_lib.wn_stack_tile_rows(B, T) == rows
     cfg = mk()

@@ -39,8 +39,8 @@ nt16 = B * ((T + 15) // 16)
 wf = int(os.environ.get('WN_STACK16_WAVES_F', 4 if (nt16 + 3) // 4 <= 256 else 8))
 gridf = min(256, (nt16 + wf - 1) // wf)
 gridb = min(256, lib.wn_stack_bwd_slabs(B, T))
-dbg = torch.zeros(gridf * 8 * L * 16 + gridf * 4, dtype=torch.int64, device='cuda')
-dbgb = torch.zeros(gridb * 8 * L * 16 + gridb * 4, dtype=torch.int64, device='cuda')
+dbg = torch.zeros(gridf * 16 * L * 16 + gridf * 4, dtype=torch.int64, device='cuda')
+dbgb = torch.zeros(gridb * 16 * L * 16 + gridb * 4, dtype=torch.int64, device='cuda')
 lib.wn_diag_stack_dbg.argtypes = [ctypes.c_void_p]
 lib.wn_diag_stack_dbg(dbg.data_ptr())
 lib.wn_diag_stack_dbg_b.argtypes = [ctypes.c_void_p]
@@ -53,9 +53,9 @@ for it in range(4):
 torch.cuda.synchronize()
 
 
-def report(raw, grid, title, seq, down):
-    s = raw[:grid * 8 * L * 16].reshape(grid, 8, L, 16).astype(np.float64)
-    cal = raw[grid * 8 * L * 16:].reshape(grid, 4).astype(np.float64)
+def report(raw, grid, title, seq, down, waves=None, first=0):
+    s = raw[:grid * 16 * L * 16].reshape(grid, 16, L, 16).astype(np.float64)
+    cal = raw[grid * 16 * L * 16:].reshape(grid, 4).astype(np.float64)
     used = cal[:, 2] > 0
     cal = cal[used]
     clk = np.median((cal[:, 3] - cal[:, 1]) / ((cal[:, 2] - cal[:, 0]) * 10.0))
@@ -64,7 +64,7 @@ def report(raw, grid, title, seq, down):
         (cal[:, 2].max() - cal[:, 0].min()) / 100.0))
     s = s[used]
     nw = int((s[:, :, L // 2, 0] > 0).any(axis=0).sum())
-    for wv in sorted({0, nw - 1}):
+    for wv in (waves if waves is not None else sorted({0, nw - 1})):
         tot = 0.0
         print('--- wave %d of %d: median (p90) over workgroups and layers 1..L-2, us' % (wv, nw))
         for a_, b_, nm in seq:
@@ -86,10 +86,23 @@ report(dbg.cpu().numpy(), gridf, 'stack_fwd16_kernel', [
     (3, 4, '32 past-tap MFMAs'), (4, 5, 'tanh / sigmoid'), (5, 6, 'dense bias + 16 MFMAs'),
     (6, 7, "x' out (stored, drained, flag posted / words stored)"),
     (7, 8, 'z / sigmoid stores issued, ring bookkeeping')], False)
-report(dbgb.cpu().numpy(), gridb, 'stack_bwd16_kernel', [
-    (0, 1, 'wait for the weight ring'), (1, 2, 'loads requested (z DMA, dZ, sigmoid, own dx, flag check, q)'),
-    (2, 3, 'wait for them'), (3, 4, 'dx_{l+1} to LDS, dWd (8 MFMA), z fragments'),
-    (4, 5, 'x DMA issued, dz (16 MFMA), gate derivatives'),
-    (5, 6, 'own / q rows (64 MFMA)'), (6, 7, 'q and own rows stored, drained, flag posted, next flags requested'),
-    (7, 8, 'weight gradients (32 MFMA)'), (8, 9, 'ring bookkeeping'),
-    (9, 10, 'ordered accumulation chain (incl. token waits)')], True)
+split = os.environ.get('WN_STACK16_SPLIT', '1') != '0'
+if not split:
+    report(dbgb.cpu().numpy(), gridb, 'stack_bwd16_kernel', [
+        (0, 1, 'wait for the weight ring'), (1, 2, 'loads requested (z DMA, dZ, sigmoid, own dx, flag check, q)'),
+        (2, 3, 'wait for them'), (3, 4, 'dx_{l+1} to LDS, dWd (8 MFMA), z fragments'),
+        (4, 5, 'x DMA issued, dz (16 MFMA), gate derivatives'),
+        (5, 6, 'own / q rows (64 MFMA)'), (6, 7, 'q and own rows stored, drained, flag posted, next flags requested'),
+        (7, 8, 'weight gradients (32 MFMA)'), (8, 9, 'ring bookkeeping'),
+        (9, 10, 'ordered accumulation chain (incl. token waits)')], True)
+else:
+    rw = int(os.environ.get('WN_STACK16_WAVES_B', 8))
+    report(dbgb.cpu().numpy(), gridb, 'stack_bwd16s_kernel, row waves', [
+        (0, 1, 'wait for the weight ring'), (1, 2, 'loads requested (dZ, sigmoid, z, own dx, flag check, q)'),
+        (2, 3, 'wait for them'), (3, 4, 'tiles free?, dx_{l+1} | dz (16 MFMA) | gates -> LDS, signal'),
+        (4, 5, 'own / q rows (64 MFMA)'), (5, 6, 'stores, ring bookkeeping, drain, flag posted, next flags')],
+        True, waves=(0, rw - 1))
+    report(dbgb.cpu().numpy(), gridb, 'stack_bwd16s_kernel, matrix waves', [
+        (0, 1, 'operands of four tiles requested'), (1, 2, 'wait for the row waves'),
+        (2, 3, 'the group\'s tiles (16 / 16 / 8 MFMA each)'), (3, 4, 'slab stores issued')],
+        True, waves=(rw, rw + 1, rw + 2))

@@ -94,8 +94,7 @@ def main():
                                 bias.stride(0) if bias is not None else 0,
                                 bias.stride(1) if bias is not None else 0,
                                 ptr(net._dil_dev), ptr(ws.stack_flags),
-                                ptr(ws.stack_ctl), ptr(ws.loss_parts),
-                                ptr(getattr(ws, 'stack_ll', None)), L, B, T,
+                                ptr(ws.stack_ctl), ptr(ws.loss_parts), L, B, T,
                                 int(os.environ.get('KB_SAVE_SG', 1)), st)
         assert code == 0, code
 

@@ -7,6 +7,11 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'tensorflow-wavenet_amd'))
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
+# WN_STACK_ROWS (default here: 32, the launches whose forward is bitwise the
+# per-layer kernels'; 16: the small-batch launches, compared to rounding --
+# WN_STACK16_SPLIT=1 / WN_STACK16_WAVES_F / _B select their variants)
+os.environ.setdefault('WN_STACK_ROWS', '32')
+ROWS16 = os.environ['WN_STACK_ROWS'] == '16'
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 from util import TINY, build_pair, cfg_with, synth_audio  # noqa: E402
@@ -29,11 +34,21 @@ for case in range(n):
     torch.cuda.synchronize()
     wa = list(a._ws.values())[0]
     assert int(wa.stack_ctl[3]) == 0 and (not wa.stack_bwd or int(wa.stack_ctl_b[3]) == 0)
-    assert float(la) == float(lb), (case, float(la), float(lb))
+    if ROWS16:
+        assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(lb)), (case, float(la), float(lb))
+        wb = list(b._ws.values())[0]
+        for pl in ('X', 'Z', 'SG'):
+            pa, pb = getattr(wa, pl), getattr(wb, pl)
+            e = float((pa - pb).abs().max()) / max(float(pb.abs().max()), 1e-30)
+            assert e <= 1e-4, (case, pl, e)
+    else:
+        assert float(la) == float(lb), (case, float(la), float(lb))
     sc = float(b.grads.abs().max())
     err = float((a.grads - b.grads).abs().max()) / max(sc, 1e-30)
     worst = max(worst, err)
     print('case %2d  L=%2d dil=%s B=%d T=%d  stack_bwd=%s  rel. grad diff %.2e' % (
         case, L, dil, B, T, bool(wa.stack_bwd), err), flush=True)
-    assert err <= 5e-6, err
+    # (16 rows: the forward differs in the last bits, and a ReLU of the
+    # post-processing net may sit on the other side of its kink)
+    assert err <= (2e-3 if ROWS16 else 5e-6), err
 print('worst relative gradient difference %.2e over %d cases' % (worst, n))

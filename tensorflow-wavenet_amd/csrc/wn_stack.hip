@@ -2619,7 +2619,7 @@ int wn_stack_bwd(const float* X, const float* Z, const float* SG,
   if (rows == 16) {
     if (!push) return WN_ERR_UNSUPPORTED;     // (the 16-row launch is "push" only)
     // WN_STACK16_SPLIT=1: the weight gradients on waves of their own
-    // (stack_bwd16s_kernel: 347 instead of 573 us alone at B = 1, but the side
+    // (stack_bwd16s_kernel: 356 instead of 532 us alone at B = 1, but the side
     // stream's weight-gradient GEMMs no longer fit beside it -- DESIGN.md)
     const char* se = getenv("WN_STACK16_SPLIT");
     if (!(se && se[0] == '1')) {

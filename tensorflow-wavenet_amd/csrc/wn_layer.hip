@@ -442,6 +442,192 @@ __global__ __launch_bounds__(256) void layer_wgrad_kernel(
   for (int e = tid; e < LAYER_BLOCK_FLOATS; e += 256) out[e] = red[e];
 }
 
+// The same for a 64-channel layer (two channel blocks, two taps) with ALL FOUR
+// (input block a, output block b) pairs in one pass: per pair and workgroup the
+// kernel above reads x_a twice, z_a, da_f / da_g / dxin of b -- every plane of
+// the layer twice per launch (89 us a layer at B x T = 128000, 4.4 TB/s).  Here
+// a workgroup stages the twelve tiles of a 32-row step ONCE (LDS-DMA through
+// buffer resources: a row outside the clip asks for an offset past the
+// resource and lands as zeros, so every step is the same number of
+// instructions and the wait for it can be counted; three buffers: two steps
+// in flight behind the one being multiplied) and its eight waves are the four
+// pairs x two halves of a step's rows: wave (a, b, half) accumulates its five
+// products over 16 of the 32 rows from the shared tiles (two waves per SIMD:
+// one's barrier / wait under the other's MFMAs; with four waves the launch
+// took 62 us, 58 % of its MFMA time), the upper halves hand their sums to the
+// lower ones through LDS at the end, and each pair writes its own slab -- half
+// the bytes of the per-pair kernel.  Slab layout as layer_wgrad_kernel.
+#define WG2_SLOTS 12   // x0[t] x1[t] x0[t-d] x1[t-d] z0 z1 | f0 f1 g0 g1 d0 d1
+#define WG2_BUFS 3
+template <bool HAS_DENSE>
+__global__ __launch_bounds__(512) void layer_wgrad_cb2_kernel(
+    const float* __restrict__ x, const float* __restrict__ daf,
+    const float* __restrict__ dag, const float* __restrict__ z,
+    const float* __restrict__ dxin, float* __restrict__ slabs, int B, int T,
+    int d, long plane_stride) {
+  __shared__ __attribute__((aligned(1024))) float lds[WG2_BUFS * WG2_SLOTS * WG_TILE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 31, h = lane >> 5;
+  const int pair = wave & 3, half = wave >> 2;   // this wave's pair, its half of a step's rows
+  const int pa = pair >> 1, pb = pair & 1;
+  const int tiles_per_clip = (T + 31) >> 5;
+  const int ntiles = tiles_per_clip * B;
+  // slot s of a step: plane base
+  auto slot_plane = [&](int s) -> const float* {
+    switch (s) {
+      case 0: case 2: return x;
+      case 1: case 3: return x + plane_stride;
+      case 4: return z;
+      case 5: return z + plane_stride;
+      case 6: return daf;
+      case 7: return daf + plane_stride;
+      case 8: return dag;
+      case 9: return dag + plane_stride;
+      case 10: return dxin;
+      default: return dxin + plane_stride;
+    }
+  };
+  // the lane's swizzled source offset inside a tile (tile_dma's layout: slot
+  // l & 7 of row l >> 3 holds global chunk (l & 7) ^ (row & 7))
+  const int vswz = ((lane >> 3) * 32 + (((lane & 7) ^ ((lane >> 3) & 7)) << 2)) * 4;
+  // wave w stages slots w and (w < 4) w + 8 of a step: 4 instructions a slot
+  int my_slots = 0;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int s = wave + 8 * k;
+    if (s < WG2_SLOTS && (HAS_DENSE || !(s == 4 || s == 5 || s >= 10))) ++my_slots;
+  }
+  auto stage = [&](int buf, int tile) {
+    const int b = tile / tiles_per_clip;
+    const int t0 = (tile - b * tiles_per_clip) * 32;
+    const int hi = min(32, T - t0);
+    const int off0 = (b * T + t0) * (WN_CH * 4);           // bytes (< 2^31: host check)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int s = wave + 8 * k;
+      if (s >= WG2_SLOTS || (!HAS_DENSE && (s == 4 || s == 5 || s >= 10))) continue;
+      const bool past = s == 2 || s == 3;
+      const int lo = past ? max(0, d - t0) : 0;
+      const int base = off0 - (past ? d * (WN_CH * 4) : 0) + vswz;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)slot_plane(s), 0, 0x7fffffff, 0x00020000);
+      float* dst = lds + (buf * WG2_SLOTS + s) * WG_TILE;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int r = 8 * c + (lane >> 3);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            rs, (__attribute__((address_space(3))) void*)(dst + c * 256), 16,
+            r >= lo && r < hi ? base + c * 1024 : (int)0x80000000u, 0, 0, 0);
+      }
+    }
+  };
+  // element [row 2 s + h][channel i] of slot n of buffer 0:
+  // tp[s & 3][n * WG_TILE + 64 * s]  (the XOR swizzle of tile_elem, once)
+  const float* tp[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int off = 32 * h + ((((i >> 2) ^ (2 * k + h)) & 7) << 2) + (i & 3);
+    asm volatile("" : "+v"(off));
+    tp[k] = lds + off;
+  }
+  f32x16 cf0 = frag_zero(), cf1 = frag_zero(), cg0 = frag_zero(),
+         cg1 = frag_zero(), cd = frag_zero();
+  float sf = 0.f, sgs = 0.f, sd = 0.f;
+  int tile = blockIdx.x, buf = 0;
+  const int G = gridDim.x;
+  if (tile < ntiles) stage(0, tile);
+  if (tile + G < ntiles) stage(1, tile + G);
+  for (; tile < ntiles; tile += G, buf = buf == WG2_BUFS - 1 ? 0 : buf + 1) {
+    // this step's tiles have landed (every wave waits for its own DMAs; the
+    // step behind it -- four instructions a slot -- may stay in flight), and
+    // every wave is through the step before: its buffer takes the step after next
+    if (tile + G < ntiles && my_slots == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (tile + G < ntiles && my_slots == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    if (tile + 2 * G < ntiles) stage(buf == 0 ? WG2_BUFS - 1 : buf - 1, tile + 2 * G);
+    const int bo = buf * WG2_SLOTS * WG_TILE;
+    const int oxc = bo + pa * WG_TILE, oxp = bo + (2 + pa) * WG_TILE, oz = bo + (4 + pa) * WG_TILE;
+    const int of = bo + (6 + pb) * WG_TILE, og = bo + (8 + pb) * WG_TILE, od = bo + (10 + pb) * WG_TILE;
+    // (the six operands of step s + 1 are requested before the MFMAs of step
+    // s, order pinned: with one wave per SIMD nobody else covers an LDS round
+    // trip per step)
+    const float* q0 = tp[0] + 512 * half;      // (step 8 half: rows 16 half ..)
+    float axc = q0[oxc], axp = q0[oxp], bf = q0[of], bg = q0[og];
+    float az = HAS_DENSE ? q0[oz] : 0.f, bd = HAS_DENSE ? q0[od] : 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const float* q = tp[(s + 1) & 3] + 64 * ((s + 1) & 7) + 512 * half;
+      const float naxc = q[oxc], naxp = q[oxp], nbf = q[of], nbg = q[og];
+      const float naz = HAS_DENSE ? q[oz] : 0.f, nbd = HAS_DENSE ? q[od] : 0.f;
+      __builtin_amdgcn_sched_barrier(0);
+      cf0 = __builtin_amdgcn_mfma_f32_32x32x2f32(axp, bf, cf0, 0, 0, 0);
+      cf1 = __builtin_amdgcn_mfma_f32_32x32x2f32(axc, bf, cf1, 0, 0, 0);
+      cg0 = __builtin_amdgcn_mfma_f32_32x32x2f32(axp, bg, cg0, 0, 0, 0);
+      cg1 = __builtin_amdgcn_mfma_f32_32x32x2f32(axc, bg, cg1, 0, 0, 0);
+      sf += bf;
+      sgs += bg;
+      if (HAS_DENSE) {
+        cd = __builtin_amdgcn_mfma_f32_32x32x2f32(az, bd, cd, 0, 0, 0);
+        sd += bd;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      axc = naxc; axp = naxp; bf = nbf; bg = nbg; az = naz; bd = nbd;
+    }
+  }
+  sf += __shfl_xor(sf, 32);
+  sgs += __shfl_xor(sgs, 32);
+  sd += __shfl_xor(sd, 32);
+  // the upper-half waves hand their sums to their pair's lower-half wave
+  // (lane-linear through the staging buffers, which nobody reads any more)
+  __syncthreads();
+  float* hand = lds + pair * (5 * 1024 + 256);
+  if (half == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      hand[(0 * 16 + r) * 64 + lane] = cf0[r];
+      hand[(1 * 16 + r) * 64 + lane] = cf1[r];
+      hand[(2 * 16 + r) * 64 + lane] = cg0[r];
+      hand[(3 * 16 + r) * 64 + lane] = cg1[r];
+      hand[(4 * 16 + r) * 64 + lane] = cd[r];
+    }
+    hand[5 * 1024 + lane] = sf;
+    hand[5 * 1024 + 64 + lane] = sgs;
+    hand[5 * 1024 + 128 + lane] = sd;
+  }
+  __syncthreads();
+  if (half == 1) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    cf0[r] += hand[(0 * 16 + r) * 64 + lane];
+    cf1[r] += hand[(1 * 16 + r) * 64 + lane];
+    cg0[r] += hand[(2 * 16 + r) * 64 + lane];
+    cg1[r] += hand[(3 * 16 + r) * 64 + lane];
+    cd[r] += hand[(4 * 16 + r) * 64 + lane];
+  }
+  sf += hand[5 * 1024 + lane];
+  sgs += hand[5 * 1024 + 64 + lane];
+  sd += hand[5 * 1024 + 128 + lane];
+  // the pair's slab; C tile row m = 8 (r >> 2) + 4 h + (r & 3) (A-operand
+  // channel), column i
+  float* out = slabs + ((size_t)pair * gridDim.x + blockIdx.x) * LAYER_BLOCK_FLOATS;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int e = (8 * (r >> 2) + 4 * h + (r & 3)) * 32 + i;
+    out[0 * 1024 + e] = cf0[r];
+    out[1 * 1024 + e] = cf1[r];
+    out[2 * 1024 + e] = cg0[r];
+    out[3 * 1024 + e] = cg1[r];
+    out[4 * 1024 + e] = cd[r];
+  }
+  if (h == 0) {
+    out[LAYER_W_FLOATS + i] = sf;
+    out[LAYER_W_FLOATS + 32 + i] = sgs;
+    out[LAYER_W_FLOATS + 64 + i] = sd;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Fused backward of one residual block: data gradient (phase B of layer l),
 // ALL weight gradients of layer l, and phase A of layer l-1, in one pass over
@@ -2001,6 +2187,19 @@ int wn_layer_wgrad_k(const float* x, const float* daf, const float* dag,
   if ((dxin != nullptr) != (z != nullptr)) return WN_ERR_NULL;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(num_slabs, CB * CB), block(256);
+  if (K == 2 && k0 == 0 && Ktot == 2 && CB == 2 && (long)B * T * WN_CH * 4 < (1L << 31) &&
+      !getenv("WN_WGRAD_CB2_OFF")) {
+    // 64 channels, two taps: all four block pairs in one pass (every plane of
+    // the layer read once; WN_WGRAD_CB2_OFF=1: the per-pair kernel, A/B)
+    dim3 grid1(num_slabs), block1(512);
+    if (dxin)
+      hipLaunchKernelGGL((layer_wgrad_cb2_kernel<true>), grid1, block1, 0, s, x, daf, dag, z,
+                         dxin, slabs, B, T, dilation, plane_stride);
+    else
+      hipLaunchKernelGGL((layer_wgrad_cb2_kernel<false>), grid1, block1, 0, s, x, daf, dag, z,
+                         dxin, slabs, B, T, dilation, plane_stride);
+    return wn_check_launch();
+  }
   if (K == 2 && k0 == 0 && Ktot == 2) {
     // two taps: the one-pass kernel of the 32-channel models per block pair
     // (same slab layout; 24 instead of 32 plane reads per layer at 64 channels)

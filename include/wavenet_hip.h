@@ -134,6 +134,15 @@ int wn_dense_planes(const float* in, long in_plane_stride, const float* W,
                     const float* bias, const float* addend, long add_plane_stride,
                     float* out, long out_plane_stride, long rows, int C,
                     void* stream);
+/* The backward's dz = dZ + dx_{l+1} Wd^T (wn_dense_planes with addend = dZ) and
+ * the gate gradients of autodiff of wavenet/model.py:264-282 in one launch:
+ * daf = dz s (1 - t^2), dag = dz s t (1 - s) with the saved tanh / sigmoid
+ * planes th / sg; dz itself is not stored.  Bitwise the planes the two launches
+ * (wn_dense_planes, then wn_layer_bwd_k with do_a only) give. */
+int wn_dense_planes_gate(const float* in, long in_plane_stride, const float* W,
+                         const float* addend, long add_plane_stride, const float* th,
+                         const float* sg, long ts_plane_stride, float* daf, float* dag,
+                         long da_plane_stride, long rows, int C, void* stream);
 
 /* more than 32 residual / dilation channels: channels are cut into 32-wide
  * blocks, each block of an activation is its own [B*T][32] plane, and one

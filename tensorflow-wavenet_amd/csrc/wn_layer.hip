@@ -1918,11 +1918,19 @@ static int layer_grid(int B, int T, int waves = LAYER_WAVES, bool spread = false
 // instruction), fragments through the wave's LDS tile, CB x CB x 16 MFMAs with
 // the weights in LDS in their own layout, the addend rows loaded meanwhile.
 // ---------------------------------------------------------------------------
-template <int CB>
+// GATE: the result is dz of the backward; instead of storing it the gate
+// gradients da_f = dz s (1 - t^2), da_g = dz s t (1 - s) (t, s: the saved tanh /
+// sigmoid planes) go out -- elementwise in the row layout the result is stored
+// in anyway, the same operations in the same order as the separate pass
+// (layer_bwd_gen_kernel, gate gradients only), which read dz back: bitwise the
+// same planes, one launch and a plane round trip per block less.
+template <int CB, bool GATE>
 __global__ __launch_bounds__(256) void dense_planes_kernel(
     const float* __restrict__ in, long in_pstride, const float* __restrict__ W,
     const float* __restrict__ bias, const float* __restrict__ addend, long add_pstride,
-    float* __restrict__ out, long out_pstride, long rows) {
+    float* __restrict__ out, long out_pstride, long rows,
+    const float* __restrict__ th, const float* __restrict__ sg, long ts_pstride,
+    float* __restrict__ dag) {
   constexpr int C = 32 * CB;
   __shared__ __attribute__((aligned(16))) float wl[C * C];
   __shared__ __attribute__((aligned(16))) float tiles[4 * 1024];
@@ -1970,6 +1978,21 @@ __global__ __launch_bounds__(256) void dense_planes_kernel(
     for (int c = 0; c < 4; ++c) {
       ro.v[c] += b4;
       if (addend) ro.v[c] += radd[ob].v[c];
+    }
+    if (GATE) {
+      // (`out` = the da_f planes, `dag` the da_g planes)
+      const RowRegs rt = rows_load(th + ob * ts_pstride + r0 * 32, lane, 0, hi);
+      const RowRegs rs = rows_load(sg + ob * ts_pstride + r0 * 32, lane, 0, hi);
+      RowRegs rg;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float zs = ro.v[c][e] * rs.v[c][e];
+          ro.v[c][e] = zs * (1.f - rt.v[c][e] * rt.v[c][e]);
+          rg.v[c][e] = zs * rt.v[c][e] * (1.f - rs.v[c][e]);
+        }
+      rows_store(dag + ob * out_pstride + r0 * 32, lane, hi, rg);
     }
     rows_store(out + ob * out_pstride + r0 * 32, lane, hi, ro);
   }
@@ -2245,8 +2268,42 @@ int wn_dense_planes(const float* in, long in_plane_stride, const float* W,
   dim3 grid((unsigned)wgs), block(256);
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(CBV)                                                              \
-  hipLaunchKernelGGL((dense_planes_kernel<CBV>), grid, block, 0, s, in, in_plane_stride, \
-                     W, bias, addend, add_plane_stride, out, out_plane_stride, rows)
+  hipLaunchKernelGGL((dense_planes_kernel<CBV, false>), grid, block, 0, s, in, in_plane_stride, \
+                     W, bias, addend, add_plane_stride, out, out_plane_stride, rows,     \
+                     nullptr, nullptr, 0L, nullptr)
+  if (C == 32) LAUNCH(1);
+  else if (C == 64) LAUNCH(2);
+  else if (C == 96) LAUNCH(3);
+  else LAUNCH(4);
+#undef LAUNCH
+  return wn_check_launch();
+}
+
+// dz = addend + in W as wn_dense_planes, then the gate gradients instead of dz:
+// daf = dz s (1 - t^2), dag = dz s t (1 - s) with the saved tanh / sigmoid planes
+// th / sg (planes ts_plane_stride apart); daf / dag planes da_plane_stride apart
+int wn_dense_planes_gate(const float* in, long in_plane_stride, const float* W,
+                         const float* addend, long add_plane_stride, const float* th,
+                         const float* sg, long ts_plane_stride, float* daf, float* dag,
+                         long da_plane_stride, long rows, int C, void* stream) {
+  if (!in || !W || !th || !sg || !daf || !dag) return WN_ERR_NULL;
+  if (rows <= 0) return WN_ERR_BAD_SHAPE;
+  if (C != 32 && C != 64 && C != 96 && C != 128) return WN_ERR_UNSUPPORTED;
+  const void* ptrs[] = {in, W, addend, th, sg, daf, dag};
+  for (const void* p : ptrs)
+    if (p && !wn_aligned16(p)) return WN_ERR_MISALIGNED;
+  if ((in_plane_stride & 3) || (add_plane_stride & 3) || (ts_plane_stride & 3) ||
+      (da_plane_stride & 3))
+    return WN_ERR_MISALIGNED;
+  const long ntiles = (rows + 31) / 32;
+  const long wgs = (ntiles + 3) / 4;
+  if (wgs > 0x7fffffffL) return WN_ERR_BAD_SHAPE;
+  dim3 grid((unsigned)wgs), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(CBV)                                                              \
+  hipLaunchKernelGGL((dense_planes_kernel<CBV, true>), grid, block, 0, s, in, in_plane_stride, \
+                     W, nullptr, addend, add_plane_stride, daf, da_plane_stride, rows,  \
+                     th, sg, ts_plane_stride, dag)
   if (C == 32) LAUNCH(1);
   else if (C == 64) LAUNCH(2);
   else if (C == 96) LAUNCH(3);

@@ -47,6 +47,8 @@ SIGNATURES = {
                                P]),
     'wn_dense_planes': (c_int, [P, c_long, P, P, P, c_long, P, c_long, c_long, c_int,
                                 P]),
+    'wn_dense_planes_gate': (c_int, [P, c_long, P, P, c_long, P, P, c_long, P, P,
+                                     c_long, c_long, c_int, P]),
     'wn_layer_fwd_k': (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int,
                                c_int, c_int, c_int, P]),
     'wn_layer_bwd_k': (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int,

@@ -139,10 +139,19 @@ def backward_layers(net, ws, ids, st):
         if dxin is not None:
             _lib.call('wn_transpose', _lib.ptr(w['wd']), C, C, C,
                       _lib.ptr(ws.wdT), C, st)
+        gated = False
         if dxin is not None:
             # dz = dZ + dx' Wd^T for all dilation-channel blocks in one
             # plane-mode GEMM (Wd^T as [res][dil]; addend dZ in plane layout)
-            if CB <= 4:
+            if CB <= 4 and net.wide_fuse_gate:
+                # ... and the gate gradients in the same launch (dz is not
+                # stored: bitwise the planes of the two launches below)
+                _lib.call('wn_dense_planes_gate', _lib.ptr(dxin[0]), pstride,
+                          _lib.ptr(ws.wdT), _lib.ptr(ws.dZ[l * CB]), pstride,
+                          _lib.ptr(ws.TH[l * CB]), _lib.ptr(ws.SG[l * CB]), pstride,
+                          _lib.ptr(daf[0]), _lib.ptr(dag[0]), pstride, N, C, st)
+                gated = True
+            elif CB <= 4:
                 _lib.call('wn_dense_planes', _lib.ptr(dxin[0]), pstride,
                           _lib.ptr(ws.wdT), None, _lib.ptr(ws.dZ[l * CB]),
                           pstride, _lib.ptr(ws.dzb[0]), pstride, N, C, st)
@@ -155,10 +164,11 @@ def backward_layers(net, ws, ids, st):
         # blockIdx.y = block; gate gradients only: the filter width just sizes
         # a weight staging area this mode does not read)
         dz0 = ws.dZ[l * CB] if dxin is None else ws.dzb[0]
-        _lib.call('wn_layer_bwd_k', None, None, None, None, None,
-                  _lib.ptr(dz0), _lib.ptr(ws.TH[l * CB]), _lib.ptr(ws.SG[l * CB]),
-                  _lib.ptr(w['all']), _lib.ptr(daf[0]), _lib.ptr(dag[0]), B, T, d,
-                  min(K, 8), 0, 1, CB, pstride, st)
+        if not gated:
+            _lib.call('wn_layer_bwd_k', None, None, None, None, None,
+                      _lib.ptr(dz0), _lib.ptr(ws.TH[l * CB]), _lib.ptr(ws.SG[l * CB]),
+                      _lib.ptr(w['all']), _lib.ptr(daf[0]), _lib.ptr(dag[0]), B, T, d,
+                      min(K, 8), 0, 1, CB, pstride, st)
         for jb in range(CB):
             if ws.dsum is not None:
                 _lib.call('wn_colsum_clip', _lib.ptr(daf[jb]), _lib.ptr(dag[jb]),

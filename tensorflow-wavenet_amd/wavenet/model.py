@@ -303,6 +303,9 @@ class WaveNetModel(object):
         # force it.
         self.overlap_tn = None
         self.overlap_tn_split_frac = 0.6
+        # channel-block models (33 - 128 channels): dz and the gate gradients
+        # in one launch (False: two launches, A/B and tests; bitwise equal)
+        self.wide_fuse_gate = os.environ.get('WN_WIDE_FUSE_GATE', '1') != '0'
         # column sums (bias gradients) of the weight-gradient GEMMs spread over
         # all tile rows of a split (WN_TN_SPREAD=0: one owner tile row, A/B)
         self.tn_spread_colsum = os.environ.get('WN_TN_SPREAD', '1') != '0'
@@ -831,7 +834,7 @@ class WaveNetModel(object):
     def _plan_key(self, tag, ws, ids, extra):
         return (tag, extra, ids is not None, self.generic_layers,
                 self.fused_bwd, self.layer_bwd, self.overlap_tn,
-                self.overlap_tn_split_frac, self.tn_spread_colsum, self.nn_chain, self.stack_fwd, self.stack_bwd, self.gemm_mode, self.causal_wgrad_segsum, self.tf_xent_zero_label_quirk,
+                self.overlap_tn_split_frac, self.wide_fuse_gate, self.tn_spread_colsum, self.nn_chain, self.stack_fwd, self.stack_bwd, self.gemm_mode, self.causal_wgrad_segsum, self.tf_xent_zero_label_quirk,
                 _lib.stream(), self.params.data_ptr(), self.grads.data_ptr())
 
     def _stage_ids(self, ws, ids):

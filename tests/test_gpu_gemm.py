@@ -641,6 +641,28 @@ def test_dense_planes_vs_float64(hip_lib, C, rows):
     assert float((out - ref_g).abs().max()) < 1e-4 * max(1.0, float(ref_g.abs().max()))
     assert hip_lib.wn_dense_planes(dx.data_ptr(), rows * 32, dW.data_ptr(), None, None, 0,
                                    out.data_ptr(), rows * 32, rows, 160, st) == -2
+    # wn_dense_planes_gate: dz = addend + in W never stored, the gate gradients
+    # da_f = dz s (1 - t^2), da_g = dz s t (1 - s) instead -- bitwise what the
+    # separate elementwise pass makes of the stored dz
+    t = np.tanh(rng.standard_normal((CB, rows, 32))).astype(np.float32)
+    sgm = (1.0 / (1.0 + np.exp(-rng.standard_normal((CB, rows, 32))))).astype(np.float32)
+    dt, ds = dev(t), dev(sgm)
+    dz = torch.empty((CB, rows, 32), device='cuda')
+    _lib.call('wn_dense_planes', dx.data_ptr(), rows * 32, dW.data_ptr(), None,
+              da.data_ptr(), rows * 32, dz.data_ptr(), rows * 32, rows, C, st)
+    daf = torch.full((CB, rows, 32), float('nan'), device='cuda')
+    dag = torch.full((CB, rows, 32), float('nan'), device='cuda')
+    _lib.call('wn_dense_planes_gate', dx.data_ptr(), rows * 32, dW.data_ptr(), da.data_ptr(),
+              rows * 32, dt.data_ptr(), ds.data_ptr(), rows * 32, daf.data_ptr(), dag.data_ptr(),
+              rows * 32, rows, C, st)
+    # (to rounding here: the kernel's 1 - t^2 may be one fused operation; the
+    # bitwise statement is test_gpu_model.py's, against the separate device pass)
+    zs = dz * ds
+    for got, want in ((daf, zs * (1.0 - dt * dt)), (dag, zs * dt * (1.0 - ds))):
+        assert float((got - want).abs().max()) <= 1e-6 * max(1.0, float(want.abs().max()))
+    assert hip_lib.wn_dense_planes_gate(dx.data_ptr(), rows * 32, dW.data_ptr(), None, 0,
+                                        None, ds.data_ptr(), rows * 32, daf.data_ptr(),
+                                        dag.data_ptr(), rows * 32, rows, C, st) == -5
 
 
 @pytest.mark.parametrize('rows,Mw,Nw,splits', [(4800, 160, 128, 9), (128000 // 8, 1600, 512, 25),

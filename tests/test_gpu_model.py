@@ -268,6 +268,28 @@ def test_generic_tap_kernels_at_k2(hip_lib):
     check_grads(net, ref_g)
 
 
+@pytest.mark.parametrize('case', ['r64', 'r48_d40_gc', 'r96_d128'])
+def test_wide_models_fused_gate_gradients_bitwise(hip_lib, case):
+    """Channel-block models: dz = dZ + dx' Wd^T and the gate gradients in one
+    launch (wn_dense_planes_gate, default) against the two launches it
+    replaces (wn_dense_planes, then the elementwise pass that reads dz back):
+    same operations in the same order, so loss and every gradient are
+    bitwise equal; 64-channel models run the all-pairs weight-gradient kernel
+    in both."""
+    name, cfg, T, gc, l2 = [c for c in CASES if c[0] == case][0]
+    a, _ = build_pair(cfg)
+    b, _ = build_pair(cfg)
+    assert a.wide_fuse_gate
+    b.wide_fuse_gate = False
+    B = cfg['batch_size']
+    audio = np.random.default_rng(7).uniform(-1, 1, (B, T)).astype(np.float32)
+    ids = np.arange(B, dtype=np.int32) % cfg['global_condition_cardinality'] if gc else None
+    la, lb = a.loss(audio, ids), b.loss(audio, ids)
+    torch.cuda.synchronize()
+    assert float(la) == float(lb)
+    assert torch.equal(a.grads, b.grads)
+
+
 def test_xent_quirk_switch(hip_lib):
     cfg = cfg_with(TINY, batch_size=2)
     net, var = build_pair(cfg)

@@ -442,61 +442,60 @@ __global__ __launch_bounds__(256) void layer_wgrad_kernel(
   for (int e = tid; e < LAYER_BLOCK_FLOATS; e += 256) out[e] = red[e];
 }
 
-// The same for a 64-channel layer (two channel blocks, two taps) with ALL FOUR
-// (input block a, output block b) pairs in one pass: per pair and workgroup the
-// kernel above reads x_a twice, z_a, da_f / da_g / dxin of b -- every plane of
-// the layer twice per launch (89 us a layer at B x T = 128000, 4.4 TB/s).  Here
-// a workgroup stages the twelve tiles of a 32-row step ONCE (LDS-DMA through
-// buffer resources: a row outside the clip asks for an offset past the
-// resource and lands as zeros, so every step is the same number of
-// instructions and the wait for it can be counted; three buffers: two steps
-// in flight behind the one being multiplied) and its eight waves are the four
-// pairs x two halves of a step's rows: wave (a, b, half) accumulates its five
-// products over 16 of the 32 rows from the shared tiles (two waves per SIMD:
-// one's barrier / wait under the other's MFMAs; with four waves the launch
-// took 62 us, 58 % of its MFMA time), the upper halves hand their sums to the
-// lower ones through LDS at the end, and each pair writes its own slab -- half
-// the bytes of the per-pair kernel.  Slab layout as layer_wgrad_kernel.
-#define WG2_SLOTS 12   // x0[t] x1[t] x0[t-d] x1[t-d] z0 z1 | f0 f1 g0 g1 d0 d1
-#define WG2_BUFS 3
-template <bool HAS_DENSE>
-__global__ __launch_bounds__(512) void layer_wgrad_cb2_kernel(
+// The same for 64- and 128-channel layers (two / four channel blocks, two taps)
+// with ALL input blocks and TWO output blocks per pass: per pair and workgroup
+// the kernel above reads x_a twice, z_a, da_f / da_g / dxin of b -- every plane
+// of a 64-channel layer twice per launch (89 us a layer at B x T = 128000,
+// 4.4 TB/s), of a 128-channel layer four times (321 us).  Here a workgroup
+// stages the tiles of a 32-row step ONCE per pass (LDS-DMA through buffer
+// resources: a row outside the clip asks for an offset past the resource and
+// lands as zeros; two buffers: the next step lands during this one's
+// products) and its eight waves are the pass's CB x 2 pairs (CB = 4), or the
+// four pairs x two halves of a step's rows (CB = 2: two waves per SIMD either
+// way, one's barrier / wait under the other's MFMAs; the upper halves hand
+// their sums to the lower ones through LDS at the end).  Every pair writes its
+// own slab: no reduction across waves.  Slab layout as layer_wgrad_kernel;
+// blockIdx.y = pass (output blocks 2 y, 2 y + 1).
+template <int CB, bool HAS_DENSE>
+__global__ __launch_bounds__(512) void layer_wgrad_cbn_kernel(
     const float* __restrict__ x, const float* __restrict__ daf,
     const float* __restrict__ dag, const float* __restrict__ z,
     const float* __restrict__ dxin, float* __restrict__ slabs, int B, int T,
     int d, long plane_stride) {
-  __shared__ __attribute__((aligned(1024))) float lds[WG2_BUFS * WG2_SLOTS * WG_TILE];
+  // slots of a step: x_a[t] | x_a[t-d] | z_a (a < CB), then f_b | g_b | d_b (b < 2)
+  // (CB = 2: three buffers, two steps in flight and a counted wait; CB = 4:
+  // two, 144 KiB either way)
+  constexpr int SLOTS = 3 * CB + 6, NH = 8 / (2 * CB), NBUF = CB == 2 ? 3 : 2;
+  __shared__ __attribute__((aligned(1024))) float lds[NBUF * SLOTS * WG_TILE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 31, h = lane >> 5;
-  const int pair = wave & 3, half = wave >> 2;   // this wave's pair, its half of a step's rows
+  const int pair = wave % (2 * CB), half = wave / (2 * CB);   // (half: CB = 2 only)
   const int pa = pair >> 1, pb = pair & 1;
+  const int b0 = 2 * blockIdx.y;                               // the pass's output blocks
   const int tiles_per_clip = (T + 31) >> 5;
   const int ntiles = tiles_per_clip * B;
-  // slot s of a step: plane base
   auto slot_plane = [&](int s) -> const float* {
-    switch (s) {
-      case 0: case 2: return x;
-      case 1: case 3: return x + plane_stride;
-      case 4: return z;
-      case 5: return z + plane_stride;
-      case 6: return daf;
-      case 7: return daf + plane_stride;
-      case 8: return dag;
-      case 9: return dag + plane_stride;
-      case 10: return dxin;
-      default: return dxin + plane_stride;
-    }
+    if (s < 2 * CB) return x + (long)(s % CB) * plane_stride;
+    if (s < 3 * CB) return z + (long)(s - 2 * CB) * plane_stride;
+    const int q = s - 3 * CB, bb = b0 + (q & 1);
+    return (q < 2 ? daf : q < 4 ? dag : dxin) + (long)bb * plane_stride;
   };
   // the lane's swizzled source offset inside a tile (tile_dma's layout: slot
   // l & 7 of row l >> 3 holds global chunk (l & 7) ^ (row & 7))
   const int vswz = ((lane >> 3) * 32 + (((lane & 7) ^ ((lane >> 3) & 7)) << 2)) * 4;
-  // wave w stages slots w and (w < 4) w + 8 of a step: 4 instructions a slot
+  // wave w stages slots w, w + 8, w + 16: 4 instructions a slot (the slots'
+  // planes looked up once, not per step)
+  const float* my_plane[3];
+  bool my_on[3], my_past[3];
   int my_slots = 0;
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < 3; ++k) {
     const int s = wave + 8 * k;
-    if (s < WG2_SLOTS && (HAS_DENSE || !(s == 4 || s == 5 || s >= 10))) ++my_slots;
+    my_on[k] = s < SLOTS && (HAS_DENSE || !((s >= 2 * CB && s < 3 * CB) || s >= 3 * CB + 4));
+    my_past[k] = s >= CB && s < 2 * CB;
+    my_plane[k] = slot_plane(my_on[k] ? s : 0);
+    my_slots += my_on[k] ? 1 : 0;
   }
   auto stage = [&](int buf, int tile) {
     const int b = tile / tiles_per_clip;
@@ -504,15 +503,15 @@ __global__ __launch_bounds__(512) void layer_wgrad_cb2_kernel(
     const int hi = min(32, T - t0);
     const int off0 = (b * T + t0) * (WN_CH * 4);           // bytes (< 2^31: host check)
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 3; ++k) {
+      if (!my_on[k]) continue;
       const int s = wave + 8 * k;
-      if (s >= WG2_SLOTS || (!HAS_DENSE && (s == 4 || s == 5 || s >= 10))) continue;
-      const bool past = s == 2 || s == 3;
+      const bool past = my_past[k];
       const int lo = past ? max(0, d - t0) : 0;
       const int base = off0 - (past ? d * (WN_CH * 4) : 0) + vswz;
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)slot_plane(s), 0, 0x7fffffff, 0x00020000);
-      float* dst = lds + (buf * WG2_SLOTS + s) * WG_TILE;
+          (void*)my_plane[k], 0, 0x7fffffff, 0x00020000);
+      float* dst = lds + (buf * SLOTS + s) * WG_TILE;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int r = 8 * c + (lane >> 3);
@@ -537,28 +536,32 @@ __global__ __launch_bounds__(512) void layer_wgrad_cb2_kernel(
   int tile = blockIdx.x, buf = 0;
   const int G = gridDim.x;
   if (tile < ntiles) stage(0, tile);
-  if (tile + G < ntiles) stage(1, tile + G);
-  for (; tile < ntiles; tile += G, buf = buf == WG2_BUFS - 1 ? 0 : buf + 1) {
-    // this step's tiles have landed (every wave waits for its own DMAs; the
-    // step behind it -- four instructions a slot -- may stay in flight), and
-    // every wave is through the step before: its buffer takes the step after next
-    if (tile + G < ntiles && my_slots == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (tile + G < ntiles && my_slots == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  if (NBUF == 3 && tile + G < ntiles) stage(1, tile + G);
+  for (; tile < ntiles; tile += G, buf = buf == NBUF - 1 ? 0 : buf + 1) {
+    // this step's tiles have landed (every wave waits for its own DMAs; with
+    // three buffers the step behind it -- four instructions a slot -- stays in
+    // flight), and every wave is through the step before: its buffer takes the
+    // step after (next)
+    if (NBUF == 3 && tile + G < ntiles && my_slots == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (NBUF == 3 && tile + G < ntiles && my_slots == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
-    if (tile + 2 * G < ntiles) stage(buf == 0 ? WG2_BUFS - 1 : buf - 1, tile + 2 * G);
-    const int bo = buf * WG2_SLOTS * WG_TILE;
-    const int oxc = bo + pa * WG_TILE, oxp = bo + (2 + pa) * WG_TILE, oz = bo + (4 + pa) * WG_TILE;
-    const int of = bo + (6 + pb) * WG_TILE, og = bo + (8 + pb) * WG_TILE, od = bo + (10 + pb) * WG_TILE;
+    if (tile + (NBUF - 1) * G < ntiles)
+      stage(buf == 0 ? NBUF - 1 : buf - 1, tile + (NBUF - 1) * G);
+    const int bo = buf * SLOTS * WG_TILE;
+    const int oxc = bo + pa * WG_TILE, oxp = bo + (CB + pa) * WG_TILE,
+              oz = bo + (2 * CB + pa) * WG_TILE;
+    const int of = bo + (3 * CB + pb) * WG_TILE, og = bo + (3 * CB + 2 + pb) * WG_TILE,
+              od = bo + (3 * CB + 4 + pb) * WG_TILE;
     // (the six operands of step s + 1 are requested before the MFMAs of step
-    // s, order pinned: with one wave per SIMD nobody else covers an LDS round
-    // trip per step)
-    const float* q0 = tp[0] + 512 * half;      // (step 8 half: rows 16 half ..)
+    // s, order pinned)
+    constexpr int NS = 16 / NH;                  // steps of two rows per wave
+    const float* q0 = tp[0] + 64 * NS * half;
     float axc = q0[oxc], axp = q0[oxp], bf = q0[of], bg = q0[og];
     float az = HAS_DENSE ? q0[oz] : 0.f, bd = HAS_DENSE ? q0[od] : 0.f;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const float* q = tp[(s + 1) & 3] + 64 * ((s + 1) & 7) + 512 * half;
+    for (int s = 0; s < NS; ++s) {
+      const float* q = tp[(s + 1) & 3] + 64 * ((s + 1) & (NS - 1)) + 64 * NS * half;
       const float naxc = q[oxc], naxp = q[oxp], nbf = q[of], nbg = q[og];
       const float naz = HAS_DENSE ? q[oz] : 0.f, nbd = HAS_DENSE ? q[od] : 0.f;
       __builtin_amdgcn_sched_barrier(0);
@@ -579,39 +582,42 @@ __global__ __launch_bounds__(512) void layer_wgrad_cb2_kernel(
   sf += __shfl_xor(sf, 32);
   sgs += __shfl_xor(sgs, 32);
   sd += __shfl_xor(sd, 32);
-  // the upper-half waves hand their sums to their pair's lower-half wave
-  // (lane-linear through the staging buffers, which nobody reads any more)
-  __syncthreads();
-  float* hand = lds + pair * (5 * 1024 + 256);
-  if (half == 1) {
+  if (NH == 2) {
+    // the upper-half waves hand their sums to their pair's lower-half wave
+    // (lane-linear through the staging buffers, which nobody reads any more)
+    __syncthreads();
+    float* hand = lds + pair * (5 * 1024 + 256);
+    if (half == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        hand[(0 * 16 + r) * 64 + lane] = cf0[r];
+        hand[(1 * 16 + r) * 64 + lane] = cf1[r];
+        hand[(2 * 16 + r) * 64 + lane] = cg0[r];
+        hand[(3 * 16 + r) * 64 + lane] = cg1[r];
+        hand[(4 * 16 + r) * 64 + lane] = cd[r];
+      }
+      hand[5 * 1024 + lane] = sf;
+      hand[5 * 1024 + 64 + lane] = sgs;
+      hand[5 * 1024 + 128 + lane] = sd;
+    }
+    __syncthreads();
+    if (half == 1) return;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      hand[(0 * 16 + r) * 64 + lane] = cf0[r];
-      hand[(1 * 16 + r) * 64 + lane] = cf1[r];
-      hand[(2 * 16 + r) * 64 + lane] = cg0[r];
-      hand[(3 * 16 + r) * 64 + lane] = cg1[r];
-      hand[(4 * 16 + r) * 64 + lane] = cd[r];
+      cf0[r] += hand[(0 * 16 + r) * 64 + lane];
+      cf1[r] += hand[(1 * 16 + r) * 64 + lane];
+      cg0[r] += hand[(2 * 16 + r) * 64 + lane];
+      cg1[r] += hand[(3 * 16 + r) * 64 + lane];
+      cd[r] += hand[(4 * 16 + r) * 64 + lane];
     }
-    hand[5 * 1024 + lane] = sf;
-    hand[5 * 1024 + 64 + lane] = sgs;
-    hand[5 * 1024 + 128 + lane] = sd;
+    sf += hand[5 * 1024 + lane];
+    sgs += hand[5 * 1024 + 64 + lane];
+    sd += hand[5 * 1024 + 128 + lane];
   }
-  __syncthreads();
-  if (half == 1) return;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    cf0[r] += hand[(0 * 16 + r) * 64 + lane];
-    cf1[r] += hand[(1 * 16 + r) * 64 + lane];
-    cg0[r] += hand[(2 * 16 + r) * 64 + lane];
-    cg1[r] += hand[(3 * 16 + r) * 64 + lane];
-    cd[r] += hand[(4 * 16 + r) * 64 + lane];
-  }
-  sf += hand[5 * 1024 + lane];
-  sgs += hand[5 * 1024 + 64 + lane];
-  sd += hand[5 * 1024 + 128 + lane];
-  // the pair's slab; C tile row m = 8 (r >> 2) + 4 h + (r & 3) (A-operand
-  // channel), column i
-  float* out = slabs + ((size_t)pair * gridDim.x + blockIdx.x) * LAYER_BLOCK_FLOATS;
+  // the pair's slab (pair index a * CB + b as the per-pair kernel's
+  // blockIdx.y); C tile row m = 8 (r >> 2) + 4 h + (r & 3) (A-operand channel),
+  // column i
+  float* out = slabs + ((size_t)(pa * CB + b0 + pb) * gridDim.x + blockIdx.x) * LAYER_BLOCK_FLOATS;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int e = (8 * (r >> 2) + 4 * h + (r & 3)) * 32 + i;
@@ -2210,17 +2216,18 @@ int wn_layer_wgrad_k(const float* x, const float* daf, const float* dag,
   if ((dxin != nullptr) != (z != nullptr)) return WN_ERR_NULL;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(num_slabs, CB * CB), block(256);
-  if (K == 2 && k0 == 0 && Ktot == 2 && CB == 2 && (long)B * T * WN_CH * 4 < (1L << 31) &&
-      !getenv("WN_WGRAD_CB2_OFF")) {
-    // 64 channels, two taps: all four block pairs in one pass (every plane of
-    // the layer read once; WN_WGRAD_CB2_OFF=1: the per-pair kernel, A/B)
-    dim3 grid1(num_slabs), block1(512);
-    if (dxin)
-      hipLaunchKernelGGL((layer_wgrad_cb2_kernel<true>), grid1, block1, 0, s, x, daf, dag, z,
-                         dxin, slabs, B, T, dilation, plane_stride);
-    else
-      hipLaunchKernelGGL((layer_wgrad_cb2_kernel<false>), grid1, block1, 0, s, x, daf, dag, z,
-                         dxin, slabs, B, T, dilation, plane_stride);
+  if (K == 2 && k0 == 0 && Ktot == 2 && (CB == 2 || CB == 4) &&
+      (long)B * T * WN_CH * 4 < (1L << 31) && !getenv("WN_WGRAD_CB2_OFF")) {
+    // 64 / 128 channels, two taps: all input blocks and two output blocks per
+    // pass (every plane of a 64-channel layer read once, of a 128-channel
+    // layer twice; WN_WGRAD_CB2_OFF=1: the per-pair kernel, A/B)
+    dim3 grid1(num_slabs, CB / 2), block1(512);
+#define LAUNCH(CBV, HD)                                                                  \
+  hipLaunchKernelGGL((layer_wgrad_cbn_kernel<CBV, HD>), grid1, block1, 0, s, x, daf, dag, z, \
+                     dxin, slabs, B, T, dilation, plane_stride)
+    if (CB == 2) { if (dxin) LAUNCH(2, true); else LAUNCH(2, false); }
+    else { if (dxin) LAUNCH(4, true); else LAUNCH(4, false); }
+#undef LAUNCH
     return wn_check_launch();
   }
   if (K == 2 && k0 == 0 && Ktot == 2) {

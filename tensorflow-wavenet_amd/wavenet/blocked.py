@@ -121,11 +121,11 @@ def backward_layers(net, ws, ids, st):
     lib = _lib.load()
     WF = (2 * K + 1) * 1024
     nslab = ws.nslab
-    if CB == 2 and K == 2:
-        # the all-pairs weight-gradient kernel of 64-channel layers holds one
-        # workgroup per CU: one round of them (256 CUs) instead of two -- 55
-        # instead of 63 us a layer, and half the slabs to reduce
-        nslab = min(nslab, 256)
+    if CB in (2, 4) and K == 2:
+        # the all-input-blocks weight-gradient kernel of 64- / 128-channel
+        # layers holds one workgroup per CU: one round of them per pass (256
+        # CUs) -- 55 instead of 63 us a 64-channel layer, and half the slabs
+        nslab = min(nslab, 256 // (CB // 2))
     # every layer-block gradient entry is rewritten below except the padding
     # and the last layer's (gradient-free) dense conv: start from zero
     lo, ln = net.segments['layers']

@@ -470,7 +470,25 @@ struct FastGenWide {
   int C;        // padded channels (multiple of 32, <= FGW_MAXC)
 };
 
-__global__ __launch_bounds__(FGW_THREADS, 1) void fastgen_wide_kernel(FastGenWide a) {
+// F64 (64 channels, at most 512 skip channels): the generic layer body pays
+// three dependent weight-load latencies per layer (past-tap ring entry ->
+// filter / gate weights -> dense + skip weights; 213 KB a layer through ONE
+// CU, 10.6 MB a sample through one XCD's 4 MB L2: 0.30 ms per sample).  None of
+// the weights depends on the data: here (512 threads) EVERY load of a layer --
+// the ring entry, a thread's 32 filter / gate weights (output o = tid & 127, a
+// quarter of the contraction each), its 8 dense weights (an eighth of the
+// contraction) a LAYER AHEAD, the 64 weights of its skip column, which the
+// layer needs last, at the layer's own top -- and the phases only synchronise
+// through LDS, four barriers a layer (207 us per sample with every load at the
+// layer's own top and 256 threads; without the skip weights' loads a sample
+// takes 144 us: they are the 54 us still exposed).
+struct FgwLayer64 {
+  float ringv, wa[16], wb[16], wdv[8], bf, bg, bdv;
+};
+template <bool F64>
+__global__ __launch_bounds__(F64 ? 512 : FGW_THREADS, 1) void fastgen_wide_kernel(FastGenWide a) {
+  constexpr int NT = F64 ? 512 : FGW_THREADS;    // threads
+  constexpr int SPT = FGW_MAXS / NT, XPT = FGW_MAXC / NT;
   const FastGen& g = a.g;
   extern __shared__ double fgw_lds[];
   const int S = g.S, Q = g.Q, L = g.L, C = a.C;
@@ -485,12 +503,13 @@ __global__ __launch_bounds__(FGW_THREADS, 1) void fastgen_wide_kernel(FastGenWid
   int* sdil = pos + L;                            // [L]
   int* roff = sdil + L;                           // [L]
   __shared__ int s_code;
+  __shared__ float f64_part[F64 ? 4 * 128 + 8 * 64 : 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long CC = (long)C * C;
   const int steps_done = g.cursors[0];
   int prev_code = g.cursors[1];
   if (tid == 0) s_code = g.samples[0];
-  for (int l = tid; l < L; l += FGW_THREADS) {
+  for (int l = tid; l < L; l += NT) {
     sdil[l] = g.dil[l];
     pos[l] = steps_done % g.dil[l];
   }
@@ -504,24 +523,117 @@ __global__ __launch_bounds__(FGW_THREADS, 1) void fastgen_wide_kernel(FastGenWid
   for (int step = 0; step < g.n_steps; ++step) {
     const int code = s_code;
     const long tpos = (long)steps_done + step;
-    float acc[FGW_SPT];
+    float acc[SPT];
 #pragma unroll
-    for (int o = 0; o < FGW_SPT; ++o) acc[o] = 0.f;
+    for (int o = 0; o < SPT; ++o) acc[o] = 0.f;
     // causal layer: one-hot input = two table rows (model.py:341-346)
-    for (int c = tid; c < C; c += FGW_THREADS) {
+    for (int c = tid; c < C; c += NT) {
       float v = 0.f;
       if (prev_code >= 0 && prev_code < Q) v = g.causal[(long)prev_code * C + c];
       if (code >= 0 && code < Q) v += g.causal[((long)Q + code) * C + c];
       xs[c] = v;
     }
     __syncthreads();
-    for (int l = 0; l < L; ++l) {
+    if (F64) {
+      const int o1 = tid & 127, kq = tid >> 7;       // filter / gate output, quarter of K
+      const int cd = tid & 63, k8 = tid >> 6;        // dense output, eighth of K
+      const int c0 = tid < S ? tid : 0;              // skip column
+      auto request = [&](int l) {
+        FgwLayer64 w;
+        const float* blk = g.layer0 + (long)l * g.layer_stride;
+        w.ringv = tid < 64 ? g.state[((long)roff[l] + pos[l]) * 64 + tid] : 0.f;
+        const float* w0 = blk + (long)(o1 >> 6) * 2 * 4096 + (o1 & 63) + kq * 16 * 64;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { w.wa[u] = w0[u * 64]; w.wb[u] = w0[4096 + u * 64]; }
+        const float* wd = blk + 4 * 4096 + cd + k8 * 8 * 64;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w.wdv[u] = wd[u * 64];
+        w.bf = tid < 64 && g.bias_fg ? g.bias_fg[(long)l * 128 + tid] : 0.f;
+        w.bg = tid < 64 && g.bias_fg ? g.bias_fg[(long)l * 128 + 64 + tid] : 0.f;
+        w.bdv = tid < 64 && g.use_dense_bias ? blk[5 * 4096 + 128 + tid] : 0.f;
+        return w;
+      };
+      FgwLayer64 cur = request(0);
+      if (tid < 64) sts[tid] = cur.ringv;
+      __syncthreads();
+      // (four workgroup barriers a layer: partial sums | gate | partial sums |
+      // x' and the next layer's past tap)
+      for (int l = 0; l < L; ++l) {
+        // (the skip column's weights, which the layer needs last, at its own
+        // top: requesting them a layer ahead -- into the registers the layer
+        // before has just multiplied out of -- sends the register allocator
+        // into 119 spills and the sample to 284 us)
+        float ws0[64];
+        {
+          const float* ws = g.skip_w + (long)l * 64 * S + c0;
+#pragma unroll
+          for (int u = 0; u < 64; ++u) ws0[u] = ws[(long)u * S];
+        }
+        FgwLayer64 nxt = cur;
+        if (l + 1 < L) nxt = request(l + 1);
+        float* ring = g.state + ((long)roff[l] + pos[l]) * 64;
+        // ---- 1. filter / gate pre-activations, a quarter of the contraction per thread
+        {
+          float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+#pragma unroll
+          for (int u = 0; u < 16; u += 2) {
+            p0 = fmaf(sts[kq * 16 + u], cur.wa[u], p0);
+            p1 = fmaf(xs[kq * 16 + u], cur.wb[u], p1);
+            p2 = fmaf(sts[kq * 16 + u + 1], cur.wa[u + 1], p2);
+            p3 = fmaf(xs[kq * 16 + u + 1], cur.wb[u + 1], p3);
+          }
+          f64_part[kq * 128 + o1] = (p0 + p1) + (p2 + p3);
+        }
+        __syncthreads();
+        // ---- 2. gate; enqueue x_l[t] in place of the entry just read
+        if (tid < 64) {
+          const float af = cur.bf + ((f64_part[tid] + f64_part[128 + tid]) +
+                                     (f64_part[256 + tid] + f64_part[384 + tid]));
+          const float ag = cur.bg + ((f64_part[64 + tid] + f64_part[192 + tid]) +
+                                     (f64_part[320 + tid] + f64_part[448 + tid]));
+          zs[tid] = wn_tanh(af) * wn_sigmoid(ag);
+          if (g.push) ring[tid] = xs[tid];
+        }
+        __syncthreads();
+        // ---- 3. residual 1x1 conv (an eighth of the contraction per thread)
+        // and this layer's skip contribution
+        {
+          float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+          for (int u = 0; u < 8; u += 2) {
+            d0 = fmaf(zs[k8 * 8 + u], cur.wdv[u], d0);
+            d1 = fmaf(zs[k8 * 8 + u + 1], cur.wdv[u + 1], d1);
+          }
+          f64_part[512 + k8 * 64 + cd] = d0 + d1;
+          float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+          for (int u = 0; u < 64; u += 4) {
+            a0 = fmaf(zs[u], ws0[u], a0);
+            a1 = fmaf(zs[u + 1], ws0[u + 1], a1);
+            a2 = fmaf(zs[u + 2], ws0[u + 2], a2);
+            a3 = fmaf(zs[u + 3], ws0[u + 3], a3);
+          }
+          if (tid < S) acc[0] += (a0 + a1) + (a2 + a3);
+        }
+        __syncthreads();
+        if (tid < 64) {
+          float t = 0.f;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) t += f64_part[512 + q * 64 + tid];
+          xs[tid] = xs[tid] + (cur.bdv + t);
+          sts[tid] = nxt.ringv;          // (the next layer's past tap)
+        }
+        __syncthreads();
+        cur = nxt;
+      }
+    }
+    for (int l = 0; !F64 && l < L; ++l) {
       const float* blk = g.layer0 + (long)l * g.layer_stride;
       float* ring = g.state + ((long)roff[l] + pos[l]) * C;
-      for (int c = tid; c < C; c += FGW_THREADS) sts[c] = ring[c];
+      for (int c = tid; c < C; c += NT) sts[c] = ring[c];
       __syncthreads();
       // ---- 1. filter / gate pre-activations
-      for (int o = tid; o < 2 * C; o += FGW_THREADS) {
+      for (int o = tid; o < 2 * C; o += NT) {
         const int which = o / C, c = o - which * C;
         const float* w0 = blk + (long)which * 2 * CC + c;   // W_which[0][:, c]
         const float* w1 = w0 + CC;                          // W_which[1][:, c]
@@ -531,16 +643,16 @@ __global__ __launch_bounds__(FGW_THREADS, 1) void fastgen_wide_kernel(FastGenWid
       }
       __syncthreads();
       // ---- 2. gate; enqueue x_l[t] in place of the entry just read
-      for (int c = tid; c < C; c += FGW_THREADS) {
+      for (int c = tid; c < C; c += NT) {
         zs[c] = wn_tanh(apre[c]) * wn_sigmoid(apre[C + c]);
         if (g.push) ring[c] = xs[c];
       }
       __syncthreads();
       // ---- 3. residual 1x1 conv and this layer's skip contribution
-      float xn[FGW_XPT];
+      float xn[XPT];
 #pragma unroll
-      for (int u = 0; u < FGW_XPT; ++u) {
-        const int c = tid + u * FGW_THREADS;
+      for (int u = 0; u < XPT; ++u) {
+        const int c = tid + u * NT;
         xn[u] = 0.f;
         if (c < C) {
           const float* wd = blk + 4 * CC + c;
@@ -551,22 +663,22 @@ __global__ __launch_bounds__(FGW_THREADS, 1) void fastgen_wide_kernel(FastGenWid
       {
         const float* ws = g.skip_w + (long)l * C * S;
 #pragma unroll
-        for (int oi = 0; oi < FGW_SPT; oi += 2) {
-          const int sc = tid + oi * FGW_THREADS;
-          if (sc + FGW_THREADS < S)             // this thread's next two columns
-            fgw_dot2(zs, ws + sc, zs, ws + sc + FGW_THREADS, S, C, acc[oi], acc[oi + 1]);
+        for (int oi = 0; oi < SPT; oi += 2) {
+          const int sc = tid + oi * NT;
+          if (sc + NT < S)             // this thread's next two columns
+            fgw_dot2(zs, ws + sc, zs, ws + sc + NT, S, C, acc[oi], acc[oi + 1]);
           else if (sc < S)
             acc[oi] = fgw_dot(zs, ws + sc, S, C, acc[oi]);
         }
       }
       __syncthreads();
 #pragma unroll
-      for (int u = 0; u < FGW_XPT; ++u)
-        if (tid + u * FGW_THREADS < C) xs[tid + u * FGW_THREADS] = xn[u];
+      for (int u = 0; u < XPT; ++u)
+        if (tid + u * NT < C) xs[tid + u * NT] = xn[u];
       __syncthreads();
     }
     if (g.push) {
-      for (int l = tid; l < L; l += FGW_THREADS) {
+      for (int l = tid; l < L; l += NT) {
         const int p = pos[l] + 1;
         pos[l] = p == sdil[l] ? 0 : p;
       }
@@ -574,19 +686,19 @@ __global__ __launch_bounds__(FGW_THREADS, 1) void fastgen_wide_kernel(FastGenWid
     // ---- post-processing (model.py:505-514)
     {
 #pragma unroll
-      for (int oi = 0; oi < FGW_SPT; ++oi) {
-        const int sc = tid + oi * FGW_THREADS;
+      for (int oi = 0; oi < SPT; ++oi) {
+        const int sc = tid + oi * NT;
         if (sc < S)
           hbuf[sc] = fmaxf(acc[oi] + (g.skip_bsum ? g.skip_bsum[sc] : 0.f), 0.f);
       }
     }
     __syncthreads();
-    for (int sc = tid; sc < S; sc += FGW_THREADS) {
+    for (int sc = tid; sc < S; sc += NT) {
       const float c0 = fgw_dot(hbuf, g.post1_w + sc, S, S, g.post1_b ? g.post1_b[sc] : 0.f);
       h2buf[sc] = fmaxf(c0, 0.f);
     }
     __syncthreads();
-    for (int q = tid; q < Q; q += FGW_THREADS) {
+    for (int q = tid; q < Q; q += NT) {
       const float c0 = fgw_dot(h2buf, g.post2_w + q, Q, S, g.post2_b ? g.post2_b[q] : 0.f);
       pd[q] = (double)c0;
     }
@@ -1785,9 +1897,14 @@ int wn_fastgen_run_wide(const float* params_causal, const float* layer0,
     return WN_ERR_UNSUPPORTED;
   const size_t lds = fgw_lds_bytes(C, S, Q, L);
   if (lds > 150 * 1024) return WN_ERR_UNSUPPORTED;
+  // 64 channels, at most 512 skip channels: every load of a layer requested
+  // at its top (WN_FGW_F64=0: the generic layer body, A/B)
+  const char* fe = getenv("WN_FGW_F64");
+  const bool f64 = C == 64 && S <= 512 && !(fe && fe[0] == '0');
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(fastgen_wide_kernel),
+        f64 ? reinterpret_cast<const void*>(fastgen_wide_kernel<true>)
+            : reinterpret_cast<const void*>(fastgen_wide_kernel<false>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return WN_ERR_LAUNCH;
   }
@@ -1806,8 +1923,12 @@ int wn_fastgen_run_wide(const float* params_causal, const float* layer0,
   g.use_dense_bias = use_biases;
   g.push = push;
   a.C = C;
-  hipLaunchKernelGGL(fastgen_wide_kernel, dim3(1), dim3(FGW_THREADS), lds,
-                     (hipStream_t)stream, a);
+  if (f64)
+    hipLaunchKernelGGL(fastgen_wide_kernel<true>, dim3(1), dim3(512), lds,
+                       (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(fastgen_wide_kernel<false>, dim3(1), dim3(FGW_THREADS), lds,
+                       (hipStream_t)stream, a);
   return wn_check_launch();
 }
 

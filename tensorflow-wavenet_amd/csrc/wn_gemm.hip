@@ -1722,11 +1722,13 @@ __global__ void reduce_slabs4_kernel(const float* __restrict__ slabs,
 // sums = bias gradient) to dst_tail, `replicate` copies rep_stride apart (the
 // skip convs' bias gradients are the same row for every layer).  Same fixed
 // order as reduce_slabs4<4>.
-// (sixteen waves per workgroup, each a sixteenth of the slabs -- and of the
-// (slab, row) pairs of a spread column-sum tail: with four the two tail
-// workgroups of a dWs reduction took 34 us, the others 19)
+// (RMT_PARTS waves per workgroup, each that share of the slabs -- and of the
+// (slab, row) pairs of a spread column-sum tail.  Measured inside the B = 8 step
+// under rocprofv3, average of the three launches: 4 waves 32.0 us, 8 32.3,
+// 16 37.8 -- the two tail workgroups of a dWs reduction are faster with sixteen,
+// the launch as a whole is not.)
 #ifndef RMT_PARTS
-#define RMT_PARTS 16
+#define RMT_PARTS 4
 #endif
 __global__ __launch_bounds__(64 * RMT_PARTS) void reduce_slabs_mt_kernel(
     const float* __restrict__ slabs, int num_slabs, long slab_stride, long n_main4,

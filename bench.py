@@ -347,6 +347,10 @@ def main():
     ap.add_argument('--gemm-mode', default='fp32',
                     choices=['fp32', 'bf16x3', 'bf16x6', 'bf16x9'],
                     help='opt-in split-bf16 NN GEMMs (default: fp32 MFMA)')
+    ap.add_argument('--set', action='append', default=[], metavar='ATTR=VALUE',
+                    help='A/B runs: set a WaveNetModel attribute (a Python '
+                         'literal), e.g. --set stack_fwd=False --set '
+                         'stack_variant=0x1010; repeatable')
     ap.add_argument('--no-secondary', action='store_true',
                     help='skip the forward-only and fast-generation figures')
     args = ap.parse_args()
@@ -394,14 +398,12 @@ def main():
                               device=dev)
     net = WaveNetModel(seed=0, **kw)
     net.gemm_mode = args.gemm_mode
-    if os.environ.get('WN_LAUNCH_PLANS') is not None:    # A/B knob
-        net.use_launch_plans = os.environ['WN_LAUNCH_PLANS'] == '1'
-    if os.environ.get('WN_FUSED_BWD') is not None:       # A/B knob
-        net.fused_bwd = os.environ['WN_FUSED_BWD'] == '1'
-    if os.environ.get('WN_OVERLAP_TN') is not None:      # A/B knob
-        net.overlap_tn = os.environ['WN_OVERLAP_TN'] == '1'
-    if os.environ.get('WN_OVERLAP_WGRAD') is not None:   # A/B knob
-        net.overlap_wgrad = os.environ['WN_OVERLAP_WGRAD'] == '1'
+    for item in args.set:        # A/B knobs: explicit model attributes
+        import ast
+        name, _, val = item.partition('=')
+        if not hasattr(net, name):
+            raise SystemExit('bench.py --set: WaveNetModel has no attribute %r' % name)
+        setattr(net, name, ast.literal_eval(val))
     parallel.broadcast_parameters(net)
     opt = optimizer_factory['adam'](learning_rate=1e-3, momentum=0.9)
     audio = torch.from_numpy(synth_audio(B, T, first_clip=rank * B)).to(dev)

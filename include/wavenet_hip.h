@@ -226,20 +226,18 @@ int wn_layer_bwd2(const float* x, const float* z, const float* sg,
  *   X, Z, SG, dZ     : [L][B*T][32] planes, layer-major (X[0] = causal layer
  *                      output; forward writes X[1..L-1], Z, SG; backward reads
  *                      X, Z, SG, dZ)
- *   DX, dx_layer_stride : the backward writes dL/dx_l at DX + l * dx_layer_stride
- *                      floats: DX[0] = dL/dx_0; for l > 0 dL/dx_l when Q is
- *                      NULL, else dL/dx_l WITHOUT the anti-causal tap's term,
- *                      which is Q[l] at the rows d_l later.  dx_layer_stride =
- *                      B*T*32 keeps every layer's plane ([L][B*T][32]); with Q
- *                      given it may be 0: ONE [B*T][32] plane rewritten in
+ *   DX, dx_layer_stride : the backward writes, at DX + l * dx_layer_stride
+ *                      floats, dL/dx_0 for l = 0 and for l > 0 dL/dx_l WITHOUT the
+ *                      anti-causal tap's term, which is Q[l] at the rows d_l
+ *                      later.  dx_layer_stride = B*T*32 keeps every layer's
+ *                      plane ([L][B*T][32]); 0: ONE [B*T][32] plane rewritten in
  *                      place from layer to layer (a tile's own rows have no
  *                      other reader; they stay in the L2 / Infinity Cache
  *                      instead of travelling to HBM and back every layer)
- *   Q                : NULL, or an [L][B*T][32] scratch like DX: the backward
- *                      then runs its "push" formulation (a tile publishes
- *                      q_l[s] = da_l[s] W[0]^T, what its rows contribute to the
- *                      rows d earlier, instead of every tile re-deriving da at
- *                      the rows d later; fewer bytes and MFMAs)
+ *   Q                : an [L][B*T][32] scratch: a tile publishes q_l[s] =
+ *                      da_l[s] W[0]^T, what its rows contribute to the rows d
+ *                      earlier (the "push" formulation; every tile re-deriving
+ *                      da at the rows d later cost more bytes and MFMAs)
  *   wimg             : [L][wn_stack_wimg_floats()] weight images out of
  *                      wn_stack_pack (rows of 36 floats so that four MFMA
  *                      operands are one 16-byte LDS read; forward: the five
@@ -259,18 +257,33 @@ int wn_layer_bwd2(const float* x, const float* z, const float* sg,
  *                      makes the failure loud without a host synchronisation
  *   forward and backward use SEPARATE flags / ctl buffers.
  *   slabs            : [L][slab_layer_stride floats], slab g of layer l at
- *                      l * slab_layer_stride + g * 5216, g < wn_stack_bwd_slabs(B, T)
+ *                      l * slab_layer_stride + g * 5216, g < wn_stack_bwd_slabs(B, T, variant)
  *   tilesum          : as wn_layer_bwd2 ([L][tiles][64] or NULL), tiles =
- *                      B * ceil(T / wn_stack_tile_rows(B, T))
+ *                      B * ceil(T / wn_stack_tile_rows(B, T, variant))
  * Tile height: 32 rows; 16 for small batches (wn_stack_tile_rows: at most four
  * 32-row tiles per CU -- the launches are then bound by one wave's dependent
  * path through a layer, and a 16-row tile on v_mfma_f32_16x16x4_f32 halves
  * that path).  Both launches of a shape use the same height; it sets the slab count
  * (wn_stack_bwd_slabs) and the tilesum layout.  The 16-row results agree with
  * the 32-row ones to rounding (another summation grouping), not bitwise.
+ *   variant          : 0 = the library's choice for the shape (what every
+ *                      production caller passes), or a word built with
+ *                      WN_STACK_VARIANT for A/B runs and tests.  The same word
+ *                      goes to wn_stack_tile_rows / wn_stack_bwd_slabs /
+ *                      wn_stack_fwd / wn_stack_bwd of one step: behaviour is a
+ *                      function of the arguments only (no process environment
+ *                      is read anywhere in the library).
  * L <= 256. */
+/* rows: 0 (auto), 16 or 32 rows per tile; waves: 0 (auto) or waves per
+ * workgroup (16-row launches: 4 / 8; 32-row backward: 1 / 2 / 4 / 8; the 32-row
+ * forward ignores it); flags: WN_STACK_SPLIT */
+#define WN_STACK_VARIANT(rows, waves, flags) \
+  (((rows) & 0x3f) | (((waves) & 0xf) << 8) | (flags))
+/* backward, 16-row tiles: the weight gradients on waves of their own
+ * (stack_bwd16s_kernel) */
+#define WN_STACK_SPLIT 0x1000
 long wn_stack_flag_count(int B, int T, int L);
-int wn_stack_tile_rows(int B, int T);
+int wn_stack_tile_rows(int B, int T, int variant);
 int wn_stack_wimg_floats(void);
 int wn_stack_pack(const float* layer0, long layer_stride, float* wimg_fwd,
                   float* wimg_bwd, int L, void* stream);
@@ -278,14 +291,14 @@ int wn_stack_fwd(float* X, float* Z, float* SG, const float* wimg,
                  const float* bias, long bias_layer_stride,
                  int bias_clip_stride, const int* dilations, unsigned* flags,
                  unsigned* ctl, float* poison, int L, int B, int T, int save_sg,
-                 void* stream);
-int wn_stack_bwd_slabs(int B, int T);
+                 int variant, void* stream);
+int wn_stack_bwd_slabs(int B, int T, int variant);
 int wn_stack_bwd(const float* X, const float* Z, const float* SG,
                  const float* dZ, float* DX, long dx_layer_stride, float* Q,
                  const float* wimg, float* slabs,
                  long slab_layer_stride, float* tilesum, const int* dilations,
                  unsigned* flags, unsigned* ctl, float* poison, int L, int B,
-                 int T, void* stream);
+                 int T, int variant, void* stream);
 
 /* ---- fp32 MFMA GEMMs: the skip sum + post-processing of
  * wavenet/model.py:303-305, 430-440 (_create_network) and their gradients.
@@ -300,36 +313,6 @@ int wn_gemm_nn(const float* A, long lda, int a_planes, long a_plane_stride,
                long ldc, int c_planes, long c_plane_stride, float* Cpre,
                long M, int N, int K, int relu, void* stream);
 
-/* ---- a CHAIN of row-wise dependent NN GEMMs in one persistent launch
- * (csrc/wn_gemm.hip, gemm_nn_chain_kernel): the skip sum -> postprocess1 ->
- * postprocess2 of wavenet/model.py:430-440 as ONE launch, and their data
- * gradients (dlogits W2^T -> . W1^T -> . Ws^T) as another.  Problem p + 1 may
- * read, as A operand / addend / mask, what problem p writes (C, Cpre) -- row
- * block by row block: a 128-row block of p + 1 starts as soon as every column
- * tile of that row block of p is stored, so one problem's ragged end overlaps
- * the next one's start.  Bitwise the results of nprob wn_gemm_nn calls.
- *   wn_nn_problem : the arguments of wn_gemm_nn; all problems the same M,
- *                   K % 16 == 0, operands < 2 GB (else WN_ERR_UNSUPPORTED:
- *                   issue the single calls)
- *   nx            : XCD work queues, the value wn_gemm_nn_chain_probe returned
- *                   (8: whole MI355X; 1: single-XCD partition; 0: do not call)
- *   ctl           : wn_gemm_nn_chain_ctl_words(M) uint32, zero before first
- *                   use, re-armed by the kernel; ctl[9] != 0 after a launch: a
- *                   bounded dependency wait (2 s) expired or tiles were left
- *                   uncomputed -- results invalid (sticky; the caller clears it)
- *   poison        : NULL, or one float that is set to NaN in that case
- * wn_gemm_nn_chain_probe launches a tiny kernel and SYNCHRONISES the stream:
- * call it once per process / device; scratch = 1024 uint32 of device memory. */
-typedef struct wn_nn_problem {
-  const float* A; long lda; int a_planes; long a_plane_stride;
-  const float* W; int ldw; const float* bias; const float* mask; long ld_mask;
-  const float* addend; long ld_add; float* C; long ldc; int c_planes;
-  long c_plane_stride; float* Cpre; long M; int N, K, relu;
-} wn_nn_problem;
-long wn_gemm_nn_chain_ctl_words(long M);
-int wn_gemm_nn_chain_probe(unsigned* scratch, void* stream);
-int wn_gemm_nn_chain(const wn_nn_problem* probs, int nprob, int nx, unsigned* ctl,
-                     float* poison, void* stream);
 /* opt-in: same contraction with fp32 accuracy rebuilt from bf16 matrix
  * instructions (every operand split exactly into three bf16 pieces, nprod =
  * 3 / 6 / 9 piece products; 6 is as accurate as the fp32 MFMA path).
@@ -529,8 +512,12 @@ int wn_fastgen_finish(int Q, int32_t* cursors, int32_t* samples_io,
  * entry.  sync: 16 uint32 (zeroed by the call; sync[12] != 0 afterwards = a
  * bounded wait expired, results invalid); ll: wn_fastgen_persist_ll_words(L, S,
  * Q) 8-byte hand-over words (payload + step in one store; zeroed by the call).
- * Needs wn_fastgen_persist_workgroups(L, S, Q) <= CUs (all resident at once),
- * else WN_ERR_UNSUPPORTED: use wn_fastgen_step. */
+ * Needs all wn_fastgen_persist_workgroups(L, S, Q) workgroups resident at once
+ * (checked against hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs for the
+ * launch configuration), else WN_ERR_UNSUPPORTED, returned before anything is
+ * written: use wn_fastgen_step.  CUs held by another process or stream are
+ * invisible to that check: they surface as sync[12] -- the caller restores its
+ * own snapshot of state / cursors / pre and takes the step kernels. */
 int wn_fastgen_persist_workgroups(int L, int S, int Q);
 long wn_fastgen_persist_ll_words(int L, int S, int Q);
 int wn_fastgen_persist(const float* params_causal, const float* layer0,

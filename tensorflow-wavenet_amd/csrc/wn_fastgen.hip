@@ -347,7 +347,10 @@ __global__ __launch_bounds__(FG_THREADS, 1) void fastgen_kernel(FastGen g) {
         const double total = __shfl(incl, 63);
         const uint64_t r = splitmix64(g.seed ^ splitmix64((uint64_t)tpos));
         const double u = (double)(r >> 11) * (1.0 / 9007199254740992.0) * total;
-        const double excl = incl - seg;
+        // (the neighbour's inclusive sum, not incl - seg: the lanes' intervals
+        // then tile [0, total) exactly -- no gap a draw could fall into)
+        const double up = __shfl_up(incl, 1);
+        const double excl = lane == 0 ? 0.0 : up;
         int pick = -1;
         if (u >= excl && u < incl) {
           double c = excl;
@@ -750,7 +753,10 @@ __global__ __launch_bounds__(F64 ? 512 : FGW_THREADS, 1) void fastgen_wide_kerne
         const double total = __shfl(incl, 63);
         const uint64_t r = splitmix64(g.seed ^ splitmix64((uint64_t)tpos));
         const double u = (double)(r >> 11) * (1.0 / 9007199254740992.0) * total;
-        const double excl = incl - seg;
+        // (the neighbour's inclusive sum, not incl - seg: the lanes' intervals
+        // then tile [0, total) exactly -- no gap a draw could fall into)
+        const double up = __shfl_up(incl, 1);
+        const double excl = lane == 0 ? 0.0 : up;
         int pick = -1;
         if (u >= excl && u < incl) {
           double c = excl;
@@ -1253,7 +1259,10 @@ __device__ __forceinline__ int fg_draw_wave(const FgStep& g, double* pd, int lan
     const double total = __shfl(incl, 63);
     const uint64_t r = splitmix64(seed ^ splitmix64((uint64_t)steps_done));
     const double u = (double)(r >> 11) * (1.0 / 9007199254740992.0) * total;
-    const double excl = incl - seg;
+    // (the neighbour's inclusive sum, not incl - seg: the lanes' intervals
+    // then tile [0, total) exactly -- no gap a draw could fall into)
+    const double up = __shfl_up(incl, 1);
+    const double excl = lane == 0 ? 0.0 : up;
     int pick = -1;
     if (u >= excl && u < incl) {
       double c = excl;
@@ -1493,10 +1502,14 @@ __device__ __forceinline__ int fg_draw_wg256(const FgStep& g, const float* lgs, 
     double offs = 0.0;
     for (int w = 0; w < wave; ++w) offs += red[12 + w];
     const double total = (red[12] + red[13]) + (red[14] + red[15]);
+    // (exclusive bound = the neighbouring thread's inclusive sum -- the same
+    // additions, so the threads' intervals tile [0, total) exactly; incl - seg
+    // could leave a gap of an ulp that a draw falls into)
+    const double up = __shfl_up(incl, 1);
+    const double excl = (lane == 0 ? 0.0 : up) + offs;
     incl += offs;
     const uint64_t r = splitmix64(seed ^ splitmix64((uint64_t)steps_done));
     const double u = (double)(r >> 11) * (1.0 / 9007199254740992.0) * total;
-    const double excl = incl - seg;
     if (q1 > q0 && u >= excl && u < incl) {
       double c = excl;
       int pick = q1 - 1;
@@ -1898,9 +1911,8 @@ int wn_fastgen_run_wide(const float* params_causal, const float* layer0,
   const size_t lds = fgw_lds_bytes(C, S, Q, L);
   if (lds > 150 * 1024) return WN_ERR_UNSUPPORTED;
   // 64 channels, at most 512 skip channels: every load of a layer requested
-  // at its top (WN_FGW_F64=0: the generic layer body, A/B)
-  const char* fe = getenv("WN_FGW_F64");
-  const bool f64 = C == 64 && S <= 512 && !(fe && fe[0] == '0');
+  // at its top (other shapes: the generic layer body)
+  const bool f64 = C == 64 && S <= 512;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(
         f64 ? reinterpret_cast<const void*>(fastgen_wide_kernel<true>)
@@ -1996,7 +2008,8 @@ int wn_fastgen_finish(int Q, int32_t* cursors, int32_t* samples_io,
 // by this call), `xhand`: 8 x 32 floats of scratch.  After the launch
 // sync[12] != 0 means a bounded wait (2 s) expired: the samples are invalid.
 // Needs every workgroup resident at once: nseg + 2 * ceil(S / 16) +
-// ceil(Q / 16) + 1 <= CUs, else WN_ERR_UNSUPPORTED (use wn_fastgen_step).
+// ceil(Q / 16) + 1 workgroups against the occupancy the runtime reports for the
+// launch configuration x CUs, else WN_ERR_UNSUPPORTED (use wn_fastgen_step).
 // 8-byte hand-over words of wn_fastgen_persist (z, h1, h2, logits, x, code)
 long wn_fastgen_persist_ll_words(int L, int S, int Q) {
   if (L <= 0 || S <= 0 || Q <= 0) return 0;
@@ -2047,7 +2060,6 @@ int wn_fastgen_persist(const float* params_causal, const float* layer0,
   a.dbg = g_fgp_dbg;
 #endif
   const int wgs = wn_fastgen_persist_workgroups(L, S, Q);
-  if (wgs > wn_device_cus()) return WN_ERR_UNSUPPORTED;
   // dynamic LDS: the largest role
   size_t chain = (size_t)per * FGC_CW + per * 64 + per * 32 + 64 + 2 * FGP_SEGL + 8 + 2 * FGP_SEGL;
   size_t skip = (size_t)((L * 32 + 3) & ~3) + (size_t)L * 32 * 16 + 256;
@@ -2063,6 +2075,15 @@ int wn_fastgen_persist(const float* params_causal, const float* layer0,
   if (hipFuncSetAttribute((const void*)fg_persist_kernel,
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
     return WN_ERR_LAUNCH;
+  // every workgroup must be resident at once: ask the runtime how many of THIS
+  // launch configuration (registers, dynamic LDS) fit on a CU instead of
+  // assuming one -- a non-resident grid is refused here, before anything is
+  // written, and the caller takes the step kernels
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)fg_persist_kernel,
+                                                   FGP_THREADS, bytes) != hipSuccess)
+    return WN_ERR_LAUNCH;
+  if (per_cu < 1 || (long)wgs > (long)per_cu * wn_device_cus()) return WN_ERR_UNSUPPORTED;
   if (hipMemsetAsync(sync, 0, FGP_WORDS * sizeof(unsigned), s) != hipSuccess ||
       hipMemsetAsync(ll, 0, (size_t)wn_fastgen_persist_ll_words(L, S, Q) * 8, s) != hipSuccess)
     return WN_ERR_LAUNCH;

@@ -16,7 +16,7 @@
 //
 // Kernels in this file
 //   gemm_nn3_kernel      default NN: LDS-DMA staging, 4 workgroups / CU
-//   gemm_nn_kernel       NN fallback (K % 16 != 0, WN_NN_MODE=tile): register
+//   gemm_nn_kernel       NN fallback (K % 16 != 0): register
 //                        staging, K chunks of 32, every edge predicated
 //   gemm_tn3_kernel      default TN for wide outputs (dWs / dW1 / dW2)
 //   gemm_tn2_kernel      its register-staged fallback (ragged row counts)
@@ -398,21 +398,13 @@ __device__ __forceinline__ void mma_split(f32x16& acc, const Split3& a, const Sp
 }
 
 // One 128 x 128 output tile of C = epi(A W): tile column `tile_n`, rows from m0
-// (the tile owns [m0, m_end)).  A_AUX: cache policy of the activation loads
-// (gemm_nn_chain_kernel: 1 = sc0, past the vector L1, for operands another
-// workgroup of the same XCD wrote earlier in the launch).
+// (the tile owns [m0, m_end)).
 // Waves whose 64 columns lie entirely beyond N (the second half of the last
 // column tile when N % 128 == 64: the dZ GEMM's N = 1600) stage and
 // synchronise but issue no MFMAs: 3.8 % of that launch's matrix work.
-// `landed()` runs once, after the first chunk's barrier: every memory
-// operation the workgroup issued BEFORE this tile has completed by then (each
-// wave waited vmcnt(0) in front of that barrier) -- the chain kernel publishes
-// its previous tile there instead of draining its stores at the tile's end.
-struct nn3_nop { __device__ __forceinline__ void operator()() const {} };
-template <int A_AUX, bool STAMPS, typename F = nn3_nop>
+template <bool STAMPS>
 __device__ __forceinline__ void nn3_tile(const GemmNN& g, float* smem, int tile_n, long m0,
-                                         long m_end, unsigned long long* dbg,
-                                         F landed = F()) {
+                                         long m_end, unsigned long long* dbg) {
 #define NSTAMP(i) if (STAMPS && threadIdx.x == 0) dbg[i] = __builtin_amdgcn_s_memtime()
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -448,8 +440,8 @@ __device__ __forceinline__ void nn3_tile(const GemmNN& g, float* smem, int tile_
     const __amdgpu_buffer_rsrc_t rsA = ep_rsrc(
         g.A + (g.a_planes ? (long)(kc >> 1) * g.a_plane_stride + (kc & 1) * 16 : (long)kc * N3_KC));
     const __amdgpu_buffer_rsrc_t rsW = ep_rsrc(g.W + (long)kc * N3_KC * g.ldw);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(base + wave * 256), 16, va0, 0, 0, A_AUX);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(base + (wave + 4) * 256), 16, va1, 0, 0, A_AUX);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(base + wave * 256), 16, va0, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(base + (wave + 4) * 256), 16, va1, 0, 0, 0);
     float* wb = base + NN_TM * N3_KC;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lptr_t)(wb + wave * 256), 16, vw0, 0, 0, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lptr_t)(wb + (wave + 4) * 256), 16, vw1, 0, 0, 0);
@@ -468,7 +460,6 @@ __device__ __forceinline__ void nn3_tile(const GemmNN& g, float* smem, int tile_
   if (!live) {
     for (int kc = 0; kc < nk; ++kc) {
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-      if (kc == 0) landed();
       if (kc + 1 < nk) stage(kc + 1, smem + ((kc & 1) ^ 1) * N3_STAGE);
     }
   }
@@ -481,7 +472,6 @@ __device__ __forceinline__ void nn3_tile(const GemmNN& g, float* smem, int tile_
     // also retires every wave's reads of the stage that is refilled next
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     if (STAMPS && kc == 0) { NSTAMP(1); }
-    if (kc == 0) landed();
     if (kc + 1 < nk) stage(kc + 1, smem + (ST ^ 1) * N3_STAGE);
     const float* As = smem + ST * N3_STAGE;
     const float* Bs = As + NN_TM * N3_KC;
@@ -556,270 +546,13 @@ __global__ __launch_bounds__(256, 4) void gemm_nn3_kernel(GemmNN g) {
   const long m0 = (long)(logical / g.tiles_n) * g.tile_rows;
   const long m_end = m0 + g.tile_rows < g.M ? m0 + g.tile_rows : g.M;
 #ifdef NN3_STAMPS
-  nn3_tile<0, true>(g, smem, tile_n, m0, m_end, dbg);
+  nn3_tile<true>(g, smem, tile_n, m0, m_end, dbg);
   if (threadIdx.x == 0) dbg[7] = __builtin_amdgcn_s_memrealtime();
 #else
-  nn3_tile<0, false>(g, smem, tile_n, m0, m_end, dbg);
+  nn3_tile<false>(g, smem, tile_n, m0, m_end, dbg);
 #endif
 }
 
-// ---------------------------------------------------------------------------
-// A CHAIN of row-wise dependent NN GEMMs in ONE persistent launch (round 4):
-//   forward   total/h1 = relu(Z Ws) -> h2 = relu(h1 W1) -> logits = h2 W2
-//   backward  dc1 = dlogits W2^T * mask -> dtotal = dc1 W1^T * mask -> dZ = dtotal Ws^T
-// (wavenet/model.py:430-440 and their gradients).  Problem p + 1 reads, as A
-// operand / addend, rows that problem p wrote -- but only the SAME rows: a
-// 128-row block of p + 1 depends on the (up to 13) column tiles of that row
-// block of p and on nothing else.  As six launches every GEMM pays its own
-// ragged end (4000 tiles on 1024 workgroup slots: the last tenth of a launch
-// runs at 35 - 40 % residency, 8 - 14 % of the K = 256 / 512 launches) and
-// its own start.  Here 4 workgroups per CU stay resident and take tiles from a
-// queue that runs through all problems in dependency order, so one problem's
-// ragged end is the next one's start.
-//   * one queue PER XCD: the row blocks are split evenly over the XCDs (as
-//     xcd_remap does for the single launches: an activation tile is fetched by
-//     one L2) and a workgroup takes tickets from the queue of the XCD it
-//     really runs on (s_getreg HW_REG_XCC_ID).  Producer and consumer of a row
-//     block therefore share an L2: the intermediate rows are handed over by
-//     plain stores (acknowledged by the L2: s_waitcnt vmcnt(0)) and loads past
-//     the vector L1 (sc0) -- no device-scope traffic for 0.26 GB operands that
-//     up to 13 tiles re-read;
-//   * done[p][row block] counts finished column tiles (agent-scope relaxed
-//     atomics, after the stores are acknowledged); a tile of problem p + 1
-//     polls the one counter of its row block (bounded, like the stack
-//     kernels: on expiry ctl error + NaN poison, the grid still drains);
-//   * tickets of a queue run problem-major, row-block-major, so a waiting
-//     tile waits only for tiles whose tickets were taken earlier: no deadlock
-//     whatever the residency; the next ticket is requested while the current
-//     tile computes;
-//   * the last workgroup out re-arms the control block (tickets, counters)
-//     and checks that every queue was drained (an XCD without workgroups would
-//     leave tiles uncomputed: error + poison, never silently).
-// Results are bitwise those of the single launches (same tile arithmetic).
-// ---------------------------------------------------------------------------
-#define NNC_MAXP 3
-#ifndef NNC_A_AUX
-#define NNC_A_AUX 1   // activation loads of the chain kernel: sc0 (past the vector L1)
-#endif
-#define NNC_CTL_HDR 16        // [0..7] tickets, [8] workgroups out, [9] error, [10] tiles done
-struct GemmNNChain {
-  GemmNN p[NNC_MAXP];         // (first member: read from the kernarg segment by index)
-  int np, nx;                 // problems, XCD queues (1 or 8)
-  int tiles_m;
-  unsigned* ctl;              // NNC_CTL_HDR + np * tiles_m words, zero before first use
-  float* poison;
-};
-
-__global__ __launch_bounds__(256, 4) void gemm_nn_chain_kernel(GemmNNChain a) {
-#ifdef NNC_STAMPS   // diagnostic build: a.poison carries a stamp buffer [grid][32 tiles][8]
-  unsigned long long* cdbg = reinterpret_cast<unsigned long long*>(a.poison) + (size_t)blockIdx.x * 256;
-  a.poison = nullptr;
-  int ctile = 0;
-#define CSTAMP(i) if (threadIdx.x == 0 && ctile < 32) cdbg[ctile * 8 + (i)] = __builtin_amdgcn_s_memrealtime()
-#else
-#define CSTAMP(i)
-#endif
-  __shared__ __attribute__((aligned(1024))) float smem[NN3_LDSF];
-  __shared__ int s_ticket, s_flag;
-  const int tid = threadIdx.x;
-  unsigned xcc = 0;
-  if (a.nx > 1) {
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    xcc &= 15u;
-  }
-  const bool lost = xcc >= (unsigned)a.nx;        // (never on a validated topology)
-  if (lost) xcc = 0;
-  const int rb0 = (int)((long)xcc * a.tiles_m / a.nx);
-  const int nrb = (int)((long)(xcc + 1) * a.tiles_m / a.nx) - rb0;
-  const int tn0 = a.p[0].tiles_n, tn1 = a.np > 1 ? a.p[1].tiles_n : 0,
-            tn2 = a.np > 2 ? a.p[2].tiles_n : 0;
-  // the current tile's problem descriptor is read from the kernarg segment by
-  // index (scalar loads into ~40 SGPRs, as in the single-problem kernel; three
-  // by-value structs selected by branches cost 320 spilled SGPRs and three
-  // inlined copies of the tile body: 2564 instead of ~2300 us per chain)
-  static_assert(offsetof(GemmNNChain, p) == 0, "descriptors lead the kernarg segment");
-  typedef const __attribute__((address_space(4))) unsigned* kernarg_u32_t;
-  const kernarg_u32_t kprobs = (kernarg_u32_t)__builtin_amdgcn_kernarg_segment_ptr();
-  static_assert(sizeof(GemmNN) % 4 == 0, "descriptor copied by dwords");
-  const int c1 = nrb * tn0, c2 = c1 + nrb * tn1, c3 = c2 + nrb * tn2;
-  unsigned* done = a.ctl + NNC_CTL_HDR;
-  if (lost && tid == 0) {
-    __hip_atomic_store(a.ctl + 9, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (a.poison) *a.poison = __builtin_nanf("");
-  }
-  // Tickets: a RETURNING atomic performed at the memory side, 3 - 5 us away
-  // (p90 12 us under load).  Written with the compiler's atomic the wave waits
-  // for the value on the spot (LLVM turns it into a wave reduction +
-  // s_waitcnt vmcnt(0) + v_readfirstlane) -- per tile: 50 - 100 us per chain at
-  // B = 8.  So thread 0 issues the instruction itself and reads the register
-  // only behind the next tile-top wait; between the two the register is
-  // "pending" and must not be copied or spilled by the compiler: it is an
-  // early-clobber asm output whose only use is the asm that waits
-  // (checked in the generated code; a broken ticket shows as a wrong tile
-  // count in ctl[10] -> error + poison, and in tests/test_gpu_gemm.py).
-  unsigned tick = (unsigned)c3;          // thread 0: the next ticket (pending after NNC_TICKET_ISSUE)
-  unsigned* const tickp = a.ctl + xcc;
-#define NNC_TICKET_ISSUE()                                                                   \
-  asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=&v"(tick) : "v"(tickp), "v"(1u) : "memory")
-#define NNC_TICKET_WAIT() asm volatile("s_waitcnt vmcnt(0)" : "+v"(tick) : : "memory")
-  if (tid == 0 && !lost) NNC_TICKET_ISSUE();
-  unsigned my_tiles = 0;
-  // the tile whose "stored" counter is still to be raised: a tile is published
-  // behind the NEXT tile's first chunk barrier (which waits for every older
-  // memory operation of the workgroup anyway) instead of behind a store drain
-  // of its own -- as the single launches do, where the next workgroup starts
-  // loading while the finished one's stores are still in flight
-  unsigned* pub = nullptr;
-  // (raw barriers: __syncthreads() waits for vmcnt(0) as well)
-#define NNC_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-  for (;;) {
-    if (tid == 0) {
-      NNC_TICKET_WAIT();
-      s_ticket = lost ? c3 : (int)tick;
-      s_flag = 0;
-    }
-    NNC_BARRIER();       // (also: every wave is through the previous tile's epilogue LDS reads)
-    const int t = __builtin_amdgcn_readfirstlane(s_ticket);
-    if (t >= c3) break;
-    CSTAMP(0);
-    // the NEXT ticket: requested now, read at the top of the next tile
-    if (tid == 0) NNC_TICKET_ISSUE();
-    const int p = t < c1 ? 0 : t < c2 ? 1 : 2;
-    const int i = t - (p == 0 ? 0 : p == 1 ? c1 : c2);
-    const int tn = p == 0 ? tn0 : p == 1 ? tn1 : tn2;
-    const int mb = rb0 + i / tn, tile_n = i - (i / tn) * tn;
-    if (p > 0) {
-      // every column tile of this row block of problem p - 1 is in the L2
-      if (tid == 0) {
-        const unsigned want = (unsigned)(p == 1 ? tn0 : tn1);
-        const unsigned* ctr = done + (size_t)(p - 1) * a.tiles_m + mb;
-        unsigned spins = 0;
-        unsigned long long t_start = 0;
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-          // (the row block may be waiting for THIS workgroup's previous tile)
-          if (pub) s_flag = 1;
-          __builtin_amdgcn_s_sleep(32);   // (~1 us: hundreds of pollers at the memory side slow the working tiles)
-          if ((++spins & 63u) == 0) {
-            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-            if (t_start == 0) t_start = now;
-            if (now - t_start > 200000000ull) {   // 2 s at 100 MHz
-              __hip_atomic_store(a.ctl + 9, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if (a.poison) *a.poison = __builtin_nanf("");
-              break;
-            }
-          }
-          if (pub) break;
-        }
-      }
-      NNC_BARRIER();
-      // dependency not there yet and a publish of our own pending: it may be
-      // the very tile awaited (same row block, previous problem) -- drain the
-      // workgroup's stores, publish, then wait properly
-      if (pub != nullptr && __builtin_amdgcn_readfirstlane(s_flag) == 1) {
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        if (tid == 0) {
-          __hip_atomic_fetch_add(pub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const unsigned want = (unsigned)(p == 1 ? tn0 : tn1);
-          const unsigned* ctr = done + (size_t)(p - 1) * a.tiles_m + mb;
-          unsigned spins = 0;
-          unsigned long long t_start = 0;
-          while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-            __builtin_amdgcn_s_sleep(32);   // (~1 us: hundreds of pollers at the memory side slow the working tiles)
-            if ((++spins & 63u) == 0) {
-              const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-              if (t_start == 0) t_start = now;
-              if (now - t_start > 200000000ull) {
-                __hip_atomic_store(a.ctl + 9, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (a.poison) *a.poison = __builtin_nanf("");
-                break;
-              }
-            }
-          }
-        }
-        pub = nullptr;
-        NNC_BARRIER();
-      }
-    }
-    CSTAMP(1);
-    const long m0 = (long)mb * NN_TM;
-    {
-      GemmNN g;
-      {
-        const kernarg_u32_t src = kprobs + p * (int)(sizeof(GemmNN) / 4);
-        unsigned* dst = reinterpret_cast<unsigned*>(&g);
-#pragma unroll
-        for (int k = 0; k < (int)(sizeof(GemmNN) / 4); ++k) dst[k] = src[k];
-      }
-      const long m_end = m0 + NN_TM < g.M ? m0 + NN_TM : g.M;
-      // (activation loads past the vector L1 for every problem: the first
-      // one's operand comes from an earlier launch, where it makes no
-      // difference -- one copy of the tile body)
-      unsigned* const pub_now = pub;
-      CSTAMP(2);
-      nn3_tile<NNC_A_AUX, false>(g, smem, tile_n, m0, m_end, nullptr, [&]() {
-        CSTAMP(3);
-        if (pub_now != nullptr && tid == 0)
-          __hip_atomic_fetch_add(pub_now, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      });
-      CSTAMP(4);
-#ifdef NNC_STAMPS
-      if (threadIdx.x == 0 && ctile < 32) cdbg[ctile * 8 + 6] = (unsigned long long)t;
-      ++ctile;
-#endif
-    }
-    pub = p + 1 < a.np ? done + (size_t)p * a.tiles_m + mb : nullptr;
-    if (tid == 0) ++my_tiles;
-  }
-  if (pub != nullptr) {
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    if (tid == 0)
-      __hip_atomic_fetch_add(pub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-#undef NNC_BARRIER
-#undef NNC_TICKET_ISSUE
-#undef NNC_TICKET_WAIT
-  // the last workgroup out: every tile computed?  re-arm the control block
-  if (tid == 0) {
-    if (my_tiles)
-      __hip_atomic_fetch_add(a.ctl + 10, my_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // (both adds are performed at the memory side; the first one is
-    // acknowledged before the second is issued.  No acquire / release here:
-    // at agent scope they write back and invalidate the XCD's whole L2 under
-    // the workgroups that are still computing -- 50 - 70 us per launch)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    s_ticket = (int)__hip_atomic_fetch_add(a.ctl + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  if (s_ticket == (int)gridDim.x - 1) {
-    if (tid == 0) {
-      const unsigned total = (unsigned)a.tiles_m * (unsigned)(tn0 + tn1 + tn2);
-      if (__hip_atomic_load(a.ctl + 10, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != total) {
-        __hip_atomic_store(a.ctl + 9, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (a.poison) *a.poison = __builtin_nanf("");
-      }
-    }
-    for (int k = tid; k < NNC_CTL_HDR + a.np * a.tiles_m; k += 256)
-      if (k != 9)
-        __hip_atomic_store(a.ctl + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
-// (Round 4 also built the chain WITHOUT the persistent loop: one tile per
-// workgroup, all problems in one grid whose linear order is the dependency
-// order, the hardware's in-order dispatch as the queue, workgroup -> XCD taken
-// as bid & 7.  It measured what the overlap is worth without any per-tile
-// loop cost -- forward chain 2176 vs 2201 us, backward 2295 vs 2290 us, the
-// step 9.39 - 9.40 vs 9.40 - 9.44 ms -- and it is not safe: which XCD
-// workgroup 0 of a launch lands on depends on what was dispatched before
-// (the in-kernel HW_REG_XCC_ID check fired behind small grids and beside
-// another stream's kernels), so same-XCD coherence cannot be taken from the
-// workgroup index.  Removed.)
-// the XCD a workgroup runs on, for wn_gemm_nn_chain_probe
-__global__ void xcc_probe_kernel(unsigned* out) {
-  unsigned x;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
-  if (threadIdx.x == 0) out[blockIdx.x] = x & 15u;
-}
 
 // ---------------------------------------------------------------------------
 // Split-bf16 NN GEMM (wn_gemm_nn_split): same tile / staging structure as
@@ -1981,12 +1714,11 @@ static int gemm_nn_launch(const float* A, long lda, int a_planes, long a_plane_s
                                   c_plane_stride, Cpre, M, N, K, relu);
   if (rc != WN_OK) return rc;
   const long nwg = g.nwg;
-  // default: three-stage LDS-DMA kernel, 3 workgroups / CU; WN_NN_MODE=tile
-  // (or K % 16 != 0): register-staged two-stage kernel
-  const char* me = getenv("WN_NN_MODE");
+  // default: LDS-DMA kernel, 4 workgroups / CU; K % 16 != 0 (or operands
+  // beyond 32-bit byte offsets): register-staged two-stage kernel
   if (wsplit && (K % N3_KC) != 0) return WN_ERR_UNSUPPORTED;
   if (wsplit && !wn_aligned16(wsplit)) return WN_ERR_MISALIGNED;
-  if (!wsplit && ((me && me[0] == 't') || !gemm_nn3_ok(g)))
+  if (!wsplit && !gemm_nn3_ok(g))
     hipLaunchKernelGGL(gemm_nn_kernel<2>, dim3((unsigned)nwg), dim3(256), 0,
                        (hipStream_t)stream, g);
   else if (wsplit) {
@@ -2013,86 +1745,6 @@ int wn_gemm_nn(const float* A, long lda, int a_planes, long a_plane_stride,
   return gemm_nn_launch(A, lda, a_planes, a_plane_stride, W, ldw, bias, mask,
                         ld_mask, addend, ld_add, C, ldc, c_planes,
                         c_plane_stride, Cpre, M, N, K, relu, stream);
-}
-
-// ---- a chain of row-wise dependent NN GEMMs in one persistent launch
-// (gemm_nn_chain_kernel).  wn_nn_problem = the arguments of wn_gemm_nn.
-struct wn_nn_problem {
-  const float* A; long lda; int a_planes; long a_plane_stride;
-  const float* W; int ldw; const float* bias; const float* mask; long ld_mask;
-  const float* addend; long ld_add; float* C; long ldc; int c_planes;
-  long c_plane_stride; float* Cpre; long M; int N, K, relu;
-};
-
-// uint32 words of the control block for problems of M rows (zero before first use)
-long wn_gemm_nn_chain_ctl_words(long M) {
-  if (M <= 0) return 0;
-  return NNC_CTL_HDR + (long)NNC_MAXP * ((M + NN_TM - 1) / NN_TM);
-}
-
-// XCD queues the chain kernel can use on the current device: 8 when the
-// device is a whole MI355X (256 CUs) whose workgroups report the eight XCC ids
-// evenly, 1 when it is a single-XCD partition, 0 = do not use the chain
-// (callers then issue the single launches).  Launches a probe kernel and
-// synchronises: call it once, outside any timed region.  `scratch`: 1024
-// uint32 of device memory.
-int wn_gemm_nn_chain_probe(unsigned* scratch, void* stream) {
-  if (!scratch) return 0;
-  const int cus = wn_device_cus();
-  if (cus <= 32) return 1;
-  if (cus != 256) return 0;
-  hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(xcc_probe_kernel, dim3(1024), dim3(64), 0, s, scratch);
-  if (hipGetLastError() != hipSuccess) return 0;
-  unsigned host[1024];
-  if (hipMemcpyAsync(host, scratch, sizeof(host), hipMemcpyDeviceToHost, s) != hipSuccess ||
-      hipStreamSynchronize(s) != hipSuccess)
-    return 0;
-  int hist[16] = {0};
-  for (int i = 0; i < 1024; ++i) hist[host[i] & 15]++;
-  for (int x = 0; x < 8; ++x)
-    if (hist[x] != 128) return 0;
-  return 8;
-}
-
-int wn_gemm_nn_chain(const wn_nn_problem* probs, int nprob, int nx, unsigned* ctl,
-                     float* poison, void* stream) {
-  if (!probs || !ctl) return WN_ERR_NULL;
-  if (nprob < 1 || nprob > NNC_MAXP || (nx != 1 && nx != 8)) return WN_ERR_BAD_SHAPE;
-  GemmNNChain a;
-  memset(&a, 0, sizeof(a));
-  GemmNN* gs[NNC_MAXP] = {&a.p[0], &a.p[1], &a.p[2]};
-  for (int i = 0; i < nprob; ++i) {
-    const wn_nn_problem& q = probs[i];
-    const int rc = gemm_nn_describe(*gs[i], q.A, q.lda, q.a_planes, q.a_plane_stride, q.W,
-                                    q.ldw, q.bias, q.mask, q.ld_mask, q.addend, q.ld_add,
-                                    q.C, q.ldc, q.c_planes, q.c_plane_stride, q.Cpre, q.M,
-                                    q.N, q.K, q.relu);
-    if (rc != WN_OK) return rc;
-    if (!gemm_nn3_ok(*gs[i])) return WN_ERR_UNSUPPORTED;
-    if (q.M != probs[0].M) return WN_ERR_BAD_SHAPE;      // row blocks must coincide
-  }
-  a.np = nprob; a.nx = nx; a.tiles_m = a.p[0].tiles_m; a.ctl = ctl; a.poison = poison;
-  long tiles = 0;
-  for (int i = 0; i < nprob; ++i) tiles += gs[i]->nwg;
-  if (tiles > 0x7fffffffL) return WN_ERR_BAD_SHAPE;
-  // Workgroups are dealt to the XCDs round robin: a multiple of nx puts the
-  // same number on every XCD, so every queue has somebody to drain it.  Per
-  // XCD: as many workgroups as its queue's LARGEST problem has tiles, at most
-  // four per CU -- a small batch (B = 1: 64 tiles of the skip sum per XCD) then
-  // runs two workgroups per CU like the single launches, instead of four on
-  // half the CUs beside 64 workgroups that wait for the next problem's rows
-  const long slots = 4L * wn_device_cus();
-  long per_x = 0;
-  const long rb_max = (a.tiles_m + nx - 1) / nx;
-  for (int i = 0; i < nprob; ++i)
-    if (rb_max * gs[i]->tiles_n > per_x) per_x = rb_max * gs[i]->tiles_n;
-  if (per_x > slots / nx) per_x = slots / nx;
-  if (per_x < 1) per_x = 1;
-  const long nwg = per_x * nx;
-  dim3 grid((unsigned)nwg);
-  hipLaunchKernelGGL(gemm_nn_chain_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
-  return wn_check_launch();
 }
 
 // Split-bf16 variant of wn_gemm_nn (opt-in): fp32 accuracy from bf16 matrix
@@ -2235,16 +1887,13 @@ int wn_gemm_tn(const float* A, long lda, int a_planes, long a_plane_stride,
       g.tiles_m = Mw / (mf2 * 32);
       g.tiles_n = Nw / (4 * nf2 * 32);
       dim3 grid2(g.tiles_m * g.tiles_n, splits), block2(256);
-      // LDS-DMA kernel when every split is whole 16-row chunks
-      // (WN_TN_MODE=reg selects the register-staged kernel)
-      const char* tme = getenv("WN_TN_MODE");
-      // (its staging addresses are 32-bit byte offsets of a buffer resource)
-      // (per workgroup: a tile's planes -- at most five -- and a split's rows)
+      // LDS-DMA kernel (its staging addresses are 32-bit byte offsets of a
+      // buffer resource: per workgroup a tile's planes -- at most five -- and a
+      // split's rows; ragged row counts: the kernel zero-fills its last chunk),
+      // else the register-staged kernel
       const long rps = (rows + splits - 1) / splits + 96;
       const long a_bytes = (a_planes ? 5 * a_plane_stride + rps * 32 : rps * lda) * 4;
-      // (ragged row counts: the kernel zero-fills its last chunk)
-      const bool dma = !(tme && tme[0] == 'r') &&
-                       a_bytes < (1L << 31) && rps * ldg * 4 < (1L << 31);
+      const bool dma = a_bytes < (1L << 31) && rps * ldg * 4 < (1L << 31);
 #define LAUNCH2(mf, nf)                                                          \
   do {                                                                           \
     if (dma) hipLaunchKernelGGL((gemm_tn3_kernel<mf, nf>), grid2, block2, 0, s, g); \

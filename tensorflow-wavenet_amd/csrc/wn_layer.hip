@@ -17,7 +17,6 @@
 // order inside each matrix), contiguous in the flat parameter buffer:
 //   Wf[2][32][32]  Wg[2][32][32]  Wd[32][32]  bf[32] bg[32] bd[32]
 #include "wn_common.h"
-#include <cstdlib>
 
 
 // Persistent workgroups: one 1024-thread workgroup (16 waves, 4 per SIMD) per
@@ -28,7 +27,7 @@
 
 // SAVE: what the backward pass will need besides x and z.  0 = nothing
 // (inference), 1 = tanh and sigmoid planes (un-fused / generic backward
-// kernels), 2 = the sigmoid plane only (layer_bwd2_kernel recovers tanh as
+// kernels), 2 = the sigmoid plane only (layer_bwd2d_kernel recovers tanh as
 // z / sigmoid: 512 instead of 640 bytes per sample and layer).
 template <bool HAS_DENSE, int SAVE>
 __global__ __launch_bounds__(LAYER_WG) void layer_fwd_kernel(
@@ -882,216 +881,6 @@ __global__ __launch_bounds__(BW_WG) void layer_bwdw_kernel(
 #define B2_WAVES 8
 // (B2_WIMG and gate_grad live in wn_common.h: wn_stack.hip shares them)
 
-// Register-staged form, kept for A/B (WN_B2_MODE=4p): WAVES = 4 is one wave
-// per SIMD with the whole register file, which is what its software pipeline
-// (PIPE: every load issued one phase ahead, through staging registers) needs;
-// with 8 waves it spills (150 - 300 VGPRs).  Measured at B*T = 128000: 46.6 us
-// vs 44.2 us for the LDS-DMA kernel below and 50.5 us for layer_bwdw_kernel.
-template <bool HAS_DXIN, int WAVES, bool PIPE>
-__global__ __launch_bounds__(WAVES * 64) void layer_bwd2_kernel(
-    const float* __restrict__ x, const float* __restrict__ z,
-    const float* __restrict__ sg, const float* __restrict__ dZ,
-    const float* __restrict__ dxin, float* __restrict__ dx_out,
-    const float* __restrict__ wblock, float* __restrict__ slabs,
-    float* __restrict__ tile_colsum, int B, int T, int d) {
-  constexpr int LDT = 33, MT = 32 * LDT;
-  __shared__ float wl[5 * MT];
-  __shared__ __attribute__((aligned(16))) float tiles[WAVES * 4 * 1024];
-  const int tid = threadIdx.x;
-  for (int i = tid; i < 5120; i += WAVES * 64) {
-    const int m = i >> 10, rr = (i >> 5) & 31, cc = i & 31;  // W[m][rr][cc]
-    wl[m * MT + cc * LDT + rr] = wblock[i];                  // m = 4: Wd
-  }
-  __syncthreads();
-  const int lane = tid & 63, wave = tid >> 6;
-  const int j = lane & 31, h = lane >> 5;
-  float* t0 = tiles + wave * 4096;
-  float* t1 = t0 + 1024;
-  float* t2 = t1 + 1024;
-  float* t3 = t2 + 1024;
-  const int tiles_per_clip = (T + 31) >> 5;
-  const int ntiles = tiles_per_clip * B;
-  f32x16 cf0 = frag_zero(), cf1 = frag_zero(), cg0 = frag_zero(),
-         cg1 = frag_zero(), cd = frag_zero();
-  float sf = 0.f, sgs = 0.f, sd = 0.f;
-  // Software pipeline over this wave's tiles: the global loads of a phase are
-  // issued one phase ahead of their use (rows t+d of the NEXT tile during the
-  // weight-gradient products, rows t during the t+d math, the x tiles during
-  // the rows-t math), so that no load latency sits on a tile's critical path.
-  const int tstep = gridDim.x * WAVES;
-  int tile = blockIdx.x * WAVES + wave;
-  RowRegs a0, a1, a2, a3;                  // rows t+d: dx_{l+1}, dZ, z, sigmoid
-  auto load_shifted = [&](int tl) {
-    const int b = tl / tiles_per_clip;
-    const int tt0 = (tl - b * tiles_per_clip) * 32;
-    const int hif = min(min(32, T - tt0), T - d - tt0);
-    const size_t offd = ((size_t)b * T + tt0 + d) * WN_CH;
-    if (hif > 0) {
-      if (HAS_DXIN) a0 = rows_load(dxin + offd, lane, 0, hif);
-      a1 = rows_load(dZ + offd, lane, 0, hif);
-      a2 = rows_load(z + offd, lane, 0, hif);
-      a3 = rows_load(sg + offd, lane, 0, hif);
-    }
-  };
-  if (PIPE && tile < ntiles) load_shifted(tile);
-  for (; tile < ntiles; tile += tstep) {
-    int woff = j + 4 * h * LDT;  // opaque: no hoisting of the weight reads
-    asm volatile("" : "+v"(woff));
-    const float* wlane = wl + woff;
-    const int b = tile / tiles_per_clip;
-    const int tt0 = (tile - b * tiles_per_clip) * 32;
-    const int hi = min(32, T - tt0);
-    const int hi_f = min(hi, T - d - tt0);  // rows whose t+d tap exists
-    const int lo_p = max(0, d - tt0);       // rows whose t-d tap exists
-    const size_t off0 = ((size_t)b * T + tt0) * WN_CH;
-    f32x16 dx = frag_zero();
-    if (!PIPE) load_shifted(tile);
-    if (hi_f > 0) {
-      if (HAS_DXIN) rows_to_lds(t0, lane, a0);
-      rows_to_lds(t1, lane, a1);
-      rows_to_lds(t2, lane, a2);
-      rows_to_lds(t3, lane, a3);
-    }
-    // rows t: in flight during the t+d math (PIPE) or loaded after it
-    RowRegs ri, rz, rzz, rs;
-    auto load_rows_t = [&]() {
-      if (HAS_DXIN) ri = rows_load(dxin + off0, lane, 0, hi);
-      rz = rows_load(dZ + off0, lane, 0, hi);
-      rzz = rows_load(z + off0, lane, 0, hi);
-      rs = rows_load(sg + off0, lane, 0, hi);
-    };
-    if (PIPE) load_rows_t();
-    __builtin_amdgcn_wave_barrier();
-    // ---- rows t+d: da[t+d] * W[0]^T
-    if (hi_f > 0) {
-      f32x16 dz = frag_from_lds(t1, j, h);
-      if (HAS_DXIN) {
-        const f32x16 di = frag_from_lds(t0, j, h);
-        mma32<LDT>(dz, di, wlane + 4 * MT);      // dx_{l+1}[t+d] * Wd^T
-      }
-      f32x16 df, dg;
-      gate_grad(dz, frag_from_lds(t2, j, h), frag_from_lds(t3, j, h), df, dg);
-      mma32<LDT>(dx, df, wlane + 0 * MT);        // da_f[t+d] * Wf[0]^T
-      mma32<LDT>(dx, dg, wlane + 2 * MT);        // da_g[t+d] * Wg[0]^T
-    }
-    __builtin_amdgcn_wave_barrier();
-    // ---- rows t
-    if (!PIPE) load_rows_t();
-    if (HAS_DXIN) rows_to_lds(t0, lane, ri);     // t0 keeps dx_{l+1}[t]
-    rows_to_lds(t1, lane, rz);
-    rows_to_lds(t2, lane, rzz);                  // t2 keeps z[t]
-    rows_to_lds(t3, lane, rs);
-    // the x tiles: in flight during the rows-t math
-    const RowRegs rxc = rows_load(x + off0, lane, 0, hi);
-    const RowRegs rxp = rows_load(x + off0 - (size_t)d * WN_CH, lane, lo_p, hi);
-    __builtin_amdgcn_wave_barrier();
-    {
-      f32x16 dz = frag_from_lds(t1, j, h);
-      if (HAS_DXIN) {
-        const f32x16 di = frag_from_lds(t0, j, h);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dx[r] += di[r];
-        mma32<LDT>(dz, di, wlane + 4 * MT);      // dx_{l+1}[t] * Wd^T
-      }
-      f32x16 df, dg;
-      gate_grad(dz, frag_from_lds(t2, j, h), frag_from_lds(t3, j, h), df, dg);
-      mma32<LDT>(dx, df, wlane + 1 * MT);        // da_f[t] * Wf[1]^T
-      mma32<LDT>(dx, dg, wlane + 3 * MT);        // da_g[t] * Wg[1]^T
-      __builtin_amdgcn_wave_barrier();
-      frag_to_lds(t1, j, h, df);                 // t1 / t3 now hold da[t]
-      frag_to_lds(t3, j, h, dg);
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (HAS_DXIN) {                              // dWd += z^T dx_{l+1}
-#pragma unroll 4
-      for (int s = 0; s < 16; ++s) {
-        const int row = 2 * s + h;
-        const float az = tile_elem(t2, row, j), bd = tile_elem(t0, row, j);
-        cd = __builtin_amdgcn_mfma_f32_32x32x2f32(az, bd, cd, 0, 0, 0);
-        sd += bd;
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-    frag_to_lds(t0, j, h, dx);
-    __builtin_amdgcn_wave_barrier();
-    rows_store(dx_out + off0, lane, hi, rows_from_lds(t0, lane));
-    __builtin_amdgcn_wave_barrier();
-    rows_to_lds(t2, lane, rxc);
-    rows_to_lds(t0, lane, rxp);
-    // next tile's rows t+d: in flight during the weight-gradient products
-    if (PIPE && tile + tstep < ntiles) load_shifted(tile + tstep);
-    __builtin_amdgcn_wave_barrier();
-    float tsf = 0.f, tsg = 0.f;          // this tile's column sums of da[t]
-#pragma unroll 4
-    for (int s = 0; s < 16; ++s) {       // dW[1] += x[t]^T da, dW[0] += x[t-d]^T da
-      const int row = 2 * s + h;
-      const float axc = tile_elem(t2, row, j), axp = tile_elem(t0, row, j);
-      const float bf = tile_elem(t1, row, j), bg = tile_elem(t3, row, j);
-      cf1 = __builtin_amdgcn_mfma_f32_32x32x2f32(axc, bf, cf1, 0, 0, 0);
-      cg1 = __builtin_amdgcn_mfma_f32_32x32x2f32(axc, bg, cg1, 0, 0, 0);
-      cf0 = __builtin_amdgcn_mfma_f32_32x32x2f32(axp, bf, cf0, 0, 0, 0);
-      cg0 = __builtin_amdgcn_mfma_f32_32x32x2f32(axp, bg, cg0, 0, 0, 0);
-      tsf += bf;
-      tsg += bg;
-    }
-    sf += tsf;
-    sgs += tsg;
-    if (tile_colsum) {
-      // per-tile column sums (a tile lies inside one clip): the per-clip sums
-      // the global-conditioning gradients need (model.py:272-284 under
-      // autodiff) without a separate pass over da
-      const float a = tsf + __shfl_xor(tsf, 32), b2 = tsg + __shfl_xor(tsg, 32);
-      if (h == 0) {
-        tile_colsum[(size_t)tile * 64 + j] = a;
-        tile_colsum[(size_t)tile * 64 + 32 + j] = b2;
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-  // ---- weight-gradient slab of this workgroup (fixed-order wave reduction)
-  sf += __shfl_xor(sf, 32);
-  sgs += __shfl_xor(sgs, 32);
-  sd += __shfl_xor(sd, 32);
-  __syncthreads();
-  float* red = tiles;
-  for (int w = 0; w < WAVES; ++w) {
-    if (wave == w) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = 8 * (r >> 2) + 4 * h + (r & 3);
-        const int e = m * 32 + j;
-        if (w == 0) {
-          red[0 * 1024 + e] = cf0[r];
-          red[1 * 1024 + e] = cf1[r];
-          red[2 * 1024 + e] = cg0[r];
-          red[3 * 1024 + e] = cg1[r];
-          red[4 * 1024 + e] = cd[r];
-        } else {
-          red[0 * 1024 + e] += cf0[r];
-          red[1 * 1024 + e] += cf1[r];
-          red[2 * 1024 + e] += cg0[r];
-          red[3 * 1024 + e] += cg1[r];
-          red[4 * 1024 + e] += cd[r];
-        }
-      }
-      if (h == 0) {
-        if (w == 0) {
-          red[LAYER_W_FLOATS + j] = sf;
-          red[LAYER_W_FLOATS + 32 + j] = sgs;
-          red[LAYER_W_FLOATS + 64 + j] = sd;
-        } else {
-          red[LAYER_W_FLOATS + j] += sf;
-          red[LAYER_W_FLOATS + 32 + j] += sgs;
-          red[LAYER_W_FLOATS + 64 + j] += sd;
-        }
-      }
-    }
-    __syncthreads();
-  }
-  float* out = slabs + (size_t)blockIdx.x * LAYER_BLOCK_FLOATS;
-  for (int e = tid; e < LAYER_BLOCK_FLOATS; e += WAVES * 64) out[e] = red[e];
-}
-
 // Weight image of layer_bwd2d_kernel: the five 32 x 32 matrices of a layer
 // block transposed with row stride 33 ([m][cout cc][cin rr] at m*1056 + cc*33 +
 // rr; the layout the kernel's LDS reads are conflict-free on), one 21 KiB
@@ -1108,9 +897,9 @@ __global__ void bwd2_pack_kernel(const float* __restrict__ layer0, long layer_st
 }
 
 // ---------------------------------------------------------------------------
-// LDS-DMA form of layer_bwd2_kernel (the default): the same arithmetic, but
-// every input tile goes global -> LDS by global_load_lds (tile_dma) instead of
-// through staging registers.  Without the 4..6 x 16 staging registers two
+// Every input tile goes global -> LDS by global_load_lds (tile_dma) instead
+// of through staging registers (the round-1 register-staged form measured 46.6
+// against 44.2 us at B*T = 128000 and is gone).  Without the 4..6 x 16 staging registers two
 // waves per SIMD fit without spills (one wave's gate math / LDS traffic runs
 // under the other's MFMAs), the rows-t tiles are in flight during the rows
 // t+d math and the x tiles during the rows-t math.
@@ -2217,10 +2006,10 @@ int wn_layer_wgrad_k(const float* x, const float* daf, const float* dag,
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(num_slabs, CB * CB), block(256);
   if (K == 2 && k0 == 0 && Ktot == 2 && (CB == 2 || CB == 4) &&
-      (long)B * T * WN_CH * 4 < (1L << 31) && !getenv("WN_WGRAD_CB2_OFF")) {
+      (long)B * T * WN_CH * 4 < (1L << 31)) {
     // 64 / 128 channels, two taps: all input blocks and two output blocks per
     // pass (every plane of a 64-channel layer read once, of a 128-channel
-    // layer twice; WN_WGRAD_CB2_OFF=1: the per-pair kernel, A/B)
+    // layer twice)
     dim3 grid1(num_slabs, CB / 2), block1(512);
 #define LAUNCH(CBV, HD)                                                                  \
   hipLaunchKernelGGL((layer_wgrad_cbn_kernel<CBV, HD>), grid1, block1, 0, s, x, daf, dag, z, \
@@ -2352,12 +2141,8 @@ int wn_layer_bwdw(const float* x, const float* z, const float* daf_cur,
 
 // number of slabs (workgroups) wn_layer_bwd2 writes for this shape (an upper
 // bound over the kernel variants: slabs past the launched grid stay unused)
-static int b2_waves() {
-  const char* e = getenv("WN_B2_MODE");   // A/B knob: "d" (default) or "4p"
-  return (e && e[0] == '4') ? 4 : B2_WAVES;
-}
 int wn_layer_bwd2_slabs(int B, int T) {
-  return layer_grid(B, T, b2_waves(), b2_waves() == B2_WAVES);
+  return layer_grid(B, T, B2_WAVES, true);
 }
 
 int wn_layer_bwd2_wimg_floats(void) { return B2_WIMG; }
@@ -2383,19 +2168,13 @@ int wn_layer_bwd2(const float* x, const float* z, const float* sg,
   const void* ptrs[] = {x, z, sg, dZ, dxin, dx_out, wblock, wimg};
   for (const void* p : ptrs)
     if (p && !wn_aligned16(p)) return WN_ERR_MISALIGNED;
-  const int waves = b2_waves();
-  dim3 grid(layer_grid(B, T, waves, waves == B2_WAVES)), block(waves * 64);
+  dim3 grid(layer_grid(B, T, B2_WAVES, true)), block(B2_WAVES * 64);
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(KERNEL, W)                                                     \
   hipLaunchKernelGGL(KERNEL, grid, block, 0, s, x, z, sg, dZ, dxin, dx_out,   \
                      W, slabs, tile_colsum, B, T, dilation)
-  if (waves == 4) {  // register-staged, one wave per SIMD (A/B)
-    if (dxin) LAUNCH((layer_bwd2_kernel<true, 4, true>), wblock);
-    else LAUNCH((layer_bwd2_kernel<false, 4, true>), wblock);
-  } else {           // default: LDS-DMA kernel, two waves per SIMD
-    if (dxin) LAUNCH((layer_bwd2d_kernel<true>), wimg);
-    else LAUNCH((layer_bwd2d_kernel<false>), wimg);
-  }
+  if (dxin) LAUNCH((layer_bwd2d_kernel<true>), wimg);
+  else LAUNCH((layer_bwd2d_kernel<false>), wimg);
 #undef LAUNCH
   return wn_check_launch();
 }

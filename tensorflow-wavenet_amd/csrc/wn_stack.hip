@@ -33,7 +33,6 @@
 // turns NaN instead of being silently wrong; the backward also poisons its dx)
 // and carries on without waiting, so the grid always drains.
 #include "wn_common.h"
-#include <stdlib.h>
 
 #define WN_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define WN_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
@@ -486,11 +485,11 @@ struct StackBwd {
   const float* Z;
   const float* SG;
   const float* dZ;
-  float* DX;           // DX + l * dx_stride = dL/dx_l (PUSH: without the tap's term, l > 0)
-  long dx_stride;      // floats between the dx planes of two layers; PUSH: 0 = ONE plane,
+  float* DX;           // DX + l * dx_stride = dL/dx_l (without the tap's term, l > 0)
+  long dx_stride;      // floats between the dx planes of two layers; 0 = ONE plane,
                        // rewritten in place from layer to layer (a tile's own rows
                        // have no other reader: they stay in the L2 / Infinity Cache)
-  float* Q;            // [L][N][32]  PUSH: q_l[s] = da_l[s] W[0]^T, the term row s sends to row s - d
+  float* Q;            // [L][N][32]  q_l[s] = da_l[s] W[0]^T, the term row s sends to row s - d
   const float* wimg;   // [L][STACK_WBUF] backward weight images (wn_stack_pack)
   float* slabs;        // [L][>= groups][LAYER_BLOCK_FLOATS]
   long slab_layer_stride;
@@ -675,16 +674,17 @@ __device__ __forceinline__ void tile_dma_rs(float* lds_tile, wn_rsrc_t rs, int s
   }
 }
 
-// PUSH (round 3, default): dx_l[t] = own_l[t] + q_l[t + d] with
+// "Push" formulation (round 3): dx_l[t] = own_l[t] + q_l[t + d] with
 //   own_l[t] = dx_{l+1}[t] + da_l[t] W[1]^T   and   q_l[s] = da_l[s] W[0]^T.
 // A tile computes da for ITS OWN rows only and publishes q (what its rows
 // contribute to the rows d earlier) instead of every tile re-reading four
-// planes at rows t + d and re-deriving da there: per tile and layer one gate
-// evaluation instead of two, 160 instead of 176 MFMAs, 9 instead of 11 plane
-// passes through memory, and the hand-over is published in the middle of a
-// tile (before its weight-gradient products) instead of at its end.
-// !PUSH: the first formulation (kept for A/B: WN_STACK_BWD_PULL=1).
-template <int WAVES, bool PUSH>
+// planes at rows t + d and re-deriving da there (the first, "pull" formulation,
+// layer_bwd2d_kernel's arithmetic: 1689 -> 1642 us at B = 8 when it was
+// replaced; removed in round 5): per tile and layer one gate evaluation
+// instead of two, 160 instead of 176 MFMAs, 9 instead of 11 plane passes
+// through memory, and the hand-over is published in the middle of a tile
+// (before its weight-gradient products) instead of at its end.
+template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
   constexpr int SLAB = WAVES > 1 ? LAYER_BLOCK_FLOATS : 16;   // ordered-accumulation slab
   __shared__ __attribute__((aligned(1024))) float wl[2 * SB_WIMG];
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
     WN_WAIT_VM0();
     __syncthreads();        // weights of the two top layers are in LDS
 
-    unsigned nfv_push = epoch;    // PUSH: flag value(s) requested ahead for the next tile
+    unsigned nfv_push = epoch;    // flag value(s) requested ahead for the next tile
     // lanes 0 / 1: index of the (at most two) flags the rows t + dd of tile tl
     // wait for, -1 on the other lanes / when there is nothing to wait for
     auto flag_idx2 = [&](int tl, int dd) -> int {
@@ -771,9 +771,9 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
     for (int l = L - 1; l >= 0; --l) {
       const int d = a.dil[l];
       const bool hx = l + 1 < L;              // a gradient flows into x_{l+1}
-      const int dn = hx ? a.dil[l + 1] : 0;   // PUSH: the tap distance of dx_{l+1}
-      const wn_rsrc_t qin = plane_rsrc(PUSH ? a.Q + (size_t)(hx ? l + 1 : l) * a.plane : a.DX);
-      const wn_rsrc_t q_out = plane_rsrc(PUSH ? a.Q + (size_t)l * a.plane : a.DX);
+      const int dn = hx ? a.dil[l + 1] : 0;   // the tap distance of dx_{l+1}
+      const wn_rsrc_t qin = plane_rsrc(a.Q + (size_t)(hx ? l + 1 : l) * a.plane);
+      const wn_rsrc_t q_out = plane_rsrc(a.Q + (size_t)l * a.plane);
       const wn_rsrc_t x = plane_rsrc(a.X + (size_t)l * a.plane);
       const wn_rsrc_t z = plane_rsrc(a.Z + (size_t)l * a.plane);
       const wn_rsrc_t sg = plane_rsrc(a.SG + (size_t)l * a.plane);
@@ -789,74 +789,17 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
       f32x16 cf0 = frag_zero(), cf1 = frag_zero(), cg0 = frag_zero(),
              cg1 = frag_zero(), cd = frag_zero();
       float sf = 0.f, sgs = 0.f, sd = 0.f;
-      RowRegs a0, a1, a2, a3;
-      // rows t+d of a tile (always assigns a0..a3); the dx_{l+1} rows wait for
-      // their owners' flags
-      // lanes 0 / 1: index of the (at most two) flags the rows t+d of tile tl
-      // wait for, -1 on the other lanes / when there is nothing to wait for
-      auto flag_idx = [&](int tl) -> int {
-        if (!hx || tl >= tend) return -1;
-        const int b = tl / tiles_per_clip;
-        const int tt = tl - b * tiles_per_clip;
-        const int tt0 = tt * 32;
-        const int hif = min(min(32, T - tt0), T - d - tt0);
-        if (hif <= 0) return -1;
-        const int first = (tt0 + d) >> 5, last = (tt0 + d + hif - 1) >> 5;
-        int idx = -1;
-        if (lane == 0 && first != tt) idx = b * tiles_per_clip + first;
-        if (lane == 1 && last != first && last != tt) idx = b * tiles_per_clip + last;
-        return idx;
-      };
-      // `pre`: the flag value read ahead of time (anything but `epoch`: unknown)
-      auto load_shifted = [&](int tl, unsigned pre) {
-        const bool any = tl < tend;
-        const int b = any ? tl / tiles_per_clip : 0;
-        const int tt = any ? tl - b * tiles_per_clip : 0;
-        const int tt0 = tt * 32;
-        const int hif = any ? min(min(32, T - tt0), T - d - tt0) : 0;
-#ifdef SB_FAKE_ADDR   // timing-only ablation: every load from one L2-resident megabyte
-        const int offd = ((b * T + tt0 + d) * (WN_CH * 4)) & 0xFFFFF;
-#else
-        const int offd = (b * T + tt0 + d) * (WN_CH * 4);   // bytes (< 2^31: host check)
-#endif
-        if (hx) {
-          if (hif > 0) {
-            const int first = (tt0 + d) >> 5, last = (tt0 + d + hif - 1) >> 5;
-            int idx = -1;
-            if (lane == 0 && first != tt) idx = b * tiles_per_clip + first;
-            if (lane == 1 && last != first && last != tt) idx = b * tiles_per_clip + last;
-            // (producers are usually a layer ahead: the value requested during
-            // the previous tile's math already shows the flag)
-            if (__builtin_amdgcn_ballot_w64(idx >= 0 && pre != epoch) != 0)
-              wait_flags(fl_in, idx, epoch, a.ctl, a.poison, dead, lane);
-          }
-          a0 = rows_ld<16>(dxin, offd, vrow, lane, 0, hif);
-        } else {
-          const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int c = 0; c < 4; ++c) a0.v[c] = zero;
-        }
-        a1 = rows_ld<0>(dZ, offd, vrow, lane, 0, hif);
-        a2 = rows_ld<0>(z, offd, vrow, lane, 0, hif);
-        a3 = rows_ld<0>(sg, offd, vrow, lane, 0, hif);
-      };
+      RowRegs a0, a1, a3;
       BSTAMP(l, 2);
       // this lane's swizzled offset of chunk h in row j of a weight matrix
       int woff = (j * 32 + ((h ^ ((j >> 1) & 7)) << 2)) + (l & 1) * SB_WIMG;
       asm volatile("" : "+v"(woff));   // opaque: no hoisting of the weight reads
       const float* const wm = wl;
-      // Order inside a tile (round 3): everything that needs only the tile's
-      // OWN rows first -- the rows-t half of dx and all weight-gradient
-      // products -- and the anti-causal tap (rows t+d of dx_{l+1}, another
-      // tile's output of the layer above) last: its flags are looked at five
-      // microseconds into the tile instead of at its start, and between "the
-      // tap has arrived" and "dx_l is published" lie 48 MFMAs instead of 112.
       for (int tile = tbase + wave; tile < tend; tile += WAVES) {
         if (tile == tbase + wave + WAVES) { BSTAMP(l, 7); }
         const int b = tile / tiles_per_clip;
         const int tt0 = (tile - b * tiles_per_clip) * 32;
         const int hi = min(32, T - tt0);
-        const int hi_f = min(hi, T - d - tt0);  // rows whose t+d tap exists
         const int lo_p = max(0, d - tt0);       // rows whose t-d tap exists
 #ifdef SB_FAKE_ADDR
         const int off0r = (b * T + tt0) * (WN_CH * 4);
@@ -867,18 +810,10 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
         // ---- rows t (dx_{l+1}[t] is this wave's own store of the layer
         // above); the sigmoid rows travel in registers
         if (tile == tbase + wave) { BSTAMP(l, 11); }
-        tile_dma_rs<(PUSH ? SB_STREAM : 0)>(t0, z, off0, vswz, lane, 0, hi);
-        if (hx && !PUSH) tile_dma_rs<16>(t1, dxin, off0, vswz, lane, 0, hi);
-        tile_dma_rs<(PUSH ? SB_STREAM : 0)>(t2, dZ, off0, vswz, lane, 0, hi);
-        a3 = rows_ld<(PUSH ? SB_STREAM : 0)>(sg, off0, vrow, lane, 0, hi);
-        // this tile's tap flags: requested now, looked at after the rows-t math
-        unsigned nfv = epoch;
-        if (!PUSH) {
-          const int nidx = flag_idx(tile);
-          if (nidx >= 0)
-            nfv = __hip_atomic_load(fl_in + nidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (PUSH && hx) {
+        tile_dma_rs<SB_STREAM>(t0, z, off0, vswz, lane, 0, hi);
+        tile_dma_rs<SB_STREAM>(t2, dZ, off0, vswz, lane, 0, hi);
+        a3 = rows_ld<SB_STREAM>(sg, off0, vrow, lane, 0, hi);
+        if (hx) {
           // complete dx_{l+1}[t] = own rows (this wave's store of the layer
           // above) + q_{l+1}[t + dn] of the tiles d rows later, whose flags were
           // requested during the previous tile (they published q in the
@@ -896,7 +831,7 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
         }
         if (tile == tbase + wave) { BSTAMP(l, 12); }
         WN_WAIT_VM0();
-        if (PUSH && hx) {
+        if (hx) {
 #pragma unroll
           for (int c = 0; c < 4; ++c) a0.v[c] += a1.v[c];
           rows_to_lds(t1, lane, a0);
@@ -957,34 +892,30 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
 #endif
           // (Wg's first chunk requested during Wf's last MFMAs: 1637 -> 1622 us)
           f32x4 wpre = *reinterpret_cast<const f32x4*>(wm + 1 * 1024 + woff);
-          mma32s_chain(dx, df, wm + 1 * 1024, woff, wpre, PUSH ? wm + 0 * 1024 : wm + 3 * 1024);  // da_f[t] * Wf[1]^T
-          if (PUSH) {
-            // q_l[t] = da[t] W[0]^T, then own_l[t]: both to memory through t2
-            // before it takes da_f (a wave's DS operations run in order)
-            f32x16 qf = frag_zero();
-            mma32s_chain(qf, df, wm + 0 * 1024, woff, wpre, wm + 3 * 1024);  // da_f[t] * Wf[0]^T
-            mma32s_chain(dx, dg, wm + 3 * 1024, woff, wpre, wm + 2 * 1024);  // da_g[t] * Wg[1]^T
-            mma32s_chain(qf, dg, wm + 2 * 1024, woff, wpre, wm + 2 * 1024);  // da_g[t] * Wg[0]^T
-            if (dead) { qf[0] = __builtin_nanf(""); dx[0] = __builtin_nanf(""); }
-            frag_to_lds(t2, j, h, qf);
-            __builtin_amdgcn_wave_barrier();
-            rows_st<16>(q_out, off0, vrow, lane, hi, rows_from_lds(t2, lane));
-            __builtin_amdgcn_wave_barrier();
-            frag_to_lds(t2, j, h, dx);
-            __builtin_amdgcn_wave_barrier();
-            rows_st<SB_OWN_ST>(dx_out, off0, vrow, lane, hi, rows_from_lds(t2, lane));
-            __builtin_amdgcn_wave_barrier();
-          } else {
-            mma32s_chain(dx, dg, wm + 3 * 1024, woff, wpre, wm + 3 * 1024);  // da_g[t] * Wg[1]^T
-          }
+          mma32s_chain(dx, df, wm + 1 * 1024, woff, wpre, wm + 0 * 1024);  // da_f[t] * Wf[1]^T
+          // q_l[t] = da[t] W[0]^T, then own_l[t]: both to memory through t2
+          // before it takes da_f (a wave's DS operations run in order)
+          f32x16 qf = frag_zero();
+          mma32s_chain(qf, df, wm + 0 * 1024, woff, wpre, wm + 3 * 1024);  // da_f[t] * Wf[0]^T
+          mma32s_chain(dx, dg, wm + 3 * 1024, woff, wpre, wm + 2 * 1024);  // da_g[t] * Wg[1]^T
+          mma32s_chain(qf, dg, wm + 2 * 1024, woff, wpre, wm + 2 * 1024);  // da_g[t] * Wg[0]^T
+          if (dead) { qf[0] = __builtin_nanf(""); dx[0] = __builtin_nanf(""); }
+          frag_to_lds(t2, j, h, qf);
+          __builtin_amdgcn_wave_barrier();
+          rows_st<16>(q_out, off0, vrow, lane, hi, rows_from_lds(t2, lane));
+          __builtin_amdgcn_wave_barrier();
+          frag_to_lds(t2, j, h, dx);
+          __builtin_amdgcn_wave_barrier();
+          rows_st<SB_OWN_ST>(dx_out, off0, vrow, lane, hi, rows_from_lds(t2, lane));
+          __builtin_amdgcn_wave_barrier();
           frag_to_lds(t2, j, h, df);                 // t2 now holds da_f[t]
         }
         if (tile == tbase + wave) { BSTAMP(l, 8); }
-        WN_WAIT_VM0();                               // x tiles in (PUSH: q and own rows stored)
-        if (PUSH) {
-          if (lane == 0)
-            __hip_atomic_store(fl_out + tile, epoch, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+        WN_WAIT_VM0();                               // x tiles in, q and own rows stored
+        if (lane == 0)
+          __hip_atomic_store(fl_out + tile, epoch, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+        {
           // the flags the NEXT tile of this wave will look at: requested now
           int ntile = tile + WAVES, nl = l;
           if (ntile >= tend) { ntile = tbase + wave; nl = l - 1; }
@@ -995,9 +926,6 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
               nfv_push = __hip_atomic_load(a.flags + (size_t)(nl + 1) * ntiles + nidx,
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
-        } else {
-          // ---- the tap's rows: requested now, used after the weight gradients
-          load_shifted(tile, nfv);
         }
         if (tile == tbase + wave) { BSTAMP(l, 10); }
         __builtin_amdgcn_wave_barrier();
@@ -1046,51 +974,6 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
         }
         WN_WAIT_LGKM0();                     // the three tiles are free
         if (tile == tbase + wave) { BSTAMP(l, 13); }
-        if (PUSH) {
-          __builtin_amdgcn_wave_barrier();
-          continue;
-        }
-        // ---- rows t+d -> LDS -> fragments -> the tap's half of dx
-        if (hi_f > 0) {
-          WN_WAIT_VM0();
-          if (hx) rows_to_lds(t0, lane, a0);
-          rows_to_lds(t1, lane, a1);
-          rows_to_lds(t2, lane, a2);
-          __builtin_amdgcn_wave_barrier();
-          if (hx) di = frag_from_lds(t0, j, h);
-          dz = frag_from_lds(t1, j, h);
-          zz = frag_from_lds(t2, j, h);
-          __builtin_amdgcn_wave_barrier();      // (a wave's DS operations run in order)
-          rows_to_lds(t0, lane, a3);
-          __builtin_amdgcn_wave_barrier();
-          ss = frag_from_lds(t0, j, h);
-          WN_WAIT_LGKM0();
-          if (hx) mma32s(dz, di, wm + 4 * 1024, woff);  // dx_{l+1}[t+d] * Wd^T
-          f32x16 df, dg2;
-#ifdef SB_NOGATE
-          df = dz; dg2 = zz;
-          asm volatile("" :: "v"(ss[0]));
-#else
-          gate_grad(dz, zz, ss, df, dg2);
-#endif
-          f32x4 wpre = *reinterpret_cast<const f32x4*>(wm + 0 * 1024 + woff);
-          mma32s_chain(dx, df, wm + 0 * 1024, woff, wpre, wm + 2 * 1024);   // da_f[t+d] * Wf[0]^T
-          mma32s_chain(dx, dg2, wm + 2 * 1024, woff, wpre, wm + 2 * 1024);  // da_g[t+d] * Wg[0]^T
-        }
-        if (dead) dx[0] = __builtin_nanf("");        // a wait expired: NaN gradients
-        frag_to_lds(t2, j, h, dx);
-        __builtin_amdgcn_wave_barrier();
-#ifdef SB_FAKE_ADDR
-        rows_st<16>(dx_out, off0r, vrow, lane, hi, rows_from_lds(t2, lane));
-#else
-        rows_st<16>(dx_out, off0, vrow, lane, hi, rows_from_lds(t2, lane));
-#endif
-        WN_WAIT_VM0();                               // dx_l is in memory: publish it
-        if (lane == 0)
-          __hip_atomic_store(fl_out + tile, epoch, __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
-        if (tile == tbase + wave) { BSTAMP(l, 9); }
-        WN_WAIT_LGKM0();                     // tiles free for the next tile's DMA
         __builtin_amdgcn_wave_barrier();
       }
       BSTAMP(l, 3);
@@ -1204,7 +1087,7 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd_kernel(StackBwd a) {
       }
       BSTAMP(l, 6);
     }
-    if (PUSH) {
+    {
       // dx_0[t] = own_0[t] + q_0[t + d_0]: completed in place for the causal
       // layer's weight gradient (nobody reads DX[0] through a flag)
       const int d0 = a.dil[0];
@@ -2407,24 +2290,19 @@ long wn_stack_flag_count(int B, int T, int L) {
 // one wave's dependent path through a layer: halve the path), else 32.
 // Measured, T = 16000, ms per training step at 32 / 16 rows: B = 1 1.780 /
 // 1.683, B = 2 2.999 / 2.947, B = 3 4.14 / 4.60, B = 4 5.01 / 5.56.
-// WN_STACK_ROWS=16 / 32 forces it (A/B, tests).
-int wn_stack_tile_rows(int B, int T) {
+// `variant` (WN_STACK_VARIANT of wavenet_hip.h) may force 16 / 32 (A/B, tests).
+int wn_stack_tile_rows(int B, int T, int variant) {
   if (B <= 0 || T <= 0) return 32;
-  if (const char* e = getenv("WN_STACK_ROWS")) {
-    const int r = atoi(e);
-    if (r == 16 || r == 32) return r;
-  }
+  const int r = variant & 0x3f;
+  if (r == 16 || r == 32) return r;
   const long ntiles = (long)B * ((T + 31) / 32);
   return ntiles <= 4L * wn_device_cus() ? 16 : 32;
 }
 
-// waves per workgroup of the 16-row launches: WN_STACK16_WAVES_F / _B = 4 / 8
-// force it for the forward / backward launch (A/B, tests)
-static int stack16_waves(const char* name, int dflt) {
-  if (const char* e = getenv(name)) {
-    const int w = atoi(e);
-    if (w == 4 || w == 8) return w;
-  }
+// waves per workgroup a variant word asks for (bits 8..11), or `dflt`
+static int variant_waves(int variant, int dflt, bool allow_small) {
+  const int w = (variant >> 8) & 0xf;
+  if (w == 4 || w == 8 || (allow_small && (w == 1 || w == 2))) return w;
   return dflt;
 }
 
@@ -2445,7 +2323,7 @@ int wn_stack_fwd(float* X, float* Z, float* SG, const float* wimg,
                  const float* bias, long bias_layer_stride,
                  int bias_clip_stride, const int* dilations, unsigned* flags,
                  unsigned* ctl, float* poison, int L, int B, int T, int save_sg,
-                 void* stream) {
+                 int variant, void* stream) {
   if (!X || !Z || !wimg || !dilations || !flags || !ctl) return WN_ERR_NULL;
   if (save_sg && !SG) return WN_ERR_NULL;
   if (L <= 0 || B <= 0 || T <= 0) return WN_ERR_BAD_SHAPE;
@@ -2463,13 +2341,13 @@ int wn_stack_fwd(float* X, float* Z, float* SG, const float* wimg,
   a.dbg = g_stack_dbg;
 #endif
   if (L > STACK_MAXL) return WN_ERR_UNSUPPORTED;
-  if (wn_stack_tile_rows(B, T) == 16) {
+  if (wn_stack_tile_rows(B, T, variant) == 16) {
     // (tile offsets inside a plane are 32-bit byte offsets of a buffer resource)
     if ((long)B * T * WN_CH * 4 >= (1L << 31)) return WN_ERR_UNSUPPORTED;
     const long nt16 = (long)B * ((T + 15) / 16);
     const int cus16 = wn_device_cus();
     // one wave per SIMD while that covers the batch in one pass, else two
-    const int w16 = stack16_waves("WN_STACK16_WAVES_F", (nt16 + 3) / 4 <= cus16 ? 4 : 8);
+    const int w16 = variant_waves(variant, (nt16 + 3) / 4 <= cus16 ? 4 : 8, false);
     long g16 = (nt16 + w16 - 1) / w16;
     if (g16 > cus16) g16 = cus16;
     dim3 grid16((unsigned)g16), block16(w16 * 64);
@@ -2526,23 +2404,20 @@ int wn_stack_fwd(float* X, float* Z, float* SG, const float* wimg,
 // big batches keep 8 waves and give every wave enough tiles that one pass of
 // at most one group per CU covers the batch; small batches use fewer waves so
 // that the tiles spread over the whole chip
-static void stack_bwd_shape(int B, int T, int* waves_out, int* tpw_out) {
-  if (wn_stack_tile_rows(B, T) == 16) {     // 16-row tiles: one per wave
-    *waves_out = stack16_waves("WN_STACK16_WAVES_B", 8);
+static void stack_bwd_shape(int B, int T, int variant, int* waves_out, int* tpw_out) {
+  if (wn_stack_tile_rows(B, T, variant) == 16) {     // 16-row tiles: one per wave
+    *waves_out = variant_waves(variant, 8, false);
     *tpw_out = 1;
     return;
   }
   const long ntiles = (long)B * ((T + 31) / 32);
   const int cus = wn_device_cus();
-  // experiments (A/B of co-residency with a side-stream GEMM, stamps):
-  // WN_STACK_BWD_WAVES=w forces w waves per workgroup
-  if (const char* e = getenv("WN_STACK_BWD_WAVES")) {
-    const int w = atoi(e);
-    if (w == 1 || w == 2 || w == 4 || w == 8) {
-      *waves_out = w;
-      *tpw_out = (int)((ntiles + (long)w * cus - 1) / ((long)w * cus));
-      return;
-    }
+  // experiments (A/B of co-residency with a side-stream GEMM, stamps): the
+  // variant word may force the waves per workgroup
+  if (const int w = variant_waves(variant, 0, true)) {
+    *waves_out = w;
+    *tpw_out = (int)((ntiles + (long)w * cus - 1) / ((long)w * cus));
+    return;
   }
   long best = -1;
   int bw = 8, bt = 1;
@@ -2562,11 +2437,11 @@ static void stack_bwd_shape(int B, int T, int* waves_out, int* tpw_out) {
 }
 
 // weight-gradient slabs per layer wn_stack_bwd writes (= tile groups)
-int wn_stack_bwd_slabs(int B, int T) {
+int wn_stack_bwd_slabs(int B, int T, int variant) {
   if (B <= 0 || T <= 0) return 0;
   int w, t;
-  stack_bwd_shape(B, T, &w, &t);
-  const int rows = wn_stack_tile_rows(B, T);
+  stack_bwd_shape(B, T, variant, &w, &t);
+  const int rows = wn_stack_tile_rows(B, T, variant);
   const long ntiles = (long)B * ((T + rows - 1) / rows);
   return (int)((ntiles + (long)w * t - 1) / ((long)w * t));
 }
@@ -2576,8 +2451,8 @@ int wn_stack_bwd(const float* X, const float* Z, const float* SG,
                  const float* wimg, float* slabs,
                  long slab_layer_stride, float* tilesum, const int* dilations,
                  unsigned* flags, unsigned* ctl, float* poison, int L, int B,
-                 int T, void* stream) {
-  if (!X || !Z || !SG || !dZ || !DX || !wimg || !slabs || !dilations ||
+                 int T, int variant, void* stream) {
+  if (!X || !Z || !SG || !dZ || !DX || !Q || !wimg || !slabs || !dilations ||
       !flags || !ctl)
     return WN_ERR_NULL;
   if (L <= 0 || B <= 0 || T <= 0) return WN_ERR_BAD_SHAPE;
@@ -2587,10 +2462,10 @@ int wn_stack_bwd(const float* X, const float* Z, const float* SG,
   const void* ptrs[] = {X, Z, SG, dZ, DX, wimg};
   for (const void* p : ptrs)
     if (!wn_aligned16(p)) return WN_ERR_MISALIGNED;
-  if (Q && !wn_aligned16(Q)) return WN_ERR_MISALIGNED;
+  if (!wn_aligned16(Q)) return WN_ERR_MISALIGNED;
   int waves, tpw;
-  stack_bwd_shape(B, T, &waves, &tpw);
-  const int rows = wn_stack_tile_rows(B, T);
+  stack_bwd_shape(B, T, variant, &waves, &tpw);
+  const int rows = wn_stack_tile_rows(B, T, variant);
   const long ntiles = (long)B * ((T + rows - 1) / rows);
   const long groups = (ntiles + (long)waves * tpw - 1) / ((long)waves * tpw);
   if (slab_layer_stride < groups * LAYER_BLOCK_FLOATS) return WN_ERR_BAD_SHAPE;
@@ -2608,21 +2483,15 @@ int wn_stack_bwd(const float* X, const float* Z, const float* SG,
   const int cus = wn_device_cus();
   dim3 grid((unsigned)(groups < cus ? groups : cus)), block(waves * 64);
   hipStream_t s = (hipStream_t)stream;
-  // Q (an [L][N][32] scratch like DX): the "push" formulation; without it (or
-  // with WN_STACK_BWD_PULL=1, for A/B) the first, "pull" one
-  const char* pe = getenv("WN_STACK_BWD_PULL");
-  const bool push = Q != nullptr && !(pe && pe[0] == '1');
-  // one dx plane per layer, or (push only: nobody but the owner reads a
-  // tile's dx rows) a single plane rewritten in place
-  if (dx_layer_stride != (long)B * T * WN_CH && !(push && dx_layer_stride == 0))
+  // one dx plane per layer, or (nobody but the owner reads a tile's dx rows)
+  // a single plane rewritten in place
+  if (dx_layer_stride != (long)B * T * WN_CH && dx_layer_stride != 0)
     return WN_ERR_BAD_SHAPE;
   if (rows == 16) {
-    if (!push) return WN_ERR_UNSUPPORTED;     // (the 16-row launch is "push" only)
-    // WN_STACK16_SPLIT=1: the weight gradients on waves of their own
+    // WN_STACK_SPLIT: the weight gradients on waves of their own
     // (stack_bwd16s_kernel: 356 instead of 532 us alone at B = 1, but the side
     // stream's weight-gradient GEMMs no longer fit beside it -- DESIGN.md)
-    const char* se = getenv("WN_STACK16_SPLIT");
-    if (!(se && se[0] == '1')) {
+    if (!(variant & WN_STACK_SPLIT)) {
       if (waves == 8) hipLaunchKernelGGL((stack_bwd16_kernel<8>), grid, block, 0, s, a);
       else hipLaunchKernelGGL((stack_bwd16_kernel<4>), grid, block, 0, s, a);
     } else {
@@ -2633,11 +2502,7 @@ int wn_stack_bwd(const float* X, const float* Z, const float* SG,
     }
     return wn_check_launch();
   }
-#define LAUNCH(W)                                                               \
-  do {                                                                          \
-    if (push) hipLaunchKernelGGL((stack_bwd_kernel<W, true>), grid, block, 0, s, a);   \
-    else hipLaunchKernelGGL((stack_bwd_kernel<W, false>), grid, block, 0, s, a);       \
-  } while (0)
+#define LAUNCH(W) hipLaunchKernelGGL((stack_bwd_kernel<W>), grid, block, 0, s, a)
   switch (waves) {
     case 8: LAUNCH(8); break;
     case 4: LAUNCH(4); break;

@@ -33,13 +33,13 @@ SIGNATURES = {
                              c_int, c_int, P]),
     'wn_stack_flag_count': (c_long, [c_int, c_int, c_int]),
     'wn_stack_wimg_floats': (c_int, []),
-    'wn_stack_tile_rows': (c_int, [c_int, c_int]),
+    'wn_stack_tile_rows': (c_int, [c_int, c_int, c_int]),
     'wn_stack_pack': (c_int, [P, c_long, P, P, c_int, P]),
     'wn_stack_fwd': (c_int, [P, P, P, P, P, c_long, c_int, P, P, P, P,
-                             c_int, c_int, c_int, c_int, P]),
-    'wn_stack_bwd_slabs': (c_int, [c_int, c_int]),
+                             c_int, c_int, c_int, c_int, c_int, P]),
+    'wn_stack_bwd_slabs': (c_int, [c_int, c_int, c_int]),
     'wn_stack_bwd': (c_int, [P, P, P, P, P, c_long, P, P, P, c_long, P, P, P,
-                             P, P, c_int, c_int, c_int, P]),
+                             P, P, c_int, c_int, c_int, c_int, P]),
     'wn_layer_bwd': (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int,
                              c_int, c_int, c_int, P]),
     'wn_layer_wgrad_slab_floats': (c_int, []),
@@ -139,32 +139,6 @@ SIGNATURES = {
 }
 
 
-
-class NNProblem(ctypes.Structure):
-    """wn_nn_problem (include/wavenet_hip.h): the arguments of wn_gemm_nn."""
-    _fields_ = [('A', P), ('lda', c_long), ('a_planes', c_int),
-                ('a_plane_stride', c_long), ('W', P), ('ldw', c_int),
-                ('bias', P), ('mask', P), ('ld_mask', c_long), ('addend', P),
-                ('ld_add', c_long), ('C', P), ('ldc', c_long),
-                ('c_planes', c_int), ('c_plane_stride', c_long), ('Cpre', P),
-                ('M', c_long), ('N', c_int), ('K', c_int), ('relu', c_int)]
-
-
-def nn_problems(arg_tuples):
-    """ctypes array of wn_nn_problem from wn_gemm_nn argument tuples (without
-    the trailing stream)."""
-    arr = (NNProblem * len(arg_tuples))()
-    for q, a in zip(arr, arg_tuples):
-        for (name, _), v in zip(NNProblem._fields_, a):
-            setattr(q, name, v)
-    return arr
-
-
-SIGNATURES.update({
-    'wn_gemm_nn_chain_ctl_words': (c_long, [c_long]),
-    'wn_gemm_nn_chain_probe': (c_int, [P, P]),
-    'wn_gemm_nn_chain': (c_int, [ctypes.POINTER(NNProblem), c_int, c_int, P, P, P]),
-})
 
 _lib = None
 
@@ -289,6 +263,15 @@ def ptr(t):
     if t is None:
         return None
     return t.data_ptr()
+
+
+WN_STACK_SPLIT = 0x1000
+
+
+def stack_variant(rows=0, waves=0, split=False):
+    """WN_STACK_VARIANT of include/wavenet_hip.h: the explicit variant word of
+    the stack launches (0 = the library's choice for the shape)."""
+    return (rows & 0x3f) | ((waves & 0xf) << 8) | (WN_STACK_SPLIT if split else 0)
 
 
 def stream():

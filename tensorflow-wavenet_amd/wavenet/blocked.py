@@ -123,9 +123,11 @@ def backward_layers(net, ws, ids, st):
     nslab = ws.nslab
     if CB in (2, 4) and K == 2:
         # the all-input-blocks weight-gradient kernel of 64- / 128-channel
-        # layers holds one workgroup per CU: one round of them per pass (256
-        # CUs) -- 55 instead of 63 us a 64-channel layer, and half the slabs
-        nslab = min(nslab, 256 // (CB // 2))
+        # layers holds one workgroup per CU: one round of them per pass (the
+        # device's CU count: 256 on a whole MI355X, 32 on a CPX partition) --
+        # 55 instead of 63 us a 64-channel layer, and half the slabs
+        cus = torch.cuda.get_device_properties(net.device).multi_processor_count
+        nslab = max(1, min(nslab, cus // (CB // 2)))
     # every layer-block gradient entry is rewritten below except the padding
     # and the last layer's (gradient-free) dense conv: start from zero
     lo, ln = net.segments['layers']

@@ -63,6 +63,8 @@ class _Workspace(object):
         N = B * T
         f32 = dict(dtype=torch.float32, device=dev)
         self.B, self.T, self.N, self.training = B, T, N, training
+        # (the variant word of the stack launches is fixed per workspace)
+        self.stack_variant = int(net.stack_variant)
         self.capacity = N if parent is None else parent.capacity
         lib = _lib.load()
 
@@ -102,12 +104,6 @@ class _Workspace(object):
         if 'stack_ctl' in fresh:         # (a view shares the owner's epoch)
             self.stack_ctl[2] = 1
         alloc('bsum', (S,))
-        # control blocks of the chained NN GEMM launches (wn_gemm_nn_chain):
-        # forward (skip sum -> post1 -> post2) and backward (their data
-        # gradients) each own one
-        nw = lib.wn_gemm_nn_chain_ctl_words(N)
-        alloc('nnc_ctl_f', (nw,), torch.int32, fill=0)
-        alloc('nnc_ctl_b', (nw,), torch.int32, fill=0)
         self.total = alloc('total', (N, S)) if net.residual_postproc else None
         self.nparts = lib.wn_xent_partials(N)
         # (the first 2 words: the NaN "poison" of wn_stack_fwd / wn_stack_bwd,
@@ -139,8 +135,7 @@ class _Workspace(object):
         # persistent backward (wn_stack_bwd), "push" formulation: a tile's
         # own dx rows have no reader but the wave that wrote them, so ONE
         # plane is rewritten in place from layer to layer (it stays in the L2
-        # / Infinity Cache; DX[0] ends up as dL/dx_0).  The "pull"
-        # formulation (WN_STACK_BWD_PULL=1, A/B) and the per-layer checks of
+        # / Infinity Cache; DX[0] ends up as dL/dx_0).  The per-layer checks of
         # tests/test_gpu_stack.py (`net.stack_bwd_keep_dx`) keep dL/dx_l of
         # EVERY layer.  Plus the q planes, flags and control block (allocated
         # whenever the option could apply, so that switching `layer_bwd` /
@@ -148,8 +143,7 @@ class _Workspace(object):
         self.stack_bwd = (net.stack_bwd and not net.blocked and not net.generic_layers
                           and L <= 256 and N * CH * 4 < 2 ** 31)
         if self.stack_bwd:
-            self.keep_dx = bool(net.stack_bwd_keep_dx) or \
-                os.environ.get('WN_STACK_BWD_PULL') == '1'
+            self.keep_dx = bool(net.stack_bwd_keep_dx)
             if parent is not None and getattr(parent, 'DX', None) is not None:
                 self.keep_dx = parent.keep_dx
             alloc('DX', (L if self.keep_dx else 1, N, CH))
@@ -184,7 +178,8 @@ class _Workspace(object):
             self.nslab = max(1, min(self.nslab, (8 << 30) // per))
         self.nslab_f = lib.wn_layer_bwdw_slabs(B, T)      # fused kernel
         self.nslab_2 = lib.wn_layer_bwd2_slabs(B, T)
-        self.nslab_s = lib.wn_stack_bwd_slabs(B, T) if self.stack_bwd else 0
+        self.nslab_s = lib.wn_stack_bwd_slabs(B, T, self.stack_variant) \
+            if self.stack_bwd else 0
         alloc('wimg', (L, lib.wn_layer_bwd2_wimg_floats()))
         if net.blocked:
             # channel-block path: one slab region per (input, output) block
@@ -218,7 +213,7 @@ class _Workspace(object):
         # per-tile column sums of da: [L][tiles][64] for 32-row tiles (the
         # per-layer kernels, wn_stack_bwd on big batches) or 16-row tiles
         # (wn_stack_bwd on small ones, wn_stack_tile_rows): two views of one buffer
-        self.stack_rows = lib.wn_stack_tile_rows(B, T)
+        self.stack_rows = lib.wn_stack_tile_rows(B, T, self.stack_variant)
         nt16 = B * ((T + 15) // 16)
         if net.G:
             buf = alloc('tilesum_buf', (L * nt16 * 64,))
@@ -248,6 +243,10 @@ class WaveNetModel(object):
         loss = net.loss(input_batch)          # forward + backward on the GPU
         optimizer.minimize(loss)              # fused TF-rule update
     '''
+
+    # variant word of the stack launches a new model starts with (0 = the
+    # library's choice per shape; tests / tools set it, see `stack_variant`)
+    DEFAULT_STACK_VARIANT = 0
 
     def __init__(self,
                  batch_size,
@@ -305,10 +304,10 @@ class WaveNetModel(object):
         self.overlap_tn_split_frac = 0.6
         # channel-block models (33 - 128 channels): dz and the gate gradients
         # in one launch (False: two launches, A/B and tests; bitwise equal)
-        self.wide_fuse_gate = os.environ.get('WN_WIDE_FUSE_GATE', '1') != '0'
+        self.wide_fuse_gate = True
         # column sums (bias gradients) of the weight-gradient GEMMs spread over
-        # all tile rows of a split (WN_TN_SPREAD=0: one owner tile row, A/B)
-        self.tn_spread_colsum = os.environ.get('WN_TN_SPREAD', '1') != '0'
+        # all tile rows of a split (False: one owner tile row, A/B)
+        self.tn_spread_colsum = True
         # backward of a residual block: 'bwd2' (default: one kernel per layer,
         # pre-activation gradients recomputed per tile, only dx goes through
         # HBM, tanh recovered as z / sigmoid); 'bwdw' (round-1 fused kernel:
@@ -319,25 +318,20 @@ class WaveNetModel(object):
         # forward of the residual stack as ONE persistent launch
         # (wn_stack_fwd: tiles stay in registers from layer to layer, the
         # dilated taps are handed over through per-tile flags) instead of one
-        # wn_layer_fwd launch per layer.  WN_STACK_FWD=0 selects the latter.
-        self.stack_fwd = os.environ.get('WN_STACK_FWD', '1') != '0'
+        # wn_layer_fwd launch per layer.  False selects the latter.
+        self.stack_fwd = True
         # the same for the backward of the stack (wn_stack_bwd instead of one
         # wn_layer_bwd2 per layer); read when a workspace is created
-        self.stack_bwd = os.environ.get('WN_STACK_BWD', '1') != '0'
+        self.stack_bwd = True
         # diagnostic: keep dL/dx_l of every layer instead of one plane
         # rewritten in place (read when a workspace is created)
-        self.stack_bwd_keep_dx = os.environ.get('WN_STACK_KEEP_DX') == '1'   # (A/B knob)
-        # OPT-IN (WN_NN_CHAIN=1; default off): the three NN GEMMs of the skip
-        # sum / post-processing (and the three of their data gradients) as ONE
-        # persistent launch each (wn_gemm_nn_chain: a problem's ragged end
-        # overlaps the next one's start; bitwise the results of the six
-        # wn_gemm_nn launches).  Measured on MI355X:
-        # what the overlap returns at B = 8 (the K = 256 / 512 launches lose
-        # 8 - 14 % to their ragged ends) a persistent workgroup pays back per
-        # tile -- its next tile's first chunk waits behind its own epilogue
-        # stores -- 4736 vs 4728 us per step; at B = 1 / 2 it loses 10 - 20 %.
-        self.nn_chain = os.environ.get('WN_NN_CHAIN', '0') == '1'
-        self._nn_chain_nx = None      # XCD queues (probed on first use)
+        self.stack_bwd_keep_dx = False
+        # explicit variant word of the stack launches (_lib.stack_variant:
+        # tile rows, waves per workgroup, split backward), 0 = the library's
+        # choice for the shape; for A/B runs and tests, read when a workspace
+        # is created (setting it drops the resident workspaces).  (The library
+        # reads no process environment.)
+        self._stack_variant = int(self.DEFAULT_STACK_VARIANT)
         # generate(): four kernels per sample over many CUs, replayed from a
         # hipGraph, instead of the single-workgroup persistent kernel
         self.fastgen_multi_cu = True
@@ -346,8 +340,8 @@ class WaveNetModel(object):
         # (wn_fastgen_persist: chain segments / skip / post-processing / draw
         # workgroups resident for the whole run, weights resident in LDS,
         # in-launch hand-overs instead of four kernel boundaries per sample);
-        # WN_FASTGEN_PERSIST=0: the step kernels replayed from a hipGraph
-        self.fastgen_persistent = os.environ.get('WN_FASTGEN_PERSIST', '1') != '0'
+        # False: the step kernels replayed from a hipGraph
+        self.fastgen_persistent = True
         # 'fp32' (default): fp32 MFMA GEMMs.  'bf16x6' / 'bf16x9' / 'bf16x3':
         # opt-in split-bf16 products for the six NN GEMMs (wn_gemm_nn_split;
         # x6 measures the same error vs float64 as the fp32 MFMA path)
@@ -416,6 +410,16 @@ class WaveNetModel(object):
         self.init_ops = []
         self.push_ops = []
         self.variables = self._create_variables(seed)
+
+    @property
+    def stack_variant(self):
+        return self._stack_variant
+
+    @stack_variant.setter
+    def stack_variant(self, v):
+        if int(v) != self._stack_variant:
+            self._stack_variant = int(v)
+            self._ws = {}          # slab counts / tile sums depend on it
 
     # ------------------------------------------------------------------ params
     def _create_variables(self, seed):
@@ -644,16 +648,8 @@ class WaveNetModel(object):
                     raise _lib.WaveNetHipError(
                         '%s: a dependency wait inside the persistent residual-'
                         'stack launch expired (2 s); the results of that step '
-                        'are invalid.  WN_STACK_FWD=0 / WN_STACK_BWD=0 select '
-                        'the one-launch-per-layer kernels.' % name)
-            for name in ('nnc_ctl_f', 'nnc_ctl_b'):
-                ctl = getattr(ws, name, None)
-                if ctl is not None and int(ctl[9]) != 0:
-                    raise _lib.WaveNetHipError(
-                        '%s: the chained NN GEMM launch left tiles uncomputed '
-                        'or a dependency wait expired (2 s); the results of '
-                        'that step are invalid.  WN_NN_CHAIN=0 selects one '
-                        'launch per GEMM.' % name)
+                        'are invalid.  net.stack_fwd / net.stack_bwd = False '
+                        'select the one-launch-per-layer kernels.' % name)
 
     def reset_device_errors(self):
         """Clear the expired-wait record (control word 3 and the NaN poison
@@ -664,10 +660,6 @@ class WaveNetModel(object):
                 ctl = getattr(ws, name, None)
                 if ctl is not None:
                     ctl[3] = 0
-            for name in ('nnc_ctl_f', 'nnc_ctl_b'):
-                ctl = getattr(ws, name, None)
-                if ctl is not None:
-                    ctl.zero_()
             ws.loss_parts[:2] = 0.0
 
     def _bwd_image_with_fwd(self, ws):
@@ -775,36 +767,15 @@ class WaveNetModel(object):
                   self.L, nb, self.CHn, _lib.stream())
         return out, (W2 if ids is not None else 0)
 
-    def _nn_chain_queues(self):
-        """XCD work queues of wn_gemm_nn_chain on this device (0: not usable).
-        Probed once (a tiny launch + one stream synchronisation)."""
-        if self._nn_chain_nx is None:
-            scratch = torch.zeros(1024, dtype=torch.int32, device=self.device)
-            self._nn_chain_nx = int(_lib.load().wn_gemm_nn_chain_probe(
-                _lib.ptr(scratch), _lib.stream()))
-        return self._nn_chain_nx
-
-    def _nn_seq(self, ws, ctl, poison, calls):
+    def _nn_seq(self, calls):
         """A sequence of row-wise dependent wn_gemm_nn calls (argument tuples
-        without the stream): ONE chained persistent launch when the option is
-        on and the shapes allow it (fp32 mode, K % 16 == 0, operands below
-        2 GB, a validated XCD topology), else one launch per call."""
+        without the stream), one launch each.  (Round 4 also ran them as ONE
+        persistent launch with row-block dependencies inside: bitwise equal,
+        worth at most 0.4 % of a B = 8 step and a loss at small batches;
+        removed in round 5, DESIGN.md.)"""
         st = _lib.stream()
-        ok = (self.nn_chain and self.gemm_mode == 'fp32' and len(calls) <= 3
-              and all(c[18] % 16 == 0 and c[17] % 4 == 0 and
-                      c[16] * max(c[1], 32) * 4 < 2 ** 31 and
-                      16 * c[5] * 4 < 2 ** 31 for c in calls)
-              and self._nn_chain_queues() > 0)
-        if not ok:
-            for c in calls:
-                self._nn(*(c + (st,)))
-            return
-        probs = _lib.nn_problems(calls)
-        flops = sum(2.0 * c[16] * c[17] * c[18] for c in calls)
-        _lib.call_timed('wn_gemm_nn_chain',
-                        (probs, len(calls), self._nn_chain_nx, _lib.ptr(ctl),
-                         _lib.ptr(poison), st), flops,
-                        getattr(self, '_gemm_events', None))
+        for c in calls:
+            self._nn(*(c + (st,)))
 
     def _nn(self, *args):
         """wn_gemm_nn (or, when `gemm_mode` asks for it, wn_gemm_nn_split),
@@ -834,7 +805,7 @@ class WaveNetModel(object):
     def _plan_key(self, tag, ws, ids, extra):
         return (tag, extra, ids is not None, self.generic_layers,
                 self.fused_bwd, self.layer_bwd, self.overlap_tn,
-                self.overlap_tn_split_frac, self.wide_fuse_gate, self.tn_spread_colsum, self.nn_chain, self.stack_fwd, self.stack_bwd, self.gemm_mode, self.causal_wgrad_segsum, self.tf_xent_zero_label_quirk,
+                self.overlap_tn_split_frac, self.wide_fuse_gate, self.tn_spread_colsum, self.stack_fwd, self.stack_bwd, ws.stack_variant, self.gemm_mode, self.causal_wgrad_segsum, self.tf_xent_zero_label_quirk,
                 _lib.stream(), self.params.data_ptr(), self.grads.data_ptr())
 
     def _stage_ids(self, ws, ids):
@@ -923,7 +894,8 @@ class WaveNetModel(object):
                       bstride, _lib.ptr(self._dil_dev),
                       _lib.ptr(ws.stack_flags), _lib.ptr(ws.stack_ctl),
                       _lib.ptr(ws.loss_parts),
-                      L, B, T, 1 if save_ts else 0, st), 0.0,
+                      L, B, T, 1 if save_ts else 0,
+                      ws.stack_variant, st), 0.0,
                       getattr(self, '_gemm_events', None))
         for l, d in enumerate(self.dilations if not self.blocked and not stack
                               else []):
@@ -952,7 +924,7 @@ class WaveNetModel(object):
         b1 = self._seg(P, 'post1_b') if self.use_biases else None
         b2 = self._seg(P, 'post2_b') if self.use_biases else None
         rp = self.residual_postproc
-        self._nn_seq(ws, ws.nnc_ctl_f, ws.loss_parts, [
+        self._nn_seq([
             (_lib.ptr(ws.Z), 0, LP, N * CH,
              _lib.ptr(self._seg(P, 'skip_w')), S, _lib.ptr(bsum), None, 0,
              None, 0, _lib.ptr(ws.h1), S, 0, 0,
@@ -1061,8 +1033,7 @@ class WaveNetModel(object):
         # (small batches: the TN GEMMs run on a side stream beside the dZ GEMM
         # and the backward stack, so the dZ GEMM stays a launch of its own
         # behind the fork)
-        self._nn_seq(ws, ws.nnc_ctl_b, ws.loss_parts[1:],
-                     [nn_dc1, nn_dtotal] if ovl else [nn_dc1, nn_dtotal, nn_dz])
+        self._nn_seq([nn_dc1, nn_dtotal] if ovl else [nn_dc1, nn_dtotal, nn_dz])
         tn(_lib.ptr(ws.h2), S, 0, 0, None, 0, _lib.ptr(dlog), Q, 'post2', S, Q,
            _lib.ptr(self._seg(Gr, 'post2_w')),
            _lib.ptr(self._seg(Gr, 'post2_b')))
@@ -1116,7 +1087,7 @@ class WaveNetModel(object):
                     None if tsum is None else _lib.ptr(tsum),
                     _lib.ptr(self._dil_dev), _lib.ptr(ws.stack_flags_b),
                     _lib.ptr(ws.stack_ctl_b),
-                    _lib.ptr(ws.loss_parts[1:]), L, B, T, st), 0.0,
+                    _lib.ptr(ws.loss_parts[1:]), L, B, T, ws.stack_variant, st), 0.0,
                     getattr(self, '_gemm_events', None))
                 self._backward_tail(ws, ids, ws.DX[0], ws.nslab_s, True,
                                     tile_rows=ws.stack_rows)
@@ -1568,24 +1539,42 @@ class WaveNetModel(object):
                 _lib.ptr(g['h1']), _lib.ptr(g['h2']), _lib.ptr(g['logits']))
 
         lib = _lib.load()
-        if self.fastgen_persistent and lib.wn_fastgen_persist_workgroups(
-                self.L, self.S, self.Q) <= torch.cuda.get_device_properties(
-                    self.device).multi_processor_count:
+        if self.fastgen_persistent and not g.get('persist_failed'):
+            # ONE persistent launch for the run.  Every workgroup has to be
+            # resident at once; the library checks that against the launch
+            # configuration's occupancy (WN_ERR_UNSUPPORTED: the step kernels
+            # below).  What it cannot see -- another process or stream holding
+            # CUs, a CU mask -- shows as an expired hand-over wait (sync[12]):
+            # the generator's state is then restored from a snapshot taken
+            # here and the run falls through to the step kernels, which always
+            # complete; `steps` advances only after a successful run.
             sync = self._gen_buf('fgp_sync', 16, torch.int32)
             ll = self._gen_buf('fgp_ll', int(lib.wn_fastgen_persist_ll_words(
                 self.L, self.S, self.Q)), torch.int64)
-            _lib.call('wn_fastgen_persist', *common, *tail, _lib.ptr(sync),
-                      _lib.ptr(ll), int(n_steps), _lib.stream())
-            g['steps'] += int(n_steps)
-            samples_io[:n_io].copy_(io[:n_io])
-            if proba_out is not None:
-                proba_out.view(-1).copy_(pb[:proba_out.numel()])
-            if int(sync[12]) != 0:       # (synchronises; a generation call ends on the host anyway)
-                raise _lib.WaveNetHipError(
+            snap = (g['state'].clone(), g['cursors'].clone(), g['pre'].clone())
+            code = lib.wn_fastgen_persist(*common, *tail, _lib.ptr(sync),
+                                          _lib.ptr(ll), int(n_steps), _lib.stream())
+            if code == 0:
+                if int(sync[12]) == 0:   # (synchronises; a generation call ends on the host anyway)
+                    g['steps'] += int(n_steps)
+                    samples_io[:n_io].copy_(io[:n_io])
+                    if proba_out is not None:
+                        proba_out.view(-1).copy_(pb[:proba_out.numel()])
+                    return
+                import warnings
+                warnings.warn(
                     'wn_fastgen_persist: a hand-over wait inside the persistent '
-                    'generation launch expired (2 s); the samples are invalid. '
-                    'WN_FASTGEN_PERSIST=0 selects the step kernels.')
-            return
+                    'generation launch expired (2 s: its workgroups were not all '
+                    'resident); state restored, continuing with the step kernels '
+                    '(net.fastgen_persistent = False selects them up front)')
+                g['state'].copy_(snap[0])
+                g['cursors'].copy_(snap[1])
+                g['pre'].copy_(snap[2])
+                io[:n_io].copy_(samples_io[:n_io])
+                g['persist_failed'] = True
+            elif code != -2:             # WN_ERR_UNSUPPORTED: not resident / shape
+                _lib.check(code, 'wn_fastgen_persist')
+            del snap
 
         def one():
             _lib.call('wn_fastgen_step', *common, *tail, _lib.stream())

@@ -67,45 +67,54 @@ def test_stack_entries_validate_without_gpu(hip_lib):
     assert hip_lib.wn_stack_flag_count(0, 33, 3) == 0
     # tile height: 16 rows while the batch has at most four 32-row tiles per CU
     # (256 CUs assumed without a device)
-    assert hip_lib.wn_stack_tile_rows(8, 16000) == 32
-    assert hip_lib.wn_stack_tile_rows(3, 16000) == 32
-    assert hip_lib.wn_stack_tile_rows(2, 16000) == 16
-    assert hip_lib.wn_stack_tile_rows(1, 16000) == 16
-    assert hip_lib.wn_stack_tile_rows(0, 16000) == 32
-    assert hip_lib.wn_stack_bwd_slabs(8, 16000) == 250           # 16 tiles per group
-    assert hip_lib.wn_stack_bwd_slabs(1, 16000) == 125           # 8 waves x one 16-row tile
-    assert hip_lib.wn_stack_bwd_slabs(0, 16000) == 0
+    assert hip_lib.wn_stack_tile_rows(8, 16000, 0) == 32
+    assert hip_lib.wn_stack_tile_rows(3, 16000, 0) == 32
+    assert hip_lib.wn_stack_tile_rows(2, 16000, 0) == 16
+    assert hip_lib.wn_stack_tile_rows(1, 16000, 0) == 16
+    assert hip_lib.wn_stack_tile_rows(0, 16000, 0) == 32
+    assert hip_lib.wn_stack_bwd_slabs(8, 16000, 0) == 250           # 16 tiles per group
+    assert hip_lib.wn_stack_bwd_slabs(1, 16000, 0) == 125           # 8 waves x one 16-row tile
+    assert hip_lib.wn_stack_bwd_slabs(0, 16000, 0) == 0
+    # the explicit variant word (WN_STACK_VARIANT of wavenet_hip.h): tile rows
+    # in bits 0..5, waves per workgroup in bits 8..11 -- the only thing besides
+    # the shape that selects a launch (the library reads no environment)
+    assert hip_lib.wn_stack_tile_rows(8, 16000, 16) == 16
+    assert hip_lib.wn_stack_tile_rows(1, 16000, 32) == 32
+    assert hip_lib.wn_stack_tile_rows(1, 16000, 17) == 16         # not a height: the shape's
+    assert hip_lib.wn_stack_bwd_slabs(1, 16000, 16 | (4 << 8)) == 250   # 4 waves x one 16-row tile
+    assert hip_lib.wn_stack_bwd_slabs(1, 16000, 32) == 125       # 32 rows: 4 waves x one tile
+    assert hip_lib.wn_stack_bwd_slabs(1, 16000, 32 | (8 << 8)) == 63    # ... 8 waves forced
     buf = (ctypes.c_float * 64)()
     a = ctypes.addressof(buf)
     assert hip_lib.wn_stack_fwd(None, a, a, a, None, 0, 0, a, a, a, None,
-                                2, 1, 64, 1, None) == -5
+                                2, 1, 64, 1, 0, None) == -5
     assert hip_lib.wn_stack_fwd(a, a, None, a, None, 0, 0, a, a, a, None,
-                                2, 1, 64, 1, None) == -5          # save_sg without SG
+                                2, 1, 64, 1, 0, None) == -5          # save_sg without SG
     assert hip_lib.wn_stack_fwd(a, a, a, a, None, 0, 0, a, a, a, None,
-                                0, 1, 64, 1, None) == -1          # L <= 0
+                                0, 1, 64, 1, 0, None) == -1          # L <= 0
     assert hip_lib.wn_stack_pack(a, 100, a, a, 2, None) == -1     # stride < block
     assert hip_lib.wn_stack_pack(a, 5216, None, None, 2, None) == -5
     assert hip_lib.wn_stack_wimg_floats() % 256 == 0
     assert hip_lib.wn_stack_fwd(a + 4, a, a, a, None, 0, 0, a, a, a, None,
-                                2, 1, 64, 1, None) == -3
+                                2, 1, 64, 1, 0, None) == -3
     assert hip_lib.wn_stack_fwd(a, a, a, a, None, 0, 0, a, a, a, None,
-                                257, 1, 64, 1, None) == -2        # L > 256
+                                257, 1, 64, 1, 0, None) == -2        # L > 256
     pl = 1 * 64 * 32
     assert hip_lib.wn_stack_bwd(a, a, a, a, None, pl, a, a, a, 5216, None, a, a, a,
-                                None, 2, 1, 64, None) == -5
+                                None, 2, 1, 64, 0, None) == -5
     assert hip_lib.wn_stack_bwd(a, a, a, a, a, pl, a, a, a, 5216, None, a, a, a,
-                                None, 2, 0, 64, None) == -1
-    assert hip_lib.wn_stack_bwd(a, a, a, a, a, pl, None, a, a, 100, None, a, a, a,
-                                None, 2, 1, 64, None) == -1       # slab stride too small
+                                None, 2, 0, 64, 0, None) == -1
+    assert hip_lib.wn_stack_bwd(a, a, a, a, a, pl, a, a, a, 100, None, a, a, a,
+                                None, 2, 1, 64, 0, None) == -1       # slab stride too small
     assert hip_lib.wn_stack_bwd(a, a + 4, a, a, a, pl, a, a, a, 5216, None, a, a, a,
-                                None, 2, 1, 64, None) == -3
+                                None, 2, 1, 64, 0, None) == -3
     assert hip_lib.wn_stack_bwd(a, a, a, a, a, pl, a + 4, a, a, 5216, None, a, a, a,
-                                None, 2, 1, 64, None) == -3       # Q misaligned
-    # one dx plane rewritten in place (stride 0) needs the push formulation's Q
+                                None, 2, 1, 64, 0, None) == -3       # Q misaligned
+    # the q planes are not optional
     assert hip_lib.wn_stack_bwd(a, a, a, a, a, 0, None, a, a, 5216, None, a, a, a,
-                                None, 2, 1, 64, None) == -1
+                                None, 2, 1, 64, 0, None) == -5
     assert hip_lib.wn_stack_bwd(a, a, a, a, a, 77, a, a, a, 5216, None, a, a, a,
-                                None, 2, 1, 64, None) == -1       # neither 0 nor a plane
+                                None, 2, 1, 64, 0, None) == -1       # neither 0 nor a plane
 
 
 @pytest.mark.parametrize('q', [2, 16, 123, 128, 256])
@@ -125,6 +134,20 @@ def test_product_does_not_import_oracle():
         if f.endswith('.py'):
             src = open(os.path.join(pkg, f)).read()
             assert 'oracle' not in src, f
+
+
+def test_library_reads_no_environment(hip_lib):
+    """Kernel selection is a function of the arguments (the `variant` word of
+    the stack launches, include/wavenet_hip.h) -- the shared object does not
+    even import getenv, and no source mentions it."""
+    import subprocess
+    from wavenet import _lib
+    out = subprocess.run(['nm', '-D', '--undefined-only', _lib.LIB_PATH],
+                         capture_output=True, text=True, check=True).stdout
+    assert 'getenv' not in out
+    csrc = os.path.join(ROOT, 'tensorflow-wavenet_amd', 'csrc')
+    for f in os.listdir(csrc):
+        assert 'getenv' not in open(os.path.join(csrc, f)).read(), f
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -136,3 +136,43 @@ def _clone_generator(gen):
     g.q0 = [a.copy() for a in gen.q0]
     g.queues = [[a.copy() for a in q] for q in gen.queues]
     return g
+
+
+def test_persistent_launch_failure_restores_state_and_falls_back(hip_lib, monkeypatch):
+    """A persistent generation launch whose workgroups cannot all be resident
+    (CUs held by another process: invisible to the launch-time occupancy check)
+    ends with an expired hand-over wait after it has rewritten part of the
+    generator's state.  The host must restore its snapshot, warn, and finish
+    the run on the step kernels: same samples as a model that took the step
+    kernels from the start, also on the following call."""
+    from wavenet import _lib
+    cfg = default_cfg()
+    a, _ = build_pair(cfg)
+    b, _ = build_pair(cfg)
+    a.fastgen_graph_steps = b.fastgen_graph_steps = 40
+    b.fastgen_persistent = False
+    lib = _lib.load()
+    real = lib.wn_fastgen_persist
+    calls = []
+
+    def failing(*args):
+        # the real launch runs (state, cursors, codes are rewritten), then
+        # reports what an expired wait reports
+        code = real(*args)
+        torch.cuda.synchronize()
+        a._gen['fgp_sync'][12] = 1
+        calls.append(code)
+        return code
+    monkeypatch.setattr(lib, 'wn_fastgen_persist', failing)
+    seed = _wave(700, 3)
+    with pytest.warns(UserWarning, match='state restored'):
+        out_a = a.generate(150, seed_samples=seed, seed=9).cpu().numpy()
+    out_b = b.generate(150, seed_samples=seed, seed=9).cpu().numpy()
+    assert calls == [0] and a._gen['persist_failed']
+    assert np.array_equal(out_a, out_b)
+    assert a._gen['steps'] == b._gen['steps']
+    more_a = a.continue_generation(90, int(out_a[-1]), seed=4).cpu().numpy()
+    more_b = b.continue_generation(90, int(out_b[-1]), seed=4).cpu().numpy()
+    assert calls == [0]                     # not tried again on this generator
+    assert np.array_equal(more_a, more_b)
+    assert torch.equal(a._gen['state'], b._gen['state'])

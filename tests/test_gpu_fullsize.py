@@ -65,8 +65,9 @@ def test_full_size_dp_identity_and_determinism(hip_lib, monkeypatch):
     continuous there: the two heights agree with the float64 oracle to 3e-6 of
     a variable EACH, taking their own side at those kinks, and with each other
     only to 1.7e-3.  The identity under test is the sharding's."""
-    monkeypatch.setenv('WN_STACK_ROWS', '32')
     from wavenet import WaveNetModel
+    from wavenet._lib import stack_variant
+    monkeypatch.setattr(WaveNetModel, 'DEFAULT_STACK_VARIANT', stack_variant(rows=32))
     T = 16000
     audio = synth_audio(8, T)
     net8 = WaveNetModel(seed=0, **model_kwargs(default_cfg(8)))

@@ -505,105 +505,43 @@ def _chain_outputs(M, S, Q, P_out):
 @pytest.mark.parametrize('M,P_in,S,Q,P_out,rp', [
     (128000 // 8 + 77, 6, 256, 128, 5, False),   # ragged M, dZ N = 160 (32 columns in the last tile)
     (3000, 4, 512, 256, 6, True),                # N = 192: a dead wave half; residual_postproc
-    (300, 2, 64, 32, 2, False),                  # fewer row blocks than XCD queues
+    (300, 2, 64, 32, 2, False),
     (1, 1, 16, 16, 1, True),
 ])
-def test_gemm_nn_chain_bitwise_equals_single_launches(hip_lib, M, P_in, S, Q, P_out, rp):
-    """wn_gemm_nn_chain (one persistent launch, row-block dependencies inside
-    the launch) against the same problems as single wn_gemm_nn launches: every
-    output bitwise equal, also on a re-used control block (the kernel re-arms
-    it), and the single launches against float64."""
+def test_gemm_nn_step_sequence_vs_float64(hip_lib, M, P_in, S, Q, P_out, rp):
+    """The six row-wise dependent NN GEMMs of a training step in miniature
+    (skip sum -> post1 -> post2, dc1 -> dtotal -> dZ; model.py:430-440 and its
+    gradient), each launch fed by the previous one's output, every output
+    against a float64 evaluation of the same sequence."""
     from wavenet import _lib
-    lib = hip_lib
     st = torch.cuda.current_stream().cuda_stream
-    scratch = torch.zeros(1024, dtype=torch.int32, device='cuda')
-    nx = lib.wn_gemm_nn_chain_probe(scratch.data_ptr(), st)
-    if nx == 0:
-        pytest.skip('XCD topology not validated on this device: single launches are used')
     t = _chain_case(M, P_in, S, Q, P_out, rp, seed=M + S)
-    ref_o, got_o = _chain_outputs(M, S, Q, P_out), _chain_outputs(M, S, Q, P_out)
-    fr, br = _chain_problems(t, ref_o, M, P_in, S, Q, P_out, rp)
+    o = _chain_outputs(M, S, Q, P_out)
+    fr, br = _chain_problems(t, o, M, P_in, S, Q, P_out, rp)
     for c in fr + br:
         _lib.call('wn_gemm_nn', *(c + (st,)))
-    fg, bg = _chain_problems(t, got_o, M, P_in, S, Q, P_out, rp)
-    ctl = torch.zeros(lib.wn_gemm_nn_chain_ctl_words(M), dtype=torch.int32, device='cuda')
-    poison = torch.zeros(1, device='cuda')
-    for rep in range(3):
-        for k in got_o.values():
-            k.fill_(float('nan'))
-        for chain in (fg, bg):
-            _lib.call('wn_gemm_nn_chain', _lib.nn_problems(chain), 3, nx, ctl.data_ptr(),
-                      poison.data_ptr(), st)
-        torch.cuda.synchronize()
-        assert int(ctl[9]) == 0 and float(poison) == 0.0
-        assert int(ctl.abs().sum()) == 0          # re-armed
-        for name in ref_o:
-            if not rp and name in ('total', 'c1', 'dh2'):
-                continue
-            assert torch.equal(ref_o[name], got_o[name]), (name, rep)
-    # a chain of two, and of one
-    for k in ('dc1', 'dtotal'):
-        got_o[k].fill_(float('nan'))
-    _lib.call('wn_gemm_nn_chain', _lib.nn_problems(bg[:2]), 2, nx, ctl.data_ptr(),
-              poison.data_ptr(), st)
-    got_o['dZ'].fill_(float('nan'))
-    _lib.call('wn_gemm_nn_chain', _lib.nn_problems(bg[2:]), 1, nx, ctl.data_ptr(),
-              poison.data_ptr(), st)
     torch.cuda.synchronize()
-    assert int(ctl[9]) == 0 and float(poison) == 0.0
-    for k in ('dc1', 'dtotal', 'dZ'):
-        assert torch.equal(ref_o[k], got_o[k]), k
-    # the single launches themselves against float64
-    Z = t['Z'].cpu().numpy().transpose(1, 0, 2).reshape(M, P_in * 32).astype(np.float64)
-    total = Z @ t['Ws'].cpu().numpy().astype(np.float64) + t['bs'].cpu().numpy()
-    assert np.abs(ref_o['h1'].cpu().numpy() - np.maximum(total, 0)).max() < \
-        1e-4 * max(1.0, np.abs(total).max())
-
-
-def test_gemm_nn_chain_argument_checks(hip_lib):
-    from wavenet import _lib
-    lib = hip_lib
-    st = torch.cuda.current_stream().cuda_stream
-    a = torch.zeros(64, 16, device='cuda')
-    ctl = torch.zeros(lib.wn_gemm_nn_chain_ctl_words(64), dtype=torch.int32, device='cuda')
-    ok = (a.data_ptr(), 16, 0, 0, a.data_ptr(), 16, None, None, 0, None, 0,
-          a.data_ptr(), 16, 0, 0, None, 64, 16, 16, 0)
-    assert lib.wn_gemm_nn_chain(_lib.nn_problems([ok]), 0, 8, ctl.data_ptr(), None, st) == -1
-    assert lib.wn_gemm_nn_chain(_lib.nn_problems([ok] * 3), 3, 3, ctl.data_ptr(), None, st) == -1
-    assert lib.wn_gemm_nn_chain(_lib.nn_problems([ok]), 1, 8, None, None, st) == -5
-    k12 = ok[:18] + (12, 0)          # K % 16 != 0: the single launch takes another kernel
-    assert lib.wn_gemm_nn_chain(_lib.nn_problems([k12]), 1, 8, ctl.data_ptr(), None, st) == -2
-    m2 = ok[:16] + (32,) + ok[17:]   # another M in the same chain
-    assert lib.wn_gemm_nn_chain(_lib.nn_problems([ok, m2]), 2, 8, ctl.data_ptr(), None, st) == -1
-
-
-@pytest.mark.parametrize('rp', [False, True])
-def test_model_with_chained_nn_gemms_bitwise_equals_default(hip_lib, rp):
-    """`net.nn_chain = True` (opt-in: the skip-sum / post-processing GEMMs and
-    their data gradients as two chained persistent launches): loss, logits and
-    every gradient bitwise equal to the default six launches, over three steps
-    on one workspace (eager, recorded and replayed launch plan)."""
-    import json
-    import os
-    from util import ROOT, build_pair, synth_audio
-    p = json.load(open(os.path.join(ROOT, 'wavenet_params.json')))
-    cfg = {k: p[k] for k in p if k != 'sample_rate'}
-    cfg.update(batch_size=3, residual_postproc=rp)
-    a, _ = build_pair(cfg)
-    b, _ = build_pair(cfg)
-    a.nn_chain = True
-    if a._nn_chain_queues() == 0:
-        pytest.skip('XCD topology not validated on this device')
-    assert not b.nn_chain
-    audio = synth_audio(3, 4100)
-    for rep in range(3):
-        la, lb = a.loss(audio), b.loss(audio)
-        torch.cuda.synchronize()
-        assert float(la) == float(lb)
-        assert torch.equal(a.grads, b.grads), rep
-    wa = list(a._ws.values())[0]
-    assert int(wa.nnc_ctl_f[9]) == 0 and int(wa.nnc_ctl_b[9]) == 0
-    a.check_device_errors()
+    f = lambda k: t[k].cpu().numpy().astype(np.float64)
+    g = lambda k: o[k].cpu().numpy().astype(np.float64)
+    Z = f('Z').transpose(1, 0, 2).reshape(M, P_in * 32)
+    total = Z @ f('Ws') + f('bs')
+    h1 = np.maximum(total, 0)
+    c1 = h1 @ f('W1') + f('b1')
+    h2 = np.maximum(c1, 0) + (total if rp else 0)       # (model.py:435-437)
+    logits = h2 @ f('W2') + f('b2')
+    # (masks are taken from the device's own pre-activations: a ReLU within
+    # rounding of its kink may legitimately fall on either side)
+    m2 = (g('c1') if rp else g('h2')) > 0
+    dpre = f('dlog') @ f('W2t')
+    dc1 = dpre * m2
+    dtotal = (dc1 @ f('W1t')) * (g('h1') > 0) + (dpre if rp else 0)
+    dZ = (dtotal @ f('Wst')).reshape(M, P_out, 32).transpose(1, 0, 2)
+    want = dict(h1=h1, h2=h2, logits=logits, dc1=dc1, dtotal=dtotal, dZ=dZ)
+    if rp:
+        want.update(total=total, c1=c1, dh2=dpre)
+    for name, w in want.items():
+        err = np.abs(g(name) - w).max()
+        assert err < 2e-5 * max(1.0, np.abs(w).max()), (name, err)
 
 
 @pytest.mark.parametrize('C', [64, 96, 128])

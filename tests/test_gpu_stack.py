@@ -11,6 +11,8 @@ import pytest
 import torch
 
 from util import ROOT, TINY, build_pair, cfg_with, synth_audio
+from wavenet import WaveNetModel
+from wavenet._lib import stack_variant
 
 pytestmark = pytest.mark.gpu
 
@@ -63,8 +65,10 @@ CASES = [
 def _tile_rows_32(monkeypatch):
     """The bitwise statements of this file are about the 32-row launches; small
     batches would otherwise run the 16-row ones (wn_stack_tile_rows), which sum
-    in another grouping -- they have their own tests below."""
-    monkeypatch.setenv('WN_STACK_ROWS', '32')
+    in another grouping -- they have their own tests below.  (The variant word
+    is an explicit argument of the C entry points; the class default is what a
+    new model passes.)"""
+    monkeypatch.setattr(WaveNetModel, 'DEFAULT_STACK_VARIANT', stack_variant(rows=32))
 
 
 @pytest.mark.parametrize('name,mk,B,T,kind', CASES, ids=[c[0] for c in CASES])
@@ -99,11 +103,11 @@ def test_stack_forward_16_row_tiles(hip_lib, monkeypatch, name, mk, B, T, kind, 
     one launch per layer: the same products summed in another grouping, so
     every plane agrees to rounding (2e-5 of the plane's largest entry after up
     to 50 layers), run to run bitwise."""
-    monkeypatch.setenv('WN_STACK_ROWS', '16')
-    monkeypatch.setenv('WN_STACK16_WAVES_F', waves)
+    var = stack_variant(rows=16, waves=int(waves))
+    monkeypatch.setattr(WaveNetModel, 'DEFAULT_STACK_VARIANT', var)
     cfg = mk()
     a, b = _pair(cfg)
-    assert hip_lib.wn_stack_tile_rows(B, T) == 16
+    assert hip_lib.wn_stack_tile_rows(B, T, var) == 16
     audio = synth_audio(B, T)
     gc = np.array([(37 * i) % 377 for i in range(B)], np.int32) if kind == 'gc' else None
     prev = None
@@ -161,13 +165,12 @@ def _f64_layer_grads(net, ws, l):
     dxn = None
     if l + 1 < L:
         dxn = f(ws.DX[l + 1])
-        if getattr(ws, 'DQ', None) is not None and os.environ.get('WN_STACK_BWD_PULL') != '1':
-            # "push" formulation: DX[l+1] holds dx_{l+1} without the term of
-            # the tap, which sits in DQ[l+1] at the rows d_{l+1} later
-            dd = int(net.dilations[l + 1])
-            dxn = dxn.clone()
-            if dd < T:
-                dxn[:, :T - dd] += f(ws.DQ[l + 1])[:, dd:]
+        # DX[l+1] holds dx_{l+1} without the term of the tap, which sits in
+        # DQ[l+1] at the rows d_{l+1} later
+        dd = int(net.dilations[l + 1])
+        dxn = dxn.clone()
+        if dd < T:
+            dxn[:, :T - dd] += f(ws.DQ[l + 1])[:, dd:]
         dz = dz + dxn @ Wd.t()
     th = torch.where(SG > 1e-30, Z / SG.clamp_min(1e-30), torch.zeros_like(Z))
     da_f = dz * (SG - Z * th)
@@ -242,13 +245,12 @@ def test_stack_backward_equals_per_layer(hip_lib, monkeypatch, name, mk, B, T, k
     rows = 16: the small-batch launch (16-row tiles), forced on every shape
     here; all three models then run the 16-row FORWARD too, so the planes the
     backward paths read are bitwise the same."""
-    monkeypatch.setenv('WN_STACK_ROWS', str(rows))
     # ('splitN': the opt-in launch with the weight gradients on waves of their
     # own, N row waves per workgroup)
-    monkeypatch.setenv('WN_STACK16_SPLIT', '1' if waves.startswith('split') else '0')
-    waves = waves.replace('split', '')
-    monkeypatch.setenv('WN_STACK16_WAVES_B', waves)
-    assert hip_lib.wn_stack_tile_rows(B, T) == rows
+    var = stack_variant(rows=rows, waves=int(waves.replace('split', '')),
+                        split=waves.startswith('split'))
+    monkeypatch.setattr(WaveNetModel, 'DEFAULT_STACK_VARIANT', var)
+    assert hip_lib.wn_stack_tile_rows(B, T, var) == rows
     cfg = mk()
     a, _ = build_pair(cfg)
     b, _ = build_pair(cfg)
@@ -290,34 +292,6 @@ def test_stack_backward_equals_per_layer(hip_lib, monkeypatch, name, mk, B, T, k
         prev = ga.clone()
         ctl = wa.stack_ctl_b.cpu().tolist()
         assert ctl[0] == 0 and ctl[1] == 0 and ctl[3] == 0 and ctl[2] == 2 + rep, ctl
-
-
-@pytest.mark.parametrize('name,mk,B,T,kind', CASES[1:6] + CASES[7:], ids=[c[0] for c in CASES[1:6] + CASES[7:]])
-def test_stack_backward_push_equals_pull(hip_lib, monkeypatch, name, mk, B, T, kind):
-    """The two formulations of the backward stack launch -- "push" (default: a
-    tile publishes what its rows contribute to the rows d earlier) and "pull"
-    (WN_STACK_BWD_PULL=1: every tile re-derives the gate gradients at the rows d
-    later) -- give the same gradients to rounding."""
-    cfg = mk()
-    audio = synth_audio(B, T)
-    gc = np.array([(37 * i) % 377 for i in range(B)], np.int32) if kind == 'gc' else None
-    grads = []
-    for pull in ('0', '1'):
-        monkeypatch.setenv('WN_STACK_BWD_PULL', pull)
-        net, _ = build_pair(cfg)
-        net.use_launch_plans = False
-        loss = net.loss(audio, global_condition_batch=gc) if gc is not None else net.loss(audio)
-        torch.cuda.synchronize()
-        ws = list(net._ws.values())[0]
-        if not ws.stack_bwd:
-            pytest.skip('configuration runs the generic backward kernels')
-        assert int(ws.stack_ctl_b[3]) == 0
-        grads.append((float(loss), net.grads.clone(), ws.DX[0].clone()))
-    assert grads[0][0] == grads[1][0]
-    sc = float(grads[1][1].abs().max())
-    assert float((grads[0][1] - grads[1][1]).abs().max()) <= 2e-6 * sc
-    sx = float(grads[1][2].abs().max())
-    assert float((grads[0][2] - grads[1][2]).abs().max()) <= 1e-5 * sx + 1e-30
 
 
 def test_child_workspace_owns_fresh_backward_control_block(hip_lib):

@@ -49,48 +49,6 @@ def nn():
         print('nn %-6s K=%4d N=%4d: %7.1f us  %.1f TFLOP/s' % (name, K, Nn, t * 1e6, 2.0 * N * K * Nn / t / 1e12))
 
 
-def nnab():
-    """128- vs 256-row NN tiles, interleaved in one process (WN_NN_ROWS)"""
-    for rep in range(2):
-        for rows in ('128', '256'):
-            os.environ['WN_NN_ROWS'] = rows
-            print('--- WN_NN_ROWS=%s' % rows)
-            nn()
-    del os.environ['WN_NN_ROWS']
-
-
-def nnexp():
-    """A/B of WN_NN_MODE[:WN_NN_EXP] configs (KB_EXPS), interleaved per shape;
-    prints the median of 5 interleaved repetitions"""
-    N = 128000
-    for (K, Nn, planes_a, planes_c, name) in [(1600, 512, 50, 0, 'skip'), (512, 512, 0, 0, 'post1'),
-                                               (512, 256, 0, 0, 'post2'), (256, 512, 0, 0, 'dh2'),
-                                               (512, 1600, 0, 50, 'dZ')]:
-        A = torch.randn(N * K, device=dev)
-        W = torch.randn(K * Nn, device=dev)
-        C = torch.empty(N * Nn, device=dev)
-        bias = torch.randn(Nn, device=dev)
-        def f():
-            _lib.call('wn_gemm_nn', A.data_ptr(), 0 if planes_a else K, planes_a, N * 32, W.data_ptr(), Nn,
-                      bias.data_ptr(), None, 0, None, 0, C.data_ptr(), 0 if planes_c else Nn, planes_c, N * 32,
-                      None, N, Nn, K, 1, st())
-        res = {v: [] for v in sys_exp}
-        for rep in range(5):
-            for v in sys_exp:
-                os.environ['WN_NN_MODE'] = v.split(':')[0]
-                os.environ['WN_NN_EXP'] = (v.split(':') + ['0'])[1]
-                res[v].append(timeit(f, n=8, warm=2))
-        line = 'nn %-6s K=%4d N=%4d:' % (name, K, Nn)
-        for v in sys_exp:
-            t = sorted(res[v])[2]
-            line += '  %s %6.1f us %5.1f TF' % (v, t * 1e6, 2.0 * N * K * Nn / t / 1e12)
-        print(line, flush=True)
-    del os.environ['WN_NN_MODE'], os.environ['WN_NN_EXP']
-
-
-sys_exp = os.environ.get('KB_EXPS', 'tile,stream').split(',')
-
-
 def nnacc():
     """speed and accuracy (vs float64) of the NN GEMM: fp32 MFMA vs the
     split-bf16 variants (wn_gemm_nn_split, nprod 3 / 6 / 9)"""
@@ -182,10 +140,8 @@ def vendor():
 
 
 def tn():
-    """weight-gradient GEMMs; WN_TN_MODE variants (KB_TN, default 'reg,dma')
-    interleaved, median of 5; splits as the model picks them and a few more"""
+    """weight-gradient GEMMs; splits as the model picks them and a few more"""
     N = 128000
-    modes = os.environ.get('KB_TN', 'reg,dma').split(',')
     for (Mw, Nw, planes, name, sps) in [(1600, 512, 50, 'dWs', (13, 19, 25, 38, 51)), (512, 512, 0, 'dW1', (32, 48, 64, 96, 128)),
                                         (512, 256, 0, 'dW2', (64, 96, 128, 192))]:
         A = torch.randn(N * Mw, device=dev)
@@ -196,17 +152,8 @@ def tn():
             def f():
                 _lib.call('wn_gemm_tn', A.data_ptr(), 0 if planes else Mw, planes, N * 32, None, 0, 16000,
                           G.data_ptr(), Nw, slabs.data_ptr(), sp, N, Mw, Nw, 1, st())
-            res = {m: [] for m in modes}
-            for rep in range(5):
-                for m in modes:
-                    os.environ['WN_TN_MODE'] = m
-                    res[m].append(timeit(f, n=6, warm=2))
-            line = 'tn %-4s %dx%d splits=%3d:' % (name, Mw, Nw, sp)
-            for m in modes:
-                t = sorted(res[m])[2]
-                line += '  %s %7.1f us %5.1f TF' % (m, t * 1e6, 2.0 * N * Mw * Nw / t / 1e12)
-            print(line, flush=True)
-    del os.environ['WN_TN_MODE']
+            t = sorted(timeit(f, n=6, warm=2) for _ in range(5))[2]
+            print('tn %-4s %dx%d splits=%3d: %7.1f us %5.1f TF' % (name, Mw, Nw, sp, t * 1e6, 2.0 * N * Mw * Nw / t / 1e12), flush=True)
 
 
 def layer():
@@ -233,10 +180,9 @@ def layer():
 
 
 def bwd2():
-    """wn_layer_bwd2 variants (WN_B2_MODE) next to wn_layer_bwdw, several batch
-    sizes: per-tile latency vs throughput"""
+    """wn_layer_bwd2 next to wn_layer_bwdw, several batch sizes: per-tile
+    latency vs throughput"""
     T = 16000
-    modes = os.environ.get('KB_B2', 'd,4p').split(',')
     for B in (1, 2, 4, 8, 16):
         N = B * T
         mk = lambda: torch.randn(N * 32, device=dev)
@@ -246,14 +192,12 @@ def bwd2():
         wimg = torch.randn(5376, device=dev) * 0.1
         for d in (4, 512):
             line = 'B=%2d d=%3d:' % (B, d)
-            for m in modes:
-                os.environ['WN_B2_MODE'] = m
-                nsl = lib.wn_layer_bwd2_slabs(B, T)
-                slabs = torch.empty(nsl * 5216, device=dev)
-                t = timeit(lambda: _lib.call('wn_layer_bwd2', x.data_ptr(), z.data_ptr(), sg.data_ptr(), dZ.data_ptr(),
-                                             dxin.data_ptr(), dxo.data_ptr(), w.data_ptr(), wimg.data_ptr(), slabs.data_ptr(), None,
-                                             B, T, d, st()), n=20, warm=3)
-                line += '  bwd2[%s] %6.1f us' % (m, t * 1e6)
+            nsl = lib.wn_layer_bwd2_slabs(B, T)
+            slabs = torch.empty(nsl * 5216, device=dev)
+            t = timeit(lambda: _lib.call('wn_layer_bwd2', x.data_ptr(), z.data_ptr(), sg.data_ptr(), dZ.data_ptr(),
+                                         dxin.data_ptr(), dxo.data_ptr(), w.data_ptr(), wimg.data_ptr(), slabs.data_ptr(), None,
+                                         B, T, d, st()), n=20, warm=3)
+            line += '  bwd2 %6.1f us' % (t * 1e6)
             nsl = lib.wn_layer_bwdw_slabs(B, T)
             slabs = torch.empty(nsl * 5216, device=dev)
             t = timeit(lambda: _lib.call('wn_layer_bwdw', x.data_ptr(), z.data_ptr(), f.data_ptr(), g.data_ptr(),
@@ -262,7 +206,6 @@ def bwd2():
                                          None, B, T, d, 1, st()), n=20, warm=3)
             line += '  bwdw %6.1f us' % (t * 1e6)
             print(line, flush=True)
-    os.environ.pop('WN_B2_MODE', None)
 
 
 def lk():

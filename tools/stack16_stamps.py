@@ -14,7 +14,6 @@ if 'WN_LIB_PATH' not in os.environ:
     os.environ['WN_LIB_PATH'] = out
     if len(sys.argv) > 1 and sys.argv[1] == 'build':
         sys.exit(0)
-os.environ.setdefault('WN_STACK_ROWS', '16')
 sys.path.insert(0, PKG)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import ctypes
@@ -24,6 +23,11 @@ import torch
 from wavenet import _lib, WaveNetModel
 from util import model_kwargs, synth_audio
 lib = _lib.load()
+# KB_SPLIT (default 1) / KB_WAVES_B: variant of the backward launch
+split = os.environ.get('KB_SPLIT', '1') != '0'
+rw = int(os.environ.get('KB_WAVES_B', 8))
+VAR = _lib.stack_variant(rows=16, waves=rw, split=split)
+WaveNetModel.DEFAULT_STACK_VARIANT = VAR
 B, T = int(os.environ.get('KB_B', 1)), 16000
 p = json.load(open(os.path.join(ROOT, 'wavenet_params.json')))
 cfg = {k: p[k] for k in p if k != 'sample_rate'}
@@ -36,9 +40,9 @@ L = net.L
 # the launches' grids, as wn_stack_fwd / wn_stack_bwd choose them (the
 # calibration words sit behind gridDim.x workgroups' stamps)
 nt16 = B * ((T + 15) // 16)
-wf = int(os.environ.get('WN_STACK16_WAVES_F', 4 if (nt16 + 3) // 4 <= 256 else 8))
+wf = rw        # (one variant word serves both launches)
 gridf = min(256, (nt16 + wf - 1) // wf)
-gridb = min(256, lib.wn_stack_bwd_slabs(B, T))
+gridb = min(256, lib.wn_stack_bwd_slabs(B, T, VAR))
 dbg = torch.zeros(gridf * 16 * L * 16 + gridf * 4, dtype=torch.int64, device='cuda')
 dbgb = torch.zeros(gridb * 16 * L * 16 + gridb * 4, dtype=torch.int64, device='cuda')
 lib.wn_diag_stack_dbg.argtypes = [ctypes.c_void_p]
@@ -86,7 +90,6 @@ report(dbg.cpu().numpy(), gridf, 'stack_fwd16_kernel', [
     (3, 4, '32 past-tap MFMAs'), (4, 5, 'tanh / sigmoid'), (5, 6, 'dense bias + 16 MFMAs'),
     (6, 7, "x' out (stored, drained, flag posted / words stored)"),
     (7, 8, 'z / sigmoid stores issued, ring bookkeeping')], False)
-split = os.environ.get('WN_STACK16_SPLIT', '1') != '0'
 if not split:
     report(dbgb.cpu().numpy(), gridb, 'stack_bwd16_kernel', [
         (0, 1, 'wait for the weight ring'), (1, 2, 'loads requested (z DMA, dZ, sigmoid, own dx, flag check, q)'),
@@ -96,7 +99,6 @@ if not split:
         (7, 8, 'weight gradients (32 MFMA)'), (8, 9, 'ring bookkeeping'),
         (9, 10, 'ordered accumulation chain (incl. token waits)')], True)
 else:
-    rw = int(os.environ.get('WN_STACK16_WAVES_B', 8))
     report(dbgb.cpu().numpy(), gridb, 'stack_bwd16s_kernel, row waves', [
         (0, 1, 'wait for the weight ring'), (1, 2, 'loads requested (dZ, sigmoid, z, own dx, flag check, q)'),
         (2, 3, 'wait for them'), (3, 4, 'tiles free?, dx_{l+1} | dz (16 MFMA) | gates -> LDS, signal'),

@@ -3,8 +3,9 @@
 
     python tools/stack_ab.py [lib_a.so lib_b.so ...]     (default: build/ab/lib_*.so)
     KB_B=1 python tools/stack_ab.py ...                  (clips per batch)
-    KB_PULL=1 python tools/stack_ab.py lib.so            (one library: the "pull" and the
-                                                          "push" formulation of wn_stack_bwd)
+    KB_VARIANTS="32:8:0,16:8:1" python tools/stack_ab.py lib.so
+                                                         (one library, several variant words
+                                                          rows:waves:split of the launches)
     KB_DX=1 python tools/stack_ab.py lib.so              (one library: a dx plane per layer
                                                           vs one plane rewritten in place)
     KB_SAVE_SG=0                                         (forward without the sigmoid planes)
@@ -59,22 +60,25 @@ def main():
     st = _lib.stream()
     ptr = _lib.ptr
     libs = [(os.path.basename(q), open_lib(q)) for q in paths]
-    if os.environ.get('KB_PULL'):
-        # one library, both formulations of the backward stack (the launch
-        # reads WN_STACK_BWD_PULL): "pull" first = the reference of the diffs
+    variants = {}
+    if os.environ.get('KB_VARIANTS'):
+        # one library, several explicit variant words of the launches; the
+        # first one is the reference of the diffs
         lib = libs[0][1]
-        libs = [('pull', lib), ('push', lib)]
+        libs = []
+        for spec in os.environ['KB_VARIANTS'].split(','):
+            r, w, sp = (int(v) for v in spec.split(':'))
+            variants[spec] = _lib.stack_variant(rows=r, waves=w, split=bool(sp))
+            libs.append((spec, lib))
     if os.environ.get('KB_DX'):
         lib = libs[0][1]
         libs = [('dx_per_layer', lib), ('dx_in_place', lib)]
-    nslab = max(l.wn_stack_bwd_slabs(B, T) for _, l in libs)
+    nslab = max(l.wn_stack_bwd_slabs(B, T, variants.get(n, 0)) for n, l in libs)
     slabs = torch.zeros(L, nslab, net.LAYER_BLOCK, device='cuda')
     wimg = torch.zeros(L, max(l.wn_stack_wimg_floats() for _, l in libs), device='cuda')
     bias = ws.bias_fg if net.use_biases else None
 
     def run_bwd(lib, name=''):
-        if os.environ.get('KB_PULL'):
-            os.environ['WN_STACK_BWD_PULL'] = '1' if name == 'pull' else '0'
         lib.wn_stack_pack(ptr(net._layer_block(P, 0)), net.layer_stride, None,
                           ptr(wimg), L, st)
         code = lib.wn_stack_bwd(ptr(ws.X), ptr(ws.Z), ptr(ws.SG), ptr(ws.dZ),
@@ -83,10 +87,10 @@ def main():
                                 slabs.shape[1] * net.LAYER_BLOCK, None,
                                 ptr(net._dil_dev), ptr(ws.stack_flags_b),
                                 ptr(ws.stack_ctl_b), ptr(ws.loss_parts[1:]),
-                                L, B, T, st)
+                                L, B, T, variants.get(name, 0), st)
         assert code == 0, code
 
-    def run_fwd(lib):
+    def run_fwd(lib, name=''):
         lib.wn_stack_pack(ptr(net._layer_block(P, 0)), net.layer_stride,
                           ptr(wimg), None, L, st)
         code = lib.wn_stack_fwd(ptr(ws.X), ptr(ws.Z), ptr(ws.SG), ptr(wimg),
@@ -95,7 +99,7 @@ def main():
                                 bias.stride(1) if bias is not None else 0,
                                 ptr(net._dil_dev), ptr(ws.stack_flags),
                                 ptr(ws.stack_ctl), ptr(ws.loss_parts), L, B, T,
-                                int(os.environ.get('KB_SAVE_SG', 1)), st)
+                                int(os.environ.get('KB_SAVE_SG', 1)), variants.get(name, 0), st)
         assert code == 0, code
 
     for what, run in (('bwd', run_bwd), ('fwd', run_fwd)):
@@ -110,13 +114,13 @@ def main():
                 e1 = torch.cuda.Event(enable_timing=True)
                 torch.cuda.synchronize()
                 e0.record()
-                run(lib, n) if what == 'bwd' else run(lib)
+                run(lib, n)
                 e1.record()
                 torch.cuda.synchronize()
                 if r:
                     times[n].append(e0.elapsed_time(e1) * 1e3)
                 elif what == 'bwd':
-                    ns = lib.wn_stack_bwd_slabs(B, T)
+                    ns = lib.wn_stack_bwd_slabs(B, T, variants.get(n, 0))
                     g = slabs[:, :ns].double().sum(1).float()
                     out = (g.clone(), ws.DX[0].clone())
                     if ref is None:

@@ -7,14 +7,20 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'tensorflow-wavenet_amd'))
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
-# WN_STACK_ROWS (default here: 32, the launches whose forward is bitwise the
+# KB_ROWS (default here: 32, the launches whose forward is bitwise the
 # per-layer kernels'; 16: the small-batch launches, compared to rounding --
-# WN_STACK16_SPLIT=1 / WN_STACK16_WAVES_F / _B select their variants)
-os.environ.setdefault('WN_STACK_ROWS', '32')
-ROWS16 = os.environ['WN_STACK_ROWS'] == '16'
+# KB_SPLIT=1 / KB_WAVES=4|8 select their variants): an explicit variant word
+# of the C entry points, set through the model class
+ROWS16 = os.environ.get('KB_ROWS', '32') == '16'
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 from util import TINY, build_pair, cfg_with, synth_audio  # noqa: E402
+from wavenet import WaveNetModel  # noqa: E402
+from wavenet._lib import stack_variant  # noqa: E402
+
+WaveNetModel.DEFAULT_STACK_VARIANT = stack_variant(
+    rows=16 if ROWS16 else 32, waves=int(os.environ.get('KB_WAVES', 0)),
+    split=os.environ.get('KB_SPLIT') == '1')
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)

@@ -42,7 +42,7 @@ grid = min(256, (ntiles + fw - 1) // fw)
 dbg = torch.zeros(grid * 16 * L * 12 + grid * 4, dtype=torch.int64, device='cuda')
 lib.wn_diag_stack_dbg.argtypes = [ctypes.c_void_p]
 lib.wn_diag_stack_dbg(dbg.data_ptr())
-gridb = min(256, lib.wn_stack_bwd_slabs(B, T))
+gridb = min(256, lib.wn_stack_bwd_slabs(B, T, net.stack_variant))
 dbgb = torch.zeros(gridb * 8 * L * 16 + gridb * 4, dtype=torch.int64, device='cuda')
 lib.wn_diag_stack_dbg_b.argtypes = [ctypes.c_void_p]
 lib.wn_diag_stack_dbg_b(dbgb.data_ptr())

@@ -398,6 +398,10 @@ def main():
                               device=dev)
     net = WaveNetModel(seed=0, **kw)
     net.gemm_mode = args.gemm_mode
+    # data-parallel: the tail of the gradient bucket is all-reduced beside the
+    # backward stack (wavenet/parallel.py); --set dp_overlap_allreduce=False
+    # for the one-call A/B
+    net.dp_overlap_allreduce = world > 1
     for item in args.set:        # A/B knobs: explicit model attributes
         import ast
         name, _, val = item.partition('=')

@@ -332,6 +332,16 @@ class WaveNetModel(object):
         # is created (setting it drops the resident workspaces).  (The library
         # reads no process environment.)
         self._stack_variant = int(self.DEFAULT_STACK_VARIANT)
+        # data-parallel runs (wavenet/parallel.py): start the all-reduce of the
+        # skip / post-processing gradients -- 82 % of the bucket, complete
+        # before the backward stack launch -- from inside the backward pass,
+        # on a communication stream beside that launch.  The training loop
+        # switches it on: it promises that optimizer.minimize (which joins)
+        # follows every loss().  Ignored outside torch.distributed and when L2
+        # regularisation is on.
+        self.dp_overlap_allreduce = False
+        self._tail_work = None
+        self._early_ok = False
         # generate(): four kernels per sample over many CUs, replayed from a
         # hipGraph, instead of the single-workgroup persistent kernel
         self.fastgen_multi_cu = True
@@ -625,6 +635,16 @@ class WaveNetModel(object):
             return bool(self.overlap_tn)
         return ws.B * ((ws.T + 31) // 32) <= 1024 and not self.blocked
 
+    def _early_on(self):
+        """The tail all-reduce starts inside this step's backward pass."""
+        from . import parallel
+        return bool(self.dp_overlap_allreduce and self._early_ok
+                    and parallel.is_distributed())
+
+    def _early_allreduce(self):
+        from . import parallel
+        _lib.call_py(lambda: parallel.begin_tail_allreduce(self))
+
     def _side_stream(self):
         if getattr(self, '_side', None) is None:
             # lower priority than the default stream: the residual-stack
@@ -805,7 +825,7 @@ class WaveNetModel(object):
     def _plan_key(self, tag, ws, ids, extra):
         return (tag, extra, ids is not None, self.generic_layers,
                 self.fused_bwd, self.layer_bwd, self.overlap_tn,
-                self.overlap_tn_split_frac, self.wide_fuse_gate, self.tn_spread_colsum, self.stack_fwd, self.stack_bwd, ws.stack_variant, self.gemm_mode, self.causal_wgrad_segsum, self.tf_xent_zero_label_quirk,
+                self.overlap_tn_split_frac, self.wide_fuse_gate, self.tn_spread_colsum, self.stack_fwd, self.stack_bwd, ws.stack_variant, self._early_on(), self.gemm_mode, self.causal_wgrad_segsum, self.tf_xent_zero_label_quirk,
                 _lib.stream(), self.params.data_ptr(), self.grads.data_ptr())
 
     def _stage_ids(self, ws, ids):
@@ -1056,6 +1076,10 @@ class WaveNetModel(object):
                 tn_now(side_s.cuda_stream, ws.slabs_tn, *a, **kw)
             _lib.call_py(lambda: ws.ev_join.record(side_s))
             self._nn(*(nn_dz + (st,)))
+        elif self._early_on():
+            # skip / post-processing gradients are complete on this stream:
+            # their all-reduce runs beside the backward stack
+            self._early_allreduce()
         if self.blocked:
             # channel-block path: residual stack, causal layer and global
             # conditioning gradients (wavenet/blocked.py)
@@ -1212,6 +1236,11 @@ class WaveNetModel(object):
         if self._overlap_tn_on(ws):
             main_s = torch.cuda.current_stream()
             _lib.call_py(lambda: main_s.wait_event(ws.ev_join))     # join
+            if self._early_on():
+                # (small batches: the side stream's weight-gradient GEMMs have
+                # just joined; the tail's all-reduce runs beside the slab
+                # reductions and the causal / conditioning gradients)
+                self._early_allreduce()
         st = _lib.stream()
         B, T, N, L, S, Q = ws.B, ws.T, ws.N, self.L, self.S, self.Q
         P, Gr = self.params, self.grads
@@ -1328,6 +1357,9 @@ class WaveNetModel(object):
                   0, 0, 1, _lib.ptr(ws.loss), 0, 1, 0, st)
         loss = ws.loss[0] / float(N)                    # reduce_mean, :666
         if backward:
+            # (L2 adds lambda * params to the WHOLE bucket after the backward
+            # pass: the tail must not have been summed over ranks before that)
+            self._early_ok = l2_regularization_strength is None
             self._backward(ws, ids)
             # the backward stack launch's poison word (0, or NaN when one of
             # its dependency waits expired) is written after the loss

@@ -8,11 +8,27 @@ B*T rows (wavenet/model.py:666), so with equal per-rank B*T
     g_global = (1/N) * sum_r g_r          (exact, incl. the zero-label row)
 
 The whole gradient lives in ONE flat fp32 bucket (6.06 MB for the default
-stack), so a step needs exactly one all-reduce(sum); the 1/N is folded into
-the optimizer kernel (`grad_scale`).  At 6 MB the ring moves 2(N-1)/N * 6 MB
-per GPU (~70 us at N=8 over per-link-bound xGMI) against a >= 7 ms step, so the
-collective is issued on the compute stream right before the update instead of
-being bucketed/overlapped.
+stack); the 1/N is folded into the optimizer kernel (`grad_scale`).  At 6 MB
+the ring moves 2(N-1)/N * 6 MB per GPU (~70 us of wire time at N=8 over
+per-link-bound xGMI, plus the collective's launch and the wait for the slowest
+rank) against a >= 7 ms step.
+
+Two calls per step (round 5, `model.dp_overlap_allreduce`, what bench.py /
+train.py switch on under torch.distributed): the bucket's TAIL -- skip convs
+and post-processing, 82 % of the bytes (76 % with global conditioning), laid
+out last -- is complete when the
+three weight-gradient GEMMs are, i.e. BEFORE the 1.5 ms backward stack launch
+starts.  `begin_tail_allreduce` (called from inside the backward pass at that
+point) issues its all-reduce on a communication stream behind an event, so it
+runs beside the backward stack; `allreduce_gradients` (optimizer.minimize)
+then reduces only the head (embedding, causal layer, residual blocks)
+and joins.  Off (or L2 regularisation on, which adds lambda * params to the
+whole bucket after the backward pass): one all-reduce of the whole bucket
+right before the update.  Both ways sum the same N values per element and
+every rank ends with the same bits as every other rank; against the one-call
+result they agree to one float32 rounding of an N-term sum, not bitwise (a
+ring adds a chunk's terms in an order that depends on the chunk's position in
+the buffer: 4 gloo ranks, max difference 1 ulp -- tests/test_parallel_gloo.py).
 
 The helpers are device-agnostic on purpose: they only touch flat tensors, so
 the sharding / averaging logic is covered on CPU by world_size-2 `gloo` tests.
@@ -91,9 +107,64 @@ def allreduce_flat_(flat):
     return 1.0 / dist.get_world_size()
 
 
+_comm_streams = {}
+
+
+def _comm_stream(device):
+    """The stream the early (tail) all-reduce is issued from: the collective
+    library orders its own stream after the CURRENT stream at the call, so the
+    call is made with this one current, after it has waited for the event that
+    marks the tail complete -- not for the backward stack behind it."""
+    key = (device.type, device.index)
+    if key not in _comm_streams:
+        _comm_streams[key] = torch.cuda.Stream(device=device)
+    return _comm_streams[key]
+
+
+def tail_start(model):
+    """First element of the bucket's tail: skip convs + post-processing
+    (wavenet/model.py `segments`: ... [layers][skip_w][skip_b][post1_w]
+    [post2_w][post1_b][post2_b]), everything the residual-stack backward does
+    not write."""
+    return int(model.segments['skip_w'][0])
+
+
+def begin_tail_allreduce(model):
+    """Issue the all-reduce(sum) of the gradient bucket's tail NOW -- the
+    caller (the backward pass) guarantees that the tail is complete on the
+    current stream and that `allreduce_gradients` follows in this step.
+    No-op when not distributed."""
+    if not is_distributed():
+        return
+    if getattr(model, '_tail_work', None) is not None:
+        raise RuntimeError('a tail all-reduce of the previous step was never '
+                           'joined (optimizer.minimize did not run)')
+    lo = tail_start(model)
+    tail = model.grads[lo:]
+    if tail.is_cuda:
+        comm = _comm_stream(tail.device)
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(comm):
+            comm.wait_event(ready)
+            work = dist.all_reduce(tail, op=dist.ReduceOp.SUM, async_op=True)
+    else:
+        work = dist.all_reduce(tail, op=dist.ReduceOp.SUM, async_op=True)
+    model._tail_work = (work, lo)
+
+
 def allreduce_gradients(model):
-    """All-reduce the model's flat gradient bucket; returns grad_scale."""
-    return allreduce_flat_(model.grads)
+    """All-reduce the model's flat gradient bucket -- or, when the backward
+    pass has already started the tail's (`begin_tail_allreduce`), the head
+    only, then join the tail; returns grad_scale."""
+    pending = getattr(model, '_tail_work', None)
+    if pending is None:
+        return allreduce_flat_(model.grads)
+    work, lo = pending
+    model._tail_work = None
+    scale = allreduce_flat_(model.grads[:lo])
+    work.wait()          # (RCCL: the current stream waits; gloo: the host does)
+    return scale
 
 
 def broadcast_parameters(model, src=0):

@@ -4,8 +4,9 @@ tests/test_gpu_parallel.py, never collected by pytest).
   mode dp    : `world` ranks share the visible GPU(s) (WN_SHARE_GPU=1, gloo:
                RCCL refuses two ranks on one device); every rank runs the REAL
                model on its clip shard: net.loss -> optimizer.minimize (flat
-               bucket all-reduce, 1/N folded into the update kernel) for
-               `steps` steps and rank 0 saves the parameters.
+               bucket all-reduce, 1/N folded into the update kernel; with
+               spec['overlap'] as two calls, the tail from inside the backward
+               pass) for `steps` steps and rank 0 saves the parameters.
   mode nccl1 : world_size-1 process group over backend "nccl" (= RCCL):
                broadcast of net.params and all-reduce of net.grads go through
                the RCCL code path on the device bucket.
@@ -56,6 +57,9 @@ def main():
     opt = optimizer_factory[spec['opt']](learning_rate=spec['lr'],
                                          momentum=0.9)
     lo, hi = parallel.shard_range(B, rank, world)
+    # (spec['overlap']: the tail of the gradient bucket all-reduced from inside
+    # the backward pass, as bench.py / train.py run under torch.distributed)
+    net.dp_overlap_allreduce = bool(spec.get('overlap', False))
     losses = []
     for s in range(steps):
         loss = net.loss(audio[s, lo:hi], ids[s, lo:hi] if gc else None)

@@ -160,19 +160,35 @@ def sample_index(n_elems, var_index):
     return rng.integers(0, n_elems, N_SAMPLED)
 
 
-def config1_fullsize():
-    """BASELINE.json configs[0] at FULL length: the default stack, one clip of
-    16000 samples (BASELINE.md's synthetic clip 0), weights of
-    create_variables(seed 0) with N(0, 0.1) biases, float64 oracle.  The
-    gradient tensors are 6 MB; committed are per variable sum, abs-sum, max
+GC4 = dict(global_condition_channels=32, global_condition_cardinality=377)
+CONFIG4_CLIP = 5          # a clip of the global batch with a non-trivial speaker id
+
+
+def fullsize_inputs(tag):
+    """(cfg, audio, speaker ids or None) of a full-length fixture; shared with
+    the tests.  config1: BASELINE.json configs[0], clip 0.  config4: one GPU's
+    share of configs[3] at one clip per GPU -- default stack + global
+    conditioning 32 x 377, GLOBAL clip 5 of BASELINE.md's synthetic batch with
+    its speaker id (37 * 5) mod 377 = 185."""
+    from util import DEFAULT, synth_audio
+    if tag == 'config1':
+        return cfg_with(DEFAULT, batch_size=1), synth_audio(1, 16000), None
+    assert tag == 'config4'
+    audio = synth_audio(CONFIG4_CLIP + 1, 16000)[CONFIG4_CLIP:]
+    ids = np.array([(37 * CONFIG4_CLIP) % 377], np.int32)
+    return cfg_with(DEFAULT, batch_size=1, **GC4), audio, ids
+
+
+def fullsize(tag):
+    """A BASELINE.json configuration at FULL length (16000 samples, one clip):
+    weights of create_variables(seed 0) with N(0, 0.1) biases, float64 oracle.
+    The gradient tensors are 6 MB; committed are per variable sum, abs-sum, max
     abs and 32 sampled entries, the float32 oracle's own error (fp32_error),
     and how many post-processing pre-activations sit within 2e-5 of the ReLU
     kink (where a float32 device may legitimately take the other side)."""
-    from util import DEFAULT, synth_audio
-    cfg = cfg_with(DEFAULT, batch_size=1)
+    cfg, audio, ids = fullsize_inputs(tag)
     var = O.create_variables(cfg, seed=0, dtype=np.float64, bias_scale=0.1)
-    audio = synth_audio(1, 16000)
-    names, err, l64, g64, c, dl = fp32_error(cfg, var, audio)
+    names, err, l64, g64, c, dl = fp32_error(cfg, var, audio, ids)
     flat = O.flatten_variables(g64)
     out = {'names': np.array(names), 'err32': err, 'loss': np.float64(l64),
            'loss_err32': np.float64(dl),
@@ -187,18 +203,21 @@ def config1_fullsize():
            'logits_first_last': np.stack([c['logits'][0, 0], c['logits'][0, -1]]),
            'audio_crc': np.array([audio.sum(dtype=np.float64),
                                   np.abs(audio).sum(dtype=np.float64)])}
-    print('config1 T=16000: loss %.9f, float32 oracle worst %.3e (%s), near-kink %s'
-          % (l64, err.max(), names[int(err.argmax())], out['near_kink']))
-    return {'config1/' + k: v for k, v in out.items()}
+    print('%s T=16000: loss %.9f, float32 oracle worst %.3e (%s), near-kink %s'
+          % (tag, l64, err.max(), names[int(err.argmax())], out['near_kink']))
+    return {tag + '/' + k: v for k, v in out.items()}
 
 
 def main():
     if '--fullsize-only' not in sys.argv:
         small()
-    np.savez_compressed(os.path.join(HERE, 'fp32_oracle_error.npz'),
-                        **fp32_error_cases())
-    np.savez_compressed(os.path.join(HERE, 'config1_fullsize.npz'),
-                        **config1_fullsize())
+        np.savez_compressed(os.path.join(HERE, 'fp32_oracle_error.npz'),
+                            **fp32_error_cases())
+    for tag in ('config1', 'config4'):
+        if '--only' in sys.argv and tag not in sys.argv:
+            continue
+        np.savez_compressed(os.path.join(HERE, tag + '_fullsize.npz'),
+                            **fullsize(tag))
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(HERE, f)))

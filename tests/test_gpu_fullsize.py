@@ -25,12 +25,13 @@ GOLD = os.path.join(ROOT, 'tests', 'golden')
 GRAD_REL = 2e-5
 
 
-def _var_tols(names):
-    """Per variable: max(2e-5, 4 x the float32 ORACLE's own error on config 1
-    at full length) -- tests/golden/config1_fullsize.npz, generated in the
-    build container by tests/golden/make_golden.py (fp32_error)."""
-    fx = np.load(os.path.join(GOLD, 'config1_fullsize.npz'))
-    e32 = dict(zip([str(n) for n in fx['config1/names']], fx['config1/err32']))
+def _var_tols(names, tag='config1'):
+    """Per variable: max(2e-5, 4 x the float32 ORACLE's own error on that
+    configuration at full length) -- tests/golden/config{1,4}_fullsize.npz,
+    generated in the build container by tests/golden/make_golden.py
+    (fp32_error)."""
+    fx = np.load(os.path.join(GOLD, tag + '_fullsize.npz'))
+    e32 = dict(zip([str(n) for n in fx[tag + '/names']], fx[tag + '/err32']))
     return np.array([max(GRAD_REL, 4.0 * float(e32[n])) for n in names])
 
 
@@ -51,7 +52,8 @@ def _log(tag, payload):
     json.dump(cur, open(path, 'w'), indent=1)
 
 
-def test_full_size_dp_identity_and_determinism(hip_lib, monkeypatch):
+@pytest.mark.parametrize('gc', [False, True], ids=['config2', 'config4_gc'])
+def test_full_size_dp_identity_and_determinism(hip_lib, monkeypatch, gc):
     """grad(B=8) == mean of the eight single-clip gradients, loss
     likewise -- EVERY variable within max(2e-5, 4 x the float32 oracle's own
     error) of that variable's largest entry; two runs are bitwise identical
@@ -64,28 +66,34 @@ def test_full_size_dp_identity_and_determinism(hip_lib, monkeypatch):
     against 11 such positions for the two tile heights), and a gradient is not
     continuous there: the two heights agree with the float64 oracle to 3e-6 of
     a variable EACH, taking their own side at those kinks, and with each other
-    only to 1.7e-3.  The identity under test is the sharding's."""
+    only to 1.7e-3.  The identity under test is the sharding's.
+    gc: BASELINE.json configs[3]'s per-GPU batch -- global conditioning 32 x 377
+    with eight DISTINCT speaker ids (37 b mod 377): the embedding rows and the
+    gc_filtweights / gc_gateweights gradients (model.py:272-284, 533-562) under
+    the same per-variable rule."""
     from wavenet import WaveNetModel
     from wavenet._lib import stack_variant
     monkeypatch.setattr(WaveNetModel, 'DEFAULT_STACK_VARIANT', stack_variant(rows=32))
     T = 16000
     audio = synth_audio(8, T)
-    net8 = WaveNetModel(seed=0, **model_kwargs(default_cfg(8)))
-    l8 = float(net8.loss(audio))
+    extra = dict(global_condition_channels=32, global_condition_cardinality=377) if gc else {}
+    ids = np.array([(37 * b) % 377 for b in range(8)], np.int32) if gc else None
+    net8 = WaveNetModel(seed=0, **model_kwargs(dict(default_cfg(8), **extra)))
+    l8 = float(net8.loss(audio, ids))
     g8 = net8.grads.clone()
-    l8b = float(net8.loss(audio))
+    l8b = float(net8.loss(audio, ids))
     assert l8 == l8b and torch.equal(g8, net8.grads)
     named8 = _flat_grads(net8)
-    net1 = WaveNetModel(seed=0, **model_kwargs(default_cfg(1)))
+    net1 = WaveNetModel(seed=0, **model_kwargs(dict(default_cfg(1), **extra)))
     assert torch.equal(net1.params, net8.params)
     lsum, acc = 0.0, None
     for b in range(8):
-        lsum += float(net1.loss(audio[b:b + 1]))
+        lsum += float(net1.loss(audio[b:b + 1], None if ids is None else ids[b:b + 1]))
         g = [a.astype(np.float64) for _, a in _flat_grads(net1)]
         acc = g if acc is None else [x + y for x, y in zip(acc, g)]
     assert abs(lsum / 8 - l8) < 1e-5
     names = [n for n, _ in named8]
-    tols = _var_tols(names)
+    tols = _var_tols(names, 'config4' if gc else 'config1')
     worst, bad = (0.0, ''), []
     for (n, a), m, tol in zip(named8, acc, tols):
         m = m / 8
@@ -95,62 +103,70 @@ def test_full_size_dp_identity_and_determinism(hip_lib, monkeypatch):
             worst = max(worst, (err / sc, n))
         if not err <= tol * sc + 1e-12:
             bad.append((n, float(err), float(sc), float(tol)))
-    _log('dp_identity_B8_vs_8xB1', {'worst_ratio': worst, 'bad': bad[:10]})
+    _log('dp_identity_B8_vs_8xB1' + ('_gc' if gc else ''), {'worst_ratio': worst, 'bad': bad[:10]})
+    if gc:
+        # every one of the eight speakers' embedding rows got a gradient
+        emb = dict(named8)['wavenet/embeddings/gc_embedding']
+        assert all(np.abs(emb[i]).max() > 0 for i in ids) and \
+            np.count_nonzero(np.abs(emb).max(axis=1)) == 8
     assert not bad, bad[:6]
 
 
-def test_config1_full_length_vs_oracle(hip_lib):
+@pytest.mark.parametrize('tag', ['config1', 'config4'])
+def test_full_length_vs_oracle(hip_lib, tag):
     """BASELINE.json configs[0] at FULL length (default stack, one clip of
-    16000 samples): the committed float64 fingerprints
-    (tests/golden/config1_fullsize.npz) pin the oracle, the oracle pins the
-    device.
+    16000 samples) and one GPU's share of configs[3] (the same with global
+    conditioning 32 x 377, global clip 5, speaker id 185): the committed
+    float64 fingerprints (tests/golden/config{1,4}_fullsize.npz) pin the
+    oracle, the oracle pins the device.
       1. the float64 oracle run here reproduces the committed loss and every
          variable's sum / abs-sum / max / 32 sampled gradient entries;
       2. the device's loss equals it to 1e-5, its logits to 1e-4;
       3. the device's ReLU decisions differ from the oracle's only where the
          oracle's pre-activation is within 2e-5 of 0, at no more positions
          than the fixture counts there;
-      4. every entry of every variable's gradient is within max(2e-5, 4 x the
-         float32 oracle's own error) of the variable's largest entry, against
-         the float64 oracle taking the device's side at those kinks."""
+      4. every entry of every variable's gradient (config4: incl. the
+         embedding table and every layer's gc_filtweights / gc_gateweights) is
+         within max(2e-5, 4 x the float32 oracle's own error) of the
+         variable's largest entry, against the float64 oracle taking the
+         device's side at those kinks."""
     sys_path_golden()
-    from make_golden import sample_index
+    from make_golden import fullsize_inputs, sample_index
     from util import build_pair, flat_named, oracle_grads_at_device_kinks
-    fx = np.load(os.path.join(GOLD, 'config1_fullsize.npz'))
+    fx = np.load(os.path.join(GOLD, tag + '_fullsize.npz'))
     T = 16000
-    cfg = cfg_with(DEFAULT, batch_size=1)
-    audio = synth_audio(1, T)
+    cfg, audio, ids = fullsize_inputs(tag)
     assert np.allclose([audio.sum(dtype=np.float64), np.abs(audio).sum(dtype=np.float64)],
-                       fx['config1/audio_crc'], rtol=0, atol=1e-9)
+                       fx[tag + '/audio_crc'], rtol=0, atol=1e-9)
     net, var = build_pair(cfg)
     # (the backward pass turns the logits into their gradient in place)
-    loss_fwd = float(net.loss(audio, backward=False))
+    loss_fwd = float(net.loss(audio, ids, backward=False))
     ws = [w for w in net._ws.values() if w.T == T][0]
     lg = ws.logits.cpu().numpy()
-    loss = float(net.loss(audio))
+    loss = float(net.loss(audio, ids))
     torch.cuda.synchronize()
     assert loss == loss_fwd
     # (1) the live oracle is the committed one
-    l64, g64 = O.loss_and_grads(cfg, var, audio, dtype=np.float64)
-    assert abs(l64 - float(fx['config1/loss'])) < 1e-12
+    l64, g64 = O.loss_and_grads(cfg, var, audio, ids, dtype=np.float64)
+    assert abs(l64 - float(fx[tag + '/loss'])) < 1e-12
     flat64 = flat_named(g64)
-    assert [n for n, _ in flat64] == [str(n) for n in fx['config1/names']]
+    assert [n for n, _ in flat64] == [str(n) for n in fx[tag + '/names']]
     for i, (n, a) in enumerate(flat64):
-        sc = float(fx['config1/absmax'][i])
+        sc = float(fx[tag + '/absmax'][i])
         assert abs(np.abs(a).max() - sc) <= 1e-9 * sc + 1e-300, n
-        assert abs(a.sum() - fx['config1/sum'][i]) <= 1e-9 * fx['config1/abssum'][i] + 1e-300, n
-        assert abs(np.abs(a).sum() - fx['config1/abssum'][i]) <= 1e-9 * fx['config1/abssum'][i] + 1e-300, n
+        assert abs(a.sum() - fx[tag + '/sum'][i]) <= 1e-9 * fx[tag + '/abssum'][i] + 1e-300, n
+        assert abs(np.abs(a).sum() - fx[tag + '/abssum'][i]) <= 1e-9 * fx[tag + '/abssum'][i] + 1e-300, n
         got = a.reshape(-1)[sample_index(a.size, i)]
-        assert np.abs(got - fx['config1/samples'][i]).max() <= 2e-7 * sc + 1e-300, n
+        assert np.abs(got - fx[tag + '/samples'][i]).max() <= 2e-7 * sc + 1e-300, n
     # (2) loss, logits
     assert abs(loss - l64) < 1e-5
-    assert np.abs(lg[0] - fx['config1/logits_first_last'][0]).max() < 1e-4
-    assert np.abs(lg[-1] - fx['config1/logits_first_last'][1]).max() < 1e-4
+    assert np.abs(lg[0] - fx[tag + '/logits_first_last'][0]).max() < 1e-4
+    assert np.abs(lg[-1] - fx[tag + '/logits_first_last'][1]).max() < 1e-4
     # (3) + (4)
-    ref_loss, ref_g, c, flips = oracle_grads_at_device_kinks(net, cfg, var, audio)
-    assert flips <= int(fx['config1/near_kink'].sum())
+    ref_loss, ref_g, c, flips = oracle_grads_at_device_kinks(net, cfg, var, audio, ids)
+    assert flips <= int(fx[tag + '/near_kink'].sum())
     named = _flat_grads(net)
-    tols = _var_tols([n for n, _ in named])
+    tols = _var_tols([n for n, _ in named], tag)
     worst, bad = (0.0, ''), []
     for (n, a), (_, b), tol in zip(named, flat_named(ref_g), tols):
         sc = np.abs(b).max()
@@ -159,8 +175,8 @@ def test_config1_full_length_vs_oracle(hip_lib):
             worst = max(worst, (err / sc, n))
         if not err <= tol * sc + 1e-12:
             bad.append((n, float(err), float(sc), float(tol)))
-    _log('config1_T16000_vs_float64', {'worst_ratio': worst, 'relu_flips': flips,
-                                       'loss_err': abs(loss - l64), 'bad': bad[:10]})
+    _log(tag + '_T16000_vs_float64', {'worst_ratio': worst, 'relu_flips': flips,
+                                      'loss_err': abs(loss - l64), 'bad': bad[:10]})
     assert not bad, bad[:6]
 
 

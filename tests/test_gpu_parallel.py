@@ -92,6 +92,37 @@ def test_many_ranks_real_model_equal_single_process(hip_lib, tmp_path):
     assert np.abs(a['params'] - b['params']).max() <= 1e-6
 
 
+@pytest.mark.parametrize('B,T', [(4, 300), (8, 17000)], ids=['side_stream_gemms', 'one_stream'])
+def test_tail_allreduce_inside_backward_equals_one_call(hip_lib, tmp_path, B, T):
+    """`dp_overlap_allreduce` (the skip / post-processing gradients' all-reduce
+    issued from inside the backward pass on a communication stream, the rest at
+    the update) against one all-reduce of the whole bucket: REHEARSAL_RANKS
+    ranks of the real model on this GPU over gloo, three Adam steps through
+    eager, recorded and replayed launch plans.  Same values summed per element;
+    gloo's ring may add a chunk's terms in another order (1 ulp of a gradient),
+    so the parameters agree to 1e-7, and to 1e-6 with one process x the whole
+    batch.  One clip of 300 samples per rank runs the weight-gradient GEMMs on
+    the side stream (the all-reduce starts after their join); two clips of
+    17000 (more than 1024 tiles) on the main stream (it starts before the
+    backward stack launch)."""
+    n = REHEARSAL_RANKS
+    spec = dict(mode='dp', B=n * (B // 4), T=T, steps=3, opt='adam', lr=1e-3,
+                cfg=dict(global_condition_channels=4, global_condition_cardinality=5))
+    env = dict(WN_SHARE_GPU='1', WN_DIST_BACKEND='gloo')
+    res = {}
+    for ov in (False, True):
+        out = str(tmp_path / ('ov%d.npz' % ov))
+        _run_ranks(dict(spec, overlap=ov, out=out), n, env)
+        res[ov] = np.load(out)
+    one = str(tmp_path / 'one.npz')
+    _run_ranks(dict(spec, out=one), 1)
+    one = np.load(one)
+    assert np.abs(res[True]['losses'] - res[False]['losses']).max() <= 1e-7
+    assert np.abs(res[True]['params'] - res[False]['params']).max() <= 1e-7
+    assert np.abs(res[True]['params'] - one['params']).max() <= 1e-6
+    assert np.abs(res[True]['losses'] - one['losses']).max() < 1e-6
+
+
 def _bench_json(args, env, timeout=900):
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args
                        + ['--no-secondary', '--no-cpu-baseline'],

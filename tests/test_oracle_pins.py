@@ -3,6 +3,7 @@ the hot path: these PIN causal_conv and mu-law."""
 import os
 
 import numpy as np
+import pytest
 
 from util import O, ROOT
 
@@ -127,31 +128,33 @@ def test_thresholds_reproduce_encode():
                               np.searchsorted(thr, x, side='right'))
 
 
-def test_config1_fullsize_fixture_is_the_oracle_at_full_length():
+@pytest.mark.parametrize('tag', ['config1', 'config4'])
+def test_fullsize_fixture_is_the_oracle_at_full_length(tag):
     """tests/golden/config1_fullsize.npz (BASELINE.json configs[0]: default
-    stack, ONE clip of 16000 samples, float64) is what this oracle computes:
-    loss, and every variable's gradient through its sum / abs-sum / max and 32
-    sampled entries.  (The GPU test of the same name pins the device to it.)"""
+    stack, ONE clip of 16000 samples, float64) and config4_fullsize.npz (one
+    GPU's share of configs[3]: the same with global conditioning 32 x 377,
+    global clip 5, speaker id 185) are what this oracle computes: loss, and
+    every variable's gradient through its sum / abs-sum / max and 32 sampled
+    entries.  (The GPU test of the same name pins the device to them.)"""
     import sys
     gold = os.path.join(ROOT, 'tests', 'golden')
     if gold not in sys.path:
         sys.path.insert(0, gold)
-    from make_golden import sample_index
-    from util import DEFAULT, cfg_with, synth_audio
-    fx = np.load(os.path.join(gold, 'config1_fullsize.npz'))
-    cfg = cfg_with(DEFAULT, batch_size=1)
+    from make_golden import fullsize_inputs, sample_index
+    fx = np.load(os.path.join(gold, tag + '_fullsize.npz'))
+    cfg, audio, ids = fullsize_inputs(tag)
     var = O.create_variables(cfg, seed=0, dtype=np.float64, bias_scale=0.1)
-    audio = synth_audio(1, 16000)
-    loss, g = O.loss_and_grads(cfg, var, audio, dtype=np.float64)
-    assert abs(loss - float(fx['config1/loss'])) < 1e-12
+    loss, g = O.loss_and_grads(cfg, var, audio, ids, dtype=np.float64)
+    assert abs(loss - float(fx[tag + '/loss'])) < 1e-12
     flat = O.flatten_variables(g)
-    assert [n for n, _ in flat] == [str(n) for n in fx['config1/names']]
-    assert len(flat) == 405
+    assert [n for n, _ in flat] == [str(n) for n in fx[tag + '/names']]
+    # 405 variables; + the embedding table and 2 x 50 conditioning convs
+    assert len(flat) == (405 if ids is None else 506)
     for i, (n, a) in enumerate(flat):
-        sc = float(fx['config1/absmax'][i])
+        sc = float(fx[tag + '/absmax'][i])
         assert abs(np.abs(a).max() - sc) <= 1e-9 * sc + 1e-300, n
-        assert abs(a.sum() - fx['config1/sum'][i]) <= 1e-9 * fx['config1/abssum'][i] + 1e-300, n
+        assert abs(a.sum() - fx[tag + '/sum'][i]) <= 1e-9 * fx[tag + '/abssum'][i] + 1e-300, n
         got = a.reshape(-1)[sample_index(a.size, i)]
-        assert np.abs(got - fx['config1/samples'][i]).max() <= 2e-7 * sc + 1e-300, n
+        assert np.abs(got - fx[tag + '/samples'][i]).max() <= 2e-7 * sc + 1e-300, n
     # the float32 oracle's own error on this case is the tests' yardstick
-    assert 0 < fx['config1/err32'].max() < 2e-5
+    assert 0 < fx[tag + '/err32'].max() < 2e-5

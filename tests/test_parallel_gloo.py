@@ -95,6 +95,64 @@ def test_dp_ranks_equal_full_batch(tmp_path, world):
                                               'l%d.npy' % r))) - loss) < 1e-12
 
 
+def _two_call_worker(rank, world, port, out_dir):
+    for p in (ROOT, PKG, os.path.join(ROOT, 'tests')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from wavenet import parallel
+    parallel.init_from_env(backend='gloo')
+    # the default stack's bucket layout on a bookkeeping-only model (device
+    # 'cpu': names / shapes / segments, no compute), float32 like the device's
+    import json
+    from wavenet import WaveNetModel
+    from util import model_kwargs
+    p_ = json.load(open(os.path.join(ROOT, 'wavenet_params.json')))
+    cfg = {k: p_[k] for k in p_ if k != 'sample_rate'}
+    cfg.update(batch_size=1, global_condition_channels=32,
+               global_condition_cardinality=377)
+    net = WaveNetModel(device='cpu', **model_kwargs(cfg))
+    lo = parallel.tail_start(net)
+    n = net.grads.numel()
+    assert n == 1630432 and n - lo == 1238784
+    assert 0.75 < (n - lo) / float(n) < 0.77   # 76 % of the bucket (82 % without conditioning)
+    g = torch.from_numpy(np.random.default_rng(100 + rank).standard_normal(n)
+                         .astype(np.float32))
+    one = _Bucket(g.clone())
+    s1 = parallel.allreduce_gradients(one)                 # one call
+    net.grads.copy_(g)
+    parallel.begin_tail_allreduce(net)                     # inside the backward pass
+    with pytest.raises(RuntimeError):
+        parallel.begin_tail_allreduce(net)                 # never joined: loud
+    s2 = parallel.allreduce_gradients(net)                 # head + join
+    assert s1 == s2 == 1.0 / world and net._tail_work is None
+    np.save(os.path.join(out_dir, 'two%d.npy' % rank),
+            np.array([float(torch.equal(one.grads, net.grads)),
+                      float((one.grads - net.grads).abs().max()),
+                      float(one.grads.abs().max())]))
+    dist.destroy_process_group()
+
+
+def test_two_call_allreduce_equals_one_bucket(tmp_path):
+    """The tail of the bucket (skip convs + post-processing) all-reduced from
+    inside the backward pass, the head at the update (round 5,
+    `dp_overlap_allreduce`) against ONE all-reduce of the whole bucket: 4 gloo
+    ranks, the default stack's float32 layout with global conditioning."""
+    world = 4
+    mp.spawn(_two_call_worker, args=(world, _free_port(), str(tmp_path)),
+             nprocs=world, join=True)
+    for r in range(world):
+        same, diff, scale = np.load(os.path.join(str(tmp_path), 'two%d.npy' % r))
+        # gloo's ring adds a chunk's four terms in an order that depends on the
+        # chunk's position in the buffer: not necessarily bitwise, always within
+        # float32 rounding of a four-term sum
+        print('rank %d: bitwise %s, max diff %.3e of %.3e' % (r, bool(same), diff, scale))
+        assert same == 1.0 or diff <= 4e-7 * scale, (r, same, diff, scale)
+
+
 def test_bench_gc_ids_of_eight_ranks():
     """configs[3] at 8 GPUs: rank r owns global clips [8 r, 8 r + 8) with
     speaker id (37 b) mod 377 -- 64 distinct ids, every one a valid row."""

@@ -227,10 +227,12 @@ def main(argv=None):
         wavenet_params = json.load(f)
 
     coord = Coordinator()
-    # (the reference computes `silence_threshold = None if below EPSILON` and
-    # then passes the raw flag, train.py:211-220; the intent is kept here)
-    silence_threshold = args.silence_threshold \
-        if args.silence_threshold > EPSILON else None
+    # The reference computes `silence_threshold = None if below EPSILON` and
+    # then passes the RAW flag to the reader (train.py:211-220; SURVEY Appendix
+    # A: "do not fix silently") -- same here: `--silence_threshold 0` trims with
+    # a threshold of 0 (only exactly silent frames go) instead of skipping the
+    # trimming.
+    silence_threshold = args.silence_threshold
     gc_enabled = args.gc_channels is not None
     if args.synthetic:
         reader = SyntheticReader(args.sample_size,
@@ -274,6 +276,9 @@ def main(argv=None):
               "the previous model.")
         raise
     parallel.broadcast_parameters(net)
+    # every loss() below is followed by optimizer.minimize(): the skip /
+    # post-processing gradients' all-reduce may start inside the backward pass
+    net.dp_overlap_allreduce = world > 1
 
     threads = reader.start_threads()
     events = None

@@ -2637,7 +2637,16 @@ __global__ __launch_bounds__((BP_MATW + BP_ROWW) * 64) void stack_bwdp_kernel(St
       // num_records = (hi - lo) rows, no scalar offset -- and the lane's
       // offset is relative to row lo, so a row before lo wraps to a huge
       // unsigned offset and a row from hi on lies past num_records: both read 0.
-      struct AReq { wn_rsrc_t ap; int vo; };
+      // The loads themselves are inline asm with HAND-COUNTED waits: through the
+      // builtin the compiler's wait-count pass kept deciding (differently from
+      // build to build) to drain every outstanding load at some point of the
+      // ticket loop -- vmcnt(0) at its top, vmcnt(1) in front of its first LDS
+      // read -- which turns a four-ticket prefetch into none.  A load of slot
+      // u, step s is used exactly 31 loads later: s_waitcnt vmcnt(31) in front
+      // of every MFMA (more memory operations in between, the layer's stores,
+      // only make that wait conservative).
+      typedef int bp_i32x4 __attribute__((ext_vector_type(4)));
+      struct AReq { bp_i32x4 ap; int vo; };
       int cur_li = 0;                            // the ticket loop's layer index
       auto dil_of = [&](int qli) {               // the left operand's shift in layer index qli
         return past && qli < L ? __builtin_amdgcn_readfirstlane(s_dil[L - 1 - qli]) : 0;
@@ -2659,22 +2668,23 @@ __global__ __launch_bounds__((BP_MATW + BP_ROWW) * 64) void stack_bwdp_kernel(St
         const int lo = max(0, d - tt0);
         const long row0 = (long)c.b * T + tt0 - d + lo;           // (>= 0: row lo is inside the clip)
         q.vo = lane4 - lo * (WN_CH * 4);
-        q.ap = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)((zplane ? a.Z : a.X) + (size_t)l * a.plane + row0 * WN_CH), 0,
-            hi > lo ? (hi - lo) * (WN_CH * 4) : 0, 0x00020000);
+        const unsigned long long base = (unsigned long long)(
+            (zplane ? a.Z : a.X) + (size_t)l * a.plane + row0 * WN_CH);
+        q.ap = bp_i32x4{(int)(unsigned)base, (int)((base >> 32) & 0xffffu),
+                        hi > lo ? (hi - lo) * (WN_CH * 4) : 0, 0x00020000};
         return q;
       };
-      auto areq_load = [&](const AReq& q, int s) {
-        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-            q.ap, q.vo + s * 256, 0, SB_X_AUX));
-      };
+#define BP_ALOAD(dst, q, s)                                                          \
+  asm volatile("buffer_load_dword %0, %1, %2, 0 offen offset:%3"                     \
+               : "=v"(dst) : "v"((q).vo), "s"((q).ap), "n"((s) * 256))
+#define BP_AWAIT(x) asm volatile("s_waitcnt vmcnt(31)" : "+v"(x))
       float ax[BP_PF][8];
       Cur qa = {0, 0, b_top, tt_top};            // the next slot to request
 #pragma unroll
       for (int u = 0; u < BP_PF; ++u) {
         const AReq q = areq_make(qa);
 #pragma unroll
-        for (int s = 0; s < 8; ++s) ax[u][s] = areq_load(q, s);
+        for (int s = 0; s < 8; ++s) BP_ALOAD(ax[u][s], q, s);
         cur_next(qa);
       }
       // B operands of a ticket (the row wave's tile in its buffer): ONE
@@ -2714,11 +2724,12 @@ __global__ __launch_bounds__((BP_MATW + BP_ROWW) * 64) void stack_bwdp_kernel(St
             float ts = 0.f;
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
+              BP_AWAIT(ax[u][s]);
               acc = sb_mfma(ax[u][s], bv[s], acc);
               if (sums) ts += bv[s];
               __builtin_amdgcn_sched_barrier(0);
               bv[s] = te.p[s & 3][bo + 64 * s];
-              ax[u][s] = areq_load(q, s);
+              BP_ALOAD(ax[u][s], q, s);
               if (s == 0)
                 fv = __hip_atomic_load(&s_full[bnn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
               __builtin_amdgcn_sched_barrier(0);
@@ -2755,6 +2766,11 @@ __global__ __launch_bounds__((BP_MATW + BP_ROWW) * 64) void stack_bwdp_kernel(St
           for (int t = h; t < ng; t += 2)        // (ticket t is tile gbase + ng - 1 - t)
             tsum[(size_t)(ng - 1 - t) * 64] = s_ts[t * 64 + (mw >> 1) * 32 + j];
         }
+        // (a store still in flight at the top of the ticket loop makes the
+        // compiler's wait-count pass protect its data registers with a
+        // vmcnt(0) INSIDE the loop, every four tickets: drained here instead,
+        // once a layer, where the pass can see it)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
         S16STAMP(l, 3);
       }
       __builtin_amdgcn_s_setprio(0);

@@ -276,15 +276,13 @@ int wn_layer_bwd2(const float* x, const float* z, const float* sg,
  * L <= 256. */
 /* rows: 0 (auto), 16 or 32 rows per tile; waves: 0 (auto) or waves per
  * workgroup (16-row launches: 4 / 8; 32-row backward: 1 / 2 / 4 / 8; the 32-row
- * forward ignores it); flags: WN_STACK_SPLIT, WN_STACK_PIPE */
+ * forward ignores it); flags: WN_STACK_PIPE */
 #define WN_STACK_VARIANT(rows, waves, flags) \
   (((rows) & 0x3f) | (((waves) & 0xf) << 8) | (flags))
-/* backward, 16-row tiles: the weight gradients on waves of their own
- * (stack_bwd16s_kernel) */
-#define WN_STACK_SPLIT 0x1000
-/* backward: the pipelined launch (stack_bwdp_kernel: 12 row waves taking
- * (layer, tile) tickets + 4 matrix waves that own the weight-gradient
- * matrices, 16-row tiles whatever the forward's height) */
+/* backward: the pipelined launch (stack_bwdp_kernel: 11 row waves taking
+ * (layer, tile) tickets + 5 matrix waves that own the weight-gradient
+ * matrices, 16-row tiles whatever the forward's height).  Opt-in: measured 9 %
+ * slower than the default launch at B = 8, T = 16000. */
 #define WN_STACK_PIPE 0x2000
 long wn_stack_flag_count(int B, int T, int L);
 int wn_stack_tile_rows(int B, int T, int variant);

@@ -1902,373 +1902,6 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd16_kernel(StackBwd a) {
   }
 }
 
-// The 16-row backward with the weight gradients on waves of their own.
-// Stamps of stack_bwd16_kernel at B = 1 (tools/stack16_stamps.py): of a layer's
-// 11.3 us, 4.3 are wave 0 in the ordered accumulation (it copies the finished
-// slab of the layer above to memory, matrix by matrix, before it starts the
-// chain -- and every other wave's sums queue behind it), and a wave's own
-// weight-gradient MFMAs are as long as its whole dx path.  Here a workgroup is
-// RW "row" waves and three "matrix" waves:
-//   * a row wave walks its tile through the dx path only (80 16x16x4 MFMAs) and
-//     leaves dx_{l+1}[t], da_f[t], da_g[t] in three LDS tiles, channel-on-lane
-//     readable, then signals;
-//   * a matrix wave owns the weight-gradient matrices of ONE left operand for
-//     the whole group -- x[t]: dWf[1], dWg[1]; x[t-d]: dWf[0], dWg[0]; z[t]:
-//     dWd -- and accumulates  A^T B  over the RW tiles in turn (A read straight
-//     from memory with the channel on the lane: a step's two rows are 256
-//     contiguous bytes; B = the row waves' tiles), holds the group's complete
-//     sums in registers and stores them into the slab: no accumulation across
-//     waves, no chain, no slab in LDS.  Fixed order over the tiles: bitwise
-//     reproducible.
-// Row waves and matrix waves are coupled by LDS counters ("written" per tile,
-// "read" per pass; bounded waits like every other one).
-template <int RW>
-__global__ __launch_bounds__((RW + 3) * 64) __attribute__((amdgpu_waves_per_eu(RW == 4 ? 4 : 1)))
-void stack_bwd16s_kernel(StackBwd a) {
-  constexpr int NW = RW + 3;
-  __shared__ __attribute__((aligned(1024))) float wl[2 * SB_WIMG];
-  __shared__ __attribute__((aligned(1024))) float tiles[RW * 1536];
-  __shared__ int s_group;
-  __shared__ int s_done[STACK_MAXL], s_ready[STACK_MAXL];
-  // layers whose tiles row wave w has written / matrix-wave passes over the
-  // group's tiles (three a layer)
-  __shared__ int s_prod[RW], s_cons;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j = lane & 31, h = lane >> 5;        // 32 x 32 products: channel, row parity
-  const int jr = lane & 15, g = lane >> 4;       // 16 x 16 products: row, piece
-  const int sw = jr & 7;
-  const int T = a.T, L = a.L;
-  const int tiles_per_clip = (T + 15) >> 4;
-  const int ntiles = tiles_per_clip * a.B;
-  const int ngroups = (ntiles + RW - 1) / RW;
-  const unsigned epoch =
-      __hip_atomic_load(a.ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  bool dead = false;
-  S16CAL(0);
-
-  auto issue_wimg = [&](int l, int p0, int step) {
-    const float* src = a.wimg + (size_t)l * STACK_WBUF;
-    float* dst = wl + (l & 1) * SB_WIMG;
-    for (int p = p0; p < SB_WIMG / 256; p += step)
-      __builtin_amdgcn_global_load_lds((wn_gptr_t)(src + p * 256 + lane * 4),
-                                       (wn_lptr_t)(dst + p * 256), 16, 0, 0);
-  };
-
-  for (;;) {
-    if (tid == 0) s_group = (int)atomicAdd(a.ctl, 1u);
-    __syncthreads();
-    const int ticket = __builtin_amdgcn_readfirstlane(s_group);
-    __syncthreads();
-    if (ticket >= ngroups) break;
-    const int gi = ngroups - 1 - ticket;
-    const int nactive = min(RW, ntiles - gi * RW);
-    for (int i = tid; i < L; i += NW * 64) {
-      s_done[i] = 0;
-      s_ready[i] = i >= L - 2;
-    }
-    if (tid < RW) s_prod[tid] = 0;
-    if (tid == 0) s_cons = 0;
-    if (wave < RW) {
-      issue_wimg(L - 1, wave, RW);
-      if (L > 1) issue_wimg(L - 2, wave, RW);
-      WN_WAIT_VM0();
-    }
-    __syncthreads();
-
-    if (wave < RW) {
-      // ================================================= a row wave: the dx path
-      const int tile = gi * RW + wave;
-      const bool any = tile < ntiles;
-      const int b = any ? tile / tiles_per_clip : 0;
-      const int tt = any ? tile - b * tiles_per_clip : 0;
-      const int tt0 = tt * 16;
-      const int hi = any ? min(16, T - tt0) : 0;
-      const bool mine = jr < hi;
-      const int off0 = (b * T + tt0) * (WN_CH * 4);            // bytes (< 2^31: host check)
-      const int voff = off0 + (jr * WN_CH + 4 * g) * 4;        // the lane's piece 0 of its row
-      float* t_di = tiles + wave * 1536;
-      float* t_f = t_di + 512;
-      float* t_g = t_di + 1024;
-      auto flag_idx2 = [&](int dd) -> int {
-        if (!any) return -1;
-        const int hif = min(hi, T - dd - tt0);
-        if (hif <= 0) return -1;
-        const int first = (tt0 + dd) >> 4, last = (tt0 + dd + hif - 1) >> 4;
-        int idx = -1;
-        if (lane == 0 && first != tt) idx = b * tiles_per_clip + first;
-        if (lane == 1 && last != first && last != tt) idx = b * tiles_per_clip + last;
-        return idx;
-      };
-      unsigned nfv_push = epoch;
-      for (int l = L - 1; any && l >= 0; --l) {
-        const int d = a.dil[l];
-        const bool hx = l + 1 < L;
-        const int dn = hx ? a.dil[l + 1] : 0;
-        const wn_rsrc_t qin = plane_rsrc(a.Q + (size_t)(hx ? l + 1 : l) * a.plane);
-        const wn_rsrc_t q_out = plane_rsrc(a.Q + (size_t)l * a.plane);
-        const wn_rsrc_t z = plane_rsrc(a.Z + (size_t)l * a.plane);
-        const wn_rsrc_t sg = plane_rsrc(a.SG + (size_t)l * a.plane);
-        const wn_rsrc_t dZ = plane_rsrc(a.dZ + (size_t)l * a.plane);
-        const wn_rsrc_t dxin = plane_rsrc(a.DX + (size_t)(hx ? l + 1 : l) * a.dx_stride);
-        const wn_rsrc_t dx_out = plane_rsrc(a.DX + (size_t)l * a.dx_stride);
-        const unsigned* fl_in = a.flags + (size_t)(hx ? l + 1 : l) * ntiles;
-        unsigned* fl_out = a.flags + (size_t)l * ntiles;
-        S16STAMP(l, 0);
-        wait_lds_ge(s_ready + l, 1, dead, a.ctl, a.poison, lane);
-        S16STAMP(l, 1);
-        int woff = jr * 32 + ((g ^ ((jr >> 1) & 7)) << 2) + (l & 1) * SB_WIMG;
-        asm volatile("" : "+v"(woff));
-        const float* const wm = wl;
-        // ---- rows t, all time-major, straight into registers
-        F16 dz = f16_ld<SB_STREAM>(dZ, voff, mine);
-        const F16 ss = f16_ld<SB_STREAM>(sg, voff, mine);
-        const F16 zz = f16_ld<SB_STREAM>(z, voff, mine);
-        F16 di = f16_zero();
-        if (hx) {
-          di = f16_ld<SB_OWN_LD>(dxin, voff, mine);
-          const int hi_q = min(hi, T - dn - tt0);
-          F16 qv = f16_zero();
-          if (hi_q > 0) {
-            const int idx = flag_idx2(dn);
-            if (__builtin_amdgcn_ballot_w64(idx >= 0 && nfv_push != epoch) != 0)
-              wait_flags(fl_in, idx, epoch, a.ctl, a.poison, dead, lane);
-            qv = f16_ld<16>(qin, voff + dn * (WN_CH * 4), jr < hi_q);
-          }
-          S16STAMP(l, 2);
-          WN_WAIT_VM0();
-          di.v[0] += qv.v[0];
-          di.v[1] += qv.v[1];
-        } else {
-          S16STAMP(l, 2);
-          WN_WAIT_VM0();
-        }
-        S16STAMP(l, 3);
-        // the matrix waves are through this wave's tiles of the layer above
-#ifndef S16_NOFREEWAIT   // (timing-only ablation: results meaningless)
-        wait_lds_ge(&s_cons, 3 * (L - 1 - l), dead, a.ctl, a.poison, lane);
-#endif
-        f16_to_lds(t_di + jr * 32, g, sw, di);
-        if (hx) mma16s(dz, di, wm + 4 * 1024, woff);            // + dx_{l+1}[t] Wd^T
-        F16 df, dg;
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            // (gate_grad of wn_common.h on this layout)
-            const float sgm = ss.v[mb][e], zv = zz.v[mb][e];
-            const float th = zv * __builtin_amdgcn_rcpf(sgm + 1e-30f);
-            df.v[mb][e] = dz.v[mb][e] * __builtin_fmaf(-zv, th, sgm);
-            dg.v[mb][e] = dz.v[mb][e] * __builtin_fmaf(-zv, sgm, zv);
-          }
-        f16_to_lds(t_f + jr * 32, g, sw, df);
-        f16_to_lds(t_g + jr * 32, g, sw, dg);
-        WN_WAIT_LGKM0();
-        if (lane == 0)
-          __hip_atomic_store(s_prod + wave, L - l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        S16STAMP(l, 4);
-        // own_l[t] = dx_{l+1}[t] + da[t] W[1]^T,  q_l[t] = da[t] W[0]^T
-        F16 dx = di, qf = f16_zero();
-        mma16s2(dx, qf, df, wm + 1 * 1024, wm + 0 * 1024, woff);   // da_f: Wf[1], Wf[0]
-        mma16s2(dx, qf, dg, wm + 3 * 1024, wm + 2 * 1024, woff);   // da_g: Wg[1], Wg[0]
-        S16STAMP(l, 5);
-        if (dead) { qf.v[0][0] = __builtin_nanf(""); dx.v[0][0] = __builtin_nanf(""); }
-        f16_st<16>(q_out, voff, mine, qf);
-        f16_st<SB_OWN_ST>(dx_out, voff, mine, dx);
-        // this wave no longer reads layer l's weights; the last one to say so
-        // refills their ring half with layer l - 2
-        bool refill = false;
-        {
-          int old = 0;
-          if (lane == 0)
-            old = __hip_atomic_fetch_add(s_done + l, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          old = __builtin_amdgcn_readfirstlane(old);
-          if (old == nactive - 1 && l >= 2) {
-            issue_wimg(l - 2, 0, 1);
-            refill = true;
-          }
-        }
-        WN_WAIT_VM0();                               // q and own rows stored (and the refill landed)
-        if (lane == 0)
-          __hip_atomic_store(fl_out + tile, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (refill && lane == 0)
-          __hip_atomic_store(s_ready + l - 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        // the flags this tile will look at in the layer below: requested now
-        // (after layer 0: by the completion of dx_0 below)
-        nfv_push = epoch;
-        {
-          const int nidx = flag_idx2(d);
-          if (nidx >= 0)
-            nfv_push = __hip_atomic_load(fl_out + nidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        S16STAMP(l, 6);
-      }
-      // dx_0[t] = own_0[t] + q_0[t + d_0], completed in place
-      if (any) {
-        const int d0 = a.dil[0];
-        const wn_rsrc_t dx0 = plane_rsrc(a.DX), q0 = plane_rsrc(a.Q);
-        F16 ro = f16_ld<SB_OWN_LD>(dx0, voff, mine);
-        const int hi_q = min(hi, T - d0 - tt0);
-        if (hi_q > 0) {
-          const int idx = flag_idx2(d0);
-          if (__builtin_amdgcn_ballot_w64(idx >= 0 && nfv_push != epoch) != 0)
-            wait_flags(a.flags, idx, epoch, a.ctl, a.poison, dead, lane);
-          const F16 rq = f16_ld<16>(q0, voff + d0 * (WN_CH * 4), jr < hi_q);
-          WN_WAIT_VM0();
-          ro.v[0] += rq.v[0];
-          ro.v[1] += rq.v[1];
-        }
-        WN_WAIT_VM0();
-        if (dead) ro.v[0][0] = __builtin_nanf("");
-        f16_st<0>(dx0, voff, mine, ro);
-      }
-    } else {
-      // ============ a matrix wave: the weight gradients of one left operand
-      const int mw = wave - RW;       // 0: x[t] (Wf[1], Wg[1])  1: x[t-d] (Wf[0], Wg[0])  2: z[t] (Wd)
-      const bool past = mw == 1, two = mw < 2;
-      // element [row 2 s + h][channel j] of row wave n's tile k (0: dx_{l+1},
-      // 1: da_f, 2: da_g):  te.p[s & 3][n * 1536 + k * 512 + 64 * s]
-      const TileElemPtr te = tile_elem_ptrs(tiles, j, h);
-      const int e0 = 4 * h * 32 + j;
-      // the group's tiles: first row in its clip, byte offset in a plane
-      int g_tt0[RW], g_off[RW];
-#pragma unroll
-      for (int n = 0; n < RW; ++n) {
-        const int tile = gi * RW + n;
-        const int b = tile / tiles_per_clip;
-        g_tt0[n] = (tile - b * tiles_per_clip) * 16;
-        g_off[n] = (b * T + g_tt0[n]) * (WN_CH * 4);
-      }
-      const int lane4 = lane * 4;
-      for (int l = L - 1; l >= 0; --l) {
-        const int d = a.dil[l];
-        const bool hx = l + 1 < L;
-        const wn_rsrc_t ap = plane_rsrc((mw == 2 ? a.Z : a.X) + (size_t)l * a.plane);
-        float* tile_colsum = a.tilesum ? a.tilesum + (size_t)l * ntiles * 64 : nullptr;
-        float* out = a.slabs + (size_t)l * a.slab_layer_stride + (size_t)gi * LAYER_BLOCK_FLOATS;
-        S16STAMP(l, 0);
-        f32x16 acc0 = frag_zero(), acc1 = frag_zero();
-        float bs0 = 0.f, bs1 = 0.f;
-        const bool work = two || hx;    // (top layer: no gradient flows into x_L)
-        // A operands, element [row 2 s + h][channel j] of a tile, straight from
-        // memory, four tiles ahead of their use (a row outside the tile asks
-        // for an offset past the resource and reads as 0)
-        float ax[4][8];
-        auto request = [&](int n, float (&dst)[8]) {
-          const int hi = n < nactive && work ? min(16, T - g_tt0[n]) : 0;
-          const int lo = past ? max(0, d - g_tt0[n]) : 0;
-          const int soff = g_off[n] - (past ? d * (WN_CH * 4) : 0);   // (>= 0 when lo == 0)
-#ifdef S16_NOLOAD   // (timing-only ablation: results meaningless)
-          if (true) {
-#pragma unroll
-            for (int s = 0; s < 8; ++s) dst[s] = 1.f + soff;
-          } else
-#endif
-          if (lo == 0 && hi == 16) {       // a whole tile: one lane offset, scalar tile offsets
-#pragma unroll
-            for (int s = 0; s < 8; ++s)
-              dst[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                     ap, lane4 + s * 256, soff, SB_X_AUX));
-          } else {
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-              const int r = 2 * s + h;
-              dst[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                  ap, r >= lo && r < hi ? soff + lane4 + s * 256 : WN_BUF_OOB, 0, SB_X_AUX));
-            }
-          }
-        };
-#pragma unroll
-        for (int n = 0; n < 4; ++n) request(n, ax[n]);
-        S16STAMP(l, 1);
-        // every row wave of the group has written its tiles of this layer
-        for (int n = 0; n < nactive; ++n)
-          wait_lds_ge(s_prod + n, L - l, dead, a.ctl, a.poison, lane);
-        S16STAMP(l, 2);
-        // B operands (the row waves' tiles); an idle row wave's tile reads as 0
-        float bv[16];
-        auto tile_read = [&](int n, float (&dst)[16]) {
-#pragma unroll
-          for (int s = 0; s < 8; ++s) {
-            const float v0 = te.p[s & 3][n * 1536 + (two ? 512 : 0) + 64 * s];
-            dst[s] = n < nactive ? v0 : 0.f;
-            if (two) {
-              const float v1 = te.p[s & 3][n * 1536 + 1024 + 64 * s];
-              dst[8 + s] = n < nactive ? v1 : 0.f;
-            }
-          }
-        };
-#pragma unroll
-        for (int n = 0; n < RW; ++n) {
-          tile_read(n, bv);
-          __builtin_amdgcn_sched_barrier(0);
-          float ts0 = 0.f, ts1 = 0.f;
-#pragma unroll
-          for (int s = 0; s < 8; ++s) {
-#ifdef S16_NOMMA    // (timing-only ablation: results meaningless)
-            acc0[s] += ax[n & 3][s] * bv[s];
-            if (two) acc1[s] += ax[n & 3][s] * bv[8 + s];
-#else
-            acc0 = sb_mfma(ax[n & 3][s], bv[s], acc0);
-            if (two) acc1 = sb_mfma(ax[n & 3][s], bv[8 + s], acc1);
-#endif
-            ts0 += bv[s];
-            if (two) ts1 += bv[8 + s];
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          if (n + 4 < RW) request(n + 4, ax[n & 3]);
-          bs0 += ts0;
-          bs1 += ts1;
-          if (tile_colsum && n < nactive && mw == 0) {
-            const float c0 = ts0 + __shfl_xor(ts0, 32), c1 = ts1 + __shfl_xor(ts1, 32);
-            if (h == 0) {
-              tile_colsum[(size_t)(gi * RW + n) * 64 + j] = c0;
-              tile_colsum[(size_t)(gi * RW + n) * 64 + 32 + j] = c1;
-            }
-          }
-        }
-        // (every LDS read above has returned: its MFMA has been issued)
-        if (lane == 0)
-          __hip_atomic_fetch_add(&s_cons, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        S16STAMP(l, 3);
-        if (!work) { acc0 = frag_zero(); bs0 = 0.f; }
-        if (dead) acc0[0] = __builtin_nanf("");
-        // slab: Wf[0] | Wf[1] | Wg[0] | Wg[1] | Wd | bf | bg | bd
-        const int m0 = mw == 0 ? 1 : mw == 1 ? 0 : 4;
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          out[m0 * 1024 + e0 + (8 * (r >> 2) + (r & 3)) * 32] = acc0[r];
-        if (two) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            out[(m0 + 2) * 1024 + e0 + (8 * (r >> 2) + (r & 3)) * 32] = acc1[r];
-        }
-        // bias sums: column sums of da_f, da_g (with x[t]'s wave) and of
-        // dx_{l+1} (with z's) over the group's rows
-        bs0 += __shfl_xor(bs0, 32);
-        bs1 += __shfl_xor(bs1, 32);
-        if (h == 0 && mw == 0) {
-          out[LAYER_W_FLOATS + j] = bs0;
-          out[LAYER_W_FLOATS + 32 + j] = bs1;
-        }
-        if (h == 0 && mw == 2) out[LAYER_W_FLOATS + 64 + j] = bs0;
-        S16STAMP(l, 4);
-      }
-    }
-    __syncthreads();
-  }
-  S16CAL(2);
-  if (tid == 0) {
-    const unsigned done = atomicAdd(a.ctl + 1, 1u);
-    if (done == gridDim.x - 1) {
-      __hip_atomic_store(a.ctl + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(a.ctl + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(a.ctl + 2, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------
 // The backward stack as a producer / consumer PIPELINE inside a workgroup
 // (round 5; big batches: B = 8, T = 16000 is 31 16-row tiles per CU and layer).
@@ -2281,7 +1914,7 @@ void stack_bwd16s_kernel(StackBwd a) {
 // at most 128 registers, four per SIMD:
 //   * 11 ROW waves take (layer, tile) TICKETS from one LDS counter -- layers
 //     top-down, the group's 16-row tiles inside a layer -- and run the dx path
-//     of that tile only (the row path of stack_bwd16s_kernel: 80 16x16x4
+//     of that tile only (stack_bwd16_kernel's, without its weight gradients: 80 16x16x4
 //     MFMAs, operands registers <-> memory), leaving dx_{l+1}[t] | da_f | da_g
 //     in one of 12 LDS hand-over buffers (6 KiB each).  Which wave computes
 //     which tile depends on timing; what is computed per tile does not.
@@ -3028,18 +2661,8 @@ int wn_stack_bwd(const float* X, const float* Z, const float* SG,
     return wn_check_launch();
   }
   if (rows == 16) {
-    // WN_STACK_SPLIT: the weight gradients on waves of their own
-    // (stack_bwd16s_kernel: 356 instead of 532 us alone at B = 1, but the side
-    // stream's weight-gradient GEMMs no longer fit beside it -- DESIGN.md)
-    if (!(variant & WN_STACK_SPLIT)) {
-      if (waves == 8) hipLaunchKernelGGL((stack_bwd16_kernel<8>), grid, block, 0, s, a);
-      else hipLaunchKernelGGL((stack_bwd16_kernel<4>), grid, block, 0, s, a);
-    } else {
-      if (waves == 8)
-        hipLaunchKernelGGL((stack_bwd16s_kernel<8>), grid, dim3(11 * 64), 0, s, a);
-      else
-        hipLaunchKernelGGL((stack_bwd16s_kernel<4>), grid, dim3(7 * 64), 0, s, a);
-    }
+    if (waves == 8) hipLaunchKernelGGL((stack_bwd16_kernel<8>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((stack_bwd16_kernel<4>), grid, block, 0, s, a);
     return wn_check_launch();
   }
 #define LAUNCH(W) hipLaunchKernelGGL((stack_bwd_kernel<W>), grid, block, 0, s, a)

@@ -266,15 +266,13 @@ def ptr(t):
     return t.data_ptr()
 
 
-WN_STACK_SPLIT = 0x1000
 WN_STACK_PIPE = 0x2000
 
 
-def stack_variant(rows=0, waves=0, split=False, pipe=False):
+def stack_variant(rows=0, waves=0, pipe=False):
     """WN_STACK_VARIANT of include/wavenet_hip.h: the explicit variant word of
     the stack launches (0 = the library's choice for the shape)."""
-    return (rows & 0x3f) | ((waves & 0xf) << 8) | (WN_STACK_SPLIT if split else 0) \
-        | (WN_STACK_PIPE if pipe else 0)
+    return (rows & 0x3f) | ((waves & 0xf) << 8) | (WN_STACK_PIPE if pipe else 0)
 
 
 def stream():

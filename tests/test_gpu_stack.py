@@ -225,14 +225,8 @@ def _check_layer_grads(a, b, wa, name):
     assert float((ga - gb).abs().max()) <= 2e-6 * max(scale, 1e-30)
 
 
-# (the opt-in split launch on the small shapes it is meant for, the ragged and
-# the conditioned ones; tools/stack_fuzz.py runs it on random shapes)
-_SPLIT_CASES = ('default_B1_T16000', 'default_B3_T5211', 'default_gc_B4_T7000', 'tiny_B2_T100',
-                'default_B2_T40', 'default_B3_T33', 'default_B300_T64', 'two_layers_B2_T500')
 _BWD_PARAMS = [pytest.param(*c, r, w, id='%s-%s-%s' % (c[0], r, w))
-               for c in CASES for r, w in [(32, '8'), (16, '8'), (16, '4'), (16, 'split8'), (16, 'split4'),
-                                           (32, 'pipe'), (16, 'pipe')]
-               if not w.startswith('split') or c[0] in _SPLIT_CASES]
+               for c in CASES for r, w in [(32, '8'), (16, '8'), (16, '4'), (32, 'pipe'), (16, 'pipe')]]
 
 
 @pytest.mark.parametrize('name,mk,B,T,kind,rows,waves', _BWD_PARAMS)
@@ -246,16 +240,13 @@ def test_stack_backward_equals_per_layer(hip_lib, monkeypatch, name, mk, B, T, k
     rows = 16: the small-batch launch (16-row tiles), forced on every shape
     here; all three models then run the 16-row FORWARD too, so the planes the
     backward paths read are bitwise the same."""
-    # ('splitN': the opt-in launch with the weight gradients on waves of their
-    # own, N row waves per workgroup)
     # ('pipe': the pipelined launch -- row waves taking (layer, tile) tickets,
     # matrix waves owning the weight-gradient matrices; 16-row tiles in the
     # backward whatever the forward's height)
     if waves == 'pipe':
         var = stack_variant(rows=rows, pipe=True)
     else:
-        var = stack_variant(rows=rows, waves=int(waves.replace('split', '')),
-                            split=waves.startswith('split'))
+        var = stack_variant(rows=rows, waves=int(waves))
     monkeypatch.setattr(WaveNetModel, 'DEFAULT_STACK_VARIANT', var)
     assert hip_lib.wn_stack_tile_rows(B, T, var) == rows
     cfg = mk()

@@ -1,19 +1,18 @@
 """Static check of stack_bwdp_kernel's machine code (csrc/wn_stack.hip).
 
-The kernel issues some loads as inline asm with hand-counted `s_waitcnt
-vmcnt(N)` (the compiler's own wait-count pass drained every outstanding load at
-points of the ticket loops).  The compiler does not know that those
-registers are written asynchronously, so it must not touch them between the
-load and its wait.  This tool compiles the file to assembly and checks, inside
-the kernel:
-  * matrix loop: a register written by an inline-asm `buffer_load_dword` is
-    read only by `v_mfma` instructions that directly follow an `s_waitcnt
-    vmcnt(31)`, and written only by those loads;
-  * row loop: between the ten inline-asm `buffer_load_dwordx4` and the
-    `s_waitcnt vmcnt(5)` that follows them in program order, no instruction
-    mentions their destination registers;
-  * no scratch (spill) access inside either hot loop.
-Exit status 0 = fine.  python tools/check_bwdp_isa.py [path/to/wn_stack.hip]"""
+The matrix waves of that kernel issue their A-operand loads as inline asm with
+a hand-counted `s_waitcnt vmcnt(31)` in front of every MFMA (the compiler's own
+wait-count pass drained every outstanding load at some point of the ticket
+loop, differently from build to build: DESIGN.md).  The compiler does not know
+that those registers are written asynchronously, so it must not touch them
+between the load and its wait.  This tool compiles the file to assembly and
+checks, inside the kernel's matrix loop:
+  * a register written by an inline-asm `buffer_load_dword` is read only by
+    `v_mfma` instructions that directly follow an `s_waitcnt vmcnt(31)`, and
+    written only by those loads (no copy, no spill, no reuse as a temporary);
+  * no scratch (spill) access and no compiler-inserted vmcnt wait there.
+Exit status 0 = fine.  python tools/check_bwdp_isa.py [path/to/wn_stack.hip]
+(tests/test_abi.py runs it when hipcc is present.)"""
 import os
 import re
 import subprocess
@@ -63,7 +62,7 @@ def main():
     idx = [i for i, (l, _) in enumerate(tagged) if 'v_mfma_f32_32x32x2' in l]
     if len(mat_dst) != 32 or not idx:
         errors.append('expected 32 A-operand registers / a matrix loop, found %d' % len(mat_dst))
-    lo, hi = idx[0] - 400, idx[-1] + 40
+    lo, hi = idx[0] - 8, idx[-1] + 8
     for i in range(max(lo, 0), min(hi, len(tagged))):
         l, ia = tagged[i]
         code = l.split(';')[0].strip()
@@ -71,6 +70,8 @@ def main():
             continue
         if 'scratch_' in code:
             errors.append('matrix loop: spill access: ' + code)
+        if 'vmcnt' in code and not ia:
+            errors.append('matrix loop: compiler-inserted wait: ' + code)
         r = regs_of(code)
         if not (r & mat_dst):
             continue
@@ -84,47 +85,10 @@ def main():
                 errors.append('matrix loop: MFMA without its vmcnt(31): ' + code)
             continue
         errors.append('matrix loop: %s touches an asynchronously loaded register' % code)
-    # ---- row loop: ten dwordx4 asm loads, then the counted wait
-    i = 0
-    groups = 0
-    while i < len(tagged):
-        l, ia = tagged[i]
-        if ia and 'buffer_load_dwordx4' in l:
-            dst, j, n = set(), i, 0
-            while n < 10 and j < len(tagged):
-                lj, iaj = tagged[j]
-                mm = re.match(r'\s*buffer_load_dwordx4 (v\[\d+:\d+\]),', lj)
-                if iaj and mm:
-                    dst |= regs_of(mm.group(1))
-                    n += 1
-                j += 1
-            groups += 1
-            # program order up to the wait (straight-line or through labels)
-            k, seen_wait = j, False
-            while k < len(tagged) and k < j + 2500:
-                lk, iak = tagged[k]
-                code = lk.split(';')[0].strip()
-                if iak and 'vmcnt(5)' in code:
-                    seen_wait = True
-                    break
-                if code and not code.endswith(':') and (regs_of(code) & dst):
-                    errors.append('row loop: "%s" touches a register of the ten row loads '
-                                  'before their wait' % code)
-                    break
-                if 'scratch_' in code:
-                    errors.append('row loop: spill access between the loads and their wait: ' + code)
-                k += 1
-            if not seen_wait:
-                errors.append('row loop: no vmcnt(5) behind the row loads at line %d' % i)
-            i = j
-        else:
-            i += 1
-    if groups != 1:
-        errors.append('expected ONE site issuing the ten row loads, found %d' % groups)
     for e in errors:
         print('FAIL:', e)
-    print('check_bwdp_isa: %s (%d A-operand registers, %d row-load site(s))' % (
-        'FAILED' if errors else 'ok', len(mat_dst), groups))
+    print('check_bwdp_isa: %s (%d A-operand registers, %d MFMAs in the ticket loop)' % (
+        'FAILED' if errors else 'ok', len(mat_dst), len(idx)))
     return 1 if errors else 0
 
 

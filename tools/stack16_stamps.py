@@ -23,13 +23,12 @@ import torch
 from wavenet import _lib, WaveNetModel
 from util import model_kwargs, synth_audio
 lib = _lib.load()
-# KB_SPLIT (default 1) / KB_WAVES_B: variant of the backward launch
-split = os.environ.get('KB_SPLIT', '1') != '0'
+# KB_WAVES_B: waves of the 16-row backward launch
 rw = int(os.environ.get('KB_WAVES_B', 8))
 # KB_PIPE=1: the pipelined backward launch (stack_bwdp_kernel; the forward keeps its own height)
 pipe = os.environ.get('KB_PIPE') == '1'
 VAR = _lib.stack_variant(rows=0, pipe=True) if pipe else \
-    _lib.stack_variant(rows=16, waves=rw, split=split)
+    _lib.stack_variant(rows=16, waves=rw)
 WaveNetModel.DEFAULT_STACK_VARIANT = VAR
 B, T = int(os.environ.get('KB_B', 1)), 16000
 p = json.load(open(os.path.join(ROOT, 'wavenet_params.json')))
@@ -105,7 +104,7 @@ if pipe:
         (0, 1, 'wait for the ticket\'s buffer'), (1, 2, '8 MFMA interleaved with the next B operands, next A operands requested'),
         (2, 3, 'layer end: slab stores')],
         True, waves=(0, 1, 4))
-elif not split:
+else:
     report(dbgb.cpu().numpy(), gridb, 'stack_bwd16_kernel', [
         (0, 1, 'wait for the weight ring'), (1, 2, 'loads requested (z DMA, dZ, sigmoid, own dx, flag check, q)'),
         (2, 3, 'wait for them'), (3, 4, 'dx_{l+1} to LDS, dWd (8 MFMA), z fragments'),
@@ -113,13 +112,3 @@ elif not split:
         (5, 6, 'own / q rows (64 MFMA)'), (6, 7, 'q and own rows stored, drained, flag posted, next flags requested'),
         (7, 8, 'weight gradients (32 MFMA)'), (8, 9, 'ring bookkeeping'),
         (9, 10, 'ordered accumulation chain (incl. token waits)')], True)
-else:
-    report(dbgb.cpu().numpy(), gridb, 'stack_bwd16s_kernel, row waves', [
-        (0, 1, 'wait for the weight ring'), (1, 2, 'loads requested (dZ, sigmoid, z, own dx, flag check, q)'),
-        (2, 3, 'wait for them'), (3, 4, 'tiles free?, dx_{l+1} | dz (16 MFMA) | gates -> LDS, signal'),
-        (4, 5, 'own / q rows (64 MFMA)'), (5, 6, 'stores, ring bookkeeping, drain, flag posted, next flags')],
-        True, waves=(0, rw - 1))
-    report(dbgb.cpu().numpy(), gridb, 'stack_bwd16s_kernel, matrix waves', [
-        (0, 1, 'operands of four tiles requested'), (1, 2, 'wait for the row waves'),
-        (2, 3, 'the group\'s tiles (16 / 16 / 8 MFMA each)'), (3, 4, 'slab stores issued')],
-        True, waves=(rw, rw + 1, rw + 2))

@@ -154,42 +154,51 @@ def cpu_baseline(params, T, max_seconds=20.0, max_steps=20):
                       '(%.2f s/step)' % (n, T, dt)}
 
 
-def pmc_traffic(kernel):
-    """(HBM bytes per launch of `kernel`, source file) from the newest
-    committed PMC summary (profiles/*_pmc_traffic.json, written by
-    tools/pmc_summary.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-    passes of this same command, with the gfx950 FETCH_SIZE x2 correction).
-    (None, None) when no summary holds the kernel."""
+def _csrc_sha16():
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    try:
+        from csrc_hash import csrc_hash
+        return csrc_hash()
+    except Exception:      # noqa: BLE001 (tools/ not shipped: unknown, never "fresh")
+        return None
+
+
+def _newest_profile(pattern, kernel):
+    """(entry of `kernel`, relative path, stale) from the newest committed
+    summary profiles/<pattern> that holds the kernel.  stale: the summary
+    records the hash of the kernel sources it was collected on
+    (tools/csrc_hash.py); True when it differs from this tree's (or when the
+    summary predates the field), i.e. the figure is a constant read from an
+    older build, not an observation of this run."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')))
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', pattern)))
     for path in reversed(files):
         try:
             with open(path) as f:
-                return (json.load(f)[kernel]['hbm_bytes_per_launch'],
-                        os.path.relpath(path, ROOT))
+                d = json.load(f)
+            e = d[kernel]
         except (KeyError, ValueError, OSError):
             continue
-    return None, None
+        sha = (d.get('_meta') or {}).get('csrc_sha16')
+        cur = _csrc_sha16()
+        return e, os.path.relpath(path, ROOT), (sha is None or cur is None or sha != cur)
+    return None, None, None
 
 
-def stream_rates():
-    """({'forward stack mix': TB/s, ...}, source file) from the newest
-    committed output of tools/ubench/hbm_stream.hip (profiles/*_hbm_stream.txt:
-    a hand-written stream with the stack launches' read : write plane mixes on
-    this part) -- the denominators of `frac_of_mix_stream`."""
-    import glob
-    import re
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_hbm_stream.txt')))
-    if not files:
-        return {}, None
-    rates = {}
-    with open(files[-1]) as f:
-        for line in f:
-            m = re.match(r'(.+?)\s+\d+ read : \d+ written.*?([0-9.]+) TB/s', line)
-            if m:
-                name = m.group(1).replace(', nt', '').strip()
-                rates[name] = max(rates.get(name, 0.0), float(m.group(2)))
-    return rates, os.path.relpath(files[-1], ROOT)
+def pmc_traffic(kernel):
+    """(HBM bytes per launch of `kernel`, source file, stale) from the newest
+    committed PMC summary (profiles/*_pmc_traffic.json, written by
+    tools/pmc_summary.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    passes of this same command, with the gfx950 FETCH_SIZE x2 correction).
+    (None, None, None) when no summary holds the kernel."""
+    e, src, stale = _newest_profile('*_pmc_traffic.json', kernel)
+    return (None, None, None) if e is None else (e['hbm_bytes_per_launch'], src, stale)
+
+
+def pmc_issue(kernel):
+    """(issue-slot summary of `kernel`, source file, stale) from the newest
+    profiles/*_issue.json (tools/pmc_issue.py), or (None, None, None)."""
+    return _newest_profile('*_issue.json', kernel)
 
 
 def secondary(net, audio, gc_ids, kw, B, T, gen_samples=16000, opt=None):
@@ -516,40 +525,49 @@ def main():
     algo_bytes = 4.0 * B * T * (
         (LC + Sk) + (3 * Sk) + (Sk + Qc) + (Qc + 2 * Sk) + (3 * Sk) + (Sk + LC)) / 6
     # (the committed PMC summary was collected at the default shape only)
-    traffic, traffic_src = pmc_traffic(dom) if (B, T) == (8, 16000) \
-        else (None, None)
-    # the two persistent residual-stack launches: HBM roofline (bytes per
-    # launch from the committed PMC summary, time live)
+    traffic, traffic_src, traffic_stale = pmc_traffic(dom) if (B, T) == (8, 16000) \
+        else (None, None, None)
+    # the two persistent residual-stack launches.  Their bound is ISSUE (on
+    # gfx950 the f32 MFMA and the vector ALU are one resource: DESIGN.md,
+    # profiles/*_mfma_valu.txt), neither HBM nor the matrix pipe alone: time
+    # live (HIP events), the issue-slot fractions and the fabric bytes from the
+    # committed PMC summaries of the kernel that RAN (name = what the library's
+    # shape / variant rules pick), each tagged stale when the kernel sources
+    # changed since it was collected.  The TB/s figure is information, not a
+    # fraction of a bound.
     stacks = {}
-    rates, rates_src = stream_rates()
-    for ev_name, kname in (('wn_stack_fwd', 'void stack_fwd_kernel<2, 16>'),
-                           ('wn_stack_bwd', 'void stack_bwd_kernel<8, true>')):
+    lib_ = net  # (kernel names follow wn_stack_tile_rows / the variant word)
+    tws = [w for w in net._ws.values() if w.training]
+    rows_f = tws[0].stack_rows if tws else 32
+    rows_b = tws[0].stack_rows_b if tws else 32
+    pipe = bool(tws and (tws[0].stack_variant & 0x2000))
+    kern = {'wn_stack_fwd': 'void stack_fwd_kernel<2, 16>' if rows_f == 32
+            else 'void stack_fwd16_kernel<2, 8>',
+            'wn_stack_bwd': 'stack_bwdp_kernel' if pipe else
+            ('void stack_bwd_kernel<8>' if rows_b == 32 else 'void stack_bwd16_kernel<8>')}
+    tile_layers = B * ((T + 31) // 32) * len(params['dilations'])
+    mfma_cyc = {'wn_stack_fwd': 80 * 64, 'wn_stack_bwd': 160 * 64}    # per 32-row tile and layer
+    for ev_name in ('wn_stack_fwd', 'wn_stack_bwd'):
         evs = [e for e in events if e[3] == ev_name]
         if not evs:
             continue
         us = sum(e[0].elapsed_time(e[1]) for e in evs) / len(evs) * 1e3
-        by, src = pmc_traffic(kname) if (B, T) == (8, 16000) else (None, None)
+        kname = kern[ev_name]
+        by, src, stale = pmc_traffic(kname) if (B, T) == (8, 16000) else (None, None, None)
+        iss, isrc, istale = pmc_issue(kname) if (B, T) == (8, 16000) else (None, None, None)
         stacks[ev_name] = {
             'kernel': kname.replace('void ', ''), 'avg_launch_us': us,
-            'bound': 'hbm', 'traffic': by, 'traffic_source': src,
-            'achieved_tb_s': None if by is None else by / us / 1e6,
-            'frac_of_spec_8tb_s': None if by is None else by / us / 1e6 / 8.0,
-            'frac_of_streaming_5p3tb_s': None if by is None else by / us / 1e6 / 5.3,
-            # a hand-written stream with this launch's read : write plane mix
-            # (tools/ubench/hbm_stream.hip: forward 1 : 3, backward 7 : 2)
-            'mix_stream_tb_s': rates.get('forward stack mix' if ev_name == 'wn_stack_fwd'
-                                         else 'backward stack mix'),
-            'mix_stream_source': rates_src}
-        mix = stacks[ev_name]['mix_stream_tb_s']
-        stacks[ev_name]['frac_of_mix_stream'] = None if (by is None or not mix) \
-            else by / us / 1e6 / mix
-        if ev_name == 'wn_stack_bwd':
-            # the PMC bytes are L2 <-> fabric requests: they include the own dx
-            # rows (one plane rewritten in place, served by the Infinity Cache)
-            # and the stream rate moves +-10 % between boxes, so this ratio can
-            # pass 1; the launch is bound by its issue slots
-            stacks[ev_name]['note'] = ('traffic counts Infinity-Cache hits; '
-                                       'indicative, not an HBM fraction')
+            'bound': 'issue',
+            # live: the launch's MFMA work (algorithmic) over its time,
+            # against 1024 SIMDs at the 2.4 GHz peak clock
+            'mfma_busy_frac_live_at_2p4ghz': tile_layers * mfma_cyc[ev_name] / 1024.0 / (us * 2400.0),
+            'issue': None if iss is None else {
+                k: iss.get(k) for k in ('mfma_busy_frac', 'valu_issue_frac', 'issue_frac',
+                                        'mfma_valu_coexec_frac', 'vmem_inst_cycles_frac',
+                                        'clock_ghz', 'avg_us')},
+            'issue_source': isrc, 'issue_stale': istale,
+            'traffic': by, 'traffic_source': src, 'traffic_stale': stale,
+            'fabric_tb_s_info': None if by is None else by / us / 1e6}
     out = {
         'metric': 'audio samples/sec (train, default wavenet_params.json)',
         'value': value, 'unit': 'audio samples/s', 'n_gpus': world,
@@ -589,6 +607,7 @@ def main():
                              '2500 / piece products)',
                      'frac': achieved / peak,
                      'traffic': traffic, 'traffic_source': traffic_src,
+                     'traffic_stale': traffic_stale,
                      'traffic_unit': 'bytes per launch (rocprofv3 PMC pass)',
                      # what the six launches of a step must move (fp32 path):
                      # A operands in, outputs out, the pre-activation plane the

@@ -164,11 +164,15 @@ def test_bench_line_carries_the_contract(hip_lib):
     assert rf['bound'] == 'mfma' and rf['peak'] == 157.3
     assert 0 < rf['frac'] < 1 and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9
     assert rf['launches_per_step'] == 6 and rf['tn_gemms']['launches_per_step'] == 3
-    # the two persistent stack launches are timed live too (their HBM bytes
-    # are quoted at the default shape only)
+    # the two persistent stack launches are timed live too; their bound is
+    # issue (f32 MFMA + vector ALU: one resource), the PMC figures are quoted
+    # at the default shape only, and no fraction of a "bound" that can exceed 1
     sl = rf['stack_launches']
     assert sl['wn_stack_fwd']['avg_launch_us'] > 0 and sl['wn_stack_bwd']['avg_launch_us'] > 0
-    assert sl['wn_stack_bwd']['bound'] == 'hbm' and sl['wn_stack_bwd']['traffic'] is None
+    assert sl['wn_stack_bwd']['bound'] == 'issue' and sl['wn_stack_bwd']['traffic'] is None
+    assert 0 < sl['wn_stack_bwd']['mfma_busy_frac_live_at_2p4ghz'] < 1
+    assert not any('frac_of_mix_stream' in v for v in sl.values())
+    assert 'traffic_stale' in rf
     assert 0 < r['step_frac'] < 1
     cb = r['cpu_baseline']
     assert cb['kind'] == 'port' and cb['cores'] >= 1 and cb['cpu_model']

@@ -9,7 +9,11 @@ usage: python tools/pmc_summary.py <fetch_counter_csv> <write_counter_csv> <out_
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from csrc_hash import csrc_hash  # noqa: E402
 
 
 def agg(path, name):
@@ -31,10 +35,13 @@ def main():
                   'write_bytes': sum(w) / len(w) * 1024}
         out[k]['hbm_bytes_per_launch'] = out[k]['fetch_bytes_corrected'] + \
             out[k]['write_bytes']
-    json.dump(out, open(sys.argv[3], 'w'), indent=1, sort_keys=True)
     for k in sorted(out, key=lambda k: -out[k]['hbm_bytes_per_launch'])[:12]:
         print('%-40s %4d launches  %8.1f MB/launch' % (
             k[:40], out[k]['launches'], out[k]['hbm_bytes_per_launch'] / 1e6))
+    # what the summary was collected on: bench.py flags it stale when the
+    # kernel sources have changed since
+    out['_meta'] = {'csrc_sha16': csrc_hash()}
+    json.dump(out, open(sys.argv[3], 'w'), indent=1, sort_keys=True)
 
 
 if __name__ == '__main__':

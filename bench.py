@@ -218,7 +218,7 @@ def secondary(net, audio, gc_ids, kw, B, T, gen_samples=16000, opt=None):
     # opt-in split-bf16 GEMM mode on the same batch (NOT the headline: fp32
     # operands rebuilt from 6 bf16 piece products, same error vs float64 as the
     # fp32 MFMA kernels)
-    optin = None
+    optin, optin_roof = None, None
     if net.gemm_mode == 'fp32' and opt is not None:
         net.gemm_mode = 'bf16x6'
         for _ in range(3):
@@ -229,8 +229,26 @@ def secondary(net, audio, gc_ids, kw, B, T, gen_samples=16000, opt=None):
             opt.minimize(net.loss(audio, gc_ids))
         torch.cuda.synchronize()
         optin = (time.perf_counter() - t0) / 10 * 1e3
+        # its own roofline: the six NN GEMMs timed live (HIP events), in
+        # fp32-EQUIVALENT TFLOP/s (the contraction's flops, not the six piece
+        # products') against the dense bf16 peak / 6
+        net._gemm_events = []
+        for _ in range(3):
+            opt.minimize(net.loss(audio, gc_ids))
+        torch.cuda.synchronize()
+        ev = [e for e in net._gemm_events if e[3] == 'wn_gemm_nn_split']
+        net._gemm_events = None
+        t_nn = sum(e[0].elapsed_time(e[1]) for e in ev) * 1e-3
+        f_nn = sum(e[2] for e in ev)
+        optin_roof = {'ms_per_step': optin,
+                      'kernel': 'gemm_nn_split_kernel<6>',
+                      'gemm_tflops_equiv': f_nn / t_nn / 1e12 if t_nn > 0 else None,
+                      'peak': 2500.0 / 6, 'peak_note': 'dense bf16 MFMA 2500 TFLOP/s / 6 piece products',
+                      'frac': f_nn / t_nn / 1e12 / (2500.0 / 6) if t_nn > 0 else None,
+                      'nn_gemm_us_per_step': t_nn / 3 * 1e6}
         net.gemm_mode = 'fp32'
-        log('opt-in bf16x6 GEMM mode: %.2f ms/step' % optin)
+        log('opt-in bf16x6 GEMM mode: %.2f ms/step, NN GEMMs %.0f fp32-equivalent TFLOP/s'
+            % (optin, optin_roof['gemm_tflops_equiv'] or 0))
     from wavenet import optimizer_factory
 
     def timed_steps(model, a, ids, n=10, warm=3):
@@ -302,7 +320,8 @@ def secondary(net, audio, gc_ids, kw, B, T, gen_samples=16000, opt=None):
             'b1_samples_per_s': T / b1_ms * 1e3,
             't100k_ms_per_step': t100k_ms,
             't100k_samples_per_s': None if t100k_ms is None else 100000 / t100k_ms * 1e3,
-            'optin_bf16x6_ms_per_step': optin}
+            'optin_bf16x6_ms_per_step': optin,
+            'optin_bf16x6': optin_roof}
 
 
 def launch_ranks(n):
@@ -636,8 +655,14 @@ def main():
     if world > 1:
         out['allreduce_us_per_step'] = ar_us
         out['allreduce_note'] = ('max over ranks of the HIP-event time around '
-                                 'the one flat-bucket gradient all-reduce '
-                                 '(includes waiting for the slowest rank)')
+                                 'the gradient all-reduce issued at the update '
+                                 '(includes waiting for the slowest rank); with '
+                                 'allreduce_calls == 2 that is the bucket\'s head '
+                                 'only: the skip / post-processing tail was '
+                                 'reduced beside the backward stack')
+        out['allreduce_calls'] = 2 if net.dp_overlap_allreduce else 1
+        out['allreduce_tail_bytes'] = int((net.grads.numel() - parallel.tail_start(net))
+                                          * net.grads.element_size())
         out['allreduce_bytes'] = int(net.grads.numel() * net.grads.element_size())
         out['collective'] = collective_env()
         out['step_ms_min'] = dt_min / args.steps * 1e3

@@ -1610,30 +1610,44 @@ __global__ __launch_bounds__(FGP_THREADS) void fg_persist_kernel(FgPersist a) {
         while (!dead && __hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < i + 1)
           __builtin_amdgcn_s_sleep(1);
         PSTAMP(i * 16 + 1 + seg);
-        for (int ll = 0; ll < nl; ++ll) {
+        // A layer's weights, past-tap pre-activation and dense bias do not
+        // depend on the chain: layer ll + 1's are requested while layer ll
+        // computes (round 5: twelve LDS reads per layer off the chain wave's
+        // dependent path), two register sets used alternately.
+        struct LW { f32x4 qw[8], pw[4]; float a0, bdl; };
+        auto lw_load = [&](LW& w, int ll) {
           const float* wl = wres + (size_t)ll * FGC_CW;
           const float* w1 = wl + gsel * 1024 + nn * 32;
           const float* wd = wl + 2 * 1024 + nn * 32;
-          f32x4 qw[8], pw[4];
 #pragma unroll
           for (int c = 0; c < 8; ++c)
-            qw[c] = *reinterpret_cast<const f32x4*>(w1 + ((c ^ (nn & 7)) << 2));
+            w.qw[c] = *reinterpret_cast<const f32x4*>(w1 + ((c ^ (nn & 7)) << 2));
 #pragma unroll
           for (int cc = 0; cc < 4; ++cc)
-            pw[cc] = *reinterpret_cast<const f32x4*>(wd + (((gsel * 4 + cc) ^ (nn & 7)) << 2));
-          float a0 = pre_s[ll * 64 + lane], a1 = 0.f, a2 = 0.f, a3 = 0.f;
-          const float bdl = bd_s[ll * 32 + (lane & 31)];
+            w.pw[cc] = *reinterpret_cast<const f32x4*>(wd + (((gsel * 4 + cc) ^ (nn & 7)) << 2));
+          w.a0 = pre_s[ll * 64 + lane];
+          w.bdl = bd_s[ll * 32 + (lane & 31)];
+        };
+        auto layer = [&](int ll, const LW& w, LW& wn) {
+          float a0 = w.a0, a1 = 0.f, a2 = 0.f, a3 = 0.f;
           if (lane < 32) {
             fgp_st(g.state + rowoff[(i & 1) * FGP_SEGL + ll] + lane, x);   // enqueue x_l[t]
             inv[lane] = x;
           }
           __builtin_amdgcn_wave_barrier();
+          f32x4 xv[8];
+#pragma unroll
+          for (int c = 0; c < 8; ++c) xv[c] = *reinterpret_cast<const f32x4*>(inv + 4 * c);
+          // (the next layer's operands behind this layer's x reads: they land
+          // under its FMAs and gate)
+          __builtin_amdgcn_sched_barrier(0);
+          if (ll + 1 < nl) lw_load(wn, ll + 1);
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int c = 0; c < 8; ++c) {
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(inv + 4 * c);
-            const f32x4 q = qw[c];
-            a0 = fmaf(xv[0], q[0], a0); a1 = fmaf(xv[1], q[1], a1);
-            a2 = fmaf(xv[2], q[2], a2); a3 = fmaf(xv[3], q[3], a3);
+            const f32x4 q = w.qw[c];
+            a0 = fmaf(xv[c][0], q[0], a0); a1 = fmaf(xv[c][1], q[1], a1);
+            a2 = fmaf(xv[c][2], q[2], a2); a3 = fmaf(xv[c][3], q[3], a3);
           }
           const float av = (a0 + a1) + (a2 + a3);
           const float sg = wn_sigmoid(gsel ? av : 2.f * av);
@@ -1652,7 +1666,7 @@ __global__ __launch_bounds__(FGP_THREADS) void fg_persist_kernel(FgPersist a) {
             for (int cc = 0; cc < 4; ++cc) {
               const int c = gsel * 4 + cc;
               const f32x4 zz = *reinterpret_cast<const f32x4*>(zv + 4 * c);
-              const f32x4 pq = pw[cc];
+              const f32x4 pq = w.pw[cc];
               d0 = fmaf(zz[0], pq[0], d0); d1 = fmaf(zz[1], pq[1], d1);
               d2 = fmaf(zz[2], pq[2], d2); d3 = fmaf(zz[3], pq[3], d3);
             }
@@ -1660,9 +1674,15 @@ __global__ __launch_bounds__(FGP_THREADS) void fg_persist_kernel(FgPersist a) {
             const auto pd2 = __builtin_amdgcn_permlane32_swap(
                 __float_as_uint(dh), __float_as_uint(dh), false, false);
             if (lane < 32)
-              x += bdl + (__uint_as_float(pd2[0]) + __uint_as_float(pd2[1]));
+              x += w.bdl + (__uint_as_float(pd2[0]) + __uint_as_float(pd2[1]));
           }
           __builtin_amdgcn_wave_barrier();
+        };
+        LW wa, wb;
+        lw_load(wa, 0);
+        for (int ll = 0; ll < nl; ll += 2) {
+          layer(ll, wa, wb);
+          if (ll + 1 < nl) layer(ll + 1, wb, wa);
         }
         // x to the next segment at once; the queue entries this segment wrote
         // are for its own helper waves: drained behind the hand-over

@@ -190,6 +190,93 @@ __device__ __forceinline__ void gemm_epilogue(const GemmNN& g, f32x16 (&acc)[2][
   }
 }
 
+// The same for a wave tile of 32 rows x 128 columns (gemm_nn_split_kernel: wave
+// w owns rows 32 w .. 32 w + 31 of the workgroup tile and all 128 columns, as
+// 2 x 8 accumulator tiles of 16 x 16): two passes of 64 columns through the
+// wave's LDS tile.
+// (accumulator register i of lane l of tile [mt][nt]: row 16 mt + (l & 15),
+// column 16 nt + 4 (l >> 4) + i)
+__device__ __forceinline__ void gemm_epilogue_wide(const GemmNN& g, f32x4 (&acc)[2][8],
+                                                   float* lds, long m0, int n0,
+                                                   int wave, int lane) {
+  const long m_end = g.M;
+  float* tile = lds + wave * (32 * EP_LD);
+  const int rr = lane >> 4, cc = (lane & 15) * 4;   // row-in-group, column
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+  const int nw = n0 + cb * 64;                      // the pass's first column
+  const bool ncol = nw + cc < g.N;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (g.bias && ncol) bias4 = *reinterpret_cast<const f32x4*>(g.bias + nw + cc);
+  // per-lane byte offsets inside the wave's 32-row half
+  const int vC = g.c_planes ? (int)(((long)(cc >> 5) * g.c_plane_stride + rr * 32 + (cc & 31)) * 4)
+                            : (int)((rr * g.ldc + cc) * 4);
+  const int sC = g.c_planes ? 4 * 32 * 4 : (int)(4 * g.ldc * 4);   // four rows further
+  const int vP = (int)((rr * g.ldc + cc) * 4);
+  const int sP = (int)(4 * g.ldc * 4);
+  const int vM = (int)((rr * g.ld_mask + cc) * 4), sM = (int)(4 * g.ld_mask * 4);
+  // (addend in the output's plane layout when ld_add == 0 and c_planes > 0:
+  // x_{l+1} planes = x_l planes + z_l Wd of the channel-block models)
+  const bool addp = g.addend && g.c_planes && g.ld_add == 0;
+  const int vA = addp ? vC : (int)((rr * g.ld_add + cc) * 4);
+  const int sA = addp ? sC : (int)(4 * g.ld_add * 4);
+  {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int ntl = 0; ntl < 4; ++ntl)
+        *reinterpret_cast<f32x4*>(tile + (mt * 16 + (lane & 15)) * EP_LD + ntl * 16 +
+                                  4 * (lane >> 4)) = acc[mt][4 * cb + ntl];
+    __builtin_amdgcn_wave_barrier();
+    const long mbase = m0 + wave * 32;
+    const long left = m_end - mbase;                 // rows of this half that exist
+    const int nrows = left > 32 ? 32 : (left < 0 ? 0 : (int)left);
+    const __amdgpu_buffer_rsrc_t rC = ep_rsrc(
+        g.c_planes ? g.C + (long)(nw >> 5) * g.c_plane_stride + mbase * 32
+                   : g.C + mbase * g.ldc + nw);
+    const __amdgpu_buffer_rsrc_t rP = ep_rsrc(g.Cpre ? g.Cpre + mbase * g.ldc + nw : g.C);
+    const __amdgpu_buffer_rsrc_t rM = ep_rsrc(g.mask ? g.mask + mbase * g.ld_mask + nw : g.C);
+    const __amdgpu_buffer_rsrc_t rA = ep_rsrc(
+        !g.addend ? g.C
+        : addp ? g.addend + (long)(nw >> 5) * g.c_plane_stride + mbase * 32
+               : g.addend + mbase * g.ld_add + nw);
+#pragma unroll
+    for (int bt = 0; bt < 2; ++bt) {
+      f32x4 v[4], mk[4], ad[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int it = bt * 4 + q, row = it * 4 + rr;
+        const bool ok = ncol && row < nrows;
+        v[q] = *reinterpret_cast<const f32x4*>(tile + row * EP_LD + cc);
+        if (g.mask && ok)
+          mk[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rM, vM, it * sM, EP_LD_AUX));
+        if (g.addend && ok)
+          ad[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, vA, it * sA, EP_LD_AUX));
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int it = bt * 4 + q, row = it * 4 + rr;
+        if (!(ncol && row < nrows)) continue;
+        f32x4 x = v[q] + bias4;
+        if (g.Cpre)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ep_u32x4, x), rP, vP, it * sP, EP_ST_AUX);
+        if (g.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[e] = fmaxf(x[e], 0.f);
+        }
+        if (g.mask) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[e] = mk[q][e] > 0.f ? x[e] : 0.f;
+        }
+        if (g.addend) x += ad[q];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ep_u32x4, x), rC, vC, it * sC, EP_ST_AUX);
+      }
+    }
+  }
+  }
+}
+
 template <int WMT>   // time-waves per workgroup: 2 -> 128-row tile, 256 threads
 __global__ __launch_bounds__(WMT * 128) void gemm_nn_kernel(GemmNN g) {
   constexpr int TM = WMT * 64, NT = WMT * 128;   // rows per tile, threads
@@ -555,128 +642,166 @@ __global__ __launch_bounds__(256, 4) void gemm_nn3_kernel(GemmNN g) {
 
 
 // ---------------------------------------------------------------------------
-// Split-bf16 NN GEMM (wn_gemm_nn_split): same tile / staging structure as
-// gemm_nn3_kernel.  The weights are split ONCE per call by split_w_kernel
-// into MFMA-fragment order ([k/16][n/32][piece][lane][8 bf16], 1 KiB per
-// piece fragment) and DMA-staged as they are, so a weight fragment is three
-// ds_read_b128 and no VALU; activations are staged as fp32 and split after the
-// LDS read (44 VALU per fragment).  Stage = 8 KB activations + 12 KB weight
-// pieces.
+// Split-bf16 NN GEMM (wn_gemm_nn_split): gemm_nn3_kernel's staging structure.
+// The weights are split ONCE per call by split_w_kernel into MFMA-fragment
+// order and DMA-staged as they are, so a weight fragment is three ds_read_b128
+// and no VALU; activations are staged as fp32 and split after the LDS read (44
+// VALU per fragment, one fragment per 48 MFMAs at nprod = 6).
 // ---------------------------------------------------------------------------
-#define NSP_STAGE (NN_TM * N3_KC + 4 * 3 * 256)   // floats per stage
+// v_mfma_f32_16x16x32_bf16, K chunks of 32: stage = 16 KB activations (rows of
+// 128 B, 16-byte slots XOR-swizzled with (row >> 1) & 7) + 24 KB weight pieces in
+// fragment order [k/32][n/16][piece][lane][8 bf16]; two stages, two workgroups
+// per CU; a wave owns 32 rows x ALL 128 columns = 2 x 8 accumulator tiles.
+// Round 5 (profiles/r05_split_nn.txt): the kernel runs at the clock the chip
+// holds under bf16 MFMA load (1.7 - 2.0 GHz in the K loop, tools/nsp_stamps.py),
+// and its time did not move with the occupancy (1 - 3 workgroups per CU), the
+// stage count (2 - 4), the activation split's VALU (removed: -4 %) or the weight
+// fragments' LDS reads (removed: 0 %); what moved it was the MFMA shape (the
+// chip holds a higher clock on 16x16x32 than on 32x32x16: -6 % time) and the
+// wave tile (64 x 64 -> 32 x 128: one activation split per weight fragment set,
+// -2 %).
+#define S16_KC 32
+#define S16_STAGE (NN_TM * S16_KC + 8 * 3 * 256)   // floats per stage
 
 __global__ void split_w_kernel(const float* __restrict__ W, int ldw, int K, int N,
-                               unsigned int* __restrict__ out, int nt32) {
+                                 unsigned int* __restrict__ out, int nt16) {
   const int kc = blockIdx.y, nt = blockIdx.x, lane = threadIdx.x;
-  const int i = lane & 31, h = lane >> 5;
-  const int n = nt * 32 + i;
+  const int n = nt * 16 + (lane & 15);
   float v[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    const int k = kc * 16 + 8 * h + e;
+    const int k = kc * S16_KC + 8 * (lane >> 4) + e;
     v[e] = (k < K && n < N) ? W[(long)k * ldw + n] : 0.f;
   }
   const Split3 s = split3(v);
-  u32x4* dst = reinterpret_cast<u32x4*>(out) + ((long)(kc * nt32 + nt) * 3) * 64 + lane;
+  u32x4* dst = reinterpret_cast<u32x4*>(out) + ((long)(kc * nt16 + nt) * 3) * 64 + lane;
 #pragma unroll
   for (int p = 0; p < 3; ++p) dst[p * 64] = __builtin_bit_cast(u32x4, s.p[p]);
 }
 
 template <int NPROD>
-__global__ __launch_bounds__(256, 3) void gemm_nn_split_kernel(GemmNN g, const unsigned int* wp,
-                                                               int nt32) {
-  constexpr int LDSF = 2 * NSP_STAGE > 4 * 32 * EP_LD ? 2 * NSP_STAGE : 4 * 32 * EP_LD;
+__device__ __forceinline__ void mma_split16(f32x4& acc, const Split3& a, const Split3& b) {
+#define WN_MM(i, k) \
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p[i], b.p[k], acc, 0, 0, 0)
+  if (NPROD >= 9) { WN_MM(2, 2); WN_MM(1, 2); WN_MM(2, 1); }
+  if (NPROD >= 6) { WN_MM(1, 1); WN_MM(0, 2); WN_MM(2, 0); }
+  WN_MM(0, 1);
+  WN_MM(1, 0);
+  WN_MM(0, 0);
+#undef WN_MM
+}
+
+template <int NPROD>
+__global__ __launch_bounds__(256, 2) void gemm_nn_split_kernel(GemmNN g, const unsigned int* wp,
+                                                                 int nt16) {
+  constexpr int LDSF = 2 * S16_STAGE;
+  static_assert(LDSF >= 4 * 32 * EP_LD, "epilogue LDS");
   __shared__ __attribute__((aligned(1024))) float smem[LDSF];
+#ifdef NSP_STAMPS   // diagnostic build: g.Cpre carries a stamp buffer [nwg][8]
+  unsigned long long* dbg = reinterpret_cast<unsigned long long*>(g.Cpre) + (size_t)blockIdx.x * 8;
+  g.Cpre = nullptr;
+  if (threadIdx.x == 0) { dbg[4] = __builtin_amdgcn_s_memtime(); dbg[5] = __builtin_amdgcn_s_memrealtime(); }
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j = lane & 31, h = lane >> 5;
-  const int wm = wave & 1, wn = wave >> 1;
+  const int r16 = lane & 15, kq = lane >> 4;
   const int logical = xcd_remap(blockIdx.x, g.nwg);
   const int tile_n = logical % g.tiles_n;
   const long m0 = (long)(logical / g.tiles_n) * NN_TM;
   const int n0 = tile_n * NN_TN;
-  const int nk = g.K / N3_KC;
+  const int nk = (g.K + S16_KC - 1) / S16_KC;
 
-  const int a_chunk = (lane & 3) ^ ((lane >> 4) & 3);
-  long am0 = m0 + 16 * wave + (lane >> 2), am1 = am0 + 64;
-  am0 = am0 < g.M ? am0 : g.M - 1;
-  am1 = am1 < g.M ? am1 : g.M - 1;
+  // activations: wave w stages row blocks b = w + 4 t (8 rows x 128 B = one
+  // 1 KB LDS-DMA instruction); lane i -> row 8 b + (i >> 3), LDS slot i & 7,
+  // which holds the row's 16-byte slot (i & 7) ^ swz, swz = (row >> 1) & 7 =
+  // (4 (w & 1) + (i >> 4)) & 7 for every t
+  const int gslot = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
+  // K % 32 == 16: the last chunk's slots 4 .. 7 lie past the row; they re-read
+  // slot 0 of the chunk (their weight pieces are zero)
+  const int gslot_tail = (g.K % S16_KC) && gslot >= 4 ? 0 : gslot;
   const long lda = g.a_planes ? 32 : g.lda;
-  const float* a0 = g.A + am0 * lda + a_chunk * 4;
-  const float* a1 = g.A + am1 * lda + a_chunk * 4;
-  // weight pieces: wave w stages pieces p = w, w+4, w+8 of the 12 (4 n-tiles x
-  // 3) of a chunk; n-tiles past the matrix are clamped (never stored)
-  const int nt0 = n0 >> 5;
-  const unsigned int* wsrc[3];
+  const float* arow[4];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
+  for (int t = 0; t < 4; ++t) {
+    long am = m0 + 8 * (wave + 4 * t) + (lane >> 3);
+    am = am < g.M ? am : g.M - 1;
+    arow[t] = g.A + am * lda;
+  }
+  // weight pieces: wave w stages blocks p = w + 4 i (i < 6) of the 24 (8
+  // n-tiles x 3 pieces) of a chunk; n-tiles past the matrix are clamped
+  const int nt0 = n0 >> 4;
+  const unsigned int* wsrc[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
     const int p = wave + 4 * i;
     int nt = nt0 + p / 3;
-    nt = nt < nt32 ? nt : nt32 - 1;
+    nt = nt < nt16 ? nt : nt16 - 1;
     wsrc[i] = wp + ((long)nt * 3 + p % 3) * 256 + lane * 4;
   }
-  const long w_chunk = (long)nt32 * 3 * 256;   // uint32 per k chunk
+  const long w_chunk = (long)nt16 * 3 * 256;   // uint32 per k chunk
   auto stage = [&](int kc, int st) {
-    float* base = smem + st * NSP_STAGE;
-    const long aoff = g.a_planes ? (long)(kc >> 1) * g.a_plane_stride + (kc & 1) * 16
-                                 : (long)kc * N3_KC;
-    __builtin_amdgcn_global_load_lds((gptr_t)(a0 + aoff), (lptr_t)(base + wave * 256), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)(a1 + aoff), (lptr_t)(base + (wave + 4) * 256), 16, 0, 0);
-    float* wb = base + NN_TM * N3_KC;
+    float* base = smem + st * S16_STAGE;
+    const long aoff = g.a_planes ? (long)kc * g.a_plane_stride : (long)kc * S16_KC;
+    const int gs = (kc == nk - 1 ? gslot_tail : gslot) * 4;
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int t = 0; t < 4; ++t)
+      __builtin_amdgcn_global_load_lds((gptr_t)(arow[t] + aoff + gs),
+                                       (lptr_t)(base + (wave + 4 * t) * 256), 16, 0, 0);
+    float* wb = base + NN_TM * S16_KC;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
       __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + kc * w_chunk),
                                        (lptr_t)(wb + (wave + 4 * i) * 256), 16, 0, 0);
   };
 
-  f32x16 acc[2][2];  // [fn][fm]
+  f32x4 acc[2][8];  // [mt][nt]
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = frag_zero();
+    for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   stage(0, 0);
   int st = 0;
+#ifdef NSP_STAMPS
+  if (threadIdx.x == 0) { dbg[0] = __builtin_amdgcn_s_memtime(); dbg[1] = __builtin_amdgcn_s_memrealtime(); }
+#endif
   for (int kc = 0; kc < nk; ++kc) {
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     if (kc + 1 < nk) stage(kc + 1, st ^ 1);
-    const float* As = smem + st * NSP_STAGE;
-    const float* Ws = As + NN_TM * N3_KC;
-    Split3 xs[2], ws[2];
+    const float* As = smem + st * S16_STAGE;
+    const float* Ws = As + NN_TM * S16_KC;
+    Split3 xs[2];
 #pragma unroll
-    for (int fn = 0; fn < 2; ++fn) {
-      const u32x4* q = reinterpret_cast<const u32x4*>(Ws + ((wn * 2 + fn) * 3) * 256) + lane;
-#pragma unroll
-      for (int p = 0; p < 3; ++p) ws[fn].p[p] = __builtin_bit_cast(bf16x8, q[p * 64]);
-    }
-    auto load_x = [&](int fm) {
-      const int row = wm * 64 + fm * 32 + j;
+    for (int mt = 0; mt < 2; ++mt) {
+      const int row = wave * 32 + mt * 16 + r16;
       float v[8];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const f32x4 t = *reinterpret_cast<const f32x4*>(
-            As + row * N3_KC + (((2 * h + u) ^ ((row >> 2) & 3)) << 2));
+            As + row * S16_KC + (((2 * kq + u) ^ ((row >> 1) & 7)) << 2));
         v[4 * u] = t[0]; v[4 * u + 1] = t[1]; v[4 * u + 2] = t[2]; v[4 * u + 3] = t[3];
       }
-      xs[fm] = split3(v);
-    };
-    load_x(0);
-    mma_split<NPROD>(acc[0][0], ws[0], xs[0]);
-    mma_split<NPROD>(acc[1][0], ws[1], xs[0]);
-    load_x(1);
-    // the second fragment's split (44 VALU) goes into the gaps of the first
-    // fragment's 2 * NPROD MFMAs: 1 MFMA, then 4 VALU, repeated
-#pragma unroll
-    for (int i = 0; i < 2 * NPROD; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, (44 + 2 * NPROD - 1) / (2 * NPROD), 0);
+      xs[mt] = split3(v);
     }
-    mma_split<NPROD>(acc[0][1], ws[0], xs[1]);
-    mma_split<NPROD>(acc[1][1], ws[1], xs[1]);
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+      Split3 ws;
+      const u32x4* q = reinterpret_cast<const u32x4*>(Ws + (nt * 3) * 256) + lane;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) ws.p[p] = __builtin_bit_cast(bf16x8, q[p * 64]);
+      mma_split16<NPROD>(acc[0][nt], ws, xs[0]);
+      mma_split16<NPROD>(acc[1][nt], ws, xs[1]);
+    }
     st ^= 1;
   }
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  gemm_epilogue(g, acc, smem, m0, n0, wm, wn, wave, lane);
+#ifdef NSP_STAMPS
+  if (threadIdx.x == 0) { dbg[2] = __builtin_amdgcn_s_memtime(); dbg[3] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  gemm_epilogue_wide(g, acc, smem, m0, n0, wave, lane);
+#ifdef NSP_STAMPS
+  if (threadIdx.x == 0) { dbg[6] = __builtin_amdgcn_s_memtime(); dbg[7] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -1722,15 +1847,15 @@ static int gemm_nn_launch(const float* A, long lda, int a_planes, long a_plane_s
     hipLaunchKernelGGL(gemm_nn_kernel<2>, dim3((unsigned)nwg), dim3(256), 0,
                        (hipStream_t)stream, g);
   else if (wsplit) {
-    const int nt32 = (N + 31) / 32;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(split_w_kernel, dim3(nt32, K / N3_KC), dim3(64), 0, s, W, ldw, K, N,
-                       (unsigned int*)wsplit, nt32);
     dim3 gr((unsigned)nwg), bl(256);
     const unsigned int* wp = (const unsigned int*)wsplit;
-    if (nprod == 3) hipLaunchKernelGGL(gemm_nn_split_kernel<3>, gr, bl, 0, s, g, wp, nt32);
-    else if (nprod == 9) hipLaunchKernelGGL(gemm_nn_split_kernel<9>, gr, bl, 0, s, g, wp, nt32);
-    else hipLaunchKernelGGL(gemm_nn_split_kernel<6>, gr, bl, 0, s, g, wp, nt32);
+    const int nt16 = (N + 15) / 16;
+    hipLaunchKernelGGL(split_w_kernel, dim3(nt16, (K + S16_KC - 1) / S16_KC), dim3(64), 0, s,
+                       W, ldw, K, N, (unsigned int*)wsplit, nt16);
+    if (nprod == 3) hipLaunchKernelGGL(gemm_nn_split_kernel<3>, gr, bl, 0, s, g, wp, nt16);
+    else if (nprod == 9) hipLaunchKernelGGL(gemm_nn_split_kernel<9>, gr, bl, 0, s, g, wp, nt16);
+    else hipLaunchKernelGGL(gemm_nn_split_kernel<6>, gr, bl, 0, s, g, wp, nt16);
   } else
     hipLaunchKernelGGL(gemm_nn3_kernel, dim3((unsigned)nwg), dim3(256), 0,
                        (hipStream_t)stream, g);
@@ -1752,7 +1877,7 @@ int wn_gemm_nn(const float* A, long lda, int a_planes, long a_plane_stride,
 // bytes, 16-byte aligned) receives the weight pieces; nprod = 3, 6 or 9.
 long wn_gemm_split_w_bytes(int K, int N) {
   if (K <= 0 || N <= 0) return 0;
-  return (long)((K + 15) / 16) * ((N + 31) / 32) * 3 * 1024;
+  return (long)((K + 31) / 32) * ((N + 15) / 16) * 3 * 1024;
 }
 
 int wn_gemm_nn_split(const float* A, long lda, int a_planes, long a_plane_stride,

@@ -115,11 +115,12 @@ def test_gemm_tn_and_reduce(hip_lib, rows, Mw, Nw, splits):
 
 @pytest.mark.parametrize('nprod,tol', [(6, 1e-5), (9, 1e-5), (3, 2e-3)])
 @pytest.mark.parametrize('M,N,K', [(37, 16, 16), (5000, 256, 512), (129, 512, 96),
-                                   (256, 200, 64), (1031, 1600, 32)])
+                                   (256, 200, 64), (1031, 1600, 32), (300, 72, 48)])
 def test_gemm_nn_split(hip_lib, nprod, tol, M, N, K):
     """wn_gemm_nn_split (opt-in): fp32 products rebuilt from exact bf16 pieces.
     nprod 6 / 9 must be as close to float64 as an fp32 GEMM (1e-5 of the
-    result scale here), nprod 3 only ~2^-16; epilogues shared with wn_gemm_nn."""
+    result scale here), nprod 3 only ~2^-16; epilogues shared with wn_gemm_nn.  (K = 16, 48: the
+    kernel's 32-deep last chunk is half empty.)"""
     from wavenet import _lib
     lib = hip_lib
     rng = np.random.default_rng(M + N + K + nprod)

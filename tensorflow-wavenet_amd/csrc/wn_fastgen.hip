@@ -1556,8 +1556,9 @@ __global__ __launch_bounds__(FGP_THREADS) void fg_persist_kernel(FgPersist a) {
   if (role < nseg) {
     // ------------------------------------------------------------ chain segment
     const int seg = role;
-    const int l0 = (int)((long)seg * L / nseg), l1 = (int)((long)(seg + 1) * L / nseg);
-    const int nl = l1 - l0;
+    const int l0 = __builtin_amdgcn_readfirstlane((int)((long)seg * L / nseg));
+    const int l1 = (int)((long)(seg + 1) * L / nseg);
+    const int nl = __builtin_amdgcn_readfirstlane(l1 - l0);
     float* wres = lds;                                 // [nl][FGC_CW]
     float* pre_s = wres + (size_t)nl * FGC_CW;         // [nl][64] this step's past-tap pre-activations
     float* bd_s = pre_s + nl * 64;                     // [nl][32] dense biases
@@ -1567,9 +1568,17 @@ __global__ __launch_bounds__(FGP_THREADS) void fg_persist_kernel(FgPersist a) {
     int* flags = meta + 2 * FGP_SEGL;                  // [0] pre ready for step, [1] chain done with step
     int* rowoff = flags + 8;                           // [2][FGP_SEGL] float offset of the ring row of
                                                        // the step (parity): no modulo on the chain
-    for (int i = tid; i < nl * FGC_CW / 4; i += FGP_THREADS)
-      reinterpret_cast<f32x4*>(wres)[i] =
+    // resident weights in LANE order: chunk c of the chain lane's row at float4
+    // [c][lane] (filter | gate rows: c < 8; dense rows: [8 + cc][lane], lane =
+    // 32 (c >> 2) + n), so a layer's twelve reads are one lane address plus
+    // immediates and conflict-free (the ring-slot image is [matrix][n][chunk ^ (n & 7)])
+    for (int i = tid; i < nl * FGC_CW / 4; i += FGP_THREADS) {
+      const int ll = i / (FGC_CW / 4), q = i % (FGC_CW / 4);
+      const int m = q >> 8, n = (q >> 3) & 31, c = (q & 7) ^ (n & 7);
+      const int dst = m < 2 ? c * 64 + m * 32 + n : 512 + (c & 3) * 64 + (c >> 2) * 32 + n;
+      reinterpret_cast<f32x4*>(wres)[ll * (FGC_CW / 4) + dst] =
           reinterpret_cast<const f32x4*>(g.cw_img + (size_t)l0 * FGC_CW)[i];
+    }
     for (int i = tid; i < nl * 64; i += FGP_THREADS) pre_s[i] = g.pre[(size_t)l0 * 64 + i];
     for (int i = tid; i < nl * 32; i += FGP_THREADS)
       bd_s[i] = g.use_dense_bias
@@ -1614,41 +1623,40 @@ __global__ __launch_bounds__(FGP_THREADS) void fg_persist_kernel(FgPersist a) {
         // depend on the chain: layer ll + 1's are requested while layer ll
         // computes (round 5: twelve LDS reads per layer off the chain wave's
         // dependent path), two register sets used alternately.
-        struct LW { f32x4 qw[8], pw[4]; float a0, bdl; };
+        struct LW { f32x4 qw[8], pw[4]; float a0, bdl; int row; };
         auto lw_load = [&](LW& w, int ll) {
-          const float* wl = wres + (size_t)ll * FGC_CW;
-          const float* w1 = wl + gsel * 1024 + nn * 32;
-          const float* wd = wl + 2 * 1024 + nn * 32;
+          const f32x4* wl = reinterpret_cast<const f32x4*>(wres) + ll * (FGC_CW / 4) + lane;
 #pragma unroll
-          for (int c = 0; c < 8; ++c)
-            w.qw[c] = *reinterpret_cast<const f32x4*>(w1 + ((c ^ (nn & 7)) << 2));
+          for (int c = 0; c < 8; ++c) w.qw[c] = wl[c * 64];
 #pragma unroll
-          for (int cc = 0; cc < 4; ++cc)
-            w.pw[cc] = *reinterpret_cast<const f32x4*>(wd + (((gsel * 4 + cc) ^ (nn & 7)) << 2));
+          for (int cc = 0; cc < 4; ++cc) w.pw[cc] = wl[512 + cc * 64];
           w.a0 = pre_s[ll * 64 + lane];
           w.bdl = bd_s[ll * 32 + (lane & 31)];
+          w.row = rowoff[(i & 1) * FGP_SEGL + ll];
         };
         auto layer = [&](int ll, const LW& w, LW& wn) {
           float a0 = w.a0, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-          if (lane < 32) {
-            fgp_st(g.state + rowoff[(i & 1) * FGP_SEGL + ll] + lane, x);   // enqueue x_l[t]
-            inv[lane] = x;
-          }
+          // x to every lane through LDS FIRST: the queue store (its ring row was
+          // requested a layer ahead) is not on the dependent path
+          if (lane < 32) inv[lane] = x;
           __builtin_amdgcn_wave_barrier();
           f32x4 xv[8];
 #pragma unroll
           for (int c = 0; c < 8; ++c) xv[c] = *reinterpret_cast<const f32x4*>(inv + 4 * c);
-          // (the next layer's operands behind this layer's x reads: they land
-          // under its FMAs and gate)
           __builtin_amdgcn_sched_barrier(0);
-          if (ll + 1 < nl) lw_load(wn, ll + 1);
-          __builtin_amdgcn_sched_barrier(0);
+          if (lane < 32) fgp_st(g.state + w.row + lane, x);   // enqueue x_l[t]
 #pragma unroll
           for (int c = 0; c < 8; ++c) {
             const f32x4 q = w.qw[c];
             a0 = fmaf(xv[c][0], q[0], a0); a1 = fmaf(xv[c][1], q[1], a1);
             a2 = fmaf(xv[c][2], q[2], a2); a3 = fmaf(xv[c][3], q[3], a3);
           }
+          // (the next layer's operands behind this layer's FMAs -- in front of
+          // them the FMAs' counted waits would include these reads: the LDS
+          // counter has 4 bits -- they land under the gate and the dense part)
+          __builtin_amdgcn_sched_barrier(0);
+          lw_load(wn, ll + 1 < nl ? ll + 1 : ll);
+          __builtin_amdgcn_sched_barrier(0);
           const float av = (a0 + a1) + (a2 + a3);
           const float sg = wn_sigmoid(gsel ? av : 2.f * av);
           const float act = gsel ? sg : fmaf(2.f, sg, -1.f);
@@ -1656,8 +1664,8 @@ __global__ __launch_bounds__(FGP_THREADS) void fg_persist_kernel(FgPersist a) {
               __float_as_uint(act), __float_as_uint(act), false, false);
           const float z = __uint_as_float(pr[0]) * __uint_as_float(pr[1]);
           if (lane < 32) {
-            fgp_put(zll + (l0 + ll) * 32 + lane, z, step);
             zv[lane] = z;
+            fgp_put(zll + (l0 + ll) * 32 + lane, z, step);
           }
           if (l0 + ll + 1 < L) {
             __builtin_amdgcn_wave_barrier();

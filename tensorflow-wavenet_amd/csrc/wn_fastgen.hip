@@ -1435,99 +1435,172 @@ __device__ __forceinline__ void fgp_get2(float* dst, const fgp_ll_t* src, int k0
   if (h1) dst[k0 + 256] = __uint_as_float((unsigned)w1);
 }
 
-// The draw of fg_draw_wave by a 256-thread workgroup (the persistent
-// kernel's draw role): float64 softmax of Q logits in LDS `lgs`, temperature,
-// inverse-CDF draw with the same random number -- one exp / log / division per
-// thread instead of Q / 64 per lane, reductions and the prefix sum by wave
-// shuffles + four partials in LDS.  Returns the code the next step consumes.
-// red: 16 doubles + 4 ints of LDS.
-__device__ __forceinline__ int fg_draw_wg256(const FgStep& g, const float* lgs, double* red,
-                                             int tid, int steps_done) {
+// ---- wave-wide reductions by DPP (row shifts inside the four 16-lane rows,
+// then lane 15 / lane 31 broadcast to the following rows): an inclusive scan in
+// six VALU steps, the total in lane 63 -- no LDS round trip per step as with
+// ds_bpermute shuffles.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float old, float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(x), CTRL,
+                                                    ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double old, double x) {
+  const long long o = __double_as_longlong(old), v = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_update_dpp((int)o, (int)v, CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(v >> 32), CTRL, ROW_MASK, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double readlane_f64(double x, int l) {
+  const long long v = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_readlane((int)v, l), hi = __builtin_amdgcn_readlane((int)(v >> 32), l);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// max over the wave, the same value in every lane
+__device__ __forceinline__ float wave_max_f32(float x) {
+  x = fmaxf(x, dpp_f32<0x111, 0xf>(x, x));   // row_shr:1
+  x = fmaxf(x, dpp_f32<0x112, 0xf>(x, x));
+  x = fmaxf(x, dpp_f32<0x114, 0xf>(x, x));
+  x = fmaxf(x, dpp_f32<0x118, 0xf>(x, x));
+  x = fmaxf(x, dpp_f32<0x142, 0xa>(x, x));   // row_bcast:15 -> rows 1, 3
+  x = fmaxf(x, dpp_f32<0x143, 0xc>(x, x));   // row_bcast:31 -> rows 2, 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+__device__ __forceinline__ double wave_max_f64(double x) {
+  x = fmax(x, dpp_f64<0x111, 0xf>(x, x));
+  x = fmax(x, dpp_f64<0x112, 0xf>(x, x));
+  x = fmax(x, dpp_f64<0x114, 0xf>(x, x));
+  x = fmax(x, dpp_f64<0x118, 0xf>(x, x));
+  x = fmax(x, dpp_f64<0x142, 0xa>(x, x));
+  x = fmax(x, dpp_f64<0x143, 0xc>(x, x));
+  return readlane_f64(x, 63);
+}
+// inclusive prefix sum over the lanes (lane 63: the wave's sum)
+__device__ __forceinline__ double wave_scan_f64(double x) {
+  x += dpp_f64<0x111, 0xf>(0.0, x);
+  x += dpp_f64<0x112, 0xf>(0.0, x);
+  x += dpp_f64<0x114, 0xf>(0.0, x);
+  x += dpp_f64<0x118, 0xf>(0.0, x);
+  x += dpp_f64<0x142, 0xa>(0.0, x);
+  x += dpp_f64<0x143, 0xc>(0.0, x);
+  return x;
+}
+
+// What the draw reads from ctl[]: constant over a launch, read once.
+struct FgDrawCtl {
+  int base, n_given, proba_every;
+  float temperature;
+  uint64_t seed;
+};
+__device__ __forceinline__ FgDrawCtl fg_draw_ctl(const FgStep& g) {
+  FgDrawCtl c;
+  c.base = g.ctl[FGCTL_BASE];
+  c.n_given = g.ctl[FGCTL_NGIVEN];
+  c.proba_every = g.ctl[FGCTL_PEVERY] > 0 ? g.ctl[FGCTL_PEVERY] : 1;
+  c.temperature = __int_as_float(g.ctl[FGCTL_TEMP]);
+  c.seed = (uint64_t)(uint32_t)g.ctl[FGCTL_SEED] | ((uint64_t)(uint32_t)g.ctl[FGCTL_SEED + 1] << 32);
+  return c;
+}
+
+// The draw of fg_draw_wave by the persistent kernel's draw workgroup (its first
+// 256 threads compute, Q <= 512): float64 softmax of the Q logits in LDS `lgs`,
+// temperature, inverse-CDF draw with the same random number.  One exp / log /
+// division per thread instead of Q / 64 per lane.  Every wave keeps its values
+// in registers: sums and the prefix sum are DPP scans inside the wave plus one
+// partial per wave in LDS (two workgroup barriers per step; round 4: five, and
+// the reductions as ds_bpermute shuffles of doubles: 2.36 us per draw).  The
+// thread whose interval holds the random number publishes the code itself.
+// part: 16 doubles of LDS; nxt: 2 ints of LDS (the code drawn at step parity).
+template <int PER>   // values per computing thread: 1 (Q <= 256) or 2
+__device__ __forceinline__ void fg_draw_wg256(const FgStep& g, const FgDrawCtl& dc, const float* lgs,
+                                              double* part, int* nxt, fgp_ll_t* codell,
+                                              unsigned step, bool publish, int tid,
+                                              int steps_done) {
   const int Q = g.Q, lane = tid & 63, wave = tid >> 6;
-  int* ired = reinterpret_cast<int*>(red + 16);
-  const int local = steps_done - g.ctl[FGCTL_BASE];
-  const int n_given = g.ctl[FGCTL_NGIVEN];
-  const int proba_every = g.ctl[FGCTL_PEVERY] > 0 ? g.ctl[FGCTL_PEVERY] : 1;
-  const float temperature = __int_as_float(g.ctl[FGCTL_TEMP]);
-  const uint64_t seed = (uint64_t)(uint32_t)g.ctl[FGCTL_SEED] |
-                        ((uint64_t)(uint32_t)g.ctl[FGCTL_SEED + 1] << 32);
-  // contiguous segment of this thread (Q <= 512: at most two values)
-  const int per = (Q + 255) / 256;
+  const int local = steps_done - dc.base;
+  const int npl = (Q + 63) >> 6;                       // logits per lane in the max pass (<= 8)
+  constexpr int per = PER;
   const int q0 = min(Q, tid * per), q1 = min(Q, q0 + per);
-  double v[2] = {-1e300, -1e300};
-  for (int q = q0; q < q1; ++q) v[q - q0] = (double)lgs[q];
-  auto wg_max = [&](double x, int slot) {
-    for (int o = 32; o >= 1; o >>= 1) x = fmax(x, __shfl_xor(x, o));
-    if (lane == 0) red[slot * 4 + wave] = x;
-    __syncthreads();
-    return fmax(fmax(red[slot * 4], red[slot * 4 + 1]), fmax(red[slot * 4 + 2], red[slot * 4 + 3]));
-  };
-  auto wg_sum = [&](double x, int slot) {
-    for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o);
-    if (lane == 0) red[slot * 4 + wave] = x;
-    __syncthreads();
-    return (red[slot * 4] + red[slot * 4 + 1]) + (red[slot * 4 + 2] + red[slot * 4 + 3]);
-  };
-  const double m = wg_max(fmax(v[0], v[1]), 0);
-  double e[2] = {0.0, 0.0};
-  for (int q = q0; q < q1; ++q) e[q - q0] = exp(v[q - q0] - m);
-  const double se = wg_sum(e[0] + e[1], 1);
-  const bool want_p = g.proba_out && (local % proba_every == 0);
-  float* po = want_p ? g.proba_out + (long)(local / proba_every) * Q : nullptr;
-  double pq[2] = {0.0, 0.0};
-  for (int q = q0; q < q1; ++q) {
-    const float p32 = (float)(e[q - q0] / se);
-    if (po) po[q] = p32;
-    pq[q - q0] = (double)p32;
-  }
-  int next;
-  if (local + 1 >= n_given) {
-    if (temperature != 1.0f) {
-      const double tau = (double)temperature;
-      double lp[2] = {-1e300, -1e300};
-      for (int q = q0; q < q1; ++q)
-        lp[q - q0] = log(pq[q - q0] > 0.0 ? pq[q - q0] : 1e-300) / tau;
-      const double mx = wg_max(fmax(lp[0], lp[1]), 2);
-      for (int q = q0; q < q1; ++q) pq[q - q0] = exp(lp[q - q0] - mx);
-    }
-    const double seg = pq[0] + pq[1];
-    double incl = seg;
-    for (int o = 1; o < 64; o <<= 1) {
-      const double t = __shfl_up(incl, o);
-      if (lane >= o) incl += t;
-    }
-    if (lane == 63) red[12 + wave] = incl;
-    if (tid == 0) ired[0] = -1;
-    __syncthreads();
-    double offs = 0.0;
-    for (int w = 0; w < wave; ++w) offs += red[12 + w];
-    const double total = (red[12] + red[13]) + (red[14] + red[15]);
-    // (exclusive bound = the neighbouring thread's inclusive sum -- the same
-    // additions, so the threads' intervals tile [0, total) exactly; incl - seg
-    // could leave a gap of an ulp that a draw falls into)
-    const double up = __shfl_up(incl, 1);
-    const double excl = (lane == 0 ? 0.0 : up) + offs;
-    incl += offs;
-    const uint64_t r = splitmix64(seed ^ splitmix64((uint64_t)steps_done));
-    const double u = (double)(r >> 11) * (1.0 / 9007199254740992.0) * total;
-    if (q1 > q0 && u >= excl && u < incl) {
-      double c = excl;
-      int pick = q1 - 1;
-      for (int q = q0; q < q1; ++q) {
-        c += pq[q - q0];
-        if (u < c) { pick = q; break; }
-      }
-      atomicMax(ired, pick);
-    }
-    __syncthreads();
-    next = ired[0];
-    if (next < 0) next = Q - 1;
-    if (tid == 0) g.samples[local + 1] = next;
+  // (the step's random number does not wait for the logits)
+  const uint64_t r = splitmix64(dc.seed ^ splitmix64((uint64_t)steps_done));
+  // the maximum: every wave for itself over all Q logits
+  float mf = -3.0e38f;
+  if (Q == 256) {                                      // (the reference's 8-bit mu-law: one read)
+    const f32x4 l4 = *reinterpret_cast<const f32x4*>(lgs + lane * 4);
+    mf = fmaxf(fmaxf(l4[0], l4[1]), fmaxf(l4[2], l4[3]));
   } else {
-    next = g.samples[local + 1];           // still inside the given samples
+    for (int j = 0; j < npl; ++j) {
+      const int q = lane * npl + j;
+      if (q < Q) mf = fmaxf(mf, lgs[q]);
+    }
   }
-  __syncthreads();                          // (red / ired are reused by the next step)
-  return next;
+  const double m = (double)wave_max_f32(mf);
+  double e[2] = {0.0, 0.0};
+#pragma unroll
+  for (int j = 0; j < PER; ++j)
+    if (q0 + j < q1) e[j] = exp((double)lgs[q0 + j] - m);
+  // waves 0 .. 3 hold values (256 threads x per); a fifth wave adds zeros
+  const double es = wave_scan_f64(PER == 2 ? e[0] + e[1] : e[0]);
+  if (lane == 63 && wave < 4) part[wave] = es;
+  __syncthreads();
+  const double se = ((part[0] + part[1]) + part[2]) + part[3];
+  const bool want_p = g.proba_out && (local % dc.proba_every == 0);
+  float* po = want_p ? g.proba_out + (long)(local / dc.proba_every) * Q : nullptr;
+  double pq[2] = {0.0, 0.0};
+#pragma unroll
+  for (int j = 0; j < PER; ++j)
+    if (q0 + j < q1) {
+      const float p32 = (float)(e[j] / se);
+      if (po) po[q0 + j] = p32;
+      pq[j] = (double)p32;
+    }
+  if (local + 1 < dc.n_given) {                        // still inside the given samples
+    if (tid == 0) {
+      const int next = g.samples[local + 1];
+      nxt[step & 1] = next;
+      if (publish) fgp_put(codell, __int_as_float(next), step);
+    }
+    return;
+  }
+  if (dc.temperature != 1.0f) {
+    const double tau = (double)dc.temperature;
+    double lp[2] = {-1e300, -1e300};
+#pragma unroll
+    for (int j = 0; j < PER; ++j)
+      if (q0 + j < q1) lp[j] = log(pq[j] > 0.0 ? pq[j] : 1e-300) / tau;
+    const double wm = wave_max_f64(PER == 2 ? fmax(lp[0], lp[1]) : lp[0]);
+    if (lane == 0 && wave < 4) part[4 + wave] = wm;
+    __syncthreads();
+    const double mx = fmax(fmax(part[4], part[5]), fmax(part[6], part[7]));
+#pragma unroll
+    for (int j = 0; j < PER; ++j)
+      if (q0 + j < q1) pq[j] = exp(lp[j] - mx);
+  }
+  // prefix sums: inside the wave by DPP, the waves' totals through LDS.  A
+  // thread's exclusive bound is its neighbour's inclusive sum and a wave's
+  // offset is the previous wave's offset plus that wave's total -- the same
+  // additions on both sides of every boundary, so the threads' intervals tile
+  // [0, total) exactly.
+  double incl = wave_scan_f64(PER == 2 ? pq[0] + pq[1] : pq[0]);
+  double excl = dpp_f64<0x138, 0xf>(0.0, incl);        // wave_shr:1, lane 0: 0
+  if (lane == 63 && wave < 4) part[8 + wave] = incl;
+  __syncthreads();
+  double offs = 0.0;
+  for (int w = 0; w < wave && w < 4; ++w) offs += part[8 + w];
+  const double total = ((part[8] + part[9]) + part[10]) + part[11];
+  incl += offs;
+  excl += offs;
+  const double u = (double)(r >> 11) * (1.0 / 9007199254740992.0) * total;
+  int next = -1;
+  if (q1 > q0 && u >= excl && u < incl)
+    next = (PER == 2 && q1 - q0 == 2 && u >= excl + pq[0]) ? q0 + 1 : q0;
+  // (u == total after rounding: the last code, as fg_draw_wave)
+  if (q1 == Q && q1 > q0 && u >= incl) next = Q - 1;
+  if (next >= 0) {
+    g.samples[local + 1] = next;
+    nxt[step & 1] = next;
+    if (publish) fgp_put(codell, __int_as_float(next), step);
+  }
 }
 
 __global__ __launch_bounds__(FGP_THREADS) void fg_persist_kernel(FgPersist a) {
@@ -1824,20 +1897,25 @@ __global__ __launch_bounds__(FGP_THREADS) void fg_persist_kernel(FgPersist a) {
   // ---------------------------------------------------------------------- draw
   // (256 threads: one logit per thread for Q <= 256)
   float* lgs = lds;                                             // [Q] the step's logits
-  double* dred = reinterpret_cast<double*>(lds + ((Q + 3) & ~3));   // 16 doubles + 4 ints
-  int cur_code = g.samples[0];     // the code step i consumed (kept in a register: this CU's
-                                   // L1 may hold an older copy of the samples line)
+  double* dpart = reinterpret_cast<double*>(lds + ((Q + 3) & ~3));  // 16 doubles: per-wave partials
+  int* nxt = reinterpret_cast<int*>(dpart + 16);                 // [2] the code drawn at step parity
+  const FgDrawCtl dc = fg_draw_ctl(g);
   for (int i = 0; i < n_steps; ++i) {
     const unsigned step = (unsigned)(i + 1);
     fgp_get2(lgs, lgll, tid, Q, step, sync, dead);
     PSTAMP(i * 16 + 14);
     __syncthreads();
-    const int next = fg_draw_wg256(g, lgs, dred, tid, base + i);
-    // the code of step i + 1 for segment 0
-    if (tid == 0 && i + 1 < n_steps) fgp_put(codell, __int_as_float(next), step);
+    // (dpart[] is rewritten a step later only after this barrier, which every
+    // wave reaches after its last read of the step before)
+    // the drawing thread publishes the code of step i + 1 for segment 0
+    if (Q <= 256) fg_draw_wg256<1>(g, dc, lgs, dpart, nxt, codell, step, i + 1 < n_steps, tid, base + i);
+    else fg_draw_wg256<2>(g, dc, lgs, dpart, nxt, codell, step, i + 1 < n_steps, tid, base + i);
     PSTAMP(i * 16 + 15);
-    if (i + 1 < n_steps) cur_code = next;
   }
+  __syncthreads();
+  // the code the last step consumed (this CU's L1 may hold an older copy of the
+  // samples line: the draws were kept in LDS)
+  const int cur_code = n_steps >= 2 ? nxt[(n_steps - 1) & 1] : g.samples[0];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   // cursors as wn_fastgen_finish leaves them: {steps done, the last code consumed, nothing pending}
   if (tid == 0) {

@@ -693,6 +693,27 @@ def test_random_configurations_vs_oracle(hip_lib):
     assert '0 of 24 cases failed' in r.stdout
 
 
+@pytest.mark.parametrize('Q', [64, 320, 512])
+def test_persistent_draw_other_quantization_channels(hip_lib, Q):
+    """The persistent launch's draw workgroup away from the reference's Q = 256
+    (fewer values than computing threads; two values per thread, 5 and 8 logits
+    per lane in the max pass): the samples of the step kernels, with and without
+    a temperature, and their probabilities."""
+    cfg = cfg_with(MID, batch_size=1, quantization_channels=Q)
+    net, var = build_pair(cfg)
+    for temp in (1.0, 0.8):
+        outs = []
+        for persist in (0, 1):
+            net.fastgen_persistent = persist
+            o, p = net.generate(150, seed_samples=[Q // 2, 3], seed=9, temperature=temp,
+                                return_proba_every=2)
+            outs.append((o.cpu().numpy(), p.cpu().numpy()))
+        assert np.array_equal(outs[0][0], outs[1][0]), temp
+        assert np.abs(outs[0][1] - outs[1][1]).max() < 1e-6
+        assert outs[1][0].min() >= 0 and outs[1][0].max() < Q
+        assert len(np.unique(outs[1][0][2:])) > 8          # not stuck on one code
+
+
 def test_persistent_generator_short_runs_and_state_continuity(hip_lib):
     """wn_fastgen_persist at the edges: runs of 1, 2, 3 and 17 steps (the helper
     waves' look-ahead loop is empty at 1), with global conditioning, a

@@ -558,12 +558,11 @@ def main():
     lib_ = net  # (kernel names follow wn_stack_tile_rows / the variant word)
     tws = [w for w in net._ws.values() if w.training]
     rows_f = tws[0].stack_rows if tws else 32
-    rows_b = tws[0].stack_rows_b if tws else 32
-    pipe = bool(tws and (tws[0].stack_variant & 0x2000))
+    rows_b = rows_f
     kern = {'wn_stack_fwd': 'void stack_fwd_kernel<2, 16>' if rows_f == 32
             else 'void stack_fwd16_kernel<2, 8>',
-            'wn_stack_bwd': 'stack_bwdp_kernel' if pipe else
-            ('void stack_bwd_kernel<8>' if rows_b == 32 else 'void stack_bwd16_kernel<8>')}
+            'wn_stack_bwd': 'void stack_bwd_kernel<8>' if rows_b == 32
+            else 'void stack_bwd16_kernel<8>'}
     tile_layers = B * ((T + 31) // 32) * len(params['dilations'])
     mfma_cyc = {'wn_stack_fwd': 80 * 64, 'wn_stack_bwd': 160 * 64}    # per 32-row tile and layer
     for ev_name in ('wn_stack_fwd', 'wn_stack_bwd'):

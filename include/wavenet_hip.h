@@ -276,14 +276,8 @@ int wn_layer_bwd2(const float* x, const float* z, const float* sg,
  * L <= 256. */
 /* rows: 0 (auto), 16 or 32 rows per tile; waves: 0 (auto) or waves per
  * workgroup (16-row launches: 4 / 8; 32-row backward: 1 / 2 / 4 / 8; the 32-row
- * forward ignores it); flags: WN_STACK_PIPE */
-#define WN_STACK_VARIANT(rows, waves, flags) \
-  (((rows) & 0x3f) | (((waves) & 0xf) << 8) | (flags))
-/* backward: the pipelined launch (stack_bwdp_kernel: 11 row waves taking
- * (layer, tile) tickets + 5 matrix waves that own the weight-gradient
- * matrices, 16-row tiles whatever the forward's height).  Opt-in: measured 9 %
- * slower than the default launch at B = 8, T = 16000. */
-#define WN_STACK_PIPE 0x2000
+ * forward ignores it) */
+#define WN_STACK_VARIANT(rows, waves) (((rows) & 0x3f) | (((waves) & 0xf) << 8))
 long wn_stack_flag_count(int B, int T, int L);
 int wn_stack_tile_rows(int B, int T, int variant);
 int wn_stack_wimg_floats(void);
@@ -295,9 +289,6 @@ int wn_stack_fwd(float* X, float* Z, float* SG, const float* wimg,
                  unsigned* ctl, float* poison, int L, int B, int T, int save_sg,
                  int variant, void* stream);
 int wn_stack_bwd_slabs(int B, int T, int variant);
-/* rows of a tile in wn_stack_bwd (tilesum layout): wn_stack_tile_rows, or 16
- * for the pipelined launch */
-int wn_stack_bwd_tile_rows(int B, int T, int variant);
 int wn_stack_bwd(const float* X, const float* Z, const float* SG,
                  const float* dZ, float* DX, long dx_layer_stride, float* Q,
                  const float* wimg, float* slabs,

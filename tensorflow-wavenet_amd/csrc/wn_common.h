@@ -33,7 +33,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define WN_ERR_LAUNCH (-4)
 #define WN_ERR_NULL (-5)
 // (variant word of the stack launches: see include/wavenet_hip.h)
-#define WN_STACK_PIPE 0x2000
 
 #define WN_CH 32  // padded residual/dilation channel count of every plane
 

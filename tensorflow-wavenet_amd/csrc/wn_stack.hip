@@ -1902,525 +1902,6 @@ __global__ __launch_bounds__(WAVES * 64) void stack_bwd16_kernel(StackBwd a) {
   }
 }
 
-// ---------------------------------------------------------------------------
-// The backward stack as a producer / consumer PIPELINE inside a workgroup
-// (round 5; big batches: B = 8, T = 16000 is 31 16-row tiles per CU and layer).
-// stack_bwd_kernel keeps two 178-register waves per SIMD, each walking whole
-// tiles (dx path, then 80 weight-gradient MFMAs into 80 private accumulator
-// registers) and meeting the others once a layer in the ordered accumulation:
-// its stamps show the SIMDs issuing 79 % of the time with 0.55 of the matrix
-// pipe busy -- one wave's dependent chain with a single partner to cover it,
-// plus 6.7 us of a 31 us layer in the chain.  Here a workgroup is 16 waves of
-// at most 128 registers, four per SIMD:
-//   * 11 ROW waves take (layer, tile) TICKETS from one LDS counter -- layers
-//     top-down, the group's 16-row tiles inside a layer -- and run the dx path
-//     of that tile only (stack_bwd16_kernel's, without its weight gradients: 80 16x16x4
-//     MFMAs, operands registers <-> memory), leaving dx_{l+1}[t] | da_f | da_g
-//     in one of 12 LDS hand-over buffers (6 KiB each).  Which wave computes
-//     which tile depends on timing; what is computed per tile does not.
-//   * 5 MATRIX waves (wave ids 0..4) consume the tickets IN ORDER.  Wave m
-//     owns ONE weight-gradient matrix for the whole group -- dWf[0], dWf[1],
-//     dWg[0], dWg[1], dWd: 8 MFMAs (32x32x2 over the tile's 16 rows) per
-//     ticket, the left operand x[t] / x[t-d] / z[t] straight from memory with
-//     the channel on the lane, requested four tickets ahead (the ticket
-//     sequence is known in advance).  No accumulation across waves, no chain,
-//     no slab in LDS; a tile's sums are added in ticket order: bitwise
-//     reproducible whichever row wave produced the tile.
-//   * nobody waits at a barrier; the matrix waves run at raised priority (5 x
-//     8 of a ticket's 120 MFMA-equivalents), and the row waves balance
-//     themselves over the SIMDs through the ticket counter (the SIMD that
-//     hosts two matrix waves simply takes fewer tickets).
-// Hand-over between tiles / workgroups (flags, sc1 rows, epochs, tickets of
-// groups, bounded waits, weight ring) as stack_bwd16_kernel; a tile's own dx
-// rows of the layer above may have been written by ANOTHER wave of the
-// workgroup, so its own flag is waited for too (device-scope loads).
-// a.tpw = tiles per group.
-// ---------------------------------------------------------------------------
-#define BP_MATW 5
-#define BP_ROWW 11
-#define BP_NB 16
-#define BP_PF 4
-#define BP_BUF 1536            // floats of a hand-over buffer: dx_{l+1} | da_f | da_g, [16][32] each
-#define BP_GMAX 64             // tiles of a group (LDS: per-tile column sums of a layer)
-
-__global__ __launch_bounds__((BP_MATW + BP_ROWW) * 64) void stack_bwdp_kernel(StackBwd a) {
-  constexpr int NW = BP_MATW + BP_ROWW;
-  __shared__ __attribute__((aligned(1024))) float wl[2 * SB_WIMG];
-  __shared__ __attribute__((aligned(1024))) float bufs[BP_NB * BP_BUF];
-  __shared__ int s_group, s_ticket;
-  __shared__ int s_done[STACK_MAXL], s_ready[STACK_MAXL], s_dil[STACK_MAXL];
-  // s_full[b]: ticket + 1 the buffer holds; s_cons[b][m]: tenants of buffer b
-  // matrix wave m is through with (a plain store per wave: no atomic)
-  __shared__ int s_full[BP_NB], s_cons[BP_NB][8];
-  __shared__ float s_ts[BP_GMAX * 64];     // per-tile column sums of da_f | da_g (conditioning)
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j = lane & 31, h = lane >> 5;        // 32 x 32 products: channel, row parity
-  const int jr = lane & 15, g = lane >> 4;       // 16 x 16 products: row, piece
-  const int sw = jr & 7;
-  const int T = a.T, L = a.L, G = a.tpw;
-  const int tiles_per_clip = (T + 15) >> 4;
-  const int ntiles = tiles_per_clip * a.B;
-  const int ngroups = (ntiles + G - 1) / G;
-  const unsigned epoch =
-      __hip_atomic_load(a.ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  bool dead = false;
-  S16CAL(0);
-
-  auto issue_wimg = [&](int l, int p0, int step) {
-    const float* src = a.wimg + (size_t)l * STACK_WBUF;
-    float* dst = wl + (l & 1) * SB_WIMG;
-    for (int p = p0; p < SB_WIMG / 256; p += step)
-      __builtin_amdgcn_global_load_lds((wn_gptr_t)(src + p * 256 + lane * 4),
-                                       (wn_lptr_t)(dst + p * 256), 16, 0, 0);
-  };
-
-  for (;;) {
-    if (tid == 0) s_group = (int)atomicAdd(a.ctl, 1u);
-    __syncthreads();
-    const int gticket = __builtin_amdgcn_readfirstlane(s_group);
-    __syncthreads();
-    if (gticket >= ngroups) break;
-    const int gi = ngroups - 1 - gticket;
-    const int gbase = gi * G;
-    const int ng = min(G, ntiles - gbase);       // tiles of this group (>= 1)
-    // tickets of a layer: the group's tiles padded to a multiple of four with
-    // PHANTOM tickets (a row wave fills the buffer with zeros; the matrix waves,
-    // whose A-operand slots rotate modulo four, see a uniform sequence)
-    const int ngp = (ng + 3) & ~3;
-    const int nticket = L * ngp;
-    for (int i = tid; i < L; i += NW * 64) {
-      s_done[i] = 0;
-      s_ready[i] = i >= L - 2;
-      s_dil[i] = a.dil[i];
-    }
-    if (tid < BP_NB) s_full[tid] = 0;
-    if (tid < BP_NB * 8) (&s_cons[0][0])[tid] = 0;
-    if (tid == 0) s_ticket = 0;
-    issue_wimg(L - 1, wave, NW);
-    if (L > 1) issue_wimg(L - 2, wave, NW);
-    // (the BUILTIN wait, not inline asm: the compiler's own wait-count pass
-    // has to know that no LDS-DMA is outstanding when the matrix waves start --
-    // else it makes every LDS read of their ticket loop wait for all but the
-    // loads issued since the loop's top: vmcnt(1) in front of the first read,
-    // and the A-operand prefetch is gone.  vmcnt(0), expcnt / lgkmcnt open.)
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
-
-    if (wave >= BP_MATW) {
-      // ================================================= a row wave: the dx path
-      const wn_rsrc_t dx0 = plane_rsrc(a.DX), q0 = plane_rsrc(a.Q);
-      // A ticket, decoded (all wave-uniform)
-      struct Tk { int k, l, ti, tile, b, tt, tt0, hi, voff, dn, bi; bool hx, real; };
-      auto take = [&]() {
-        Tk t;
-        int k = 0;
-        if (lane == 0)
-          k = __hip_atomic_fetch_add(&s_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        t.k = __builtin_amdgcn_readfirstlane(k);
-        const int li = t.k / ngp;
-        t.l = L - 1 - li;
-        t.ti = t.k - li * ngp;
-        t.bi = t.k % BP_NB;
-        t.real = t.k < nticket && t.ti < ng;
-        t.tile = gbase + (ng - 1 - t.ti);
-        t.b = t.tile / tiles_per_clip;
-        t.tt = t.tile - t.b * tiles_per_clip;
-        t.tt0 = t.tt * 16;
-        t.hi = min(16, T - t.tt0);
-        t.voff = (t.b * T + t.tt0) * (WN_CH * 4) + (jr * WN_CH + 4 * g) * 4;   // bytes (< 2^31: host check)
-        t.hx = t.l + 1 < L;
-        t.dn = t.real && t.hx ? __builtin_amdgcn_readfirstlane(s_dil[t.l + 1]) : 0;
-        return t;
-      };
-      // lanes 0 / 1 / 2: index of the flags of layer l + 1 a ticket waits for --
-      // the (at most two) tiles its rows t + dn come from, and its OWN tile
-      // (whichever wave of this workgroup held that ticket stored its dx rows)
-      auto flag_idx = [&](const Tk& t) -> int {
-        int idx = lane == 2 ? t.tile : -1;
-        const int hi_q = min(t.hi, T - t.dn - t.tt0);
-        if (hi_q > 0) {
-          const int first = (t.tt0 + t.dn) >> 4, last = (t.tt0 + t.dn + hi_q - 1) >> 4;
-          if (lane == 0 && first != t.tt) idx = t.b * tiles_per_clip + first;
-          if (lane == 1 && last != first && last != t.tt) idx = t.b * tiles_per_clip + last;
-        }
-        return idx;
-      };
-      // The first loads of a ticket -- dZ, sigmoid, z rows and its flag words: 7
-      // memory instructions -- are requested while the PREVIOUS ticket's stores
-      // drain (the wait behind them counts: vmcnt(7)); the flags are looked at
-      // when the ticket starts.
-      F16 dz, ss, zz;
-      unsigned fval = epoch;
-      auto first_loads = [&](const Tk& t) {
-        const bool mine = jr < t.hi;
-        dz = f16_ld<SB_STREAM>(plane_rsrc(a.dZ + (size_t)t.l * a.plane), t.voff, mine);
-        ss = f16_ld<SB_STREAM>(plane_rsrc(a.SG + (size_t)t.l * a.plane), t.voff, mine);
-        zz = f16_ld<SB_STREAM>(plane_rsrc(a.Z + (size_t)t.l * a.plane), t.voff, mine);
-        // (one load instruction whatever the lanes' indices: a lane without a
-        // flag asks for an offset past the resource)
-        const int idx = t.hx ? flag_idx(t) : -1;
-        const wn_rsrc_t fr = plane_rsrc(reinterpret_cast<const float*>(
-            a.flags + (size_t)(t.hx ? t.l + 1 : t.l) * ntiles));
-        fval = __builtin_amdgcn_raw_buffer_load_b32(fr, idx >= 0 ? idx * 4 : WN_BUF_OOB, 0, 16);
-      };
-      // this ticket no longer reads layer l's weights; the one that completes
-      // the layer refills their ring half with layer l - 2 (true: a DMA is in
-      // flight, publish s_ready[l - 2] once it has landed)
-      auto ring_done = [&](int l) {
-        int old = 0;
-        if (lane == 0)
-          old = __hip_atomic_fetch_add(s_done + l, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        old = __builtin_amdgcn_readfirstlane(old);
-        if (old == ngp - 1 && l >= 2) {
-          issue_wimg(l - 2, 0, 1);
-          return true;
-        }
-        return false;
-      };
-      // the matrix waves are through the buffer's previous tenants (lanes 0 .. 4
-      // look at one wave's word each)
-      auto buffer_free = [&](const Tk& t) {
-        const int need = t.k / BP_NB;
-        unsigned spins = 0;
-        for (;;) {
-          const bool behind = lane < BP_MATW &&
-              __hip_atomic_load(&s_cons[t.bi][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need;
-          if (dead || __builtin_amdgcn_ballot_w64(behind) == 0) break;
-          __builtin_amdgcn_s_sleep(1);
-          if (++spins > (1u << 24)) {
-            dead = true;
-            if (lane == 0) {
-              __hip_atomic_store(a.ctl + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if (a.poison) *a.poison = __builtin_nanf("");
-            }
-          }
-        }
-        asm volatile("" ::: "memory");
-      };
-      Tk t = take();
-      if (t.real) first_loads(t);
-      while (t.k < nticket) {
-        const int l = t.l;
-        float* t_di = bufs + t.bi * BP_BUF;
-        if (!t.real) {
-          // a phantom ticket: zeros for the matrix waves, nothing else
-          buffer_free(t);
-          const F16 zf = f16_zero();
-          f16_to_lds(t_di + jr * 32, g, sw, zf);
-          f16_to_lds(t_di + 512 + jr * 32, g, sw, zf);
-          f16_to_lds(t_di + 1024 + jr * 32, g, sw, zf);
-          WN_WAIT_LGKM0();
-          if (lane == 0)
-            __hip_atomic_store(&s_full[t.bi], t.k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          if (ring_done(l)) {
-            WN_WAIT_VM0();
-            if (lane == 0)
-              __hip_atomic_store(s_ready + l - 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          }
-          t = take();
-          if (t.real) first_loads(t);
-          continue;
-        }
-        const bool mine = jr < t.hi;
-        const int voff = t.voff;
-        const bool hx = t.hx;
-        S16STAMP(l, 0);
-        wait_lds_ge(s_ready + l, 1, dead, a.ctl, a.poison, lane);
-        S16STAMP(l, 1);
-        int woff = jr * 32 + ((g ^ ((jr >> 1) & 7)) << 2) + (l & 1) * SB_WIMG;
-        asm volatile("" : "+v"(woff));
-        const float* const wm = wl;
-        F16 di = f16_zero();
-        if (hx) {
-          // dx_{l+1}[t] = own rows + q_{l+1}[t + dn] of the tiles dn rows later,
-          // once their flags (requested with the first loads) are set
-          const int idx = flag_idx(t);
-          if (__builtin_amdgcn_ballot_w64(idx >= 0 && fval != epoch) != 0)
-            wait_flags(a.flags + (size_t)(l + 1) * ntiles, idx, epoch, a.ctl, a.poison, dead, lane);
-          // (device-scope loads: the own rows may be another wave's store)
-          di = f16_ld<16>(plane_rsrc(a.DX + (size_t)(l + 1) * a.dx_stride), voff, mine);
-          const int hi_q = min(t.hi, T - t.dn - t.tt0);
-          const F16 qv = f16_ld<16>(plane_rsrc(a.Q + (size_t)(l + 1) * a.plane),
-                                    voff + t.dn * (WN_CH * 4), jr < hi_q);
-          S16STAMP(l, 2);
-          WN_WAIT_VM0();
-          di.v[0] += qv.v[0];
-          di.v[1] += qv.v[1];
-        } else {
-          S16STAMP(l, 2);
-          WN_WAIT_VM0();
-        }
-        S16STAMP(l, 3);
-        buffer_free(t);
-        f16_to_lds(t_di + jr * 32, g, sw, di);
-        if (hx) mma16s(dz, di, wm + 4 * 1024, woff);            // + dx_{l+1}[t] Wd^T
-        F16 df, dg;
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            // (gate_grad of wn_common.h on this layout)
-            const float sgm = ss.v[mb][e], zv = zz.v[mb][e];
-            const float th = zv * __builtin_amdgcn_rcpf(sgm + 1e-30f);
-            df.v[mb][e] = dz.v[mb][e] * __builtin_fmaf(-zv, th, sgm);
-            dg.v[mb][e] = dz.v[mb][e] * __builtin_fmaf(-zv, sgm, zv);
-          }
-        f16_to_lds(t_di + 512 + jr * 32, g, sw, df);
-        f16_to_lds(t_di + 1024 + jr * 32, g, sw, dg);
-        WN_WAIT_LGKM0();
-        if (lane == 0)
-          __hip_atomic_store(&s_full[t.bi], t.k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        S16STAMP(l, 4);
-        // own_l[t] = dx_{l+1}[t] + da[t] W[1]^T,  q_l[t] = da[t] W[0]^T
-        F16 dx = di, qf = f16_zero();
-        mma16s2(dx, qf, df, wm + 1 * 1024, wm + 0 * 1024, woff);   // da_f: Wf[1], Wf[0]
-        mma16s2(dx, qf, dg, wm + 3 * 1024, wm + 2 * 1024, woff);   // da_g: Wg[1], Wg[0]
-        S16STAMP(l, 5);
-        if (dead) { qf.v[0][0] = __builtin_nanf(""); dx.v[0][0] = __builtin_nanf(""); }
-        f16_st<16>(plane_rsrc(a.Q + (size_t)l * a.plane), voff, mine, qf);
-        f16_st<SB_OWN_ST>(plane_rsrc(a.DX + (size_t)l * a.dx_stride), voff, mine, dx);
-        const bool refill = ring_done(l);
-        // the next ticket: its first loads go out behind this one's stores
-        const Tk n = take();
-        if (n.real && !refill) {
-          first_loads(n);
-          asm volatile("s_waitcnt vmcnt(7)" ::: "memory");   // q and own rows stored
-        } else {
-          WN_WAIT_VM0();                             // ... (and the refill landed)
-          if (n.real) first_loads(n);
-        }
-        if (lane == 0)
-          __hip_atomic_store(a.flags + (size_t)l * ntiles + t.tile, epoch, __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
-        if (refill && lane == 0)
-          __hip_atomic_store(s_ready + l - 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        S16STAMP(l, 6);
-        t = n;
-      }
-      // dx_0[t] = own_0[t] + q_0[t + d_0], completed in place (a tile's own
-      // layer-0 rows: whichever wave held that ticket, its flag first)
-      const int d0 = __builtin_amdgcn_readfirstlane(s_dil[0]);
-      for (int n = wave - BP_MATW; n < ng; n += BP_ROWW) {
-        const int tile = gbase + n;
-        const int b = tile / tiles_per_clip;
-        const int tt = tile - b * tiles_per_clip;
-        const int tt0 = tt * 16;
-        const int hi = min(16, T - tt0);
-        const bool mine = jr < hi;
-        const int voff = (b * T + tt0) * (WN_CH * 4) + (jr * WN_CH + 4 * g) * 4;
-        const int hi_q = min(hi, T - d0 - tt0);
-        int idx = lane == 2 ? tile : -1;
-        if (hi_q > 0) {
-          const int first = (tt0 + d0) >> 4, last = (tt0 + d0 + hi_q - 1) >> 4;
-          if (lane == 0 && first != tt) idx = b * tiles_per_clip + first;
-          if (lane == 1 && last != first && last != tt) idx = b * tiles_per_clip + last;
-        }
-        wait_flags(a.flags, idx, epoch, a.ctl, a.poison, dead, lane);
-        F16 ro = f16_ld<16>(dx0, voff, mine);
-        if (hi_q > 0) {
-          const F16 rq = f16_ld<16>(q0, voff + d0 * (WN_CH * 4), jr < hi_q);
-          WN_WAIT_VM0();
-          ro.v[0] += rq.v[0];
-          ro.v[1] += rq.v[1];
-        }
-        WN_WAIT_VM0();
-        if (dead) ro.v[0][0] = __builtin_nanf("");
-        f16_st<0>(dx0, voff, mine, ro);
-      }
-    } else {
-      // ===== a matrix wave: one weight-gradient matrix for the whole group
-      const int mw = wave;            // 0: Wf[0]  1: Wf[1]  2: Wg[0]  3: Wg[1]  4: Wd
-      const bool zplane = mw == 4;    // left operand z[t]
-      const bool past = !zplane && !(mw & 1);    // left operand x[t - d] (else x[t])
-      // right operand: dx_{l+1} (Wd) / da_f / da_g tile of the buffer
-      const int bsel = zplane ? 0 : 512 + (mw >> 1) * 512;
-      const bool sums = zplane || (mw & 1);      // this wave's column sums are a bias gradient
-      // (the consumers of every ticket: when they have operands they go first)
-      __builtin_amdgcn_s_setprio(2);
-      // element [row 2 s + h][channel j] of a buffer's tile n (0: dx_{l+1},
-      // 1: da_f, 2: da_g):  te.p[s & 3][buffer * BP_BUF + n * 512 + 64 * s]
-      const TileElemPtr te = tile_elem_ptrs(bufs, j, h);
-      const int lane4 = lane * 4;
-      // The ticket sequence is known in advance.  A wave keeps the A operands
-      // of four tickets in registers, slot = ticket & 3 (a layer is a multiple
-      // of four tickets: phantom tickets are requested as out-of-range
-      // offsets), and a cursor walks the sequence without divisions: layers
-      // top-down, the group's tiles from the last one down.
-      struct Cur { int li, ti, b, tt; };
-      const int top = gbase + ng - 1;
-      const int b_top = top / tiles_per_clip, tt_top = top - b_top * tiles_per_clip;
-      auto cur_next = [&](Cur& c) {
-        if (++c.ti == ngp) { c.ti = 0; ++c.li; c.b = b_top; c.tt = tt_top; }
-        else if (--c.tt < 0) { c.tt = tiles_per_clip - 1; --c.b; }
-      };
-      // A operands: element [row 2 s + h][channel j] of the cursor's tile
-      // straight from memory (a step's two rows are 256 contiguous bytes),
-      // requested four tickets ahead of their use; a row outside the tile, a
-      // phantom ticket or one past the last layer asks for an offset past the
-      // resource: reads 0.  No branch around a load (not even one that loads on
-      // both sides: the join copies the registers and waits for the loads) and
-      // NO store inside the ticket loop: the compiler's count of outstanding
-      // loads stays exact (else every MFMA waits for the YOUNGEST request).
-      // The rows' validity costs no vector instruction (on gfx950 a vector
-      // instruction under a running MFMA issues at about a third of its rate,
-      // and five matrix waves pay it per ticket): the resource covers exactly
-      // the tile's valid rows [lo, hi) -- base = the address of row lo,
-      // num_records = (hi - lo) rows, no scalar offset -- and the lane's
-      // offset is relative to row lo, so a row before lo wraps to a huge
-      // unsigned offset and a row from hi on lies past num_records: both read 0.
-      // The loads themselves are inline asm with HAND-COUNTED waits: through the
-      // builtin the compiler's wait-count pass kept deciding (differently from
-      // build to build) to drain every outstanding load at some point of the
-      // ticket loop -- vmcnt(0) at its top, vmcnt(1) in front of its first LDS
-      // read -- which turns a four-ticket prefetch into none.  A load of slot
-      // u, step s is used exactly 31 loads later: s_waitcnt vmcnt(31) in front
-      // of every MFMA (more memory operations in between, the layer's stores,
-      // only make that wait conservative).
-      typedef int bp_i32x4 __attribute__((ext_vector_type(4)));
-      struct AReq { bp_i32x4 ap; int vo; };
-      int cur_li = 0;                            // the ticket loop's layer index
-      auto dil_of = [&](int qli) {               // the left operand's shift in layer index qli
-        return past && qli < L ? __builtin_amdgcn_readfirstlane(s_dil[L - 1 - qli]) : 0;
-      };
-      int d_cur = dil_of(0), d_next = dil_of(1);
-      auto areq_make = [&](const Cur& c) {
-        AReq q;
-        const bool valid = c.li < L && c.ti < ng;
-        const int l = c.li < L ? L - 1 - c.li : 0;
-        const int tt0 = c.tt * 16;
-        // (the cursor is at most a layer ahead of the ticket loop, which keeps
-        // both dilations in scalar registers: no LDS read, no vector temporary
-        // -- a vector temporary that lands in a register an outstanding load
-        // will write makes the compiler drain every load at the loop's top)
-        const int d = c.li == cur_li ? d_cur : d_next;
-        const int hi = valid ? min(16, T - tt0) : 0;
-        // (not clamped to 16: max + min would become v_med3, a vector
-        // instruction; lo >= hi simply makes the resource empty)
-        const int lo = max(0, d - tt0);
-        const long row0 = (long)c.b * T + tt0 - d + lo;           // (>= 0: row lo is inside the clip)
-        q.vo = lane4 - lo * (WN_CH * 4);
-        const unsigned long long base = (unsigned long long)(
-            (zplane ? a.Z : a.X) + (size_t)l * a.plane + row0 * WN_CH);
-        q.ap = bp_i32x4{(int)(unsigned)base, (int)((base >> 32) & 0xffffu),
-                        hi > lo ? (hi - lo) * (WN_CH * 4) : 0, 0x00020000};
-        return q;
-      };
-#define BP_ALOAD(dst, q, s)                                                          \
-  asm volatile("buffer_load_dword %0, %1, %2, 0 offen offset:%3"                     \
-               : "=v"(dst) : "v"((q).vo), "s"((q).ap), "n"((s) * 256))
-#define BP_AWAIT(x) asm volatile("s_waitcnt vmcnt(31)" : "+v"(x))
-      float ax[BP_PF][8];
-      Cur qa = {0, 0, b_top, tt_top};            // the next slot to request
-#pragma unroll
-      for (int u = 0; u < BP_PF; ++u) {
-        const AReq q = areq_make(qa);
-#pragma unroll
-        for (int s = 0; s < 8; ++s) BP_ALOAD(ax[u][s], q, s);
-        cur_next(qa);
-      }
-      // B operands of a ticket (the row wave's tile in its buffer): ONE
-      // register set -- operand s of the next ticket is requested right behind
-      // the MFMA that read operand s of this one and lands under the MFMAs
-      // that follow; so are the next A operands of this slot, and the "full"
-      // word of the ticket after the next (looked at one ticket later).
-      float bv[8];
-      int k = 0, bi = 0;                         // the current ticket and its buffer
-      wait_lds_ge(&s_full[0], 1, dead, a.ctl, a.poison, lane);
-#pragma unroll
-      for (int s = 0; s < 8; ++s) bv[s] = te.p[s & 3][bsel + 64 * s];
-      // the "full" word of ticket 1's buffer, requested ahead
-      int fv = __hip_atomic_load(&s_full[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      for (int li = 0; li < L; ++li) {
-        const int l = L - 1 - li;
-        f32x16 acc = frag_zero();
-        float bs = 0.f;
-        if (li > 0) {
-          cur_li = li;
-          d_cur = d_next;
-          d_next = dil_of(li + 1);
-        }
-        for (int t0 = 0; t0 < ngp; t0 += BP_PF) {
-#pragma unroll
-          for (int u = 0; u < BP_PF; ++u) {
-            const AReq q = areq_make(qa);
-            const int bn = bi + 1 == BP_NB ? 0 : bi + 1;
-            const int bnn = bn + 1 == BP_NB ? 0 : bn + 1;
-            const bool more = k + 1 < nticket;
-            S16STAMP(l, 0);
-            // the next ticket's operands are read during this ticket's MFMAs:
-            // its buffer must be full (the word was requested a ticket ago)
-            if (more && fv < k + 2) wait_lds_ge(&s_full[bn], k + 2, dead, a.ctl, a.poison, lane);
-            S16STAMP(l, 1);
-            const int bo = (more ? bn * BP_BUF : 0) + bsel;
-            float ts = 0.f;
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-              BP_AWAIT(ax[u][s]);
-              acc = sb_mfma(ax[u][s], bv[s], acc);
-              if (sums) ts += bv[s];
-              __builtin_amdgcn_sched_barrier(0);
-              bv[s] = te.p[s & 3][bo + 64 * s];
-              BP_ALOAD(ax[u][s], q, s);
-              if (s == 0)
-                fv = __hip_atomic_load(&s_full[bnn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              __builtin_amdgcn_sched_barrier(0);
-            }
-            // (this ticket's LDS reads returned before its MFMAs were issued)
-            if (lane == 0)
-              __hip_atomic_store(&s_cons[bi][mw], k / BP_NB + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            bs += ts;
-            if (a.tilesum && !zplane && (mw & 1) && t0 + u < ng) {
-              // per-tile column sums of da_f (wave 1) / da_g (wave 3): through
-              // LDS, to memory at the layer's end
-              const float c = ts + __shfl_xor(ts, 32);
-              if (h == 0) s_ts[(t0 + u) * 64 + (mw >> 1) * 32 + j] = c;
-            }
-            bi = bn;
-            ++k;
-            S16STAMP(l, 2);
-            cur_next(qa);
-          }
-        }
-        // ---- the layer's sums: this wave's matrix (+ bias row) to the slab:
-        // Wf[0] | Wf[1] | Wg[0] | Wg[1] | Wd | bf | bg | bd
-        float* out = a.slabs + (size_t)l * a.slab_layer_stride + (size_t)gi * LAYER_BLOCK_FLOATS;
-        const int e0 = 4 * h * 32 + j;
-        if (dead) acc[0] = __builtin_nanf("");
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          out[mw * 1024 + e0 + (8 * (r >> 2) + (r & 3)) * 32] = acc[r];
-        bs += __shfl_xor(bs, 32);
-        if (h == 0 && sums) out[LAYER_W_FLOATS + (mw >> 1) * 32 + j] = bs;
-        if (a.tilesum && !zplane && (mw & 1)) {
-          WN_WAIT_LGKM0();
-          float* tsum = a.tilesum + ((size_t)l * ntiles + gbase) * 64 + (mw >> 1) * 32 + j;
-          for (int t = h; t < ng; t += 2)        // (ticket t is tile gbase + ng - 1 - t)
-            tsum[(size_t)(ng - 1 - t) * 64] = s_ts[t * 64 + (mw >> 1) * 32 + j];
-        }
-        // (a store still in flight at the top of the ticket loop makes the
-        // compiler's wait-count pass protect its data registers with a
-        // vmcnt(0) INSIDE the loop, every four tickets: drained here instead,
-        // once a layer, where the pass can see it)
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        S16STAMP(l, 3);
-      }
-      __builtin_amdgcn_s_setprio(0);
-    }
-    __syncthreads();
-  }
-  S16CAL(2);
-  if (tid == 0) {
-    const unsigned done = atomicAdd(a.ctl + 1, 1u);
-    if (done == gridDim.x - 1) {
-      __hip_atomic_store(a.ctl + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(a.ctl + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(a.ctl + 2, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
 #ifdef STACK_STAMPS
 static unsigned long long* g_stack_dbg = nullptr;
 static unsigned long long* g_stack_dbg_b = nullptr;
@@ -2449,13 +1930,6 @@ int wn_stack_tile_rows(int B, int T, int variant) {
   if (r == 16 || r == 32) return r;
   const long ntiles = (long)B * ((T + 31) / 32);
   return ntiles <= 4L * wn_device_cus() ? 16 : 32;
-}
-
-// Rows of a tile in wn_stack_bwd: the pipelined launch (WN_STACK_PIPE) runs on
-// 16-row tiles whatever the forward's height; else the shape's / variant's.
-int wn_stack_bwd_tile_rows(int B, int T, int variant) {
-  if (variant & WN_STACK_PIPE) return 16;
-  return wn_stack_tile_rows(B, T, variant);
 }
 
 // waves per workgroup a variant word asks for (bits 8..11), or `dflt`
@@ -2564,16 +2038,6 @@ int wn_stack_fwd(float* X, float* Z, float* SG, const float* wimg,
 // at most one group per CU covers the batch; small batches use fewer waves so
 // that the tiles spread over the whole chip
 static void stack_bwd_shape(int B, int T, int variant, int* waves_out, int* tpw_out) {
-  if (variant & WN_STACK_PIPE) {
-    // pipelined launch: a workgroup = one GROUP of 16-row tiles for all layers;
-    // one pass of at most one group per CU
-    const long nt16 = (long)B * ((T + 15) / 16);
-    const int cus = wn_device_cus();
-    *waves_out = 1;
-    const long per = (nt16 + cus - 1) / cus;
-    *tpw_out = (int)(per < 1 ? 1 : per > BP_GMAX ? BP_GMAX : per);
-    return;
-  }
   if (wn_stack_tile_rows(B, T, variant) == 16) {     // 16-row tiles: one per wave
     *waves_out = variant_waves(variant, 8, false);
     *tpw_out = 1;
@@ -2610,7 +2074,7 @@ int wn_stack_bwd_slabs(int B, int T, int variant) {
   if (B <= 0 || T <= 0) return 0;
   int w, t;
   stack_bwd_shape(B, T, variant, &w, &t);
-  const int rows = wn_stack_bwd_tile_rows(B, T, variant);
+  const int rows = wn_stack_tile_rows(B, T, variant);
   const long ntiles = (long)B * ((T + rows - 1) / rows);
   return (int)((ntiles + (long)w * t - 1) / ((long)w * t));
 }
@@ -2634,7 +2098,7 @@ int wn_stack_bwd(const float* X, const float* Z, const float* SG,
   if (!wn_aligned16(Q)) return WN_ERR_MISALIGNED;
   int waves, tpw;
   stack_bwd_shape(B, T, variant, &waves, &tpw);
-  const int rows = wn_stack_bwd_tile_rows(B, T, variant);
+  const int rows = wn_stack_tile_rows(B, T, variant);
   const long ntiles = (long)B * ((T + rows - 1) / rows);
   const long groups = (ntiles + (long)waves * tpw - 1) / ((long)waves * tpw);
   if (slab_layer_stride < groups * LAYER_BLOCK_FLOATS) return WN_ERR_BAD_SHAPE;
@@ -2656,10 +2120,6 @@ int wn_stack_bwd(const float* X, const float* Z, const float* SG,
   // a single plane rewritten in place
   if (dx_layer_stride != (long)B * T * WN_CH && dx_layer_stride != 0)
     return WN_ERR_BAD_SHAPE;
-  if (variant & WN_STACK_PIPE) {
-    hipLaunchKernelGGL(stack_bwdp_kernel, grid, dim3((BP_MATW + BP_ROWW) * 64), 0, s, a);
-    return wn_check_launch();
-  }
   if (rows == 16) {
     if (waves == 8) hipLaunchKernelGGL((stack_bwd16_kernel<8>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((stack_bwd16_kernel<4>), grid, block, 0, s, a);

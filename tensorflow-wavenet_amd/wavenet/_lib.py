@@ -38,7 +38,6 @@ SIGNATURES = {
     'wn_stack_fwd': (c_int, [P, P, P, P, P, c_long, c_int, P, P, P, P,
                              c_int, c_int, c_int, c_int, c_int, P]),
     'wn_stack_bwd_slabs': (c_int, [c_int, c_int, c_int]),
-    'wn_stack_bwd_tile_rows': (c_int, [c_int, c_int, c_int]),
     'wn_stack_bwd': (c_int, [P, P, P, P, P, c_long, P, P, P, c_long, P, P, P,
                              P, P, c_int, c_int, c_int, c_int, P]),
     'wn_layer_bwd': (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int,
@@ -266,13 +265,10 @@ def ptr(t):
     return t.data_ptr()
 
 
-WN_STACK_PIPE = 0x2000
-
-
-def stack_variant(rows=0, waves=0, pipe=False):
+def stack_variant(rows=0, waves=0):
     """WN_STACK_VARIANT of include/wavenet_hip.h: the explicit variant word of
     the stack launches (0 = the library's choice for the shape)."""
-    return (rows & 0x3f) | ((waves & 0xf) << 8) | (WN_STACK_PIPE if pipe else 0)
+    return (rows & 0x3f) | ((waves & 0xf) << 8)
 
 
 def stream():

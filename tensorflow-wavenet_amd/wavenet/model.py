@@ -214,8 +214,6 @@ class _Workspace(object):
         # per-layer kernels, wn_stack_bwd on big batches) or 16-row tiles
         # (wn_stack_bwd on small ones, wn_stack_tile_rows): two views of one buffer
         self.stack_rows = lib.wn_stack_tile_rows(B, T, self.stack_variant)
-        # (the backward's height: the pipelined launch is 16-row whatever the forward's)
-        self.stack_rows_b = lib.wn_stack_bwd_tile_rows(B, T, self.stack_variant)
         nt16 = B * ((T + 15) // 16)
         if net.G:
             buf = alloc('tilesum_buf', (L * nt16 * 64,))
@@ -1098,7 +1096,7 @@ class WaveNetModel(object):
             dxin, xp = None, 0
             tsum = None if ws.dsum is None else ws.tilesum
             if self._stack_bwd_ok() and getattr(ws, 'stack_bwd', False):
-                if ws.stack_rows_b == 16 and tsum is not None:
+                if ws.stack_rows == 16 and tsum is not None:
                     tsum = ws.tilesum16
                 # all L layers in one persistent launch (csrc/wn_stack.hip)
                 if not self._bwd_image_with_fwd(ws):
@@ -1116,7 +1114,7 @@ class WaveNetModel(object):
                     _lib.ptr(ws.loss_parts[1:]), L, B, T, ws.stack_variant, st), 0.0,
                     getattr(self, '_gemm_events', None))
                 self._backward_tail(ws, ids, ws.DX[0], ws.nslab_s, True,
-                                    tile_rows=ws.stack_rows_b)
+                                    tile_rows=ws.stack_rows)
                 return
             # transposed weight images of all layers (the kernels DMA them
             # into LDS): one small launch per step

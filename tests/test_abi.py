@@ -150,22 +150,6 @@ def test_library_reads_no_environment(hip_lib):
         assert 'getenv' not in open(os.path.join(csrc, f)).read(), f
 
 
-def test_pipelined_backward_machine_code_keeps_its_async_registers():
-    """stack_bwdp_kernel's matrix waves load their A operands through inline
-    asm with hand-counted waits: the compiler must not touch those registers
-    between a load and its wait (tools/check_bwdp_isa.py compiles the source to
-    assembly and checks exactly that)."""
-    import subprocess
-    import sys
-    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    if not os.path.exists(hipcc):
-        pytest.skip('no hipcc')
-    p = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_bwdp_isa.py')],
-                       capture_output=True, text=True, timeout=900)
-    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
-    assert 'check_bwdp_isa: ok (32 A-operand registers' in p.stdout
-
-
 def test_missing_library_fails_loudly(monkeypatch):
     from wavenet import _lib
     monkeypatch.setattr(_lib, '_lib', None)

@@ -226,7 +226,7 @@ def _check_layer_grads(a, b, wa, name):
 
 
 _BWD_PARAMS = [pytest.param(*c, r, w, id='%s-%s-%s' % (c[0], r, w))
-               for c in CASES for r, w in [(32, '8'), (16, '8'), (16, '4'), (32, 'pipe'), (16, 'pipe')]]
+               for c in CASES for r, w in [(32, '8'), (16, '8'), (16, '4')]]
 
 
 @pytest.mark.parametrize('name,mk,B,T,kind,rows,waves', _BWD_PARAMS)
@@ -240,13 +240,7 @@ def test_stack_backward_equals_per_layer(hip_lib, monkeypatch, name, mk, B, T, k
     rows = 16: the small-batch launch (16-row tiles), forced on every shape
     here; all three models then run the 16-row FORWARD too, so the planes the
     backward paths read are bitwise the same."""
-    # ('pipe': the pipelined launch -- row waves taking (layer, tile) tickets,
-    # matrix waves owning the weight-gradient matrices; 16-row tiles in the
-    # backward whatever the forward's height)
-    if waves == 'pipe':
-        var = stack_variant(rows=rows, pipe=True)
-    else:
-        var = stack_variant(rows=rows, waves=int(waves))
+    var = stack_variant(rows=rows, waves=int(waves))
     monkeypatch.setattr(WaveNetModel, 'DEFAULT_STACK_VARIANT', var)
     assert hip_lib.wn_stack_tile_rows(B, T, var) == rows
     cfg = mk()

@@ -25,10 +25,7 @@ from util import model_kwargs, synth_audio
 lib = _lib.load()
 # KB_WAVES_B: waves of the 16-row backward launch
 rw = int(os.environ.get('KB_WAVES_B', 8))
-# KB_PIPE=1: the pipelined backward launch (stack_bwdp_kernel; the forward keeps its own height)
-pipe = os.environ.get('KB_PIPE') == '1'
-VAR = _lib.stack_variant(rows=0, pipe=True) if pipe else \
-    _lib.stack_variant(rows=16, waves=rw)
+VAR = _lib.stack_variant(rows=16, waves=rw)
 WaveNetModel.DEFAULT_STACK_VARIANT = VAR
 B, T = int(os.environ.get('KB_B', 1)), 16000
 p = json.load(open(os.path.join(ROOT, 'wavenet_params.json')))
@@ -86,29 +83,16 @@ def report(raw, grid, title, seq, down, waves=None, first=0):
         print('%-58s %6.2f   (sum of medians %.2f)' % ('layer period', np.median(per), tot))
 
 
-if not pipe:
-  report(dbg.cpu().numpy(), gridf, 'stack_fwd16_kernel', [
-    (0, 1, 'wait for the weight ring'), (1, 2, 'bias, tap requested, 32 current-tap MFMAs'),
-    (2, 3, 'tap rows in registers (flag wait + load, or word poll)'),
-    (3, 4, '32 past-tap MFMAs'), (4, 5, 'tanh / sigmoid'), (5, 6, 'dense bias + 16 MFMAs'),
-    (6, 7, "x' out (stored, drained, flag posted / words stored)"),
-    (7, 8, 'z / sigmoid stores issued, ring bookkeeping')], False)
-if pipe:
-    # (a wave's stamps of a layer are those of its LAST ticket in that layer)
-    report(dbgb.cpu().numpy(), gridb, 'stack_bwdp_kernel, row waves', [
-        (0, 1, 'ticket taken -> weight ring ready'), (1, 2, 'loads requested, flags polled, own / q rows requested'),
-        (2, 3, 'wait for them'), (3, 4, 'buffer free?, dx_{l+1} | dz (16 MFMA) | gates -> LDS, signal'),
-        (4, 5, 'own / q rows (64 MFMA)'), (5, 6, 'stores, ring bookkeeping, drain, flag posted')],
-        True, waves=(5, 9, 15))
-    report(dbgb.cpu().numpy(), gridb, 'stack_bwdp_kernel, matrix waves', [
-        (0, 1, 'wait for the ticket\'s buffer'), (1, 2, '8 MFMA interleaved with the next B operands, next A operands requested'),
-        (2, 3, 'layer end: slab stores')],
-        True, waves=(0, 1, 4))
-else:
-    report(dbgb.cpu().numpy(), gridb, 'stack_bwd16_kernel', [
-        (0, 1, 'wait for the weight ring'), (1, 2, 'loads requested (z DMA, dZ, sigmoid, own dx, flag check, q)'),
-        (2, 3, 'wait for them'), (3, 4, 'dx_{l+1} to LDS, dWd (8 MFMA), z fragments'),
-        (4, 5, 'x DMA issued, dz (16 MFMA), gate derivatives'),
-        (5, 6, 'own / q rows (64 MFMA)'), (6, 7, 'q and own rows stored, drained, flag posted, next flags requested'),
-        (7, 8, 'weight gradients (32 MFMA)'), (8, 9, 'ring bookkeeping'),
-        (9, 10, 'ordered accumulation chain (incl. token waits)')], True)
+report(dbg.cpu().numpy(), gridf, 'stack_fwd16_kernel', [
+  (0, 1, 'wait for the weight ring'), (1, 2, 'bias, tap requested, 32 current-tap MFMAs'),
+  (2, 3, 'tap rows in registers (flag wait + load, or word poll)'),
+  (3, 4, '32 past-tap MFMAs'), (4, 5, 'tanh / sigmoid'), (5, 6, 'dense bias + 16 MFMAs'),
+  (6, 7, "x' out (stored, drained, flag posted / words stored)"),
+  (7, 8, 'z / sigmoid stores issued, ring bookkeeping')], False)
+report(dbgb.cpu().numpy(), gridb, 'stack_bwd16_kernel', [
+    (0, 1, 'wait for the weight ring'), (1, 2, 'loads requested (z DMA, dZ, sigmoid, own dx, flag check, q)'),
+    (2, 3, 'wait for them'), (3, 4, 'dx_{l+1} to LDS, dWd (8 MFMA), z fragments'),
+    (4, 5, 'x DMA issued, dz (16 MFMA), gate derivatives'),
+    (5, 6, 'own / q rows (64 MFMA)'), (6, 7, 'q and own rows stored, drained, flag posted, next flags requested'),
+    (7, 8, 'weight gradients (32 MFMA)'), (8, 9, 'ring bookkeeping'),
+    (9, 10, 'ordered accumulation chain (incl. token waits)')], True)

@@ -5,7 +5,7 @@
     KB_B=1 python tools/stack_ab.py ...                  (clips per batch)
     KB_VARIANTS="32:0,16:8,32:0:1" python tools/stack_ab.py lib.so
                                                          (one library, several variant words
-                                                          rows:waves[:pipe] of the launches)
+                                                          rows:waves of the launches)
     KB_DX=1 python tools/stack_ab.py lib.so              (one library: a dx plane per layer
                                                           vs one plane rewritten in place)
     KB_SAVE_SG=0                                         (forward without the sigmoid planes)
@@ -67,8 +67,8 @@ def main():
         lib = libs[0][1]
         libs = []
         for spec in os.environ['KB_VARIANTS'].split(','):
-            r, w, pp = (int(v) for v in (spec + ':0').split(':')[:3])
-            variants[spec] = _lib.stack_variant(rows=r, waves=w, pipe=bool(pp))
+            r, w = (int(v) for v in spec.split(':')[:2])
+            variants[spec] = _lib.stack_variant(rows=r, waves=w)
             libs.append((spec, lib))
     if os.environ.get('KB_DX'):
         lib = libs[0][1]

@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tensorflow-wavenet_amd'))
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 # KB_ROWS (default here: 32, the launches whose forward is bitwise the
 # per-layer kernels'; 16: the small-batch launches, compared to rounding --
-# KB_PIPE=1 / KB_WAVES=4|8 select their variants): an explicit variant word
+# KB_WAVES=4|8 selects their variant): an explicit variant word
 # of the C entry points, set through the model class
 ROWS16 = os.environ.get('KB_ROWS', '32') == '16'
 import numpy as np  # noqa: E402
@@ -19,8 +19,7 @@ from wavenet import WaveNetModel  # noqa: E402
 from wavenet._lib import stack_variant  # noqa: E402
 
 WaveNetModel.DEFAULT_STACK_VARIANT = stack_variant(
-    rows=16 if ROWS16 else 32, waves=int(os.environ.get('KB_WAVES', 0)),
-    pipe=os.environ.get('KB_PIPE') == '1')
+    rows=16 if ROWS16 else 32, waves=int(os.environ.get('KB_WAVES', 0)))
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)

@@ -1406,9 +1406,12 @@ __device__ __forceinline__ float fgp_get(const fgp_ll_t* p, unsigned step, unsig
 
 // up to two words per thread, both polled in ONE loop (two dependent polls
 // cost two memory round trips): words k0 and k0 + 256 of `src` into `dst`
+// (d0, d1: where the two values go in `dst`; default: their own index)
 __device__ __forceinline__ void fgp_get2(float* dst, const fgp_ll_t* src, int k0, int n,
-                                         unsigned step, unsigned* sync, bool& dead) {
+                                         unsigned step, unsigned* sync, bool& dead,
+                                         int d0 = -1, int d1 = -1) {
   const bool h0 = k0 < n, h1 = k0 + 256 < n;
+  if (d0 < 0) { d0 = k0; d1 = k0 + 256; }
   if (!h0) return;
   fgp_ll_t w0 = __hip_atomic_load(src + k0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   fgp_ll_t w1 = h1 ? __hip_atomic_load(src + k0 + 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -1431,8 +1434,8 @@ __device__ __forceinline__ void fgp_get2(float* dst, const fgp_ll_t* src, int k0
       }
     }
   }
-  dst[k0] = __uint_as_float((unsigned)w0);
-  if (h1) dst[k0 + 256] = __uint_as_float((unsigned)w1);
+  dst[d0] = __uint_as_float((unsigned)w0);
+  if (h1) dst[d1] = __uint_as_float((unsigned)w1);
 }
 
 // ---- wave-wide reductions by DPP (row shifts inside the four 16-lane rows,
@@ -1866,6 +1869,58 @@ __global__ __launch_bounds__(FGP_THREADS) void fg_persist_kernel(FgPersist a) {
     const int col0 = (lg ? role - nsk : role) * 16, N = lg ? Q : S;
     const float* W = lg ? g.post2_w : g.post1_w;
     const float* bias = lg ? g.post2_b : g.post1_b;
+    const fgp_ll_t* src = lg ? h2ll : h1ll;
+    fgp_ll_t* dst = lg ? lgll : h2ll;
+    if ((S & 63) == 0) {
+      // Round 5: the thread's 32 weights stay in REGISTERS for the run, the 16
+      // K-slices of an output sit on 16 adjacent lanes (slice p = lane & 15 of a
+      // row), the input vector is stored slice-interleaved ([unit i of the
+      // slice][slice]: the lanes' eight 16-byte reads are conflict-free), and the
+      // slices' partial sums are added by fifteen DPP row shifts -- in slice
+      // order with the same four chains per slice as fgp_mv16 / the step
+      // kernels, so the bits are theirs.  One barrier a step (the input buffer
+      // alternates), no weight or partial-sum traffic through LDS.
+      const int o2 = tid >> 4, p2 = tid & 15;
+      const int upp = S >> 6, per = S >> 4;          // 16-byte units / floats of a slice
+      float wr[8][4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          wr[u][e] = (u < upp && col0 + o2 < N)
+                         ? W[(size_t)(p2 * per + 4 * u + e) * N + col0 + o2] : 0.f;
+      const float bv = (bias && col0 + o2 < N) ? bias[col0 + o2] : 0.f;
+      // word k -> float ((u % upp) * 16 + u / upp) * 4 + (k & 3), u = k >> 2
+      auto spos = [&](int k) { const int u = k >> 2; return ((u % upp) * 16 + u / upp) * 4 + (k & 3); };
+      const int d0 = spos(tid), d1 = spos(tid + 256);
+      for (int i = 0; i < n_steps; ++i) {
+        const unsigned step = (unsigned)(i + 1);
+        float* buf = in_s + (i & 1) * S;
+        fgp_get2(buf, src, tid, S, step, sync, dead, d0, d1);
+        __syncthreads();
+        const f32x4* b4 = reinterpret_cast<const f32x4*>(buf) + p2;
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (u < upp) {
+            const f32x4 v = b4[u * 16];
+            c0 = fmaf(v[0], wr[u][0], c0); c1 = fmaf(v[1], wr[u][1], c1);
+            c2 = fmaf(v[2], wr[u][2], c2); c3 = fmaf(v[3], wr[u][3], c3);
+          }
+        const float r = (c0 + c1) + (c2 + c3);
+        // lane 15 of the row: ((r_0 + r_1) + ...) + r_15
+        float t = r;
+#pragma unroll
+        for (int q = 0; q < 15; ++q) t = dpp_f32<0x111, 0xf>(0.f, t) + r;
+        if (p2 == 15 && col0 + o2 < N) {
+          t += bv;
+          fgp_put(dst + col0 + o2, lg ? t : fmaxf(t, 0.f), step);
+        }
+        if (role == 0) { PSTAMP(i * 16 + 12); }
+        if (role == nsk) { PSTAMP(i * 16 + 13); }
+      }
+      return;
+    }
     float* w_s = lds + ((S + 3) & ~3);                // [S][16]
     float* red = w_s + (size_t)S * 16;
     for (int i = tid; i < S * 16; i += 256) {
@@ -1873,8 +1928,6 @@ __global__ __launch_bounds__(FGP_THREADS) void fg_persist_kernel(FgPersist a) {
       w_s[i] = col0 + c < N ? W[(size_t)k * N + col0 + c] : 0.f;
     }
     __syncthreads();
-    const fgp_ll_t* src = lg ? h2ll : h1ll;
-    fgp_ll_t* dst = lg ? lgll : h2ll;
     for (int i = 0; i < n_steps; ++i) {
       const unsigned step = (unsigned)(i + 1);
       fgp_get2(in_s, src, tid, S, step, sync, dead);

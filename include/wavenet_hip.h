@@ -459,7 +459,17 @@ int wn_fastgen_run(const float* params_causal, const float* layer0,
  * L <= 1024 and 8 Q + 4 (5 C + 2 S + 3 L) <= 150 KB of LDS; C = 32 is accepted
  * too (the host uses this entry for 32-channel models beyond the S / Q <= 512,
  * L <= 64 of wn_fastgen_run / wn_fastgen_step).  One persistent workgroup,
- * correctness first. */
+ * correctness first -- except 64 channels (C = 64, S <= 512 a multiple of 16,
+ * Q <= 512, L <= 256) with `coop` scratch: a COOPERATIVE launch,
+ * workgroup 0 runs the layers and the draw, 2 S / 16 + Q / 16 more workgroups the
+ * skip sum and the post-processing mat-vecs (hand-over words in `coop`; the
+ * same samples up to the rounding of the skip sum's order).  It is taken only
+ * when the runtime reports every workgroup resident; otherwise, or with
+ * coop = NULL, the single workgroup runs.
+ * coop: NULL, or wn_fastgen_wide_coop_bytes(L, C, S, Q) bytes (16-byte aligned,
+ * zeroed by the call).  After a cooperative run ((unsigned*)coop)[12] != 0
+ * means a hand-over wait expired (2 s): that run's samples are not valid. */
+long wn_fastgen_wide_coop_bytes(int L, int C, int S, int Q);
 int wn_fastgen_run_wide(const float* params_causal, const float* layer0,
                         long layer_stride, const float* skip_w,
                         const float* skip_bsum, const float* post1_w,
@@ -469,7 +479,7 @@ int wn_fastgen_run_wide(const float* params_causal, const float* layer0,
                         float* state, int32_t* cursors, int32_t* samples_io,
                         int n_given, int n_steps, float temperature,
                         uint64_t seed, float* proba_out, int proba_every,
-                        int use_biases, int push, void* stream);
+                        int use_biases, int push, void* coop, void* stream);
 
 /* Multi-CU variant: enqueues ONE generation step as four kernels (chain on
  * one CU, current tap only, preceded by the previous step's float64 softmax +

@@ -382,411 +382,6 @@ __global__ __launch_bounds__(FG_THREADS, 1) void fastgen_kernel(FastGen g) {
 }
 
 // ===========================================================================
-// Wide fast generation: the same incremental generator for MORE than 32
-// residual / dilation channels (C = 32 * blocks padded channels, weights in the
-// reference's [K][C][C] layout of wavenet/blocked.py; the reference's
-// generator has no width limit, model.py:444-516).  One persistent workgroup,
-// correctness first: per layer three phases separated by workgroup barriers
-//   1. thread (which, c): a_which[c] = bias + st . W_which[0][:, c] + x . W_which[1][:, c]
-//   2. z = tanh(a_f) sigmoid(a_g); the queue entry is replaced by x (push)
-//   3. x += bd + z . Wd  (every layer, as model.py:377-380); total += z . Ws_l
-// then the post-processing mat-vecs, the float64 softmax and the same
-// counter-based draw as fastgen_kernel (same seed -> same uniform per step).
-// Queues: layer l's ring holds d_l rows of C floats at state + roff[l] * C.
-// ===========================================================================
-#define FGW_THREADS 256
-#define FGW_MAXC 1024
-#define FGW_MAXS 4096
-#define FGW_MAXQ 4096
-#define FGW_MAXL 1024
-#define FGW_XPT (FGW_MAXC / FGW_THREADS)   // residual channels per thread
-#define FGW_SPT (FGW_MAXS / FGW_THREADS)   // skip channels per thread
-
-// dynamic LDS of the wide generator: Q doubles, then 5 C + 2 S floats, 3 L ints
-static size_t fgw_lds_bytes(int C, int S, int Q, int L) {
-  return (size_t)Q * 8 + ((size_t)5 * C + 2 * (size_t)S + 3 * (size_t)L) * 4;
-}
-
-// sum_k in[k] * w[k * stride]: the weight loads in batches (all of a batch in
-// flight before its FMAs: 64, then 16, 4 and 1 for what is left) into four
-// partial sums -- a plain loop waits for every load before the next one is
-// issued, and the wide generator is nothing but such loops (64 channels,
-// default stack: 3.5 ms per sample with one load per FMA, 0.77 / 0.50 / 0.37 /
-// 0.31 ms with batches of 8 / 16 / 32 / 64).
-#define FGW_BATCH 64
-__device__ __forceinline__ float fgw_dot(const float* in, const float* __restrict__ w,
-                                         long stride, int K, float init) {
-  float c[4] = {init, 0.f, 0.f, 0.f};
-  int k = 0;
-  for (; k + FGW_BATCH <= K; k += FGW_BATCH) {
-    float wv[FGW_BATCH];
-#pragma unroll
-    for (int u = 0; u < FGW_BATCH; ++u) wv[u] = w[(long)(k + u) * stride];
-#pragma unroll
-    for (int u = 0; u < FGW_BATCH; ++u) c[u & 3] = fmaf(in[k + u], wv[u], c[u & 3]);
-  }
-  for (; k + 16 <= K; k += 16) {
-    float wv[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) wv[u] = w[(long)(k + u) * stride];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) c[u & 3] = fmaf(in[k + u], wv[u], c[u & 3]);
-  }
-  for (; k + 4 <= K; k += 4) {
-    float wv[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) wv[u] = w[(long)(k + u) * stride];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) c[u] = fmaf(in[k + u], wv[u], c[u]);
-  }
-  for (; k < K; ++k) c[0] = fmaf(in[k], w[(long)k * stride], c[0]);
-  return (c[0] + c[1]) + (c[2] + c[3]);
-}
-
-// two such sums at once (both batches of weight loads in flight together)
-__device__ __forceinline__ void fgw_dot2(const float* in0, const float* __restrict__ w0,
-                                         const float* in1, const float* __restrict__ w1,
-                                         long stride, int K, float& r0, float& r1) {
-  float a[4] = {r0, 0.f, 0.f, 0.f}, b[4] = {r1, 0.f, 0.f, 0.f};
-  int k = 0;
-  for (; k + 32 <= K; k += 32) {
-    float u0[32], u1[32];
-#pragma unroll
-    for (int u = 0; u < 32; ++u) u0[u] = w0[(long)(k + u) * stride];
-#pragma unroll
-    for (int u = 0; u < 32; ++u) u1[u] = w1[(long)(k + u) * stride];
-#pragma unroll
-    for (int u = 0; u < 32; ++u) a[u & 3] = fmaf(in0[k + u], u0[u], a[u & 3]);
-#pragma unroll
-    for (int u = 0; u < 32; ++u) b[u & 3] = fmaf(in1[k + u], u1[u], b[u & 3]);
-  }
-  r0 = (a[0] + a[1]) + (a[2] + a[3]);
-  r1 = (b[0] + b[1]) + (b[2] + b[3]);
-  if (k < K) {
-    r0 = fgw_dot(in0 + k, w0 + (long)k * stride, stride, K - k, r0);
-    r1 = fgw_dot(in1 + k, w1 + (long)k * stride, stride, K - k, r1);
-  }
-}
-
-struct FastGenWide {
-  FastGen g;
-  int C;        // padded channels (multiple of 32, <= FGW_MAXC)
-};
-
-// F64 (64 channels, at most 512 skip channels): the generic layer body pays
-// three dependent weight-load latencies per layer (past-tap ring entry ->
-// filter / gate weights -> dense + skip weights; 213 KB a layer through ONE
-// CU, 10.6 MB a sample through one XCD's 4 MB L2: 0.30 ms per sample).  None of
-// the weights depends on the data: here (512 threads) EVERY load of a layer --
-// the ring entry, a thread's 32 filter / gate weights (output o = tid & 127, a
-// quarter of the contraction each), its 8 dense weights (an eighth of the
-// contraction) a LAYER AHEAD, the 64 weights of its skip column, which the
-// layer needs last, at the layer's own top -- and the phases only synchronise
-// through LDS, four barriers a layer (207 us per sample with every load at the
-// layer's own top and 256 threads; without the skip weights' loads a sample
-// takes 144 us: they are the 54 us still exposed).
-struct FgwLayer64 {
-  float ringv, wa[16], wb[16], wdv[8], bf, bg, bdv;
-};
-template <bool F64>
-__global__ __launch_bounds__(F64 ? 512 : FGW_THREADS, 1) void fastgen_wide_kernel(FastGenWide a) {
-  constexpr int NT = F64 ? 512 : FGW_THREADS;    // threads
-  constexpr int SPT = FGW_MAXS / NT, XPT = FGW_MAXC / NT;
-  const FastGen& g = a.g;
-  extern __shared__ double fgw_lds[];
-  const int S = g.S, Q = g.Q, L = g.L, C = a.C;
-  double* pd = fgw_lds;                           // [Q]
-  float* xs = reinterpret_cast<float*>(pd + Q);   // [C]
-  float* sts = xs + C;                            // [C]
-  float* zs = sts + C;                            // [C]
-  float* apre = zs + C;                           // [2 C]
-  float* hbuf = apre + 2 * C;                     // [S]
-  float* h2buf = hbuf + S;                        // [S]
-  int* pos = reinterpret_cast<int*>(h2buf + S);   // [L]
-  int* sdil = pos + L;                            // [L]
-  int* roff = sdil + L;                           // [L]
-  __shared__ int s_code;
-  __shared__ float f64_part[F64 ? 4 * 128 + 8 * 64 : 1];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const long CC = (long)C * C;
-  const int steps_done = g.cursors[0];
-  int prev_code = g.cursors[1];
-  if (tid == 0) s_code = g.samples[0];
-  for (int l = tid; l < L; l += NT) {
-    sdil[l] = g.dil[l];
-    pos[l] = steps_done % g.dil[l];
-  }
-  __syncthreads();
-  if (tid == 0) {
-    int off = 0;
-    for (int l = 0; l < L; ++l) { roff[l] = off; off += sdil[l]; }
-  }
-  __syncthreads();
-
-  for (int step = 0; step < g.n_steps; ++step) {
-    const int code = s_code;
-    const long tpos = (long)steps_done + step;
-    float acc[SPT];
-#pragma unroll
-    for (int o = 0; o < SPT; ++o) acc[o] = 0.f;
-    // causal layer: one-hot input = two table rows (model.py:341-346)
-    for (int c = tid; c < C; c += NT) {
-      float v = 0.f;
-      if (prev_code >= 0 && prev_code < Q) v = g.causal[(long)prev_code * C + c];
-      if (code >= 0 && code < Q) v += g.causal[((long)Q + code) * C + c];
-      xs[c] = v;
-    }
-    __syncthreads();
-    if (F64) {
-      const int o1 = tid & 127, kq = tid >> 7;       // filter / gate output, quarter of K
-      const int cd = tid & 63, k8 = tid >> 6;        // dense output, eighth of K
-      const int c0 = tid < S ? tid : 0;              // skip column
-      auto request = [&](int l) {
-        FgwLayer64 w;
-        const float* blk = g.layer0 + (long)l * g.layer_stride;
-        w.ringv = tid < 64 ? g.state[((long)roff[l] + pos[l]) * 64 + tid] : 0.f;
-        const float* w0 = blk + (long)(o1 >> 6) * 2 * 4096 + (o1 & 63) + kq * 16 * 64;
-#pragma unroll
-        for (int u = 0; u < 16; ++u) { w.wa[u] = w0[u * 64]; w.wb[u] = w0[4096 + u * 64]; }
-        const float* wd = blk + 4 * 4096 + cd + k8 * 8 * 64;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) w.wdv[u] = wd[u * 64];
-        w.bf = tid < 64 && g.bias_fg ? g.bias_fg[(long)l * 128 + tid] : 0.f;
-        w.bg = tid < 64 && g.bias_fg ? g.bias_fg[(long)l * 128 + 64 + tid] : 0.f;
-        w.bdv = tid < 64 && g.use_dense_bias ? blk[5 * 4096 + 128 + tid] : 0.f;
-        return w;
-      };
-      FgwLayer64 cur = request(0);
-      if (tid < 64) sts[tid] = cur.ringv;
-      __syncthreads();
-      // (four workgroup barriers a layer: partial sums | gate | partial sums |
-      // x' and the next layer's past tap)
-      for (int l = 0; l < L; ++l) {
-        // (the skip column's weights, which the layer needs last, at its own
-        // top: requesting them a layer ahead -- into the registers the layer
-        // before has just multiplied out of -- sends the register allocator
-        // into 119 spills and the sample to 284 us)
-        float ws0[64];
-        {
-          const float* ws = g.skip_w + (long)l * 64 * S + c0;
-#pragma unroll
-          for (int u = 0; u < 64; ++u) ws0[u] = ws[(long)u * S];
-        }
-        FgwLayer64 nxt = cur;
-        if (l + 1 < L) nxt = request(l + 1);
-        float* ring = g.state + ((long)roff[l] + pos[l]) * 64;
-        // ---- 1. filter / gate pre-activations, a quarter of the contraction per thread
-        {
-          float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
-#pragma unroll
-          for (int u = 0; u < 16; u += 2) {
-            p0 = fmaf(sts[kq * 16 + u], cur.wa[u], p0);
-            p1 = fmaf(xs[kq * 16 + u], cur.wb[u], p1);
-            p2 = fmaf(sts[kq * 16 + u + 1], cur.wa[u + 1], p2);
-            p3 = fmaf(xs[kq * 16 + u + 1], cur.wb[u + 1], p3);
-          }
-          f64_part[kq * 128 + o1] = (p0 + p1) + (p2 + p3);
-        }
-        __syncthreads();
-        // ---- 2. gate; enqueue x_l[t] in place of the entry just read
-        if (tid < 64) {
-          const float af = cur.bf + ((f64_part[tid] + f64_part[128 + tid]) +
-                                     (f64_part[256 + tid] + f64_part[384 + tid]));
-          const float ag = cur.bg + ((f64_part[64 + tid] + f64_part[192 + tid]) +
-                                     (f64_part[320 + tid] + f64_part[448 + tid]));
-          zs[tid] = wn_tanh(af) * wn_sigmoid(ag);
-          if (g.push) ring[tid] = xs[tid];
-        }
-        __syncthreads();
-        // ---- 3. residual 1x1 conv (an eighth of the contraction per thread)
-        // and this layer's skip contribution
-        {
-          float d0 = 0.f, d1 = 0.f;
-#pragma unroll
-          for (int u = 0; u < 8; u += 2) {
-            d0 = fmaf(zs[k8 * 8 + u], cur.wdv[u], d0);
-            d1 = fmaf(zs[k8 * 8 + u + 1], cur.wdv[u + 1], d1);
-          }
-          f64_part[512 + k8 * 64 + cd] = d0 + d1;
-          float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-          for (int u = 0; u < 64; u += 4) {
-            a0 = fmaf(zs[u], ws0[u], a0);
-            a1 = fmaf(zs[u + 1], ws0[u + 1], a1);
-            a2 = fmaf(zs[u + 2], ws0[u + 2], a2);
-            a3 = fmaf(zs[u + 3], ws0[u + 3], a3);
-          }
-          if (tid < S) acc[0] += (a0 + a1) + (a2 + a3);
-        }
-        __syncthreads();
-        if (tid < 64) {
-          float t = 0.f;
-#pragma unroll
-          for (int q = 0; q < 8; ++q) t += f64_part[512 + q * 64 + tid];
-          xs[tid] = xs[tid] + (cur.bdv + t);
-          sts[tid] = nxt.ringv;          // (the next layer's past tap)
-        }
-        __syncthreads();
-        cur = nxt;
-      }
-    }
-    for (int l = 0; !F64 && l < L; ++l) {
-      const float* blk = g.layer0 + (long)l * g.layer_stride;
-      float* ring = g.state + ((long)roff[l] + pos[l]) * C;
-      for (int c = tid; c < C; c += NT) sts[c] = ring[c];
-      __syncthreads();
-      // ---- 1. filter / gate pre-activations
-      for (int o = tid; o < 2 * C; o += NT) {
-        const int which = o / C, c = o - which * C;
-        const float* w0 = blk + (long)which * 2 * CC + c;   // W_which[0][:, c]
-        const float* w1 = w0 + CC;                          // W_which[1][:, c]
-        float s0 = g.bias_fg ? g.bias_fg[(long)l * 2 * C + o] : 0.f, s1 = 0.f;
-        fgw_dot2(sts, w0, xs, w1, C, C, s0, s1);
-        apre[o] = s0 + s1;
-      }
-      __syncthreads();
-      // ---- 2. gate; enqueue x_l[t] in place of the entry just read
-      for (int c = tid; c < C; c += NT) {
-        zs[c] = wn_tanh(apre[c]) * wn_sigmoid(apre[C + c]);
-        if (g.push) ring[c] = xs[c];
-      }
-      __syncthreads();
-      // ---- 3. residual 1x1 conv and this layer's skip contribution
-      float xn[XPT];
-#pragma unroll
-      for (int u = 0; u < XPT; ++u) {
-        const int c = tid + u * NT;
-        xn[u] = 0.f;
-        if (c < C) {
-          const float* wd = blk + 4 * CC + c;
-          const float d0 = fgw_dot(zs, wd, C, C, g.use_dense_bias ? blk[5 * CC + 2 * C + c] : 0.f);
-          xn[u] = xs[c] + d0;
-        }
-      }
-      {
-        const float* ws = g.skip_w + (long)l * C * S;
-#pragma unroll
-        for (int oi = 0; oi < SPT; oi += 2) {
-          const int sc = tid + oi * NT;
-          if (sc + NT < S)             // this thread's next two columns
-            fgw_dot2(zs, ws + sc, zs, ws + sc + NT, S, C, acc[oi], acc[oi + 1]);
-          else if (sc < S)
-            acc[oi] = fgw_dot(zs, ws + sc, S, C, acc[oi]);
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int u = 0; u < XPT; ++u)
-        if (tid + u * NT < C) xs[tid + u * NT] = xn[u];
-      __syncthreads();
-    }
-    if (g.push) {
-      for (int l = tid; l < L; l += NT) {
-        const int p = pos[l] + 1;
-        pos[l] = p == sdil[l] ? 0 : p;
-      }
-    }
-    // ---- post-processing (model.py:505-514)
-    {
-#pragma unroll
-      for (int oi = 0; oi < SPT; ++oi) {
-        const int sc = tid + oi * NT;
-        if (sc < S)
-          hbuf[sc] = fmaxf(acc[oi] + (g.skip_bsum ? g.skip_bsum[sc] : 0.f), 0.f);
-      }
-    }
-    __syncthreads();
-    for (int sc = tid; sc < S; sc += NT) {
-      const float c0 = fgw_dot(hbuf, g.post1_w + sc, S, S, g.post1_b ? g.post1_b[sc] : 0.f);
-      h2buf[sc] = fmaxf(c0, 0.f);
-    }
-    __syncthreads();
-    for (int q = tid; q < Q; q += NT) {
-      const float c0 = fgw_dot(h2buf, g.post2_w + q, Q, S, g.post2_b ? g.post2_b[q] : 0.f);
-      pd[q] = (double)c0;
-    }
-    __syncthreads();
-    // ---- softmax in float64, temperature, draw: as fastgen_kernel
-    if (wave == 0) {
-      double m = -1e300;
-      for (int q = lane; q < Q; q += 64) m = fmax(m, pd[q]);
-      for (int o = 32; o >= 1; o >>= 1) m = fmax(m, __shfl_xor(m, o));
-      double se = 0.0;
-      for (int q = lane; q < Q; q += 64) {
-        const double e = exp(pd[q] - m);
-        pd[q] = e;
-        se += e;
-      }
-      for (int o = 32; o >= 1; o >>= 1) se += __shfl_xor(se, o);
-      const bool want_p = g.proba_out && (step % g.proba_every == 0);
-      float* po = want_p ? g.proba_out + (long)(step / g.proba_every) * Q : nullptr;
-      for (int q = lane; q < Q; q += 64) {
-        const float p32 = (float)(pd[q] / se);
-        if (po) po[q] = p32;
-        pd[q] = (double)p32;
-      }
-    }
-    __syncthreads();
-    if (step + 1 >= g.n_given) {
-      if (wave == 0) {
-        const double tau = (double)g.temperature;
-        if (g.temperature != 1.0f) {
-          double mx = -1e300;
-          for (int q = lane; q < Q; q += 64) {
-            const double lp = log(pd[q] > 0.0 ? pd[q] : 1e-300) / tau;
-            pd[q] = lp;
-            mx = fmax(mx, lp);
-          }
-          for (int o = 32; o >= 1; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
-          for (int q = lane; q < Q; q += 64) pd[q] = exp(pd[q] - mx);
-        }
-        __builtin_amdgcn_wave_barrier();
-        const int per = (Q + 63) / 64;
-        const int q0 = lane * per, q1 = min(Q, q0 + per);
-        double seg = 0.0;
-        for (int q = q0; q < q1; ++q) seg += pd[q];
-        double incl = seg;
-        for (int o = 1; o < 64; o <<= 1) {
-          const double v = __shfl_up(incl, o);
-          if (lane >= o) incl += v;
-        }
-        const double total = __shfl(incl, 63);
-        const uint64_t r = splitmix64(g.seed ^ splitmix64((uint64_t)tpos));
-        const double u = (double)(r >> 11) * (1.0 / 9007199254740992.0) * total;
-        // (the neighbour's inclusive sum, not incl - seg: the lanes' intervals
-        // then tile [0, total) exactly -- no gap a draw could fall into)
-        const double up = __shfl_up(incl, 1);
-        const double excl = lane == 0 ? 0.0 : up;
-        int pick = -1;
-        if (u >= excl && u < incl) {
-          double c = excl;
-          pick = q1 - 1;
-          for (int q = q0; q < q1; ++q) {
-            c += pd[q];
-            if (u < c) { pick = q; break; }
-          }
-        }
-        int best = pick;
-        for (int o = 32; o >= 1; o >>= 1) best = max(best, __shfl_xor(best, o));
-        if (best < 0) best = Q - 1;
-        if (lane == 0) {
-          g.samples[step + 1] = best;
-          s_code = best;
-        }
-      }
-    } else if (tid == 0) {
-      s_code = g.samples[step + 1];
-    }
-    prev_code = code;
-    __syncthreads();
-  }
-  if (tid == 0 && g.push) {
-    g.cursors[0] = steps_done + g.n_steps;
-    g.cursors[1] = prev_code;
-  }
-}
-
-// ===========================================================================
 // Multi-CU fast generation: one generated sample = four small kernels on the
 // stream (captured into a hipGraph by the host, hundreds of samples per
 // replay):
@@ -1606,6 +1201,91 @@ __device__ __forceinline__ void fg_draw_wg256(const FgStep& g, const FgDrawCtl& 
   }
 }
 
+// A post-processing mat-vec role of the persistent launches (postprocess1 /
+// logits): 16 outputs col0 .. col0 + 15 of out = act(in[S] W[:, N] + bias), the
+// input from the hand-over words `src`, the outputs to `dst`, one step after
+// the other.  256 threads; lds: 2 S floats (S a multiple of 64) or S + 16 S + 256.
+// stamp: diagnostic builds, one slot every 16 per step, or null.
+__device__ __forceinline__ void fgp_post_role(const float* W, const float* bias, int col0, int N,
+                                              int S, bool lg, const fgp_ll_t* src, fgp_ll_t* dst,
+                                              int n_steps, float* lds, unsigned* sync, bool& dead,
+                                              int tid, unsigned long long* stamp) {
+  float* in_s = lds;
+  const int o = tid & 15, part = tid >> 4;
+  if ((S & 63) == 0) {
+    // Round 5: the thread's 32 weights stay in REGISTERS for the run, the 16
+    // K-slices of an output sit on 16 adjacent lanes (slice p = lane & 15 of a
+    // row), the input vector is stored slice-interleaved ([unit i of the
+    // slice][slice]: the lanes' eight 16-byte reads are conflict-free), and the
+    // slices' partial sums are added by fifteen DPP row shifts -- in slice
+    // order with the same four chains per slice as fgp_mv16 / the step
+    // kernels, so the bits are theirs.  One barrier a step (the input buffer
+    // alternates), no weight or partial-sum traffic through LDS.
+    const int o2 = tid >> 4, p2 = tid & 15;
+    const int upp = S >> 6, per = S >> 4;          // 16-byte units / floats of a slice
+    float wr[8][4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        wr[u][e] = (u < upp && col0 + o2 < N)
+                       ? W[(size_t)(p2 * per + 4 * u + e) * N + col0 + o2] : 0.f;
+    const float bv = (bias && col0 + o2 < N) ? bias[col0 + o2] : 0.f;
+    // word k -> float ((u % upp) * 16 + u / upp) * 4 + (k & 3), u = k >> 2
+    auto spos = [&](int k) { const int u = k >> 2; return ((u % upp) * 16 + u / upp) * 4 + (k & 3); };
+    const int d0 = spos(tid), d1 = spos(tid + 256);
+    for (int i = 0; i < n_steps; ++i) {
+      const unsigned step = (unsigned)(i + 1);
+      float* buf = in_s + (i & 1) * S;
+      fgp_get2(buf, src, tid, S, step, sync, dead, d0, d1);
+      __syncthreads();
+      const f32x4* b4 = reinterpret_cast<const f32x4*>(buf) + p2;
+      float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (u < upp) {
+          const f32x4 v = b4[u * 16];
+          c0 = fmaf(v[0], wr[u][0], c0); c1 = fmaf(v[1], wr[u][1], c1);
+          c2 = fmaf(v[2], wr[u][2], c2); c3 = fmaf(v[3], wr[u][3], c3);
+        }
+      const float r = (c0 + c1) + (c2 + c3);
+      // lane 15 of the row: ((r_0 + r_1) + ...) + r_15
+      float t = r;
+#pragma unroll
+      for (int q = 0; q < 15; ++q) t = dpp_f32<0x111, 0xf>(0.f, t) + r;
+      if (p2 == 15 && col0 + o2 < N) {
+        t += bv;
+        fgp_put(dst + col0 + o2, lg ? t : fmaxf(t, 0.f), step);
+      }
+      if (stamp && (tid & 63) == 0) stamp[(size_t)i * 16] = __builtin_amdgcn_s_memrealtime();
+    }
+    return;
+  }
+  float* w_s = lds + ((S + 3) & ~3);                // [S][16]
+  float* red = w_s + (size_t)S * 16;
+  for (int i = tid; i < S * 16; i += 256) {
+    const int k = i >> 4, c = i & 15;
+    w_s[i] = col0 + c < N ? W[(size_t)k * N + col0 + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = 0; i < n_steps; ++i) {
+    const unsigned step = (unsigned)(i + 1);
+    fgp_get2(in_s, src, tid, S, step, sync, dead);
+    __syncthreads();
+    red[part * 16 + o] = fgp_mv16(in_s, w_s, S, o, part, 16);
+    __syncthreads();
+    if (part == 0 && col0 + o < N) {
+      float t = 0.f;
+#pragma unroll
+      for (int p = 0; p < 16; ++p) t += red[p * 16 + o];
+      t += bias ? bias[col0 + o] : 0.f;
+      fgp_put(dst + col0 + o, lg ? t : fmaxf(t, 0.f), step);
+    }
+    if (stamp && (tid & 63) == 0) stamp[(size_t)i * 16] = __builtin_amdgcn_s_memrealtime();
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(FGP_THREADS) void fg_persist_kernel(FgPersist a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const FgStep& g = a.g;
@@ -1866,85 +1546,10 @@ __global__ __launch_bounds__(FGP_THREADS) void fg_persist_kernel(FgPersist a) {
   if (role < nsk + nlg) {
     // ------------------------------------------------------- post1 / logits
     const bool lg = role >= nsk;
-    const int col0 = (lg ? role - nsk : role) * 16, N = lg ? Q : S;
-    const float* W = lg ? g.post2_w : g.post1_w;
-    const float* bias = lg ? g.post2_b : g.post1_b;
-    const fgp_ll_t* src = lg ? h2ll : h1ll;
-    fgp_ll_t* dst = lg ? lgll : h2ll;
-    if ((S & 63) == 0) {
-      // Round 5: the thread's 32 weights stay in REGISTERS for the run, the 16
-      // K-slices of an output sit on 16 adjacent lanes (slice p = lane & 15 of a
-      // row), the input vector is stored slice-interleaved ([unit i of the
-      // slice][slice]: the lanes' eight 16-byte reads are conflict-free), and the
-      // slices' partial sums are added by fifteen DPP row shifts -- in slice
-      // order with the same four chains per slice as fgp_mv16 / the step
-      // kernels, so the bits are theirs.  One barrier a step (the input buffer
-      // alternates), no weight or partial-sum traffic through LDS.
-      const int o2 = tid >> 4, p2 = tid & 15;
-      const int upp = S >> 6, per = S >> 4;          // 16-byte units / floats of a slice
-      float wr[8][4];
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          wr[u][e] = (u < upp && col0 + o2 < N)
-                         ? W[(size_t)(p2 * per + 4 * u + e) * N + col0 + o2] : 0.f;
-      const float bv = (bias && col0 + o2 < N) ? bias[col0 + o2] : 0.f;
-      // word k -> float ((u % upp) * 16 + u / upp) * 4 + (k & 3), u = k >> 2
-      auto spos = [&](int k) { const int u = k >> 2; return ((u % upp) * 16 + u / upp) * 4 + (k & 3); };
-      const int d0 = spos(tid), d1 = spos(tid + 256);
-      for (int i = 0; i < n_steps; ++i) {
-        const unsigned step = (unsigned)(i + 1);
-        float* buf = in_s + (i & 1) * S;
-        fgp_get2(buf, src, tid, S, step, sync, dead, d0, d1);
-        __syncthreads();
-        const f32x4* b4 = reinterpret_cast<const f32x4*>(buf) + p2;
-        float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (u < upp) {
-            const f32x4 v = b4[u * 16];
-            c0 = fmaf(v[0], wr[u][0], c0); c1 = fmaf(v[1], wr[u][1], c1);
-            c2 = fmaf(v[2], wr[u][2], c2); c3 = fmaf(v[3], wr[u][3], c3);
-          }
-        const float r = (c0 + c1) + (c2 + c3);
-        // lane 15 of the row: ((r_0 + r_1) + ...) + r_15
-        float t = r;
-#pragma unroll
-        for (int q = 0; q < 15; ++q) t = dpp_f32<0x111, 0xf>(0.f, t) + r;
-        if (p2 == 15 && col0 + o2 < N) {
-          t += bv;
-          fgp_put(dst + col0 + o2, lg ? t : fmaxf(t, 0.f), step);
-        }
-        if (role == 0) { PSTAMP(i * 16 + 12); }
-        if (role == nsk) { PSTAMP(i * 16 + 13); }
-      }
-      return;
-    }
-    float* w_s = lds + ((S + 3) & ~3);                // [S][16]
-    float* red = w_s + (size_t)S * 16;
-    for (int i = tid; i < S * 16; i += 256) {
-      const int k = i >> 4, c = i & 15;
-      w_s[i] = col0 + c < N ? W[(size_t)k * N + col0 + c] : 0.f;
-    }
-    __syncthreads();
-    for (int i = 0; i < n_steps; ++i) {
-      const unsigned step = (unsigned)(i + 1);
-      fgp_get2(in_s, src, tid, S, step, sync, dead);
-      __syncthreads();
-      red[part * 16 + o] = fgp_mv16(in_s, w_s, S, o, part, 16);
-      __syncthreads();
-      if (part == 0 && col0 + o < N) {
-        float t = 0.f;
-#pragma unroll
-        for (int p = 0; p < 16; ++p) t += red[p * 16 + o];
-        t += bias ? bias[col0 + o] : 0.f;
-        fgp_put(dst + col0 + o, lg ? t : fmaxf(t, 0.f), step);
-      }
-      if (role == 0) { PSTAMP(i * 16 + 12); }
-      if (role == nsk) { PSTAMP(i * 16 + 13); }
-      __syncthreads();
-    }
+    fgp_post_role(lg ? g.post2_w : g.post1_w, lg ? g.post2_b : g.post1_b,
+                  (lg ? role - nsk : role) * 16, lg ? Q : S, S, lg, lg ? h2ll : h1ll,
+                  lg ? lgll : h2ll, n_steps, lds, sync, dead, tid,
+                  a.dbg && role == 0 ? a.dbg + 12 : (a.dbg && role == nsk ? a.dbg + 13 : nullptr));
     return;
   }
   // ---------------------------------------------------------------------- draw
@@ -1978,6 +1583,500 @@ __global__ __launch_bounds__(FGP_THREADS) void fg_persist_kernel(FgPersist a) {
   }
 #undef PSTAMP
 }
+
+// ===========================================================================
+// Wide fast generation: the same incremental generator for MORE than 32
+// residual / dilation channels (C = 32 * blocks padded channels, weights in the
+// reference's [K][C][C] layout of wavenet/blocked.py; the reference's
+// generator has no width limit, model.py:444-516).  One persistent workgroup,
+// correctness first: per layer three phases separated by workgroup barriers
+//   1. thread (which, c): a_which[c] = bias + st . W_which[0][:, c] + x . W_which[1][:, c]
+//   2. z = tanh(a_f) sigmoid(a_g); the queue entry is replaced by x (push)
+//   3. x += bd + z . Wd  (every layer, as model.py:377-380); total += z . Ws_l
+// then the post-processing mat-vecs, the float64 softmax and the same
+// counter-based draw as fastgen_kernel (same seed -> same uniform per step).
+// Queues: layer l's ring holds d_l rows of C floats at state + roff[l] * C.
+// ===========================================================================
+#define FGW_THREADS 256
+#define FGW_MAXC 1024
+#define FGW_MAXS 4096
+#define FGW_MAXQ 4096
+#define FGW_MAXL 1024
+#define FGW_XPT (FGW_MAXC / FGW_THREADS)   // residual channels per thread
+#define FGW_SPT (FGW_MAXS / FGW_THREADS)   // skip channels per thread
+
+// dynamic LDS of the wide generator: Q doubles, then 5 C + 2 S floats, 3 L ints
+static size_t fgw_lds_bytes(int C, int S, int Q, int L) {
+  return (size_t)Q * 8 + ((size_t)5 * C + 2 * (size_t)S + 3 * (size_t)L) * 4;
+}
+
+// sum_k in[k] * w[k * stride]: the weight loads in batches (all of a batch in
+// flight before its FMAs: 64, then 16, 4 and 1 for what is left) into four
+// partial sums -- a plain loop waits for every load before the next one is
+// issued, and the wide generator is nothing but such loops (64 channels,
+// default stack: 3.5 ms per sample with one load per FMA, 0.77 / 0.50 / 0.37 /
+// 0.31 ms with batches of 8 / 16 / 32 / 64).
+#define FGW_BATCH 64
+__device__ __forceinline__ float fgw_dot(const float* in, const float* __restrict__ w,
+                                         long stride, int K, float init) {
+  float c[4] = {init, 0.f, 0.f, 0.f};
+  int k = 0;
+  for (; k + FGW_BATCH <= K; k += FGW_BATCH) {
+    float wv[FGW_BATCH];
+#pragma unroll
+    for (int u = 0; u < FGW_BATCH; ++u) wv[u] = w[(long)(k + u) * stride];
+#pragma unroll
+    for (int u = 0; u < FGW_BATCH; ++u) c[u & 3] = fmaf(in[k + u], wv[u], c[u & 3]);
+  }
+  for (; k + 16 <= K; k += 16) {
+    float wv[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) wv[u] = w[(long)(k + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) c[u & 3] = fmaf(in[k + u], wv[u], c[u & 3]);
+  }
+  for (; k + 4 <= K; k += 4) {
+    float wv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) wv[u] = w[(long)(k + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) c[u] = fmaf(in[k + u], wv[u], c[u]);
+  }
+  for (; k < K; ++k) c[0] = fmaf(in[k], w[(long)k * stride], c[0]);
+  return (c[0] + c[1]) + (c[2] + c[3]);
+}
+
+// two such sums at once (both batches of weight loads in flight together)
+__device__ __forceinline__ void fgw_dot2(const float* in0, const float* __restrict__ w0,
+                                         const float* in1, const float* __restrict__ w1,
+                                         long stride, int K, float& r0, float& r1) {
+  float a[4] = {r0, 0.f, 0.f, 0.f}, b[4] = {r1, 0.f, 0.f, 0.f};
+  int k = 0;
+  for (; k + 32 <= K; k += 32) {
+    float u0[32], u1[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) u0[u] = w0[(long)(k + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) u1[u] = w1[(long)(k + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) a[u & 3] = fmaf(in0[k + u], u0[u], a[u & 3]);
+#pragma unroll
+    for (int u = 0; u < 32; ++u) b[u & 3] = fmaf(in1[k + u], u1[u], b[u & 3]);
+  }
+  r0 = (a[0] + a[1]) + (a[2] + a[3]);
+  r1 = (b[0] + b[1]) + (b[2] + b[3]);
+  if (k < K) {
+    r0 = fgw_dot(in0 + k, w0 + (long)k * stride, stride, K - k, r0);
+    r1 = fgw_dot(in1 + k, w1 + (long)k * stride, stride, K - k, r1);
+  }
+}
+
+struct FastGenWide {
+  FastGen g;
+  int C;        // padded channels (multiple of 32, <= FGW_MAXC)
+  // cooperative launch (64 channels): FGP_WORDS sync words, then the hand-over
+  // words z [L][64] | h1 [S] | h2 [S] | logits [Q]; zero before the launch
+  unsigned* sync;
+  fgp_ll_t* ll;
+};
+
+// Cooperative 64-channel generator (round 5).  The single workgroup above pulls
+// 10.4 MB of weights per sample through ONE CU: 208 KB a layer, 128 KB of them
+// the layer's skip weights, and 1.5 MB for the two post-processing mat-vecs.
+// Here workgroup 0 keeps the serial part -- the layers' filter / gate / dense
+// mat-vecs and the draw -- and publishes every layer's z as tagged hand-over
+// words; S / 16 skip workgroups add z_l Ws_l[:, their 16 columns] as the words
+// arrive (their weights from their own CUs' L2 share, a layer ahead), then
+// S / 16 + Q / 16 post-processing workgroups (fgp_post_role, weights in
+// registers) turn h1 into the logits, which workgroup 0 polls.  Same
+// arithmetic per output as the single workgroup up to the order of the skip
+// sum's additions.  Every workgroup must be resident (checked by the host).
+
+// F64 (64 channels, at most 512 skip channels): the generic layer body pays
+// three dependent weight-load latencies per layer (past-tap ring entry ->
+// filter / gate weights -> dense + skip weights; 213 KB a layer through ONE
+// CU, 10.6 MB a sample through one XCD's 4 MB L2: 0.30 ms per sample).  None of
+// the weights depends on the data: here (512 threads) EVERY load of a layer --
+// the ring entry, a thread's 32 filter / gate weights (output o = tid & 127, a
+// quarter of the contraction each), its 8 dense weights (an eighth of the
+// contraction) a LAYER AHEAD, the 64 weights of its skip column, which the
+// layer needs last, at the layer's own top -- and the phases only synchronise
+// through LDS, four barriers a layer (207 us per sample with every load at the
+// layer's own top and 256 threads; without the skip weights' loads a sample
+// takes 144 us: they are the 54 us still exposed).
+struct FgwLayer64 {
+  float ringv, wa[16], wb[16], wdv[8], bf, bg, bdv;
+};
+template <bool F64, bool COOP>
+__global__ __launch_bounds__(F64 ? 512 : FGW_THREADS, 1) void fastgen_wide_kernel(FastGenWide a) {
+  static_assert(F64 || !COOP, "the cooperative launch is the 64-channel one");
+  constexpr int NT = F64 ? 512 : FGW_THREADS;    // threads
+  constexpr int SPT = FGW_MAXS / NT, XPT = FGW_MAXC / NT;
+  const FastGen& g = a.g;
+  extern __shared__ double fgw_lds[];
+  const int S = g.S, Q = g.Q, L = g.L, C = a.C;
+  double* pd = fgw_lds;                           // [Q]
+  float* xs = reinterpret_cast<float*>(pd + Q);   // [C]
+  float* sts = xs + C;                            // [C]
+  float* zs = sts + C;                            // [C]
+  float* apre = zs + C;                           // [2 C]
+  float* hbuf = apre + 2 * C;                     // [S]
+  float* h2buf = hbuf + S;                        // [S]
+  int* pos = reinterpret_cast<int*>(h2buf + S);   // [L]
+  int* sdil = pos + L;                            // [L]
+  int* roff = sdil + L;                           // [L]
+  __shared__ int s_code;
+  __shared__ float f64_part[F64 ? 4 * 128 + 8 * 64 : 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long CC = (long)C * C;
+  fgp_ll_t* zll = a.ll;                            // [L][64]
+  fgp_ll_t* h1ll = COOP ? zll + (size_t)L * 64 : nullptr;
+  fgp_ll_t* h2ll = COOP ? h1ll + S : nullptr;
+  fgp_ll_t* lgll = COOP ? h2ll + S : nullptr;
+  bool dead = false;
+  if (COOP && blockIdx.x > 0) {
+    if (tid >= 256) return;                        // the workers are 256-thread roles
+    float* wlds = reinterpret_cast<float*>(fgw_lds);
+    const int nsk = (S + 15) / 16;
+    int role = blockIdx.x - 1;
+    if (role < nsk) {
+      // ---- skip worker: columns col0 .. col0 + 15, thread (o, part) adds the
+      // products of z_l[4 part .. 4 part + 3] for every layer; the layer's four
+      // weights are requested a layer ahead
+      const int o = tid & 15, part = tid >> 4, col = role * 16 + o;
+      float* zb = wlds;                            // [2][64]
+      float* red = wlds + 128;                     // [16][16]
+      const bool live = col < S;
+      auto wload = [&](int l, float (&w)[4]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          w[e] = live ? g.skip_w[((size_t)l * 64 + 4 * part + e) * S + col] : 0.f;
+      };
+      const float bsum = (live && g.skip_bsum) ? g.skip_bsum[col] : 0.f;
+      for (int step = 0; step < g.n_steps; ++step) {
+        const unsigned tag = (unsigned)(step + 1);
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+        float wc[4], wn[4];
+        wload(0, wc);
+        for (int l = 0; l < L; ++l) {
+          if (l + 1 < L) wload(l + 1, wn);
+          float* zl = zb + (l & 1) * 64;
+          if (tid < 64) zl[tid] = fgp_get(zll + (size_t)l * 64 + tid, tag, a.sync, dead);
+          __syncthreads();
+          const f32x4 zv = *reinterpret_cast<const f32x4*>(zl + 4 * part);
+          c0 = fmaf(zv[0], wc[0], c0); c1 = fmaf(zv[1], wc[1], c1);
+          c2 = fmaf(zv[2], wc[2], c2); c3 = fmaf(zv[3], wc[3], c3);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) wc[e] = wn[e];
+        }
+        red[part * 16 + o] = (c0 + c1) + (c2 + c3);
+        __syncthreads();
+        if (part == 0 && live) {
+          float t = 0.f;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) t += red[q * 16 + o];
+          fgp_put(h1ll + col, fmaxf(bsum + t, 0.f), tag);
+        }
+        __syncthreads();                           // (red is rewritten in the next step)
+      }
+      return;
+    }
+    role -= nsk;
+    const bool lg = role >= nsk;
+    fgp_post_role(lg ? g.post2_w : g.post1_w, lg ? g.post2_b : g.post1_b,
+                  (lg ? role - nsk : role) * 16, lg ? Q : S, S, lg, lg ? h2ll : h1ll,
+                  lg ? lgll : h2ll, g.n_steps, wlds, a.sync, dead, tid, nullptr);
+    return;
+  }
+  const int steps_done = g.cursors[0];
+  int prev_code = g.cursors[1];
+  if (tid == 0) s_code = g.samples[0];
+  for (int l = tid; l < L; l += NT) {
+    sdil[l] = g.dil[l];
+    pos[l] = steps_done % g.dil[l];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int off = 0;
+    for (int l = 0; l < L; ++l) { roff[l] = off; off += sdil[l]; }
+  }
+  __syncthreads();
+
+  for (int step = 0; step < g.n_steps; ++step) {
+    const int code = s_code;
+    const long tpos = (long)steps_done + step;
+    float acc[SPT];
+#pragma unroll
+    for (int o = 0; o < SPT; ++o) acc[o] = 0.f;
+    // causal layer: one-hot input = two table rows (model.py:341-346)
+    for (int c = tid; c < C; c += NT) {
+      float v = 0.f;
+      if (prev_code >= 0 && prev_code < Q) v = g.causal[(long)prev_code * C + c];
+      if (code >= 0 && code < Q) v += g.causal[((long)Q + code) * C + c];
+      xs[c] = v;
+    }
+    __syncthreads();
+    if (F64) {
+      const int o1 = tid & 127, kq = tid >> 7;       // filter / gate output, quarter of K
+      const int cd = tid & 63, k8 = tid >> 6;        // dense output, eighth of K
+      const int c0 = tid < S ? tid : 0;              // skip column
+      auto request = [&](int l) {
+        FgwLayer64 w;
+        const float* blk = g.layer0 + (long)l * g.layer_stride;
+        w.ringv = tid < 64 ? g.state[((long)roff[l] + pos[l]) * 64 + tid] : 0.f;
+        const float* w0 = blk + (long)(o1 >> 6) * 2 * 4096 + (o1 & 63) + kq * 16 * 64;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { w.wa[u] = w0[u * 64]; w.wb[u] = w0[4096 + u * 64]; }
+        const float* wd = blk + 4 * 4096 + cd + k8 * 8 * 64;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w.wdv[u] = wd[u * 64];
+        w.bf = tid < 64 && g.bias_fg ? g.bias_fg[(long)l * 128 + tid] : 0.f;
+        w.bg = tid < 64 && g.bias_fg ? g.bias_fg[(long)l * 128 + 64 + tid] : 0.f;
+        w.bdv = tid < 64 && g.use_dense_bias ? blk[5 * 4096 + 128 + tid] : 0.f;
+        return w;
+      };
+      FgwLayer64 cur = request(0);
+      if (tid < 64) sts[tid] = cur.ringv;
+      __syncthreads();
+      // (four workgroup barriers a layer: partial sums | gate | partial sums |
+      // x' and the next layer's past tap)
+      for (int l = 0; l < L; ++l) {
+        // (the skip column's weights, which the layer needs last, at its own
+        // top: requesting them a layer ahead -- into the registers the layer
+        // before has just multiplied out of -- sends the register allocator
+        // into 119 spills and the sample to 284 us)
+        float ws0[COOP ? 1 : 64];
+        if (!COOP) {
+          const float* ws = g.skip_w + (long)l * 64 * S + c0;
+#pragma unroll
+          for (int u = 0; u < 64; ++u) ws0[u] = ws[(long)u * S];
+        }
+        FgwLayer64 nxt = cur;
+        if (l + 1 < L) nxt = request(l + 1);
+        float* ring = g.state + ((long)roff[l] + pos[l]) * 64;
+        // ---- 1. filter / gate pre-activations, a quarter of the contraction per thread
+        {
+          float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+#pragma unroll
+          for (int u = 0; u < 16; u += 2) {
+            p0 = fmaf(sts[kq * 16 + u], cur.wa[u], p0);
+            p1 = fmaf(xs[kq * 16 + u], cur.wb[u], p1);
+            p2 = fmaf(sts[kq * 16 + u + 1], cur.wa[u + 1], p2);
+            p3 = fmaf(xs[kq * 16 + u + 1], cur.wb[u + 1], p3);
+          }
+          f64_part[kq * 128 + o1] = (p0 + p1) + (p2 + p3);
+        }
+        __syncthreads();
+        // ---- 2. gate; enqueue x_l[t] in place of the entry just read
+        if (tid < 64) {
+          const float af = cur.bf + ((f64_part[tid] + f64_part[128 + tid]) +
+                                     (f64_part[256 + tid] + f64_part[384 + tid]));
+          const float ag = cur.bg + ((f64_part[64 + tid] + f64_part[192 + tid]) +
+                                     (f64_part[320 + tid] + f64_part[448 + tid]));
+          const float zv = wn_tanh(af) * wn_sigmoid(ag);
+          zs[tid] = zv;
+          // (cooperative launch: the skip workgroups take it from here)
+          if (COOP) fgp_put(zll + (size_t)l * 64 + tid, zv, (unsigned)(step + 1));
+          if (g.push) ring[tid] = xs[tid];
+        }
+        __syncthreads();
+        // ---- 3. residual 1x1 conv (an eighth of the contraction per thread)
+        // and this layer's skip contribution
+        {
+          float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+          for (int u = 0; u < 8; u += 2) {
+            d0 = fmaf(zs[k8 * 8 + u], cur.wdv[u], d0);
+            d1 = fmaf(zs[k8 * 8 + u + 1], cur.wdv[u + 1], d1);
+          }
+          f64_part[512 + k8 * 64 + cd] = d0 + d1;
+          if (!COOP) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+            for (int u = 0; u < 64; u += 4) {
+              a0 = fmaf(zs[u], ws0[u], a0);
+              a1 = fmaf(zs[u + 1], ws0[u + 1], a1);
+              a2 = fmaf(zs[u + 2], ws0[u + 2], a2);
+              a3 = fmaf(zs[u + 3], ws0[u + 3], a3);
+            }
+            if (tid < S) acc[0] += (a0 + a1) + (a2 + a3);
+          }
+        }
+        __syncthreads();
+        if (tid < 64) {
+          float t = 0.f;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) t += f64_part[512 + q * 64 + tid];
+          xs[tid] = xs[tid] + (cur.bdv + t);
+          sts[tid] = nxt.ringv;          // (the next layer's past tap)
+        }
+        __syncthreads();
+        cur = nxt;
+      }
+    }
+    for (int l = 0; !F64 && l < L; ++l) {
+      const float* blk = g.layer0 + (long)l * g.layer_stride;
+      float* ring = g.state + ((long)roff[l] + pos[l]) * C;
+      for (int c = tid; c < C; c += NT) sts[c] = ring[c];
+      __syncthreads();
+      // ---- 1. filter / gate pre-activations
+      for (int o = tid; o < 2 * C; o += NT) {
+        const int which = o / C, c = o - which * C;
+        const float* w0 = blk + (long)which * 2 * CC + c;   // W_which[0][:, c]
+        const float* w1 = w0 + CC;                          // W_which[1][:, c]
+        float s0 = g.bias_fg ? g.bias_fg[(long)l * 2 * C + o] : 0.f, s1 = 0.f;
+        fgw_dot2(sts, w0, xs, w1, C, C, s0, s1);
+        apre[o] = s0 + s1;
+      }
+      __syncthreads();
+      // ---- 2. gate; enqueue x_l[t] in place of the entry just read
+      for (int c = tid; c < C; c += NT) {
+        zs[c] = wn_tanh(apre[c]) * wn_sigmoid(apre[C + c]);
+        if (g.push) ring[c] = xs[c];
+      }
+      __syncthreads();
+      // ---- 3. residual 1x1 conv and this layer's skip contribution
+      float xn[XPT];
+#pragma unroll
+      for (int u = 0; u < XPT; ++u) {
+        const int c = tid + u * NT;
+        xn[u] = 0.f;
+        if (c < C) {
+          const float* wd = blk + 4 * CC + c;
+          const float d0 = fgw_dot(zs, wd, C, C, g.use_dense_bias ? blk[5 * CC + 2 * C + c] : 0.f);
+          xn[u] = xs[c] + d0;
+        }
+      }
+      {
+        const float* ws = g.skip_w + (long)l * C * S;
+#pragma unroll
+        for (int oi = 0; oi < SPT; oi += 2) {
+          const int sc = tid + oi * NT;
+          if (sc + NT < S)             // this thread's next two columns
+            fgw_dot2(zs, ws + sc, zs, ws + sc + NT, S, C, acc[oi], acc[oi + 1]);
+          else if (sc < S)
+            acc[oi] = fgw_dot(zs, ws + sc, S, C, acc[oi]);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < XPT; ++u)
+        if (tid + u * NT < C) xs[tid + u * NT] = xn[u];
+      __syncthreads();
+    }
+    if (g.push) {
+      for (int l = tid; l < L; l += NT) {
+        const int p = pos[l] + 1;
+        pos[l] = p == sdil[l] ? 0 : p;
+      }
+    }
+    // ---- post-processing (model.py:505-514)
+    if (COOP) {
+      // (the worker workgroups: skip sum -> postprocess1 -> logits)
+      for (int q = tid; q < Q; q += NT)
+        pd[q] = (double)fgp_get(lgll + q, (unsigned)(step + 1), a.sync, dead);
+      __syncthreads();
+    } else {
+      {
+#pragma unroll
+        for (int oi = 0; oi < SPT; ++oi) {
+          const int sc = tid + oi * NT;
+          if (sc < S)
+            hbuf[sc] = fmaxf(acc[oi] + (g.skip_bsum ? g.skip_bsum[sc] : 0.f), 0.f);
+        }
+      }
+      __syncthreads();
+      for (int sc = tid; sc < S; sc += NT) {
+        const float c0 = fgw_dot(hbuf, g.post1_w + sc, S, S, g.post1_b ? g.post1_b[sc] : 0.f);
+        h2buf[sc] = fmaxf(c0, 0.f);
+      }
+      __syncthreads();
+      for (int q = tid; q < Q; q += NT) {
+        const float c0 = fgw_dot(h2buf, g.post2_w + q, Q, S, g.post2_b ? g.post2_b[q] : 0.f);
+        pd[q] = (double)c0;
+      }
+      __syncthreads();
+    }
+    // ---- softmax in float64, temperature, draw: as fastgen_kernel
+    if (wave == 0) {
+      double m = -1e300;
+      for (int q = lane; q < Q; q += 64) m = fmax(m, pd[q]);
+      for (int o = 32; o >= 1; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+      double se = 0.0;
+      for (int q = lane; q < Q; q += 64) {
+        const double e = exp(pd[q] - m);
+        pd[q] = e;
+        se += e;
+      }
+      for (int o = 32; o >= 1; o >>= 1) se += __shfl_xor(se, o);
+      const bool want_p = g.proba_out && (step % g.proba_every == 0);
+      float* po = want_p ? g.proba_out + (long)(step / g.proba_every) * Q : nullptr;
+      for (int q = lane; q < Q; q += 64) {
+        const float p32 = (float)(pd[q] / se);
+        if (po) po[q] = p32;
+        pd[q] = (double)p32;
+      }
+    }
+    __syncthreads();
+    if (step + 1 >= g.n_given) {
+      if (wave == 0) {
+        const double tau = (double)g.temperature;
+        if (g.temperature != 1.0f) {
+          double mx = -1e300;
+          for (int q = lane; q < Q; q += 64) {
+            const double lp = log(pd[q] > 0.0 ? pd[q] : 1e-300) / tau;
+            pd[q] = lp;
+            mx = fmax(mx, lp);
+          }
+          for (int o = 32; o >= 1; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+          for (int q = lane; q < Q; q += 64) pd[q] = exp(pd[q] - mx);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int per = (Q + 63) / 64;
+        const int q0 = lane * per, q1 = min(Q, q0 + per);
+        double seg = 0.0;
+        for (int q = q0; q < q1; ++q) seg += pd[q];
+        double incl = seg;
+        for (int o = 1; o < 64; o <<= 1) {
+          const double v = __shfl_up(incl, o);
+          if (lane >= o) incl += v;
+        }
+        const double total = __shfl(incl, 63);
+        const uint64_t r = splitmix64(g.seed ^ splitmix64((uint64_t)tpos));
+        const double u = (double)(r >> 11) * (1.0 / 9007199254740992.0) * total;
+        // (the neighbour's inclusive sum, not incl - seg: the lanes' intervals
+        // then tile [0, total) exactly -- no gap a draw could fall into)
+        const double up = __shfl_up(incl, 1);
+        const double excl = lane == 0 ? 0.0 : up;
+        int pick = -1;
+        if (u >= excl && u < incl) {
+          double c = excl;
+          pick = q1 - 1;
+          for (int q = q0; q < q1; ++q) {
+            c += pd[q];
+            if (u < c) { pick = q; break; }
+          }
+        }
+        int best = pick;
+        for (int o = 32; o >= 1; o >>= 1) best = max(best, __shfl_xor(best, o));
+        if (best < 0) best = Q - 1;
+        if (lane == 0) {
+          g.samples[step + 1] = best;
+          s_code = best;
+        }
+      }
+    } else if (tid == 0) {
+      s_code = g.samples[step + 1];
+    }
+    prev_code = code;
+    __syncthreads();
+  }
+  if (tid == 0 && g.push) {
+    g.cursors[0] = steps_done + g.n_steps;
+    g.cursors[1] = prev_code;
+  }
+}
+
 
 #ifdef FGP_STAMPS
 static unsigned long long* g_fgp_dbg = nullptr;   // [n_steps][16] (diagnostic build only)
@@ -2049,6 +2148,17 @@ int wn_fastgen_run(const float* params_causal, const float* layer0,
 // Wf[2][C][C] Wg[2][C][C] Wd[C][C] bf[C] bg[C] bd[C], causal [2][Q][C], skip
 // [L][C][S], gc_bias_fg [L][2 C], queues of C floats per entry:
 // state_floats = sum(dilations) * C).
+// Scratch of the cooperative 64-channel launch of wn_fastgen_run_wide (`coop`):
+// FGP_WORDS sync words (after a run word [12] != 0 = a hand-over wait expired:
+// the samples of that run are not valid) + the hand-over words; 0 = the shape
+// has no cooperative launch (C != 64, S > 512 or not a multiple of 16, Q > 512,
+// L > 256).
+long wn_fastgen_wide_coop_bytes(int L, int C, int S, int Q) {
+  if (C != 64 || S <= 0 || S > 512 || (S & 15) || Q <= 0 || Q > 512 || L <= 0 || L > 256)
+    return 0;
+  return (long)FGP_WORDS * 4 + ((long)L * 64 + 2L * S + Q) * 8;
+}
+
 int wn_fastgen_run_wide(const float* params_causal, const float* layer0,
                         long layer_stride, const float* skip_w,
                         const float* skip_bsum, const float* post1_w,
@@ -2058,7 +2168,7 @@ int wn_fastgen_run_wide(const float* params_causal, const float* layer0,
                         float* state, int32_t* cursors, int32_t* samples_io,
                         int n_given, int n_steps, float temperature,
                         uint64_t seed, float* proba_out, int proba_every,
-                        int use_biases, int push, void* stream) {
+                        int use_biases, int push, void* coop, void* stream) {
   if (!params_causal || !layer0 || !skip_w || !post1_w || !post2_w ||
       !dilations_dev || !state || !cursors || !samples_io)
     return WN_ERR_NULL;
@@ -2074,8 +2184,8 @@ int wn_fastgen_run_wide(const float* params_causal, const float* layer0,
   const bool f64 = C == 64 && S <= 512;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(
-        f64 ? reinterpret_cast<const void*>(fastgen_wide_kernel<true>)
-            : reinterpret_cast<const void*>(fastgen_wide_kernel<false>),
+        f64 ? reinterpret_cast<const void*>(fastgen_wide_kernel<true, false>)
+            : reinterpret_cast<const void*>(fastgen_wide_kernel<false, false>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return WN_ERR_LAUNCH;
   }
@@ -2094,12 +2204,36 @@ int wn_fastgen_run_wide(const float* params_causal, const float* layer0,
   g.use_dense_bias = use_biases;
   g.push = push;
   a.C = C;
+  a.sync = nullptr; a.ll = nullptr;
+  hipStream_t s = (hipStream_t)stream;
+  // cooperative launch: a shape it covers (pushed runs and the one-step peek
+  // alike, so that both give the same bits), with every
+  // workgroup resident (asked of the runtime for THIS configuration); anything
+  // else -- also a caller without scratch -- takes the single workgroup
+  if (coop && wn_fastgen_wide_coop_bytes(L, C, S, Q) > 0) {
+    if (!wn_aligned16(coop)) return WN_ERR_MISALIGNED;
+    const int wgs = 1 + 2 * ((S + 15) / 16) + (Q + 15) / 16;
+    // workers: at most S + 16 S + 256 floats (fgp_post_role); workgroup 0: as above
+    const size_t wl = ((size_t)17 * S + 512) * 4;
+    const size_t cl = lds > wl ? lds : wl;
+    const void* kf = reinterpret_cast<const void*>(fastgen_wide_kernel<true, true>);
+    int per_cu = 0;
+    if (hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cl) ==
+            hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kf, 512, cl) == hipSuccess &&
+        per_cu >= 1 && (long)wgs <= (long)per_cu * wn_device_cus()) {
+      a.sync = reinterpret_cast<unsigned*>(coop);
+      a.ll = reinterpret_cast<fgp_ll_t*>(a.sync + FGP_WORDS);
+      if (hipMemsetAsync(coop, 0, (size_t)wn_fastgen_wide_coop_bytes(L, C, S, Q), s) != hipSuccess)
+        return WN_ERR_LAUNCH;
+      hipLaunchKernelGGL((fastgen_wide_kernel<true, true>), dim3(wgs), dim3(512), cl, s, a);
+      return wn_check_launch();
+    }
+  }
   if (f64)
-    hipLaunchKernelGGL(fastgen_wide_kernel<true>, dim3(1), dim3(512), lds,
-                       (hipStream_t)stream, a);
+    hipLaunchKernelGGL((fastgen_wide_kernel<true, false>), dim3(1), dim3(512), lds, s, a);
   else
-    hipLaunchKernelGGL(fastgen_wide_kernel<false>, dim3(1), dim3(FGW_THREADS), lds,
-                       (hipStream_t)stream, a);
+    hipLaunchKernelGGL((fastgen_wide_kernel<false, false>), dim3(1), dim3(FGW_THREADS), lds, s, a);
   return wn_check_launch();
 }
 

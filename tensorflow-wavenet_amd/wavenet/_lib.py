@@ -124,7 +124,8 @@ SIGNATURES = {
     'wn_fastgen_run_wide': (c_int, [P, P, c_long, P, P, P, P, P, P, P, P,
                                     c_int, c_int, c_int, c_int, P, P, P, c_int,
                                     c_int, c_float, c_u64, P, c_int, c_int,
-                                    c_int, P]),
+                                    c_int, P, P]),
+    'wn_fastgen_wide_coop_bytes': (c_long, [c_int, c_int, c_int, c_int]),
     'wn_fastgen_step': (c_int, [P, P, c_long, P, P, P, P, P, P, P, P, c_int,
                                 c_int, c_int, P, P, P, P, P, c_int, P, P, P,
                                 P, P, P, P]),

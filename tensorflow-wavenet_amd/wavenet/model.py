@@ -352,6 +352,8 @@ class WaveNetModel(object):
         # in-launch hand-overs instead of four kernel boundaries per sample);
         # False: the step kernels replayed from a hipGraph
         self.fastgen_persistent = True
+        # 64-channel models: wn_fastgen_run_wide's cooperative launch
+        self.fastgen_wide_coop = True
         # 'fp32' (default): fp32 MFMA GEMMs.  'bf16x6' / 'bf16x9' / 'bf16x3':
         # opt-in split-bf16 products for the six NN GEMMs (wn_gemm_nn_split;
         # x6 measures the same error vs float64 as the fp32 MFMA path)
@@ -1522,11 +1524,31 @@ class WaveNetModel(object):
             # more than 32 channels, or more skip / quantization channels or
             # layers than the tuned kernels hold in LDS (FG_MAXS / FG_MAXQ /
             # FG_MAXL): the wide single-workgroup generator
+            # 64 channels: the cooperative launch (skip sum and post-processing
+            # on other CUs) when the library has one for the shape; it falls
+            # back to the single workgroup by itself when the workgroups would
+            # not all be resident
+            coop = None
+            if self.fastgen_wide_coop:
+                if 'coop' not in g:
+                    nb = _lib.load().wn_fastgen_wide_coop_bytes(
+                        self.L, self.CHn, self.S, self.Q)
+                    g['coop'] = torch.zeros(nb // 4, dtype=torch.int32,
+                                            device=self.device) if nb else None
+                coop = g['coop']
             _lib.call('wn_fastgen_run_wide', *common[:11], self.L, self.CHn,
                       self.S, self.Q, *common[14:], int(n_given), int(n_steps),
                       float(temperature), sd, _lib.ptr(proba_out),
                       int(proba_every), 1 if ub else 0, 1 if push else 0,
-                      _lib.stream())
+                      _lib.ptr(coop), _lib.stream())
+            if coop is not None and int(coop[12]) != 0:
+                # (never seen with every workgroup resident, which the library
+                # checks before it launches)
+                raise _lib.WaveNetHipError(
+                    'wn_fastgen_run_wide: a hand-over wait inside the '
+                    'cooperative launch expired; the generator state is not '
+                    'valid -- reset_generator() and generate again with '
+                    'net.fastgen_wide_coop = False')
             if push:
                 g['steps'] += int(n_steps)
             return

@@ -644,6 +644,39 @@ def test_fast_generation_above_32_channels(hip_lib, name, cfg, gc):
     assert a.min() >= 0 and a.max() < Q
 
 
+@pytest.mark.parametrize('gc', [None, 2])
+def test_wide_cooperative_generator_equals_single_workgroup(hip_lib, gc):
+    """64 channels: wn_fastgen_run_wide's cooperative launch (skip sum and
+    post-processing mat-vecs on other workgroups, hand-over words) against its
+    single workgroup: the same drawn samples, with a temperature, probabilities
+    to rounding (the skip sum adds in another order), queues and cursors that
+    continue on either path."""
+    kw = dict(global_condition_channels=4, global_condition_cardinality=5) if gc is not None else {}
+    cfg = cfg_with(MID, batch_size=1, residual_channels=64, dilation_channels=64,
+                   skip_channels=128, **kw)
+    net, var = build_pair(cfg)
+    assert hip_lib.wn_fastgen_wide_coop_bytes(len(cfg['dilations']), 64, 128, 256) > 0
+    assert hip_lib.wn_fastgen_wide_coop_bytes(len(cfg['dilations']), 96, 128, 256) == 0
+    res = []
+    for coop in (True, False):
+        net.fastgen_wide_coop = coop
+        net.reset_generator()
+        o, p = net.generate(200, seed_samples=[128, 7, 250], seed=5, temperature=0.9,
+                            global_condition=gc, return_proba_every=3)
+        assert ('coop' in net._gen and net._gen['coop'] is not None) or not coop
+        res.append((o.cpu().numpy(), p.cpu().numpy(), net._gen['state'].clone(),
+                    net._gen['cursors'].clone()))
+    assert np.array_equal(res[0][0], res[1][0])
+    assert np.abs(res[0][1] - res[1][1]).max() < 1e-6
+    assert torch.equal(res[0][3][:2], res[1][3][:2])
+    scale = max(1.0, res[1][2].abs().max().item())
+    assert (res[0][2] - res[1][2]).abs().max().item() < 1e-5 * scale
+    # a run continued on the other path
+    net.fastgen_wide_coop = True
+    more_a = net.continue_generation(50, int(res[1][0][-1]), 1.0, gc, 6).cpu().numpy()
+    assert more_a.shape == (50,) and more_a.min() >= 0 and more_a.max() < 256
+
+
 def test_unsupported_configs_raise(hip_lib):
     from wavenet import WaveNetModel
     for kw in (dict(filter_width=65), dict(residual_channels=1025),

@@ -459,8 +459,8 @@ int wn_fastgen_run(const float* params_causal, const float* layer0,
  * L <= 1024 and 8 Q + 4 (5 C + 2 S + 3 L) <= 150 KB of LDS; C = 32 is accepted
  * too (the host uses this entry for 32-channel models beyond the S / Q <= 512,
  * L <= 64 of wn_fastgen_run / wn_fastgen_step).  One persistent workgroup,
- * correctness first -- except 64 channels (C = 64, S <= 512 a multiple of 16,
- * Q <= 512, L <= 256) with `coop` scratch: a COOPERATIVE launch,
+ * correctness first -- except with `coop` scratch (S <= 512 a multiple of 16,
+ * Q <= 512): a COOPERATIVE launch,
  * workgroup 0 runs the layers and the draw, 2 S / 16 + Q / 16 more workgroups the
  * skip sum and the post-processing mat-vecs (hand-over words in `coop`; the
  * same samples up to the rounding of the skip sum's order).  It is taken only

@@ -1709,7 +1709,6 @@ struct FgwLayer64 {
 };
 template <bool F64, bool COOP>
 __global__ __launch_bounds__(F64 ? 512 : FGW_THREADS, 1) void fastgen_wide_kernel(FastGenWide a) {
-  static_assert(F64 || !COOP, "the cooperative launch is the 64-channel one");
   constexpr int NT = F64 ? 512 : FGW_THREADS;    // threads
   constexpr int SPT = FGW_MAXS / NT, XPT = FGW_MAXC / NT;
   const FastGen& g = a.g;
@@ -1729,8 +1728,8 @@ __global__ __launch_bounds__(F64 ? 512 : FGW_THREADS, 1) void fastgen_wide_kerne
   __shared__ float f64_part[F64 ? 4 * 128 + 8 * 64 : 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long CC = (long)C * C;
-  fgp_ll_t* zll = a.ll;                            // [L][64]
-  fgp_ll_t* h1ll = COOP ? zll + (size_t)L * 64 : nullptr;
+  fgp_ll_t* zll = a.ll;                            // [L][C]
+  fgp_ll_t* h1ll = COOP ? zll + (size_t)L * C : nullptr;
   fgp_ll_t* h2ll = COOP ? h1ll + S : nullptr;
   fgp_ll_t* lgll = COOP ? h2ll + S : nullptr;
   bool dead = false;
@@ -1740,36 +1739,41 @@ __global__ __launch_bounds__(F64 ? 512 : FGW_THREADS, 1) void fastgen_wide_kerne
     const int nsk = (S + 15) / 16;
     int role = blockIdx.x - 1;
     if (role < nsk) {
-      // ---- skip worker: columns col0 .. col0 + 15, thread (o, part) adds the
-      // products of z_l[4 part .. 4 part + 3] for every layer; the layer's four
-      // weights are requested a layer ahead
+      // ---- skip worker: columns col0 .. col0 + 15; thread (o, part) adds the
+      // products of z_l[k], k = part, part + 16, ... for every layer, the
+      // layer's weights requested a layer ahead (C / 16 <= 64 per thread)
       const int o = tid & 15, part = tid >> 4, col = role * 16 + o;
-      float* zb = wlds;                            // [2][64]
-      float* red = wlds + 128;                     // [16][16]
+      float* zb = wlds;                            // [2][C]
+      float* red = wlds + 2 * C;                   // [16][16]
       const bool live = col < S;
-      auto wload = [&](int l, float (&w)[4]) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          w[e] = live ? g.skip_w[((size_t)l * 64 + 4 * part + e) * S + col] : 0.f;
-      };
+      const int npt = C >> 4;                      // inputs per thread and layer (C % 32 == 0)
       const float bsum = (live && g.skip_bsum) ? g.skip_bsum[col] : 0.f;
       for (int step = 0; step < g.n_steps; ++step) {
         const unsigned tag = (unsigned)(step + 1);
-        float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
-        float wc[4], wn[4];
-        wload(0, wc);
+        float c0 = 0.f, c1 = 0.f;
+        // (two inputs per pass: npt is even)
+        float wc[2], wn[2];
+        auto wload = [&](int l, int i, float (&w)[2]) {
+          w[0] = live ? g.skip_w[((size_t)l * C + part + 16 * i) * S + col] : 0.f;
+          w[1] = live ? g.skip_w[((size_t)l * C + part + 16 * (i + 1)) * S + col] : 0.f;
+        };
+        wload(0, 0, wc);
         for (int l = 0; l < L; ++l) {
-          if (l + 1 < L) wload(l + 1, wn);
-          float* zl = zb + (l & 1) * 64;
-          if (tid < 64) zl[tid] = fgp_get(zll + (size_t)l * 64 + tid, tag, a.sync, dead);
+          float* zl = zb + (l & 1) * C;
+          for (int c = tid; c < C; c += 256)
+            zl[c] = fgp_get(zll + (size_t)l * C + c, tag, a.sync, dead);
           __syncthreads();
-          const f32x4 zv = *reinterpret_cast<const f32x4*>(zl + 4 * part);
-          c0 = fmaf(zv[0], wc[0], c0); c1 = fmaf(zv[1], wc[1], c1);
-          c2 = fmaf(zv[2], wc[2], c2); c3 = fmaf(zv[3], wc[3], c3);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) wc[e] = wn[e];
+          for (int i = 0; i < npt; i += 2) {
+            // the next pair's weights (of this layer, or the first of the next)
+            const bool more = i + 2 < npt;
+            if (more) wload(l, i + 2, wn);
+            else if (l + 1 < L) wload(l + 1, 0, wn);
+            c0 = fmaf(zl[part + 16 * i], wc[0], c0);
+            c1 = fmaf(zl[part + 16 * (i + 1)], wc[1], c1);
+            wc[0] = wn[0]; wc[1] = wn[1];
+          }
         }
-        red[part * 16 + o] = (c0 + c1) + (c2 + c3);
+        red[part * 16 + o] = c0 + c1;
         __syncthreads();
         if (part == 0 && live) {
           float t = 0.f;
@@ -1931,7 +1935,9 @@ __global__ __launch_bounds__(F64 ? 512 : FGW_THREADS, 1) void fastgen_wide_kerne
       __syncthreads();
       // ---- 2. gate; enqueue x_l[t] in place of the entry just read
       for (int c = tid; c < C; c += NT) {
-        zs[c] = wn_tanh(apre[c]) * wn_sigmoid(apre[C + c]);
+        const float zv = wn_tanh(apre[c]) * wn_sigmoid(apre[C + c]);
+        zs[c] = zv;
+        if (COOP) fgp_put(zll + (size_t)l * C + c, zv, (unsigned)(step + 1));
         if (g.push) ring[c] = xs[c];
       }
       __syncthreads();
@@ -1947,7 +1953,7 @@ __global__ __launch_bounds__(F64 ? 512 : FGW_THREADS, 1) void fastgen_wide_kerne
           xn[u] = xs[c] + d0;
         }
       }
-      {
+      if (!COOP) {
         const float* ws = g.skip_w + (long)l * C * S;
 #pragma unroll
         for (int oi = 0; oi < SPT; oi += 2) {
@@ -2151,12 +2157,12 @@ int wn_fastgen_run(const float* params_causal, const float* layer0,
 // Scratch of the cooperative 64-channel launch of wn_fastgen_run_wide (`coop`):
 // FGP_WORDS sync words (after a run word [12] != 0 = a hand-over wait expired:
 // the samples of that run are not valid) + the hand-over words; 0 = the shape
-// has no cooperative launch (C != 64, S > 512 or not a multiple of 16, Q > 512,
-// L > 256).
+// has no cooperative launch (S > 512 or not a multiple of 16, Q > 512).
 long wn_fastgen_wide_coop_bytes(int L, int C, int S, int Q) {
-  if (C != 64 || S <= 0 || S > 512 || (S & 15) || Q <= 0 || Q > 512 || L <= 0 || L > 256)
+  if (C < 32 || C > FGW_MAXC || (C & 31) || S <= 0 || S > 512 || (S & 15) || Q <= 0 ||
+      Q > 512 || L <= 0 || L > FGW_MAXL)
     return 0;
-  return (long)FGP_WORDS * 4 + ((long)L * 64 + 2L * S + Q) * 8;
+  return (long)FGP_WORDS * 4 + ((long)L * C + 2L * S + Q) * 8;
 }
 
 int wn_fastgen_run_wide(const float* params_causal, const float* layer0,
@@ -2214,19 +2220,25 @@ int wn_fastgen_run_wide(const float* params_causal, const float* layer0,
     if (!wn_aligned16(coop)) return WN_ERR_MISALIGNED;
     const int wgs = 1 + 2 * ((S + 15) / 16) + (Q + 15) / 16;
     // workers: at most S + 16 S + 256 floats (fgp_post_role); workgroup 0: as above
-    const size_t wl = ((size_t)17 * S + 512) * 4;
+    size_t wl = ((size_t)17 * S + 512) * 4;              // post roles
+    if (wl < ((size_t)2 * C + 256) * 4) wl = ((size_t)2 * C + 256) * 4;   // skip role
     const size_t cl = lds > wl ? lds : wl;
-    const void* kf = reinterpret_cast<const void*>(fastgen_wide_kernel<true, true>);
+    const void* kf = f64 ? reinterpret_cast<const void*>(fastgen_wide_kernel<true, true>)
+                         : reinterpret_cast<const void*>(fastgen_wide_kernel<false, true>);
+    const int nthr = f64 ? 512 : FGW_THREADS;
     int per_cu = 0;
     if (hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cl) ==
             hipSuccess &&
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kf, 512, cl) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kf, nthr, cl) == hipSuccess &&
         per_cu >= 1 && (long)wgs <= (long)per_cu * wn_device_cus()) {
       a.sync = reinterpret_cast<unsigned*>(coop);
       a.ll = reinterpret_cast<fgp_ll_t*>(a.sync + FGP_WORDS);
       if (hipMemsetAsync(coop, 0, (size_t)wn_fastgen_wide_coop_bytes(L, C, S, Q), s) != hipSuccess)
         return WN_ERR_LAUNCH;
-      hipLaunchKernelGGL((fastgen_wide_kernel<true, true>), dim3(wgs), dim3(512), cl, s, a);
+      if (f64)
+        hipLaunchKernelGGL((fastgen_wide_kernel<true, true>), dim3(wgs), dim3(512), cl, s, a);
+      else
+        hipLaunchKernelGGL((fastgen_wide_kernel<false, true>), dim3(wgs), dim3(FGW_THREADS), cl, s, a);
       return wn_check_launch();
     }
   }

@@ -644,19 +644,19 @@ def test_fast_generation_above_32_channels(hip_lib, name, cfg, gc):
     assert a.min() >= 0 and a.max() < Q
 
 
-@pytest.mark.parametrize('gc', [None, 2])
-def test_wide_cooperative_generator_equals_single_workgroup(hip_lib, gc):
-    """64 channels: wn_fastgen_run_wide's cooperative launch (skip sum and
+@pytest.mark.parametrize('gc,ch', [(None, 64), (2, 64), (None, 96), (2, 160)])
+def test_wide_cooperative_generator_equals_single_workgroup(hip_lib, gc, ch):
+    """More than 32 channels: wn_fastgen_run_wide's cooperative launch (skip sum and
     post-processing mat-vecs on other workgroups, hand-over words) against its
     single workgroup: the same drawn samples, with a temperature, probabilities
     to rounding (the skip sum adds in another order), queues and cursors that
     continue on either path."""
     kw = dict(global_condition_channels=4, global_condition_cardinality=5) if gc is not None else {}
-    cfg = cfg_with(MID, batch_size=1, residual_channels=64, dilation_channels=64,
+    cfg = cfg_with(MID, batch_size=1, residual_channels=ch, dilation_channels=ch - 8,
                    skip_channels=128, **kw)
     net, var = build_pair(cfg)
     assert hip_lib.wn_fastgen_wide_coop_bytes(len(cfg['dilations']), 64, 128, 256) > 0
-    assert hip_lib.wn_fastgen_wide_coop_bytes(len(cfg['dilations']), 96, 128, 256) == 0
+    assert hip_lib.wn_fastgen_wide_coop_bytes(len(cfg['dilations']), 64, 520, 256) == 0
     res = []
     for coop in (True, False):
         net.fastgen_wide_coop = coop

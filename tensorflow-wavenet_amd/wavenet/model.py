@@ -1529,26 +1529,45 @@ class WaveNetModel(object):
             # back to the single workgroup by itself when the workgroups would
             # not all be resident
             coop = None
-            if self.fastgen_wide_coop:
+            if self.fastgen_wide_coop and not g.get('coop_failed'):
                 if 'coop' not in g:
                     nb = _lib.load().wn_fastgen_wide_coop_bytes(
                         self.L, self.CHn, self.S, self.Q)
                     g['coop'] = torch.zeros(nb // 4, dtype=torch.int32,
                                             device=self.device) if nb else None
                 coop = g['coop']
-            _lib.call('wn_fastgen_run_wide', *common[:11], self.L, self.CHn,
-                      self.S, self.Q, *common[14:], int(n_given), int(n_steps),
-                      float(temperature), sd, _lib.ptr(proba_out),
-                      int(proba_every), 1 if ub else 0, 1 if push else 0,
-                      _lib.ptr(coop), _lib.stream())
-            if coop is not None and int(coop[12]) != 0:
-                # (never seen with every workgroup resident, which the library
-                # checks before it launches)
-                raise _lib.WaveNetHipError(
-                    'wn_fastgen_run_wide: a hand-over wait inside the '
-                    'cooperative launch expired; the generator state is not '
-                    'valid -- reset_generator() and generate again with '
-                    'net.fastgen_wide_coop = False')
+
+            def run(scratch):
+                _lib.call('wn_fastgen_run_wide', *common[:11], self.L, self.CHn,
+                          self.S, self.Q, *common[14:], int(n_given), int(n_steps),
+                          float(temperature), sd, _lib.ptr(proba_out),
+                          int(proba_every), 1 if ub else 0, 1 if push else 0,
+                          _lib.ptr(scratch), _lib.stream())
+            if coop is None:
+                run(None)
+            else:
+                # What the library's residency check cannot see -- another
+                # process or stream holding CUs, a CU mask -- shows as an
+                # expired hand-over wait (word 12 of the scratch): the queues,
+                # cursors and samples are then restored from a snapshot taken
+                # here and the run is repeated by the single workgroup, which
+                # always completes.
+                snap = (g['state'].clone(), g['cursors'].clone(), samples_io.clone())
+                run(coop)
+                if int(coop[12]) != 0:     # (synchronises; the call ends on the host anyway)
+                    import warnings
+                    warnings.warn(
+                        'wn_fastgen_run_wide: a hand-over wait inside the '
+                        'cooperative generation launch expired (2 s: its '
+                        'workgroups were not all resident); state restored, '
+                        'continuing with the single workgroup '
+                        '(net.fastgen_wide_coop = False selects it up front)')
+                    g['state'].copy_(snap[0])
+                    g['cursors'].copy_(snap[1])
+                    samples_io.copy_(snap[2])
+                    g['coop_failed'] = True
+                    run(None)
+                del snap
             if push:
                 g['steps'] += int(n_steps)
             return

@@ -677,6 +677,44 @@ def test_wide_cooperative_generator_equals_single_workgroup(hip_lib, gc, ch):
     assert more_a.shape == (50,) and more_a.min() >= 0 and more_a.max() < 256
 
 
+def test_wide_cooperative_launch_failure_restores_state_and_falls_back(hip_lib, monkeypatch):
+    """A cooperative launch of the wide generator that reports an expired
+    hand-over wait (workgroups not all resident: invisible to the launch-time
+    occupancy check) after it has rewritten queues, cursors and samples: the
+    host restores its snapshot, warns, repeats the run on the single workgroup
+    -- the samples of a model that took the single workgroup from the start --
+    and does not try the cooperative launch again on this generator."""
+    from wavenet import _lib
+    cfg = cfg_with(MID, batch_size=1, residual_channels=64, dilation_channels=64,
+                   skip_channels=128)
+    a, _ = build_pair(cfg)
+    b, _ = build_pair(cfg)
+    b.fastgen_wide_coop = False
+    lib = _lib.load()
+    real = lib.wn_fastgen_run_wide
+    coop_calls = []
+
+    def failing(*args):
+        code = real(*args)
+        if args[-2]:                      # a cooperative launch: report a failed wait
+            torch.cuda.synchronize()
+            a._gen['coop'][12] = 1
+            coop_calls.append(code)
+        return code
+    monkeypatch.setattr(lib, 'wn_fastgen_run_wide', failing)
+    with pytest.warns(UserWarning, match='state restored'):
+        out_a = a.generate(120, seed_samples=[128, 3, 77], seed=9).cpu().numpy()
+    out_b = b.generate(120, seed_samples=[128, 3, 77], seed=9).cpu().numpy()
+    assert coop_calls == [0] and a._gen['coop_failed']
+    assert np.array_equal(out_a, out_b)
+    assert a._gen['steps'] == b._gen['steps']
+    more_a = a.continue_generation(60, int(out_a[-1]), seed=4).cpu().numpy()
+    more_b = b.continue_generation(60, int(out_b[-1]), seed=4).cpu().numpy()
+    assert coop_calls == [0]              # not tried again on this generator
+    assert np.array_equal(more_a, more_b)
+    assert torch.equal(a._gen['state'], b._gen['state'])
+
+
 def test_unsupported_configs_raise(hip_lib):
     from wavenet import WaveNetModel
     for kw in (dict(filter_width=65), dict(residual_channels=1025),

@@ -566,7 +566,8 @@ def main():
     tile_layers = B * ((T + 31) // 32) * len(params['dilations'])
     mfma_cyc = {'wn_stack_fwd': 80 * 64, 'wn_stack_bwd': 160 * 64}    # per 32-row tile and layer
     for ev_name in ('wn_stack_fwd', 'wn_stack_bwd'):
-        evs = [e for e in events if e[3] == ev_name]
+        evs = [e for e in events if e[3] == ev_name or
+               (ev_name == 'wn_stack_fwd' and e[3] == 'wn_stack_fwd_skip')]
         if not evs:
             continue
         us = sum(e[0].elapsed_time(e[1]) for e in evs) / len(evs) * 1e3

@@ -288,6 +288,24 @@ int wn_stack_fwd(float* X, float* Z, float* SG, const float* wimg,
                  int bias_clip_stride, const int* dilations, unsigned* flags,
                  unsigned* ctl, float* poison, int L, int B, int T, int save_sg,
                  int variant, void* stream);
+/* Small batches (wn_stack_fwd_skip_ok: the 16-row launch with one tile per
+ * SIMD, 512 skip channels): wn_stack_fwd that ALSO computes the skip sum,
+ *   h1[B*T][512] = relu(sum_l z_l Ws_l + skip_bsum)
+ * (model.py:505-509: what wn_gemm_nn over the Z planes computes afterwards) in
+ * the same launch -- a partner wave per tile takes the tile's z of every layer
+ * through LDS while the chain wave goes on; the launch's matrix pipe is three
+ * quarters idle otherwise.  skip_img: wn_stack_skip_img_floats(L) floats written
+ * by wn_stack_skip_pack from skip_w [L * 32][512] (once per weight update);
+ * skip_bsum: [512] or NULL.  Same sums as the GEMM up to the order of additions. */
+int wn_stack_fwd_skip_ok(int B, int T, int S, int variant);
+long wn_stack_skip_img_floats(int L);
+int wn_stack_skip_pack(const float* skip_w, int L, float* img, void* stream);
+int wn_stack_fwd_skip(float* X, float* Z, float* SG, const float* wimg,
+                      const float* bias, long bias_layer_stride,
+                      int bias_clip_stride, const int* dilations, unsigned* flags,
+                      unsigned* ctl, float* poison, int L, int B, int T, int save_sg,
+                      int variant, const float* skip_img, const float* skip_bsum,
+                      float* h1, void* stream);
 int wn_stack_bwd_slabs(int B, int T, int variant);
 int wn_stack_bwd(const float* X, const float* Z, const float* SG,
                  const float* dZ, float* DX, long dx_layer_stride, float* Q,

@@ -65,10 +65,28 @@ struct StackFwd {
   float* poison;       // set to NaN when a bounded wait expires (or null)
   int L, B, T;
   long plane;          // N * 32 floats
+  // fused skip sum (stack_fwd16_kernel<.., true>): the skip weights as
+  // half-stage images (wn_stack_skip_pack), sum_l bs_l or null, h1 out [N][512]
+  const float* skimg;
+  const float* sk_bsum;
+  float* sk_out;
 #ifdef STACK_STAMPS
   unsigned long long* dbg;   // diagnostic build: [grid][16][L][12] s_memtime stamps
 #endif
 };
+
+// Fused skip sum of the 16-row forward (small batches), S = 512.  Partner wave j
+// of a workgroup adds the products of ALL four tiles of the group for skip
+// columns 128 j .. 128 j + 127; its operands -- Ws_l[k][column] as 16x16x4 A
+// fragments -- come straight from memory in the lane order it consumes them:
+// image [L][4 j][8 n-tiles][2 k-halves][64 lanes][4 floats], lane (jr, g):
+// Ws_l[16 half + 4 g + e][128 j + 16 nt + jr], e = 0 .. 3 (one 1-KiB load
+// instruction per fragment pair), SK_AHEAD n-tiles ahead of their use.
+#define SK_S 512
+#define SK_NT 8                              // 16-column n-tiles of a partner wave
+#define SK_WAVE (SK_NT * 2 * 256)            // floats of a (layer, wave) image: 16 KiB
+#define SK_AHEAD 3
+#define SK_ZB 4                              // z hand-over tiles per slot (layers a chain wave may run ahead)
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -205,6 +223,17 @@ __device__ __forceinline__ void wait_lds(const int* p, bool& dead, unsigned* ctl
     }
   }
   asm volatile("" ::: "memory");
+}
+
+// skip weights [L * 32][512] -> per-(layer, partner wave) operand images (see SK_WAVE)
+__global__ void stack_skip_pack_kernel(const float* __restrict__ skip_w, float* __restrict__ img) {
+  const int l = blockIdx.x >> 2, j = blockIdx.x & 3;
+  float* out = img + (size_t)blockIdx.x * SK_WAVE;
+  for (int i = threadIdx.x; i < SK_WAVE; i += blockDim.x) {
+    const int e = i & 3, lane = (i >> 2) & 63, half = (i >> 8) & 1, nt = i >> 9;
+    const int jr = lane & 15, g = lane >> 4;
+    out[i] = skip_w[((size_t)l * 32 + 16 * half + 4 * g + e) * SK_S + 128 * j + 16 * nt + jr];
+  }
 }
 
 template <int SAVE, int WAVES>
@@ -1195,6 +1224,14 @@ struct F16 {
 #define S16STAMP(l, i)
 #define S16CAL(k)
 #endif
+#ifdef STACK_STAMPS
+#define P16STAMP(l, i)                                                       \
+  if (lane == 0)                                                             \
+    a.dbg[(((size_t)blockIdx.x * 16 + wave_raw) * L + (l)) * 16 + (i)] =     \
+        __builtin_amdgcn_s_memtime()
+#else
+#define P16STAMP(l, i)
+#endif
 #define wn_mfma16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
 
 __device__ __forceinline__ F16 f16_zero() {
@@ -1287,14 +1324,39 @@ __device__ __forceinline__ void f16_to_lds(float* lt, int g, int sw, const F16& 
 // 0.35, but 4 KiB of words per tile and layer on top of the planes make every
 // other memory phase slower (weight ring 0.17 -> 0.47 us, z / sigmoid stores
 // 0.21 -> 0.48).)
-template <int SAVE, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void stack_fwd16_kernel(StackFwd a) {
+// SKIP (round 5, small batches): the launch also computes h1 = relu(sum_l z_l Ws_l
+// + sum_l bs_l).  At one 16-row tile per SIMD a layer period is 4.1 us of which
+// the wave's own 80 MFMAs are 1.1 us, while the skip GEMM (194 us at B = 1) waits
+// for the whole stack.  Here a workgroup has WAVES more PARTNER waves (one per
+// SIMD beside a chain wave): every chain wave hands its tile's z of a layer over
+// through LDS (its accumulator registers, lane for lane; SK_ZB layers deep),
+// partner wave j adds z_l[16 x 32] Ws_l[32 x 128 j ..] for ALL tiles of the group
+// -- 256 MFMAs per layer into 128 accumulator registers, the operand fragments
+// streamed from memory SK_AHEAD n-tiles ahead in the order it consumes them
+// (no LDS ring: two were built first, 2 half-stages and 4 quarter-stages by
+// LDS-DMA; a refill took 2 us from "slot free" to "landed" and the waves waited
+// 2.4 - 4 us a layer for it).  What it buys is bounded by the SIMD the two waves
+// share: under the partner's MFMA stream the chain wave's vector instructions
+// issue at a fraction of their rate (wn_common.h) and the layer period grows
+// from 4.1 to 8.4 us -- the launch takes 440 us against 232 + 194 for stack and
+// GEMM apart; a step at B = 1 goes from 1.68 to 1.62 ms.
+template <int SAVE, int WAVES, bool SKIP = false>
+__global__ __launch_bounds__((SKIP ? 2 : 1) * WAVES * 64) void stack_fwd16_kernel(StackFwd a) {
   __shared__ __attribute__((aligned(1024))) float wl[2 * STACK_WBUF];
   __shared__ int s_group;
   __shared__ int s_done[STACK_MAXL], s_ready[STACK_MAXL];
+  // SKIP: [WAVES][SK_ZB][512] z hand-over tiles (dynamic)
+  extern __shared__ __attribute__((aligned(1024))) float sk_lds[];
+  __shared__ int s_zflag[WAVES], s_zdone[WAVES];   // layers published by chain slot t / consumed by partner j
+  __shared__ int s_dil[STACK_MAXL];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_raw = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // (waves w and w + WAVES of a workgroup share a SIMD: measured -- pairing
+  // 2 s with 2 s + 1 put two partner waves on one SIMD and cost 5 % of a step)
+  const bool skipw = SKIP && wave_raw >= WAVES;          // a partner wave
+  const int wave = skipw ? wave_raw - WAVES : wave_raw;  // the tile slot / the partner's column quarter
+  float* ztile = sk_lds + wave * (SK_ZB * 512);          // [SK_ZB][512] of this slot
   const int jr = lane & 15, g = lane >> 4;
   const int T = a.T, L = a.L;
   const int tiles_per_clip = (T + 15) >> 4;
@@ -1304,6 +1366,8 @@ __global__ __launch_bounds__(WAVES * 64) void stack_fwd16_kernel(StackFwd a) {
       __hip_atomic_load(a.ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   bool dead = false;
   S16CAL(0);
+  for (int i = tid; i < L; i += (SKIP ? 2 : 1) * WAVES * 64) s_dil[i] = a.dil[i];
+  // (visible after the first barrier of the group loop)
 
   auto issue_weights = [&](int l, int p0, int step) {
     const float* wb = a.wimg + (size_t)l * STACK_WBUF;
@@ -1330,10 +1394,107 @@ __global__ __launch_bounds__(WAVES * 64) void stack_fwd16_kernel(StackFwd a) {
     // the lane's byte offset of piece 0 of ITS row in a plane
     const int voff = ((b * T + t0 + jr) * WN_CH + 4 * g) * 4;
 
-    for (int i = tid; i < L; i += WAVES * 64) {
+    for (int i = tid; i < L; i += (SKIP ? 2 : 1) * WAVES * 64) {
       s_done[i] = 0;
       s_ready[i] = i < 2;
     }
+    if (SKIP && tid < WAVES) { s_zflag[tid] = 0; s_zdone[tid] = 0; }
+    if (skipw) {
+      // ------------------------------------------------ partner (skip) wave
+      // operand stream: fragment pair n = l * SK_NT + nt of this wave, requested
+      // SK_AHEAD n-tiles ahead (the weights do not depend on the data: the
+      // stream runs across layers)
+      const float* wsrc = a.skimg + (size_t)wave * SK_WAVE + lane * 4;
+      const long lstride = 4L * SK_WAVE;
+      const int nfr = L * SK_NT;
+      auto frag_ld = [&](int n, f32x4 (&w)[2]) {
+        const int nn = n < nfr ? n : nfr - 1;
+        const float* pw = wsrc + (size_t)(nn / SK_NT) * lstride + (nn % SK_NT) * 512;
+        w[0] = *reinterpret_cast<const f32x4*>(pw);
+        w[1] = *reinterpret_cast<const f32x4*>(pw + 256);
+      };
+      f32x4 win[SK_AHEAD + 1][2];
+#pragma unroll
+      for (int n0 = 0; n0 < SK_AHEAD; ++n0) frag_ld(n0, win[n0]);
+      f32x4 acc[WAVES][SK_NT];
+#pragma unroll
+      for (int t = 0; t < WAVES; ++t)
+#pragma unroll
+        for (int n = 0; n < SK_NT; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      __syncthreads();      // (the chain waves' barrier: their weights of layers 0, 1 are in LDS)
+      const bool run = nactive > 0;
+      for (int l = 0; run && l < L; ++l) {
+        // the z of layer l of the group's tiles (the chain waves' accumulator
+        // registers, lane for lane; a slot without a tile: zeros)
+        P16STAMP(l, 0);
+        F16 zf[WAVES];
+#pragma unroll
+        for (int t = 0; t < WAVES; ++t) {
+          zf[t] = f16_zero();
+          if (t < nactive) {
+            wait_lds_ge(s_zflag + t, l + 1, dead, a.ctl, a.poison, lane);
+            const float* zt = sk_lds + t * (SK_ZB * 512) + (l & (SK_ZB - 1)) * 512 + lane * 8;
+            zf[t].v[0] = *reinterpret_cast<const f32x4*>(zt);
+            zf[t].v[1] = *reinterpret_cast<const f32x4*>(zt + 4);
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0)
+          __hip_atomic_store(s_zdone + wave, l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        P16STAMP(l, 1);
+#pragma unroll
+        for (int nt = 0; nt < SK_NT; ++nt) {
+          // (static slot of the rolling window: (l * 8 + nt) % 6 would not be a
+          // compile-time register index; the window is rotated by copies)
+          frag_ld(l * SK_NT + nt + SK_AHEAD, win[SK_AHEAD]);
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * SK_AHEAD) : "memory");
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int t = 0; t < WAVES; ++t)
+              acc[t][nt] = wn_mfma16(win[0][q >> 2][q & 3], zf[t].v[q >> 2][q & 3], acc[t][nt]);
+          __builtin_amdgcn_sched_barrier(0);
+          // (a pause per 32 MFMAs: the chain wave on this SIMD issues its vector
+          // instructions at a fraction of their rate under a running MFMA
+          // stream, and it is the chain that sets the layer period; B = 1:
+          // 1.641 / 1.633 / 1.623 / 1.671 ms per step at 0 / 2 / 6 / 12)
+          __builtin_amdgcn_s_sleep(6);
+#pragma unroll
+          for (int n0 = 0; n0 < SK_AHEAD; ++n0) {
+            win[n0][0] = win[n0 + 1][0];
+            win[n0][1] = win[n0 + 1][1];
+          }
+        }
+        P16STAMP(l, 3);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // h1 rows of every tile of the group, columns 128 j ..: accumulator register
+      // i of n-tile nt = column 128 j + 16 nt + 4 g + i, row jr of tile t
+#pragma unroll
+      for (int t = 0; t < WAVES; ++t) {
+        const int tl = gi * WAVES + t;
+        if (tl < ntiles) {
+          const int bt = tl / tiles_per_clip, t0t = (tl - bt * tiles_per_clip) * 16;
+          if (jr < min(16, T - t0t)) {
+            float* orow = a.sk_out + ((size_t)bt * T + t0t + jr) * SK_S + 128 * wave + 4 * g;
+#pragma unroll
+            for (int nt = 0; nt < SK_NT; ++nt) {
+              f32x4 v = acc[t][nt];
+              if (a.sk_bsum)
+                v += *reinterpret_cast<const f32x4*>(a.sk_bsum + 128 * wave + 16 * nt + 4 * g);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+              *reinterpret_cast<f32x4*>(orow + 16 * nt) = v;
+            }
+          }
+        }
+      }
+      __syncthreads();      // (the chain waves' barrier at the group's end)
+      continue;
+    }
+    // (the chain wave's instructions go first on the SIMD it shares with a partner)
+    if (SKIP) __builtin_amdgcn_s_setprio(3);
     issue_weights(0, wave, WAVES);
     if (L > 1) issue_weights(1, wave, WAVES);
     F16 xc = f16_ld<16>(plane_rsrc(a.X), voff, mine);
@@ -1356,7 +1517,9 @@ __global__ __launch_bounds__(WAVES * 64) void stack_fwd16_kernel(StackFwd a) {
     int publish = 0;
 
     for (int l = 0; any && l < L; ++l) {
-      const int d = a.dil[l];
+      // (from LDS: the load from memory waited, with vmcnt(0), for the layer's
+      // plane stores as well)
+      const int d = s_dil[l];
       S16STAMP(l, 0);
       wait_lds(s_ready + l, dead, a.ctl, a.poison, lane);
       S16STAMP(l, 1);
@@ -1408,6 +1571,20 @@ __global__ __launch_bounds__(WAVES * 64) void stack_fwd16_kernel(StackFwd a) {
           zz.v[mb][e] = af.v[mb][e] * ag.v[mb][e];
         }
       S16STAMP(l, 5);
+      if (SKIP) {
+        // z to the partner wave (its hand-over tile of two layers ago is free
+        // once the partner has it in registers)
+        if (l >= SK_ZB) {
+#pragma unroll
+          for (int j = 0; j < WAVES; ++j)
+            wait_lds_ge(s_zdone + j, l - SK_ZB + 1, dead, a.ctl, a.poison, lane);
+        }
+        float* zt = ztile + (l & (SK_ZB - 1)) * 512 + lane * 8;
+        *reinterpret_cast<f32x4*>(zt) = zz.v[0];
+        *reinterpret_cast<f32x4*>(zt + 4) = zz.v[1];
+        if (lane == 0)
+          __hip_atomic_store(s_zflag + wave, l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
       if (l + 1 < L) {
         const float* bd = wl + (l & 1) * STACK_WBUF + SF_OFF_BD + 4 * g;
         xc.v[0] += *reinterpret_cast<const f32x4*>(bd);
@@ -1952,11 +2129,32 @@ int wn_stack_pack(const float* layer0, long layer_stride, float* wimg_fwd,
   return wn_check_launch();
 }
 
-int wn_stack_fwd(float* X, float* Z, float* SG, const float* wimg,
+// floats of the skip image wn_stack_skip_pack writes for wn_stack_fwd_skip
+long wn_stack_skip_img_floats(int L) { return L > 0 ? (long)4 * L * SK_WAVE : 0; }
+
+// 1 when wn_stack_fwd_skip covers the shape: the 16-row launch with one wave per
+// SIMD (small batches), 512 skip channels
+int wn_stack_fwd_skip_ok(int B, int T, int S, int variant) {
+  if (B <= 0 || T <= 0 || S != SK_S) return 0;
+  if (wn_stack_tile_rows(B, T, variant) != 16) return 0;
+  const long nt16 = (long)B * ((T + 15) / 16);
+  return variant_waves(variant, (nt16 + 3) / 4 <= wn_device_cus() ? 4 : 8, false) == 4;
+}
+
+int wn_stack_skip_pack(const float* skip_w, int L, float* img, void* stream) {
+  if (!skip_w || !img) return WN_ERR_NULL;
+  if (L <= 0) return WN_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(stack_skip_pack_kernel, dim3(4 * L), dim3(256), 0, (hipStream_t)stream,
+                     skip_w, img);
+  return wn_check_launch();
+}
+
+static int stack_fwd_launch(float* X, float* Z, float* SG, const float* wimg,
                  const float* bias, long bias_layer_stride,
                  int bias_clip_stride, const int* dilations, unsigned* flags,
                  unsigned* ctl, float* poison, int L, int B, int T, int save_sg,
-                 int variant, void* stream) {
+                 int variant, void* stream, const float* skimg, const float* sk_bsum,
+                 float* sk_out) {
   if (!X || !Z || !wimg || !dilations || !flags || !ctl) return WN_ERR_NULL;
   if (save_sg && !SG) return WN_ERR_NULL;
   if (L <= 0 || B <= 0 || T <= 0) return WN_ERR_BAD_SHAPE;
@@ -1969,11 +2167,35 @@ int wn_stack_fwd(float* X, float* Z, float* SG, const float* wimg,
   a.bias_clip_stride = bias_clip_stride; a.dil = dilations; a.flags = flags;
   a.ctl = ctl; a.poison = poison; a.L = L; a.B = B; a.T = T;
   a.plane = (long)B * T * WN_CH;
+  a.skimg = skimg; a.sk_bsum = sk_bsum; a.sk_out = sk_out;
 #ifdef STACK_STAMPS
   if (!g_stack_dbg) return WN_ERR_NULL;
   a.dbg = g_stack_dbg;
 #endif
   if (L > STACK_MAXL) return WN_ERR_UNSUPPORTED;
+  if (skimg) {
+    // the 16-row launch with a partner wave per tile (stack_fwd16_kernel<.., true>)
+    if (!sk_out || !wn_aligned16(skimg) || !wn_aligned16(sk_out) ||
+        (sk_bsum && !wn_aligned16(sk_bsum)))
+      return sk_out ? WN_ERR_MISALIGNED : WN_ERR_NULL;
+    if (!wn_stack_fwd_skip_ok(B, T, SK_S, variant)) return WN_ERR_UNSUPPORTED;
+    if ((long)B * T * WN_CH * 4 >= (1L << 31)) return WN_ERR_UNSUPPORTED;
+    const long nt16 = (long)B * ((T + 15) / 16);
+    long g16 = (nt16 + 3) / 4;
+    if (g16 > wn_device_cus()) g16 = wn_device_cus();
+    const size_t dyn = (size_t)4 * SK_ZB * 512 * sizeof(float);
+    const void* kf = save_sg ? reinterpret_cast<const void*>(stack_fwd16_kernel<2, 4, true>)
+                             : reinterpret_cast<const void*>(stack_fwd16_kernel<0, 4, true>);
+    if (hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess)
+      return WN_ERR_LAUNCH;
+    if (save_sg)
+      hipLaunchKernelGGL((stack_fwd16_kernel<2, 4, true>), dim3((unsigned)g16), dim3(512), dyn,
+                         (hipStream_t)stream, a);
+    else
+      hipLaunchKernelGGL((stack_fwd16_kernel<0, 4, true>), dim3((unsigned)g16), dim3(512), dyn,
+                         (hipStream_t)stream, a);
+    return wn_check_launch();
+  }
   if (wn_stack_tile_rows(B, T, variant) == 16) {
     // (tile offsets inside a plane are 32-bit byte offsets of a buffer resource)
     if ((long)B * T * WN_CH * 4 >= (1L << 31)) return WN_ERR_UNSUPPORTED;
@@ -2031,6 +2253,30 @@ int wn_stack_fwd(float* X, float* Z, float* SG, const float* wimg,
   }
 #undef LAUNCH
   return wn_check_launch();
+}
+
+int wn_stack_fwd(float* X, float* Z, float* SG, const float* wimg,
+                 const float* bias, long bias_layer_stride,
+                 int bias_clip_stride, const int* dilations, unsigned* flags,
+                 unsigned* ctl, float* poison, int L, int B, int T, int save_sg,
+                 int variant, void* stream) {
+  return stack_fwd_launch(X, Z, SG, wimg, bias, bias_layer_stride, bias_clip_stride, dilations,
+                          flags, ctl, poison, L, B, T, save_sg, variant, stream, nullptr,
+                          nullptr, nullptr);
+}
+
+// wn_stack_fwd + the skip sum in the same launch: h1[N][512] = relu(sum_l z_l Ws_l
+// + skip_bsum) (wn_stack_fwd_skip_ok shapes; skip_img from wn_stack_skip_pack)
+int wn_stack_fwd_skip(float* X, float* Z, float* SG, const float* wimg,
+                      const float* bias, long bias_layer_stride,
+                      int bias_clip_stride, const int* dilations, unsigned* flags,
+                      unsigned* ctl, float* poison, int L, int B, int T, int save_sg,
+                      int variant, const float* skip_img, const float* skip_bsum,
+                      float* h1, void* stream) {
+  if (!skip_img || !h1) return WN_ERR_NULL;
+  return stack_fwd_launch(X, Z, SG, wimg, bias, bias_layer_stride, bias_clip_stride, dilations,
+                          flags, ctl, poison, L, B, T, save_sg, variant, stream, skip_img,
+                          skip_bsum, h1);
 }
 
 // (waves per workgroup, tiles per wave and layer) of wn_stack_bwd for a shape:

@@ -37,6 +37,11 @@ SIGNATURES = {
     'wn_stack_pack': (c_int, [P, c_long, P, P, c_int, P]),
     'wn_stack_fwd': (c_int, [P, P, P, P, P, c_long, c_int, P, P, P, P,
                              c_int, c_int, c_int, c_int, c_int, P]),
+    'wn_stack_fwd_skip': (c_int, [P, P, P, P, P, c_long, c_int, P, P, P, P,
+                                  c_int, c_int, c_int, c_int, c_int, P, P, P, P]),
+    'wn_stack_fwd_skip_ok': (c_int, [c_int, c_int, c_int, c_int]),
+    'wn_stack_skip_img_floats': (c_long, [c_int]),
+    'wn_stack_skip_pack': (c_int, [P, c_int, P, P]),
     'wn_stack_bwd_slabs': (c_int, [c_int, c_int, c_int]),
     'wn_stack_bwd': (c_int, [P, P, P, P, P, c_long, P, P, P, c_long, P, P, P,
                              P, P, c_int, c_int, c_int, c_int, P]),

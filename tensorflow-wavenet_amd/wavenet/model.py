@@ -320,6 +320,9 @@ class WaveNetModel(object):
         # dilated taps are handed over through per-tile flags) instead of one
         # wn_layer_fwd launch per layer.  False selects the latter.
         self.stack_fwd = True
+        # ... with the skip sum inside that launch where the library has it
+        # (wn_stack_fwd_skip: small batches, 512 skip channels)
+        self.stack_fwd_skip = True
         # the same for the backward of the stack (wn_stack_bwd instead of one
         # wn_layer_bwd2 per layer); read when a workspace is created
         self.stack_bwd = True
@@ -827,7 +830,7 @@ class WaveNetModel(object):
     def _plan_key(self, tag, ws, ids, extra):
         return (tag, extra, ids is not None, self.generic_layers,
                 self.fused_bwd, self.layer_bwd, self.overlap_tn,
-                self.overlap_tn_split_frac, self.wide_fuse_gate, self.tn_spread_colsum, self.stack_fwd, self.stack_bwd, ws.stack_variant, self._early_on(), self.gemm_mode, self.causal_wgrad_segsum, self.tf_xent_zero_label_quirk,
+                self.overlap_tn_split_frac, self.wide_fuse_gate, self.tn_spread_colsum, self.stack_fwd, self.stack_fwd_skip, self.stack_bwd, ws.stack_variant, self._early_on(), self.gemm_mode, self.causal_wgrad_segsum, self.tf_xent_zero_label_quirk,
                 _lib.stream(), self.params.data_ptr(), self.grads.data_ptr())
 
     def _stage_ids(self, ws, ids):
@@ -898,6 +901,7 @@ class WaveNetModel(object):
             blocked.forward_layers(self, ws, bias, bstride, bool(save_ts), st)
         stack = (self.stack_fwd and not self.blocked and not self.generic_layers
                  and save_ts in (0, 2) and L <= 256)
+        fuse_skip = False
         if stack:
             # all L layers in one persistent launch (csrc/wn_stack.hip)
             # (its transposed weight images, one small launch per call)
@@ -907,18 +911,41 @@ class WaveNetModel(object):
             _lib.call('wn_stack_pack', _lib.ptr(self._layer_block(P, 0)),
                       self.layer_stride, _lib.ptr(ws.wimg_f),
                       _lib.ptr(ws.wimg_b) if both else None, L, st)
-            # (flops 0: timed in bench.py's instrumented pass for its HBM roofline)
-            _lib.call_timed('wn_stack_fwd', (_lib.ptr(ws.X), _lib.ptr(ws.Z),
-                      _lib.ptr(ws.SG) if save_ts else None,
-                      _lib.ptr(ws.wimg_f),
-                      None if bias is None else _lib.ptr(bias),
-                      0 if bias is None else bias.shape[1] * bias.shape[2],
-                      bstride, _lib.ptr(self._dil_dev),
-                      _lib.ptr(ws.stack_flags), _lib.ptr(ws.stack_ctl),
-                      _lib.ptr(ws.loss_parts),
-                      L, B, T, 1 if save_ts else 0,
-                      ws.stack_variant, st), 0.0,
-                      getattr(self, '_gemm_events', None))
+            stack_args = (_lib.ptr(ws.X), _lib.ptr(ws.Z),
+                          _lib.ptr(ws.SG) if save_ts else None,
+                          _lib.ptr(ws.wimg_f),
+                          None if bias is None else _lib.ptr(bias),
+                          0 if bias is None else bias.shape[1] * bias.shape[2],
+                          bstride, _lib.ptr(self._dil_dev),
+                          _lib.ptr(ws.stack_flags), _lib.ptr(ws.stack_ctl),
+                          _lib.ptr(ws.loss_parts),
+                          L, B, T, 1 if save_ts else 0, ws.stack_variant)
+            # small batches: the skip sum h1 = relu(sum_l z_l Ws_l + sum_l bs_l)
+            # inside the stack launch (wn_stack_fwd_skip: a partner wave per
+            # tile; the launch's matrix pipe is three quarters idle otherwise)
+            fuse_skip = bool(
+                self.stack_fwd_skip and self.gemm_mode == 'fp32' and
+                not self.residual_postproc and
+                _lib.load().wn_stack_fwd_skip_ok(B, T, S, ws.stack_variant))
+            if fuse_skip:
+                if getattr(ws, 'skimg', None) is None:
+                    ws.skimg = torch.empty(
+                        int(_lib.load().wn_stack_skip_img_floats(L)),
+                        dtype=torch.float32, device=self.device)
+                bsum_f = None
+                if self.use_biases:
+                    _lib.call('wn_sum_rows', _lib.ptr(self._seg(P, 'skip_b')), L,
+                              S, _lib.ptr(ws.bsum), st)
+                    bsum_f = ws.bsum
+                _lib.call('wn_stack_skip_pack', _lib.ptr(self._seg(P, 'skip_w')),
+                          L, _lib.ptr(ws.skimg), st)
+                _lib.call_timed('wn_stack_fwd_skip', stack_args + (
+                    _lib.ptr(ws.skimg), _lib.ptr(bsum_f), _lib.ptr(ws.h1), st),
+                    0.0, getattr(self, '_gemm_events', None))
+            else:
+                # (flops 0: timed in bench.py's instrumented pass for its HBM roofline)
+                _lib.call_timed('wn_stack_fwd', stack_args + (st,), 0.0,
+                                getattr(self, '_gemm_events', None))
         for l, d in enumerate(self.dilations if not self.blocked and not stack
                               else []):
             last = l == L - 1
@@ -946,12 +973,13 @@ class WaveNetModel(object):
         b1 = self._seg(P, 'post1_b') if self.use_biases else None
         b2 = self._seg(P, 'post2_b') if self.use_biases else None
         rp = self.residual_postproc
-        self._nn_seq([
+        skip_gemm = [] if fuse_skip else [
             (_lib.ptr(ws.Z), 0, LP, N * CH,
              _lib.ptr(self._seg(P, 'skip_w')), S, _lib.ptr(bsum), None, 0,
              None, 0, _lib.ptr(ws.h1), S, 0, 0,
              _lib.ptr(ws.total) if self.residual_postproc else None,
-             N, S, L * C, 1),
+             N, S, L * C, 1)]
+        self._nn_seq(skip_gemm + [
             (_lib.ptr(ws.h1), S, 0, 0,
              _lib.ptr(self._seg(P, 'post1_w')), S, _lib.ptr(b1), None, 0,
              _lib.ptr(ws.total) if rp else None, S, _lib.ptr(ws.h2), S, 0,

@@ -163,7 +163,9 @@ def test_bench_line_carries_the_contract(hip_lib):
     rf = r['roofline']
     assert rf['bound'] == 'mfma' and rf['peak'] == 157.3
     assert 0 < rf['frac'] < 1 and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9
-    assert rf['launches_per_step'] == 6 and rf['tn_gemms']['launches_per_step'] == 3
+    # (five NN GEMMs at this small shape: the skip sum runs inside the forward
+    # stack launch, wn_stack_fwd_skip; six at the headline shape)
+    assert rf['launches_per_step'] == 5 and rf['tn_gemms']['launches_per_step'] == 3
     # the two persistent stack launches are timed live too; their bound is
     # issue (f32 MFMA + vector ALU: one resource), the PMC figures are quoted
     # at the default shape only, and no fraction of a "bound" that can exceed 1

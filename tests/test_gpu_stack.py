@@ -344,3 +344,47 @@ def test_bounded_wait_expires_loudly(hip_lib):
     assert torch.equal(ws.Z, wb.Z)
     assert ws.stack_ctl.cpu().tolist()[3] == 0
     a.check_device_errors()
+
+
+@pytest.mark.parametrize('B,T,gc', [(1, 700, False), (1, 1500, False), (2, 333, True), (3, 40, False),
+                                    (1, 5200, True)])
+def test_forward_with_fused_skip_sum_equals_stack_plus_gemm(hip_lib, monkeypatch, B, T, gc):
+    """wn_stack_fwd_skip (small batches, 512 skip channels: the skip sum by partner
+    waves inside the 16-row forward launch) against wn_stack_fwd + the skip GEMM:
+    the same X / Z / sigmoid planes bitwise, h1 to rounding (another order of
+    the sum), loss and every gradient; forward-only too; ragged last tiles,
+    groups of fewer than four tiles, global conditioning."""
+    from util import DEFAULT
+    monkeypatch.setattr(WaveNetModel, 'DEFAULT_STACK_VARIANT', 0)   # (the library's choice: 16-row tiles)
+    kw = dict(global_condition_channels=32, global_condition_cardinality=377) if gc else {}
+    cfg = cfg_with(DEFAULT, batch_size=B, **kw)
+    assert hip_lib.wn_stack_fwd_skip_ok(B, T, 512, 0) == 1
+    assert hip_lib.wn_stack_fwd_skip_ok(B, T, 256, 0) == 0
+    assert hip_lib.wn_stack_fwd_skip_ok(8, 16000, 512, 0) == 0
+    a, _ = build_pair(cfg)
+    b, _ = build_pair(cfg)
+    assert a.stack_fwd_skip
+    b.stack_fwd_skip = False
+    audio = synth_audio(B, T)
+    ids = np.array([(37 * i) % 377 for i in range(B)], np.int32) if gc else None
+    la, lb = a.loss(audio, ids), b.loss(audio, ids)
+    torch.cuda.synchronize()
+    wa = [w for w in a._ws.values() if w.training][0]
+    wb = [w for w in b._ws.values() if w.training][0]
+    assert getattr(wa, 'skimg', None) is not None and getattr(wb, 'skimg', None) is None
+    assert torch.equal(wa.X, wb.X) and torch.equal(wa.Z, wb.Z) and torch.equal(wa.SG, wb.SG)
+    assert abs(float(la) - float(lb)) <= 1e-6 * max(1.0, abs(float(lb)))
+    scale = float(b.grads.abs().max())
+    # (h1 differs by rounding, so a ReLU at a kink may flip -- more of them in a
+    # longer clip; the oracle comparison at the device's kinks is test_gpu_model's)
+    assert float((a.grads - b.grads).abs().max()) <= 1e-3 * scale
+    assert float((a.grads - b.grads).norm()) <= 1e-5 * max(1.0, T / 250.0) * float(b.grads.norm())
+    # the same twice
+    g1 = a.grads.clone()
+    la2 = a.loss(audio, ids)
+    assert float(la2) == float(la) and torch.equal(a.grads, g1)
+    # forward only
+    fa, fb = a.loss(audio, ids, backward=False), b.loss(audio, ids, backward=False)
+    assert abs(float(fa) - float(fb)) <= 1e-6 * max(1.0, abs(float(fb)))
+    assert int(wa.stack_ctl[3]) == 0 and not bool(torch.isnan(wa.loss_parts[:2]).any())
+

@@ -89,6 +89,11 @@ report(dbg.cpu().numpy(), gridf, 'stack_fwd16_kernel', [
   (3, 4, '32 past-tap MFMAs'), (4, 5, 'tanh / sigmoid'), (5, 6, 'dense bias + 16 MFMAs'),
   (6, 7, "x' out (stored, drained, flag posted / words stored)"),
   (7, 8, 'z / sigmoid stores issued, ring bookkeeping')], False)
+if os.environ.get('KB_WAVES_B') == '4':
+    # the fused skip sum's partner waves (wn_stack_fwd_skip: waves 4 .. 7)
+    report(dbg.cpu().numpy(), gridf, 'stack_fwd16_kernel<.., skip>, partner waves', [
+        (0, 1, "the four tiles' z of the layer in registers (waits for the chain waves)"),
+        (1, 3, '8 n-tiles x 4 tiles: 256 MFMAs, operand stream')], False, waves=(4, 7))
 report(dbgb.cpu().numpy(), gridb, 'stack_bwd16_kernel', [
     (0, 1, 'wait for the weight ring'), (1, 2, 'loads requested (z DMA, dZ, sigmoid, own dx, flag check, q)'),
     (2, 3, 'wait for them'), (3, 4, 'dx_{l+1} to LDS, dWd (8 MFMA), z fragments'),

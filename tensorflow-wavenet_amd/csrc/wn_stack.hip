@@ -1450,16 +1450,23 @@ __global__ __launch_bounds__((SKIP ? 2 : 1) * WAVES * 64) void stack_fwd16_kerne
           __builtin_amdgcn_sched_barrier(0);
           asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * SK_AHEAD) : "memory");
 #pragma unroll
-          for (int q = 0; q < 8; ++q)
+          for (int q = 0; q < 8; ++q) {
 #pragma unroll
             for (int t = 0; t < WAVES; ++t)
               acc[t][nt] = wn_mfma16(win[0][q >> 2][q & 3], zf[t].v[q >> 2][q & 3], acc[t][nt]);
+            // (a pause of 128 cycles per eight MFMAs: the chain wave on this SIMD
+            // issues its vector instructions at a fraction of their rate under a
+            // running MFMA stream, and it is the chain that sets the layer
+            // period.  B = 1, ms per step: no pause 1.641; 384 cycles per 32
+            // MFMAs 1.626; 64 / 128 / 192 / 256 per 8: 1.629 / 1.611 / 1.649 /
+            // 1.692; 128 / 256 / 384 per 16: 1.619 / 1.626 / 1.666)
+            if (q & 1) {
+              __builtin_amdgcn_sched_barrier(0);
+              __builtin_amdgcn_s_sleep(2);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
           __builtin_amdgcn_sched_barrier(0);
-          // (a pause per 32 MFMAs: the chain wave on this SIMD issues its vector
-          // instructions at a fraction of their rate under a running MFMA
-          // stream, and it is the chain that sets the layer period; B = 1:
-          // 1.641 / 1.633 / 1.623 / 1.671 ms per step at 0 / 2 / 6 / 12)
-          __builtin_amdgcn_s_sleep(6);
 #pragma unroll
           for (int n0 = 0; n0 < SK_AHEAD; ++n0) {
             win[n0][0] = win[n0 + 1][0];

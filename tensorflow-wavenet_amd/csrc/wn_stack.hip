@@ -1338,8 +1338,8 @@ __device__ __forceinline__ void f16_to_lds(float* lt, int g, int sw, const F16& 
 // 2.4 - 4 us a layer for it).  What it buys is bounded by the SIMD the two waves
 // share: under the partner's MFMA stream the chain wave's vector instructions
 // issue at a fraction of their rate (wn_common.h) and the layer period grows
-// from 4.1 to 8.4 us -- the launch takes 440 us against 232 + 194 for stack and
-// GEMM apart; a step at B = 1 goes from 1.68 to 1.62 ms.
+// from 4.1 to 7.4 us -- the launch takes 390 us against 232 + 194 for stack and
+// GEMM apart; a step at B = 1 goes from 1.68 to 1.61 ms.
 template <int SAVE, int WAVES, bool SKIP = false>
 __global__ __launch_bounds__((SKIP ? 2 : 1) * WAVES * 64) void stack_fwd16_kernel(StackFwd a) {
   __shared__ __attribute__((aligned(1024))) float wl[2 * STACK_WBUF];

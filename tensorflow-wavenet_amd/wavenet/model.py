@@ -964,7 +964,7 @@ class WaveNetModel(object):
                 _lib.call('wn_layer_fwd', *fargs, 0 if last else 1,
                           int(save_ts), st)
         bsum = None
-        if self.use_biases:
+        if self.use_biases and not fuse_skip:
             _lib.call('wn_sum_rows', _lib.ptr(self._seg(P, 'skip_b')), L, S,
                       _lib.ptr(ws.bsum), st)
             bsum = ws.bsum

@@ -324,6 +324,107 @@ def secondary(net, audio, gc_ids, kw, B, T, gen_samples=16000, opt=None):
             'optin_bf16x6': optin_roof}
 
 
+class _Emitter:
+    """Prints the ONE JSON line, exactly once, from whichever comes first: the
+    normal end of the run or the watchdog of a guarded region (N > 1: the
+    two-call all-reduce trial and every collective after it).  When a guarded
+    region does not return within its bound -- a collective that never
+    completes on some rank -- rank 0 prints the line it prepared from the
+    schedule already measured (`fallback`, "overlap_failed": true) and every
+    rank leaves with os._exit(0): a process whose device queue is stuck cannot
+    be unwound, must not be re-executed (GPU box rule), and the measured
+    figures are still valid."""
+
+    def __init__(self):
+        import threading
+        self.lock = threading.Lock()
+        self.done = False
+        self.fallback = None
+
+    def line(self, text):
+        with self.lock:
+            if not self.done:
+                self.done = True
+                sys.stdout.write(text + '\n')
+                sys.stdout.flush()
+
+    def _expired(self, what, bound):
+        log('%s did not return within %.0f s: giving up on it' % (what, bound))
+        if self.fallback is not None:
+            self.line(self.fallback.replace(
+                '@WHY@', '%s did not return within %.0f s' % (what, bound)))
+        sys.stderr.flush()
+        os._exit(0)
+
+    def guarded(self, fn, what='a collective', bound=None):
+        """fn() under a watchdog thread."""
+        import threading
+        if bound is None:
+            bound = float(os.environ.get('WN_OVERLAP_TRIAL_TIMEOUT', '120'))
+        t = threading.Timer(bound, self._expired, (what, bound))
+        t.daemon = True
+        t.start()
+        try:
+            return fn()
+        finally:
+            t.cancel()
+
+
+def overlap_trial(net, parallel, timed, instrumented, over_ranks, args, isteps,
+                  dev, emit):
+    """N > 1: the two-call gradient exchange (`dp_overlap_allreduce`: the skip /
+    post-processing tail all-reduced on a communication stream beside the
+    backward stack, the head at the update) timed in THIS process after the
+    one-call schedule: 2 warm-up steps (the launch plans are re-recorded), K
+    timed steps, the instrumented pass.  Guarded three ways, each leaving the
+    process usable for the one-call figures already in hand:
+      * an exception (a collective error) is caught, a dangling tail joined;
+      * a non-finite loss or an expired dependency wait inside a persistent
+        stack launch (the collective's kernel held CUs for seconds) is a
+        failure, agreed over the ranks with an all-reduce(MAX);
+      * the whole trial runs under the emitter's watchdog (a hang).
+    Returns {'failed': reason} or the schedule's figures."""
+    import math
+
+    def body():
+        why = None
+        res = {}
+        try:
+            net.dp_overlap_allreduce = True
+            for _ in range(2):
+                net_step_loss = timed(1)[1]
+            dt, loss = timed(args.steps)
+            _, ar_us = instrumented(isteps)
+            lossf = float(loss)
+            if not math.isfinite(lossf) or not math.isfinite(float(net_step_loss)):
+                why = 'non-finite loss under the two-call schedule'
+            try:
+                net.check_device_errors()
+            except Exception as e:         # noqa: BLE001
+                why = 'expired dependency wait in a stack launch: %s' % (e,)
+                net.reset_device_errors()
+            res = dict(dt=dt, loss=loss, ar_us=ar_us)
+        except Exception as e:             # noqa: BLE001
+            why = 'exception under the two-call schedule: %r' % (e,)
+            parallel.abandon_tail_allreduce(net)
+        # the ranks agree (a failure on one is a failure of the schedule)
+        bad = parallel.any_rank(why is not None, device=dev)
+        if bad:
+            net.dp_overlap_allreduce = False
+            log('two-call all-reduce trial failed: %s' % (why or 'on another rank'))
+            return {'failed': why or 'failed on another rank'}
+        dt_max, dt_min, ar = over_ranks(res['dt'], res['ar_us'])
+        gl = float(parallel.allreduce_mean_scalar(res['loss'].reshape(1).float())[0])
+        entry = {'ms_per_step': dt_max / args.steps * 1e3,
+                 'step_ms_min': dt_min / args.steps * 1e3,
+                 'step_ms_max': dt_max / args.steps * 1e3,
+                 'allreduce_us_per_step': ar, 'final_loss': float(res['loss'])}
+        return {'entry': entry, 'dt_max': dt_max, 'dt_min': dt_min, 'ar_us': ar,
+                'final_loss': float(res['loss']), 'global_loss': gl}
+
+    return emit.guarded(body, 'the two-call all-reduce trial')
+
+
 def launch_ranks(n):
     """Start `n` copies of this script as rank processes (what
     `python -m torch.distributed.run --nproc-per-node n` would do) and return
@@ -379,6 +480,9 @@ def main():
                     help='A/B runs: set a WaveNetModel attribute (a Python '
                          'literal), e.g. --set stack_fwd=False --set '
                          'stack_variant=0x1010; repeatable')
+    ap.add_argument('--no-overlap-trial', action='store_true',
+                    help='N > 1: time the one-call gradient all-reduce only '
+                         '(default: both schedules, value from the faster)')
     ap.add_argument('--no-secondary', action='store_true',
                     help='skip the forward-only and fast-generation figures')
     args = ap.parse_args()
@@ -426,10 +530,10 @@ def main():
                               device=dev)
     net = WaveNetModel(seed=0, **kw)
     net.gemm_mode = args.gemm_mode
-    # data-parallel: the tail of the gradient bucket is all-reduced beside the
-    # backward stack (wavenet/parallel.py); --set dp_overlap_allreduce=False
-    # for the one-call A/B
-    net.dp_overlap_allreduce = world > 1
+    # data-parallel: N > 1 times BOTH gradient-exchange schedules in this
+    # process (one all-reduce at the update; or the bucket's tail beside the
+    # backward stack + the head at the update, wavenet/parallel.py) and reports
+    # the faster; --set dp_overlap_allreduce=... pins one
     for item in args.set:        # A/B knobs: explicit model attributes
         import ast
         name, _, val = item.partition('=')
@@ -463,34 +567,59 @@ def main():
                         rank * B, (rank + 1) * B))
     sys.stderr.flush()
     log('rank %d/%d: model built, warming up' % (rank, world))
+
+    def timed(k):
+        """EXACTLY k steps between barrier + device sync on both sides."""
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            loss = step()
+        sync_all()
+        return time.perf_counter() - t0, loss
+
+    def instrumented(n):
+        """(NOT part of `value`) the same step with HIP events around every
+        GEMM / stack launch and around the gradient all-reduce"""
+        net._gemm_events = []
+        parallel.timing_events = [] if world > 1 else None
+        for _ in range(n):
+            step()
+        sync_all()
+        ev = net._gemm_events or []
+        net._gemm_events = None
+        ar = parallel.timing_events or []
+        parallel.timing_events = None
+        us = sum(a.elapsed_time(b) for a, b in ar) / n * 1e3 if ar else None
+        return ev, us
+
+    def over_ranks(dt, ar_us):
+        """(max, min) of the timed region and max of the all-reduce time"""
+        if world == 1:
+            return dt, dt, ar_us
+        tt = torch.tensor([dt, -dt, ar_us or 0.0], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        return float(tt[0]), -float(tt[1]), float(tt[2])
+
+    # N > 1: the ONE-call schedule (a single all-reduce of the whole bucket at
+    # the update) is timed first, unless --set names a schedule: it is the
+    # path every rehearsal has run, and its figures are in hand before the
+    # two-call schedule -- whose tail collective runs on a communication
+    # stream beside the persistent backward-stack launch and has never met
+    # RCCL with N >= 2 -- is tried in this same process (overlap_trial below).
+    explicit = any(i.partition('=')[0] == 'dp_overlap_allreduce' for i in args.set)
+    if world > 1 and not explicit:
+        net.dp_overlap_allreduce = False
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     log('warm-up done, timing %d steps' % args.steps)
     net._gemm_events = None          # the headline loop is un-instrumented
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    sync_all()
-    dt = time.perf_counter() - t0
-    # instrumented pass (NOT part of `value`): the same step with HIP events
-    # around every GEMM launch and around the gradient all-reduce
+    dt, loss = timed(args.steps)
     isteps = max(1, min(5, args.steps))
-    net._gemm_events = []
-    parallel.timing_events = [] if world > 1 else None
-    for _ in range(isteps):
-        step()
-    sync_all()
-    events = net._gemm_events or []
-    net._gemm_events = None
-    ar_events = parallel.timing_events or []
-    parallel.timing_events = None
-    ar_us = None
-    if ar_events:
-        ar_us = sum(a.elapsed_time(b) for a, b in ar_events) / isteps * 1e3
+    events, ar_us = instrumented(isteps)
     ranks_seen = 1
-    dt_min = dt_max = dt
+    dt_max, dt_min, ar_us = over_ranks(dt, ar_us)
+    dt = dt_max
     global_loss, ids_all = float(loss), None
     if world > 1:
         gl = parallel.allreduce_mean_scalar(loss.reshape(1).float())
@@ -499,183 +628,224 @@ def main():
             got = [torch.empty_like(gc_ids) for _ in range(world)]
             torch.distributed.all_gather(got, gc_ids)
             ids_all = [int(v) for t in got for v in t.cpu().tolist()]
-        tt = torch.tensor([dt, -dt, ar_us or 0.0], dtype=torch.float64,
-                          device=dev)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt_max, dt_min, ar_us = float(tt[0]), -float(tt[1]), float(tt[2])
-        dt = dt_max
         ones = torch.ones(1, dtype=torch.float32, device=dev)
         torch.distributed.all_reduce(ones)          # RCCL: every rank adds 1
         ranks_seen = int(round(float(ones[0])))
         if ranks_seen != args.gpus:
             raise SystemExit('all-reduce saw %d ranks, expected %d'
                              % (ranks_seen, args.gpus))
+    cur = {'dt': dt, 'dt_min': dt_min, 'dt_max': dt_max, 'ar_us': ar_us,
+           'final_loss': float(loss), 'global_loss': global_loss,
+           'calls': 2 if net.dp_overlap_allreduce else 1,
+           'schedules': {}, 'overlap_failed': None, 'overlap_failure': None}
+    cur['schedules']['two_call' if cur['calls'] == 2 else 'one_call'] = {
+        'ms_per_step': dt / args.steps * 1e3,
+        'step_ms_min': dt_min / args.steps * 1e3,
+        'step_ms_max': dt_max / args.steps * 1e3,
+        'allreduce_us_per_step': ar_us, 'final_loss': float(loss)}
+
+    def result_line(cur):
+        """The JSON line from the figures of the schedule in `cur` (the
+        roofline objects come from the instrumented pass of the first
+        schedule: the kernels are the same under both)."""
+        dt, dt_min, dt_max, ar_us = cur['dt'], cur['dt_min'], cur['dt_max'], cur['ar_us']
+        final_loss, global_loss = cur['final_loss'], cur['global_loss']
+        value = world * B * T * args.steps / dt
+        # dominant kernel = the NN GEMM launches (skip sum, post1, post2 and
+        # their data gradients); the TN weight-gradient GEMMs are reported beside
+        nn = [e for e in events if 'gemm_nn' in e[3]]
+        tn = [e for e in events if 'gemm_tn' in e[3]]
+        flops = sum(e[2] for e in nn)
+        ktime = sum(e[0].elapsed_time(e[1]) for e in nn) * 1e-3
+        achieved = flops / ktime / 1e12 if ktime > 0 else 0.0
+        nlaunch = len(nn)
+        tn_flops = sum(e[2] for e in tn)
+        tn_time = sum(e[0].elapsed_time(e[1]) for e in tn) * 1e-3
+        # small batches run the TN GEMMs on a side stream beside the backward
+        # stack (net.overlap_tn): the event pairs, recorded on the main stream,
+        # then bracket nothing -- no TN figure rather than a meaningless one
+        tn_side = any(net._overlap_tn_on(w) for w in net._ws.values() if w.training)
+        if tn_side:
+            tn_time = 0.0
+        step_tflops = STEP_FLOP_PER_SAMPLE * B * T / (dt / args.steps) / 1e12
+        peak = FP32_MFMA_PEAK_TFLOPS if args.gemm_mode == 'fp32' else \
+            2500.0 / int(args.gemm_mode[-1])
+        dom = 'gemm_nn3_kernel' if args.gemm_mode == 'fp32' else \
+            'gemm_nn_split_kernel'
+        Sk, Qc = int(params['skip_channels']), int(params['quantization_channels'])
+        LC = len(params['dilations']) * 32
+        algo_bytes = 4.0 * B * T * (
+            (LC + Sk) + (3 * Sk) + (Sk + Qc) + (Qc + 2 * Sk) + (3 * Sk) + (Sk + LC)) / 6
+        # (the committed PMC summary was collected at the default shape only)
+        traffic, traffic_src, traffic_stale = pmc_traffic(dom) if (B, T) == (8, 16000) \
+            else (None, None, None)
+        # the two persistent residual-stack launches.  Their bound is ISSUE (on
+        # gfx950 the f32 MFMA and the vector ALU are one resource: DESIGN.md,
+        # profiles/*_mfma_valu.txt), neither HBM nor the matrix pipe alone: time
+        # live (HIP events), the issue-slot fractions and the fabric bytes from the
+        # committed PMC summaries of the kernel that RAN (name = what the library's
+        # shape / variant rules pick), each tagged stale when the kernel sources
+        # changed since it was collected.  The TB/s figure is information, not a
+        # fraction of a bound.
+        stacks = {}
+        lib_ = net  # (kernel names follow wn_stack_tile_rows / the variant word)
+        tws = [w for w in net._ws.values() if w.training]
+        rows_f = tws[0].stack_rows if tws else 32
+        rows_b = rows_f
+        kern = {'wn_stack_fwd': 'void stack_fwd_kernel<2, 16>' if rows_f == 32
+                else 'void stack_fwd16_kernel<2, 8>',
+                'wn_stack_bwd': 'void stack_bwd_kernel<8>' if rows_b == 32
+                else 'void stack_bwd16_kernel<8>'}
+        tile_layers = B * ((T + 31) // 32) * len(params['dilations'])
+        mfma_cyc = {'wn_stack_fwd': 80 * 64, 'wn_stack_bwd': 160 * 64}    # per 32-row tile and layer
+        for ev_name in ('wn_stack_fwd', 'wn_stack_bwd'):
+            evs = [e for e in events if e[3] == ev_name or
+                   (ev_name == 'wn_stack_fwd' and e[3] == 'wn_stack_fwd_skip')]
+            if not evs:
+                continue
+            us = sum(e[0].elapsed_time(e[1]) for e in evs) / len(evs) * 1e3
+            kname = kern[ev_name]
+            by, src, stale = pmc_traffic(kname) if (B, T) == (8, 16000) else (None, None, None)
+            iss, isrc, istale = pmc_issue(kname) if (B, T) == (8, 16000) else (None, None, None)
+            stacks[ev_name] = {
+                'kernel': kname.replace('void ', ''), 'avg_launch_us': us,
+                'bound': 'issue',
+                # live: the launch's MFMA work (algorithmic, SURVEY 8d) over its time,
+                # against 1024 SIMDs at the 2.4 GHz peak clock
+                'mfma_busy_frac_live_at_2p4ghz': tile_layers * mfma_cyc[ev_name] / 1024.0 / (us * 2400.0),
+                'issue': None if iss is None else {
+                    k: iss.get(k) for k in ('mfma_busy_frac', 'valu_issue_frac', 'issue_frac',
+                                            'mfma_valu_coexec_frac', 'vmem_inst_cycles_frac',
+                                            'clock_ghz', 'avg_us')},
+                'issue_source': isrc, 'issue_stale': istale,
+                'traffic': by, 'traffic_source': src, 'traffic_stale': stale,
+                'fabric_tb_s_info': None if by is None else by / us / 1e6}
+        out = {
+            'metric': 'audio samples/sec (train, default wavenet_params.json)',
+            'value': value, 'unit': 'audio samples/s', 'n_gpus': world,
+            'ranks_seen': ranks_seen,
+            'dist_backend': torch.distributed.get_backend() if world > 1 else None,
+            'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+            'step_tflops': step_tflops,
+            'step_frac': step_tflops / FP32_MFMA_PEAK_TFLOPS,
+            'step_tflops_note': 'whole step per GPU: 8.804 MFLOP per audio sample '
+                                '(SURVEY 8d) x samples / step time, against the '
+                                '157.3 TFLOP/s fp32 MFMA peak',
+            'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if args.gemm_mode == 'fp32' else
+                     'f32 (NN GEMM products rebuilt from %s split pieces on bf16 '
+                     'MFMA, fp32 accumulate; opt-in)' % args.gemm_mode,
+            'data': 'synthetic',
+            'config': {'workload': 'default wavenet_params.json stack (50 dilation '
+                                   'layers, R=D=32, S=512, Q=256), full training '
+                                   'step, %d clips x %d samples per GPU, fp32%s'
+                                   % (B, T, ', global conditioning 32x377'
+                                      if args.gc else ''),
+                       'clips_per_gpu': B, 'samples_per_clip': T,
+                       'global_batch': world * B,
+                       'parallelism': 'dp%d' % world,
+                       'final_loss': final_loss,
+                       # mean over ranks = the loss of the global batch (equal
+                       # per-rank B*T, wavenet/parallel.py)
+                       'global_loss': global_loss,
+                       'gc_ids': ids_all if ids_all is not None else
+                       (None if gc_ids is None else gc_ids.cpu().tolist())},
+            'roofline': {'bound': 'mfma',
+                         'kernel': dom,
+                         'achieved': achieved, 'peak': peak,
+                         'unit': 'TFLOP/s' if args.gemm_mode == 'fp32' else
+                                 'TFLOP/s (fp32-equivalent; peak = bf16 dense '
+                                 '2500 / piece products)',
+                         'frac': achieved / peak,
+                         'traffic': traffic, 'traffic_source': traffic_src,
+                         'traffic_stale': traffic_stale,
+                         'traffic_unit': 'bytes per launch (rocprofv3 PMC pass)',
+                         # what the six launches of a step must move (fp32 path):
+                         # A operands in, outputs out, the pre-activation plane the
+                         # ReLU backward needs out, its two masks in; per launch
+                         'traffic_algorithmic': algo_bytes,
+                         'traffic_ratio': None if traffic is None
+                         else traffic / algo_bytes,
+                         'launches_per_step': nlaunch // isteps,
+                         'avg_launch_us': ktime / max(nlaunch, 1) * 1e6,
+                         'flops_per_step': flops / isteps,
+                         'measured_over': '%d instrumented steps after the timed '
+                                          'region' % isteps,
+                         'tn_gemms': {
+                             'kernel': 'gemm_tn3_kernel',
+                             'achieved': tn_flops / tn_time / 1e12
+                             if tn_time > 0 else None,
+                             'frac': tn_flops / tn_time / 1e12 / peak
+                             if tn_time > 0 else None,
+                             'launches_per_step': len(tn) // isteps,
+                             'us_per_step': tn_time / isteps * 1e6
+                             if tn_time > 0 else None,
+                             'note': 'on a side stream beside the backward stack '
+                                     '(small batch): not timed' if tn_side else None},
+                         'stack_launches': stacks},
+        }
+        if world > 1:
+            out['allreduce_us_per_step'] = ar_us
+            out['allreduce_note'] = ('max over ranks of the HIP-event time around '
+                                     'the gradient all-reduce issued at the update '
+                                     '(includes waiting for the slowest rank); with '
+                                     'allreduce_calls == 2 that is the bucket\'s head '
+                                     'only: the skip / post-processing tail was '
+                                     'reduced beside the backward stack.  N > 1 '
+                                     'times BOTH schedules in this process, K steps '
+                                     'each (allreduce_schedules); value is the '
+                                     'faster one\'s')
+            # which schedule `value` / `ms_per_step` are from (the faster of the
+            # two timed in this process), both schedules' figures, and whether
+            # the two-call trial failed (then: one call, value from it)
+            out['allreduce_calls'] = cur['calls']
+            out['allreduce_schedules'] = cur['schedules']
+            out['overlap_failed'] = cur['overlap_failed']
+            out['overlap_failure'] = cur['overlap_failure']
+            out['allreduce_tail_bytes'] = int((net.grads.numel() - parallel.tail_start(net))
+                                              * net.grads.element_size())
+            out['allreduce_bytes'] = int(net.grads.numel() * net.grads.element_size())
+            out['collective'] = collective_env()
+            out['step_ms_min'] = dt_min / args.steps * 1e3
+            out['step_ms_max'] = dt_max / args.steps * 1e3
+        return out
+
+    emit = _Emitter()
+    if world > 1 and not explicit and not args.no_overlap_trial:
+        # everything the line needs from the one-call schedule is in hand:
+        # rank 0 prints it from the watchdog if the trial never returns
+        # (as TEXT, built now: no HIP call is made from the watchdog thread)
+        if rank == 0:
+            emit.fallback = json.dumps(result_line(dict(
+                cur, overlap_failed=True, overlap_failure='@WHY@')))
+        two = overlap_trial(net, parallel, timed, instrumented, over_ranks,
+                            args, isteps, dev, emit)
+        if two.get('failed'):
+            cur['overlap_failed'], cur['overlap_failure'] = True, two['failed']
+        else:
+            cur['overlap_failed'] = False
+            cur['schedules']['two_call'] = two['entry']
+            if two['dt_max'] < cur['dt']:
+                # the faster schedule is the job's throughput
+                cur.update(dt=two['dt_max'], dt_min=two['dt_min'], dt_max=two['dt_max'],
+                           ar_us=two['ar_us'], final_loss=two['final_loss'],
+                           global_loss=two['global_loss'], calls=2)
     if rank != 0:
         if world > 1:
-            torch.distributed.barrier()
+            emit.guarded(torch.distributed.barrier)
             torch.distributed.destroy_process_group()
         return
-
-    value = world * B * T * args.steps / dt
-    log('gpu: %.0f samples/s, %.2f ms/step' % (value, dt / args.steps * 1e3))
-    # dominant kernel = the NN GEMM launches (skip sum, post1, post2 and
-    # their data gradients); the TN weight-gradient GEMMs are reported beside
-    nn = [e for e in events if 'gemm_nn' in e[3]]
-    tn = [e for e in events if 'gemm_tn' in e[3]]
-    flops = sum(e[2] for e in nn)
-    ktime = sum(e[0].elapsed_time(e[1]) for e in nn) * 1e-3
-    achieved = flops / ktime / 1e12 if ktime > 0 else 0.0
-    nlaunch = len(nn)
-    tn_flops = sum(e[2] for e in tn)
-    tn_time = sum(e[0].elapsed_time(e[1]) for e in tn) * 1e-3
-    # small batches run the TN GEMMs on a side stream beside the backward
-    # stack (net.overlap_tn): the event pairs, recorded on the main stream,
-    # then bracket nothing -- no TN figure rather than a meaningless one
-    tn_side = any(net._overlap_tn_on(w) for w in net._ws.values() if w.training)
-    if tn_side:
-        tn_time = 0.0
-    step_tflops = STEP_FLOP_PER_SAMPLE * B * T / (dt / args.steps) / 1e12
-    peak = FP32_MFMA_PEAK_TFLOPS if args.gemm_mode == 'fp32' else \
-        2500.0 / int(args.gemm_mode[-1])
-    dom = 'gemm_nn3_kernel' if args.gemm_mode == 'fp32' else \
-        'gemm_nn_split_kernel'
-    Sk, Qc = int(params['skip_channels']), int(params['quantization_channels'])
-    LC = len(params['dilations']) * 32
-    algo_bytes = 4.0 * B * T * (
-        (LC + Sk) + (3 * Sk) + (Sk + Qc) + (Qc + 2 * Sk) + (3 * Sk) + (Sk + LC)) / 6
-    # (the committed PMC summary was collected at the default shape only)
-    traffic, traffic_src, traffic_stale = pmc_traffic(dom) if (B, T) == (8, 16000) \
-        else (None, None, None)
-    # the two persistent residual-stack launches.  Their bound is ISSUE (on
-    # gfx950 the f32 MFMA and the vector ALU are one resource: DESIGN.md,
-    # profiles/*_mfma_valu.txt), neither HBM nor the matrix pipe alone: time
-    # live (HIP events), the issue-slot fractions and the fabric bytes from the
-    # committed PMC summaries of the kernel that RAN (name = what the library's
-    # shape / variant rules pick), each tagged stale when the kernel sources
-    # changed since it was collected.  The TB/s figure is information, not a
-    # fraction of a bound.
-    stacks = {}
-    lib_ = net  # (kernel names follow wn_stack_tile_rows / the variant word)
-    tws = [w for w in net._ws.values() if w.training]
-    rows_f = tws[0].stack_rows if tws else 32
-    rows_b = rows_f
-    kern = {'wn_stack_fwd': 'void stack_fwd_kernel<2, 16>' if rows_f == 32
-            else 'void stack_fwd16_kernel<2, 8>',
-            'wn_stack_bwd': 'void stack_bwd_kernel<8>' if rows_b == 32
-            else 'void stack_bwd16_kernel<8>'}
-    tile_layers = B * ((T + 31) // 32) * len(params['dilations'])
-    mfma_cyc = {'wn_stack_fwd': 80 * 64, 'wn_stack_bwd': 160 * 64}    # per 32-row tile and layer
-    for ev_name in ('wn_stack_fwd', 'wn_stack_bwd'):
-        evs = [e for e in events if e[3] == ev_name or
-               (ev_name == 'wn_stack_fwd' and e[3] == 'wn_stack_fwd_skip')]
-        if not evs:
-            continue
-        us = sum(e[0].elapsed_time(e[1]) for e in evs) / len(evs) * 1e3
-        kname = kern[ev_name]
-        by, src, stale = pmc_traffic(kname) if (B, T) == (8, 16000) else (None, None, None)
-        iss, isrc, istale = pmc_issue(kname) if (B, T) == (8, 16000) else (None, None, None)
-        stacks[ev_name] = {
-            'kernel': kname.replace('void ', ''), 'avg_launch_us': us,
-            'bound': 'issue',
-            # live: the launch's MFMA work (algorithmic) over its time,
-            # against 1024 SIMDs at the 2.4 GHz peak clock
-            'mfma_busy_frac_live_at_2p4ghz': tile_layers * mfma_cyc[ev_name] / 1024.0 / (us * 2400.0),
-            'issue': None if iss is None else {
-                k: iss.get(k) for k in ('mfma_busy_frac', 'valu_issue_frac', 'issue_frac',
-                                        'mfma_valu_coexec_frac', 'vmem_inst_cycles_frac',
-                                        'clock_ghz', 'avg_us')},
-            'issue_source': isrc, 'issue_stale': istale,
-            'traffic': by, 'traffic_source': src, 'traffic_stale': stale,
-            'fabric_tb_s_info': None if by is None else by / us / 1e6}
-    out = {
-        'metric': 'audio samples/sec (train, default wavenet_params.json)',
-        'value': value, 'unit': 'audio samples/s', 'n_gpus': world,
-        'ranks_seen': ranks_seen,
-        'dist_backend': torch.distributed.get_backend() if world > 1 else None,
-        'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
-        'step_tflops': step_tflops,
-        'step_frac': step_tflops / FP32_MFMA_PEAK_TFLOPS,
-        'step_tflops_note': 'whole step per GPU: 8.804 MFLOP per audio sample '
-                            '(SURVEY 8d) x samples / step time, against the '
-                            '157.3 TFLOP/s fp32 MFMA peak',
-        'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32' if args.gemm_mode == 'fp32' else
-                 'f32 (NN GEMM products rebuilt from %s split pieces on bf16 '
-                 'MFMA, fp32 accumulate; opt-in)' % args.gemm_mode,
-        'data': 'synthetic',
-        'config': {'workload': 'default wavenet_params.json stack (50 dilation '
-                               'layers, R=D=32, S=512, Q=256), full training '
-                               'step, %d clips x %d samples per GPU, fp32%s'
-                               % (B, T, ', global conditioning 32x377'
-                                  if args.gc else ''),
-                   'clips_per_gpu': B, 'samples_per_clip': T,
-                   'global_batch': world * B,
-                   'parallelism': 'dp%d' % world,
-                   'final_loss': float(loss),
-                   # mean over ranks = the loss of the global batch (equal
-                   # per-rank B*T, wavenet/parallel.py)
-                   'global_loss': global_loss,
-                   'gc_ids': ids_all if ids_all is not None else
-                   (None if gc_ids is None else gc_ids.cpu().tolist())},
-        'roofline': {'bound': 'mfma',
-                     'kernel': dom,
-                     'achieved': achieved, 'peak': peak,
-                     'unit': 'TFLOP/s' if args.gemm_mode == 'fp32' else
-                             'TFLOP/s (fp32-equivalent; peak = bf16 dense '
-                             '2500 / piece products)',
-                     'frac': achieved / peak,
-                     'traffic': traffic, 'traffic_source': traffic_src,
-                     'traffic_stale': traffic_stale,
-                     'traffic_unit': 'bytes per launch (rocprofv3 PMC pass)',
-                     # what the six launches of a step must move (fp32 path):
-                     # A operands in, outputs out, the pre-activation plane the
-                     # ReLU backward needs out, its two masks in; per launch
-                     'traffic_algorithmic': algo_bytes,
-                     'traffic_ratio': None if traffic is None
-                     else traffic / algo_bytes,
-                     'launches_per_step': nlaunch // isteps,
-                     'avg_launch_us': ktime / max(nlaunch, 1) * 1e6,
-                     'flops_per_step': flops / isteps,
-                     'measured_over': '%d instrumented steps after the timed '
-                                      'region' % isteps,
-                     'tn_gemms': {
-                         'kernel': 'gemm_tn3_kernel',
-                         'achieved': tn_flops / tn_time / 1e12
-                         if tn_time > 0 else None,
-                         'frac': tn_flops / tn_time / 1e12 / peak
-                         if tn_time > 0 else None,
-                         'launches_per_step': len(tn) // isteps,
-                         'us_per_step': tn_time / isteps * 1e6
-                         if tn_time > 0 else None,
-                         'note': 'on a side stream beside the backward stack '
-                                 '(small batch): not timed' if tn_side else None},
-                     'stack_launches': stacks},
-    }
-    if world > 1:
-        out['allreduce_us_per_step'] = ar_us
-        out['allreduce_note'] = ('max over ranks of the HIP-event time around '
-                                 'the gradient all-reduce issued at the update '
-                                 '(includes waiting for the slowest rank); with '
-                                 'allreduce_calls == 2 that is the bucket\'s head '
-                                 'only: the skip / post-processing tail was '
-                                 'reduced beside the backward stack')
-        out['allreduce_calls'] = 2 if net.dp_overlap_allreduce else 1
-        out['allreduce_tail_bytes'] = int((net.grads.numel() - parallel.tail_start(net))
-                                          * net.grads.element_size())
-        out['allreduce_bytes'] = int(net.grads.numel() * net.grads.element_size())
-        out['collective'] = collective_env()
-        out['step_ms_min'] = dt_min / args.steps * 1e3
-        out['step_ms_max'] = dt_max / args.steps * 1e3
+    out = result_line(cur)
+    log('gpu: %.0f samples/s, %.2f ms/step' % (out['value'], out['ms_per_step']))
     if world == 1 and not args.no_secondary:
         out['secondary'] = secondary(net, audio, gc_ids, kw, B, T, opt=opt)
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(params, T)
-        out['gpu_over_cpu'] = value / out['cpu_baseline']['value']
-    print(json.dumps(out))
-    sys.stdout.flush()
+        out['gpu_over_cpu'] = out['value'] / out['cpu_baseline']['value']
+    emit.line(json.dumps(out))
     if world > 1:
-        torch.distributed.barrier()
+        emit.guarded(torch.distributed.barrier)
         torch.distributed.destroy_process_group()
 
 

@@ -1367,6 +1367,17 @@ class WaveNetModel(object):
         T = q.shape[1]
         N = B * T
         ws = self._workspace(B, T, backward)
+        if backward and self._tail_work is not None:
+            # the previous backward pass started its tail all-reduce and no
+            # optimizer.minimize joined it: join before this pass rewrites the
+            # bucket (parallel.begin_tail_allreduce documents why this keeps
+            # the ranks in step)
+            import warnings
+            from . import parallel
+            warnings.warn('the tail all-reduce of the previous backward pass '
+                          'was never joined (no optimizer.minimize followed): '
+                          'joined and dropped now')
+            parallel.abandon_tail_allreduce(self)
         ws.q.copy_(q.reshape(-1))
         if self.scalar_input:
             # network input is the raw float audio (model.py:645-648)
@@ -1390,7 +1401,14 @@ class WaveNetModel(object):
             # (L2 adds lambda * params to the WHOLE bucket after the backward
             # pass: the tail must not have been summed over ranks before that)
             self._early_ok = l2_regularization_strength is None
-            self._backward(ws, ids)
+            try:
+                self._backward(ws, ids)
+            except BaseException:
+                # (a launch error after the tail's all-reduce was issued: join
+                # it, so that the next step does not find it dangling)
+                from . import parallel
+                parallel.abandon_tail_allreduce(self)
+                raise
             # the backward stack launch's poison word (0, or NaN when one of
             # its dependency waits expired) is written after the loss
             # reduction above: add it here so that THIS step's loss is NaN

@@ -39,9 +39,16 @@ import torch
 import torch.distributed as dist
 
 
+# Rehearsal switch (tests only): treat an initialised world-size-1 group as
+# distributed, so that the collective calls -- incl. the tail all-reduce on the
+# communication stream beside the backward stack -- run through RCCL on a box
+# with one GPU.  A sum over one rank is the identity: results must not change.
+rehearse_world_one = False
+
+
 def is_distributed():
     return dist.is_available() and dist.is_initialized() and \
-        dist.get_world_size() > 1
+        (dist.get_world_size() > 1 or rehearse_world_one)
 
 
 def init_from_env(backend=None):
@@ -137,8 +144,16 @@ def begin_tail_allreduce(model):
     if not is_distributed():
         return
     if getattr(model, '_tail_work', None) is not None:
-        raise RuntimeError('a tail all-reduce of the previous step was never '
-                           'joined (optimizer.minimize did not run)')
+        # loss(backward=True) without optimizer.minimize (an evaluation, a
+        # gradient check): the previous tail was issued on EVERY rank (the
+        # ranks run the same program), so joining it here keeps the ranks'
+        # collective sequences equal; its sums went into gradients this pass
+        # has already overwritten.
+        import warnings
+        warnings.warn('the tail all-reduce of the previous backward pass was '
+                      'never joined (no optimizer.minimize followed): joined '
+                      'and dropped now')
+        abandon_tail_allreduce(model)
     lo = tail_start(model)
     tail = model.grads[lo:]
     if tail.is_cuda:
@@ -151,6 +166,24 @@ def begin_tail_allreduce(model):
     else:
         work = dist.all_reduce(tail, op=dist.ReduceOp.SUM, async_op=True)
     model._tail_work = (work, lo)
+
+
+def abandon_tail_allreduce(model):
+    """Join and forget a tail all-reduce that `allreduce_gradients` will not
+    join (an exception later in the same backward pass, a backward pass that
+    no update follows).  The collective itself was issued and completes on
+    every rank -- only this rank's bookkeeping is reset -- so the next step
+    starts from a clean sequence.  Returns True when there was one."""
+    pending = getattr(model, '_tail_work', None)
+    if pending is None:
+        return False
+    model._tail_work = None
+    try:
+        pending[0].wait()
+    except Exception as e:           # a failed collective: report, do not mask
+        import warnings
+        warnings.warn('joining the abandoned tail all-reduce failed: %r' % (e,))
+    return True
 
 
 def allreduce_gradients(model):

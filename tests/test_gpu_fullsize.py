@@ -112,41 +112,17 @@ def test_full_size_dp_identity_and_determinism(hip_lib, monkeypatch, gc):
     assert not bad, bad[:6]
 
 
-@pytest.mark.parametrize('tag', ['config1', 'config4'])
-def test_full_length_vs_oracle(hip_lib, tag):
-    """BASELINE.json configs[0] at FULL length (default stack, one clip of
-    16000 samples) and one GPU's share of configs[3] (the same with global
-    conditioning 32 x 377, global clip 5, speaker id 185): the committed
-    float64 fingerprints (tests/golden/config{1,4}_fullsize.npz) pin the
-    oracle, the oracle pins the device.
-      1. the float64 oracle run here reproduces the committed loss and every
-         variable's sum / abs-sum / max / 32 sampled gradient entries;
-      2. the device's loss equals it to 1e-5, its logits to 1e-4;
-      3. the device's ReLU decisions differ from the oracle's only where the
-         oracle's pre-activation is within 2e-5 of 0, at no more positions
-         than the fixture counts there;
-      4. every entry of every variable's gradient (config4: incl. the
-         embedding table and every layer's gc_filtweights / gc_gateweights) is
-         within max(2e-5, 4 x the float32 oracle's own error) of the
-         variable's largest entry, against the float64 oracle taking the
-         device's side at those kinks."""
-    sys_path_golden()
-    from make_golden import fullsize_inputs, sample_index
-    from util import build_pair, flat_named, oracle_grads_at_device_kinks
-    fx = np.load(os.path.join(GOLD, tag + '_fullsize.npz'))
-    T = 16000
-    cfg, audio, ids = fullsize_inputs(tag)
-    assert np.allclose([audio.sum(dtype=np.float64), np.abs(audio).sum(dtype=np.float64)],
-                       fx[tag + '/audio_crc'], rtol=0, atol=1e-9)
-    net, var = build_pair(cfg)
-    # (the backward pass turns the logits into their gradient in place)
-    loss_fwd = float(net.loss(audio, ids, backward=False))
-    ws = [w for w in net._ws.values() if w.T == T][0]
-    lg = ws.logits.cpu().numpy()
-    loss = float(net.loss(audio, ids))
-    torch.cuda.synchronize()
-    assert loss == loss_fwd
-    # (1) the live oracle is the committed one
+_ORACLE64 = {}
+
+
+def _oracle64(tag, cfg, var, audio, ids, fx):
+    """float64 oracle of a full-length fixture, run ONCE per test session and
+    checked against the committed fingerprints (step 1 of
+    test_full_length_vs_oracle): (loss, forward cache incl. every logits row)."""
+    if tag in _ORACLE64:
+        return _ORACLE64[tag]
+    from make_golden import sample_index
+    from util import flat_named
     l64, g64 = O.loss_and_grads(cfg, var, audio, ids, dtype=np.float64)
     assert abs(l64 - float(fx[tag + '/loss'])) < 1e-12
     flat64 = flat_named(g64)
@@ -158,15 +134,39 @@ def test_full_length_vs_oracle(hip_lib, tag):
         assert abs(np.abs(a).sum() - fx[tag + '/abssum'][i]) <= 1e-9 * fx[tag + '/abssum'][i] + 1e-300, n
         got = a.reshape(-1)[sample_index(a.size, i)]
         assert np.abs(got - fx[tag + '/samples'][i]).max() <= 2e-7 * sc + 1e-300, n
-    # (2) loss, logits
+    _, c = O.loss(cfg, var, audio, ids, None, np.float64, keep=True)
+    _ORACLE64[tag] = (l64, c)
+    return _ORACLE64[tag]
+
+
+def _compare_with_oracle(hip_lib, net, cfg, var, audio, ids, l64, c, tols_tag, rows,
+                         max_flips=None):
+    """Steps 2 - 4 of test_full_length_vs_oracle for one model / kernel path;
+    returns the log entry."""
+    from util import flat_named, oracle_grads_at_device_kinks
+    B, T = audio.shape
+    # (the backward pass turns the logits into their gradient in place)
+    loss_fwd = float(net.loss(audio, ids, backward=False))
+    ws = [w for w in net._ws.values() if w.T == T][0]
+    lg = ws.logits.cpu().numpy().reshape(B, T, -1)
+    loss = float(net.loss(audio, ids))
+    torch.cuda.synchronize()
+    assert loss == loss_fwd
+    wst = [w for w in net._ws.values() if w.T == T and w.training][0]
+    # the launches under test are the ones that ran
+    assert wst.stack_rows == rows == hip_lib.wn_stack_tile_rows(B, T, wst.stack_variant)
+    assert net.stack_fwd and wst.stack_bwd and net._stack_bwd_ok()
+    # (2) loss; EVERY logits row
     assert abs(loss - l64) < 1e-5
-    assert np.abs(lg[0] - fx[tag + '/logits_first_last'][0]).max() < 1e-4
-    assert np.abs(lg[-1] - fx[tag + '/logits_first_last'][1]).max() < 1e-4
+    logits_err = float(np.abs(lg - c['logits']).max())
+    assert logits_err < 1e-4, logits_err
     # (3) + (4)
-    ref_loss, ref_g, c, flips = oracle_grads_at_device_kinks(net, cfg, var, audio, ids)
-    assert flips <= int(fx[tag + '/near_kink'].sum())
+    ref_loss, ref_g, _, flips = oracle_grads_at_device_kinks(net, cfg, var, audio, ids,
+                                                             cache=c)
+    if max_flips is not None:
+        assert flips <= max_flips
     named = _flat_grads(net)
-    tols = _var_tols([n for n, _ in named], tag)
+    tols = _var_tols([n for n, _ in named], tols_tag)
     worst, bad = (0.0, ''), []
     for (n, a), (_, b), tol in zip(named, flat_named(ref_g), tols):
         sc = np.abs(b).max()
@@ -175,8 +175,74 @@ def test_full_length_vs_oracle(hip_lib, tag):
             worst = max(worst, (err / sc, n))
         if not err <= tol * sc + 1e-12:
             bad.append((n, float(err), float(sc), float(tol)))
-    _log(tag + '_T16000_vs_float64', {'worst_ratio': worst, 'relu_flips': flips,
-                                      'loss_err': abs(loss - l64), 'bad': bad[:10]})
+    entry = {'tile_rows': rows, 'worst_ratio': worst, 'relu_flips': flips,
+             'loss_err': abs(loss - l64), 'logits_rows_compared': B * T,
+             'logits_max_err': logits_err, 'bad': bad[:10]}
+    return entry, bad
+
+
+@pytest.mark.parametrize('rows', [16, 32], ids=['rows16', 'rows32'])
+@pytest.mark.parametrize('tag', ['config1', 'config4'])
+def test_full_length_vs_oracle(hip_lib, tag, rows):
+    """BASELINE.json configs[0] at FULL length (default stack, one clip of
+    16000 samples) and one GPU's share of configs[3] (the same with global
+    conditioning 32 x 377, global clip 5, speaker id 185): the committed
+    float64 fingerprints (tests/golden/config{1,4}_fullsize.npz) pin the
+    oracle, the oracle pins the device -- on BOTH tile heights of the stack
+    launches: rows16 = what the library picks for one clip (stack_fwd16_kernel
+    with the fused skip sum, stack_bwd16_kernel), rows32 = the launches of the
+    benchmark's 8 x 16000 batch forced by the variant word
+    (stack_fwd_kernel<2,16> + the K = 1600 skip GEMM + stack_bwd_kernel<8>).
+      1. the float64 oracle run here reproduces the committed loss and every
+         variable's sum / abs-sum / max / 32 sampled gradient entries;
+      2. the device's loss equals it to 1e-5, ALL 16000 logits rows to 1e-4;
+      3. the device's ReLU decisions differ from the oracle's only where the
+         oracle's pre-activation is within 2e-5 of 0, at no more positions
+         than the fixture counts there;
+      4. every entry of every variable's gradient (config4: incl. the
+         embedding table and every layer's gc_filtweights / gc_gateweights) is
+         within max(2e-5, 4 x the float32 oracle's own error) of the
+         variable's largest entry, against the float64 oracle taking the
+         device's side at those kinks."""
+    sys_path_golden()
+    from make_golden import fullsize_inputs
+    from util import build_pair
+    from wavenet._lib import stack_variant
+    fx = np.load(os.path.join(GOLD, tag + '_fullsize.npz'))
+    cfg, audio, ids = fullsize_inputs(tag)
+    assert np.allclose([audio.sum(dtype=np.float64), np.abs(audio).sum(dtype=np.float64)],
+                       fx[tag + '/audio_crc'], rtol=0, atol=1e-9)
+    net, var = build_pair(cfg)
+    if rows == 32:
+        net.stack_variant = stack_variant(rows=32)
+    else:
+        assert hip_lib.wn_stack_tile_rows(1, 16000, 0) == 16     # the library's own choice
+    l64, c = _oracle64(tag, cfg, var, audio, ids, fx)
+    # the committed first / last logits rows pin the live oracle's logits
+    assert np.abs(c['logits'][0, 0] - fx[tag + '/logits_first_last'][0]).max() < 1e-9
+    assert np.abs(c['logits'][0, -1] - fx[tag + '/logits_first_last'][1]).max() < 1e-9
+    entry, bad = _compare_with_oracle(hip_lib, net, cfg, var, audio, ids, l64, c, tag, rows,
+                                      max_flips=int(fx[tag + '/near_kink'].sum()))
+    _log('%s_T16000_vs_float64%s' % (tag, '' if rows == 16 else '_rows32'), entry)
+    assert not bad, bad[:6]
+
+
+def test_natural_32_row_batch_vs_oracle(hip_lib):
+    """B = 3, T = 11000 of the default stack: 1032 32-row tiles, one more than
+    four per CU allows, so the LIBRARY picks the 32-row launches
+    (stack_fwd_kernel<2,16>, stack_bwd_kernel<8>: the benchmark's kernels)
+    without a forced variant -- loss, every logits row, every gradient entry
+    against the float64 oracle, as in test_full_length_vs_oracle."""
+    from util import build_pair
+    cfg = default_cfg(3)
+    B, T = 3, 11000
+    assert hip_lib.wn_stack_tile_rows(B, T, 0) == 32
+    audio = synth_audio(B, T, seed=77)
+    net, var = build_pair(cfg)
+    l64, c = O.loss(cfg, var, audio, None, None, np.float64, keep=True)
+    entry, bad = _compare_with_oracle(hip_lib, net, cfg, var, audio, None, l64, c,
+                                      'config1', 32)
+    _log('default_B3_T11000_vs_float64_rows32_natural', entry)
     assert not bad, bad[:6]
 
 

@@ -32,7 +32,7 @@ def _fp32_oracle_error(tag):
     return dict(zip([str(n) for n in fx[tag + '/names']], fx[tag + '/err32']))
 
 
-def check_grads(net, ref_g, tol=TOL, rel=GRAD_REL, tag=None):
+def check_grads(net, ref_g, tol=TOL, rel=GRAD_REL, tag=None, log_tag=None):
     """Every variable's gradient against the float64 oracle: <= GRAD_REL of
     the variable's largest entry (exact-fp32 MFMA accumulation over <= a few
     10^4 rows observes ~1e-6; a missing small term would be orders above).
@@ -49,7 +49,7 @@ def check_grads(net, ref_g, tol=TOL, rel=GRAD_REL, tag=None):
         scale = np.abs(b).max()
         rel_v = max(rel, 4.0 * float(e32.get(n, 0.0)))
         if tag is not None:
-            _ERRLOG.setdefault(tag, {})[n] = (float(err), float(scale))
+            _ERRLOG.setdefault(log_tag or tag, {})[n] = (float(err), float(scale))
         if not (err <= rel_v * scale + 1e-9 and err <= tol * max(1.0, scale)):
             bad.append((n, float(err), float(scale)))
     assert not bad, bad[:6]
@@ -168,10 +168,52 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize('name,cfg,T,gc,l2', CASES, ids=[c[0] for c in CASES])
-def test_loss_and_gradients_vs_oracle(hip_lib, name, cfg, T, gc, l2):
+def _stack_case(c):
+    """the cases the persistent stack launches / per-layer kernels of the
+    default-width model cover: <= 32 residual / dilation channels, two taps"""
+    return max(c[1]['residual_channels'], c[1]['dilation_channels']) <= 32 and \
+        c[1]['filter_width'] == 2
+
+
+# kernel path of the residual stack (model.py:236-330 x L):
+#   auto     -- the library's choice for the shape (wn_stack_tile_rows: every
+#               case here is small enough for the 16-row launches
+#               stack_fwd16_kernel / stack_bwd16_kernel; wider / more-tap
+#               models run the block / generic-tap kernels)
+#   rows32   -- the 32-row launches stack_fwd_kernel<2,16> / stack_bwd_kernel<8>
+#               forced by the variant word: the kernels bench.py's headline
+#               (8 x 16000) is measured on
+#   perlayer -- one launch per layer: layer_fwd_kernel / layer_bwd2d_kernel
+_PATH_CASES = [pytest.param(*c, 'auto', id=c[0]) for c in CASES] + \
+    [pytest.param(*c, path, id='%s-%s' % (c[0], path)) for c in CASES
+     if _stack_case(c) for path in ('rows32', 'perlayer')]
+
+
+def _select_path(net, path):
+    from wavenet._lib import stack_variant
+    if path == 'rows32':
+        net.stack_variant = stack_variant(rows=32)
+    elif path == 'perlayer':
+        net.stack_fwd = net.stack_bwd = False
+
+
+def _assert_path(hip_lib, net, ws, cfg, B, T, path):
+    """the launches the test MEANT to compare with the oracle are the ones
+    that ran (the launch decisions of WaveNetModel, read back)"""
+    if path == 'rows32':
+        assert ws.stack_rows == 32 and ws.stack_bwd and net._stack_bwd_ok()
+        assert hip_lib.wn_stack_tile_rows(B, T, ws.stack_variant) == 32
+    elif path == 'perlayer':
+        assert not net.stack_fwd and not net._stack_bwd_ok()
+    elif _stack_case((None, cfg)):
+        assert ws.stack_rows == hip_lib.wn_stack_tile_rows(B, T, 0)
+
+
+@pytest.mark.parametrize('name,cfg,T,gc,l2,path', _PATH_CASES)
+def test_loss_and_gradients_vs_oracle(hip_lib, name, cfg, T, gc, l2, path):
     B = cfg['batch_size']
     net, var = build_pair(cfg)
+    _select_path(net, path)
     rng = np.random.default_rng(7)
     audio = rng.uniform(-1, 1, (B, T)).astype(np.float32)
     ids = rng.integers(0, cfg['global_condition_cardinality'], B) if gc \
@@ -182,15 +224,16 @@ def test_loss_and_gradients_vs_oracle(hip_lib, name, cfg, T, gc, l2):
     # side after checking that the two differ only within forward rounding
     ref_loss, ref_g, c, flips = oracle_grads_at_device_kinks(
         net, cfg, var, audio, ids, l2)
-    _ERRLOG.setdefault('relu_flips', {})[name] = (flips, 0)
+    tag = name if path == 'auto' else '%s-%s' % (name, path)
+    _ERRLOG.setdefault('relu_flips', {})[tag] = (flips, 0)
     ws = list(net._ws.values())[0]
+    _assert_path(hip_lib, net, ws, cfg, B, T, path)
     # codes: bit exact
     assert np.array_equal(ws.q.cpu().numpy().reshape(B, T),
                           O.mu_law_encode(audio, cfg['quantization_channels']))
     assert abs(float(loss) - ref_loss) < TOL
-    check_grads(net, ref_g, tag=name)
-    if max(cfg['residual_channels'], cfg['dilation_channels']) <= 32 and \
-            cfg['filter_width'] == 2:
+    check_grads(net, ref_g, tag=name, log_tag=tag)
+    if _stack_case((None, cfg)):
         check_planes(net, cfg, c, B, T)
     # forward-only path gives the same loss and identical logits to the oracle
     loss2 = net.loss(audio, ids, l2, backward=False)

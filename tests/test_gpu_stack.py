@@ -1,8 +1,14 @@
 """The persistent residual-stack launch (csrc/wn_stack.hip, `net.stack_fwd`)
 against the one-launch-per-layer kernels it replaces: same arithmetic in the
 same order, so every activation plane, the logits, the loss and every gradient
-must be BITWISE equal (model.py:236-330 x L, model.py:417-428).  The
-per-layer path is itself checked against the oracle in test_gpu_model.py."""
+must be BITWISE equal (model.py:236-330 x L, model.py:417-428).  These are
+SELF-comparisons of two device paths.  The oracle comparisons of each path are
+elsewhere: tests/test_gpu_model.py::test_loss_and_gradients_vs_oracle runs
+every <= 32-channel two-tap case three times -- the library's choice (16-row
+launches), `-rows32` (stack_fwd_kernel<2,16> / stack_bwd_kernel<8>, forced)
+and `-perlayer` (layer_fwd_kernel / layer_bwd2d_kernel) -- and
+tests/test_gpu_fullsize.py::test_full_length_vs_oracle[*-rows32] /
+test_natural_32_row_batch_vs_oracle do the same at 16000 / 3 x 11000 samples."""
 import json
 import os
 

@@ -76,15 +76,19 @@ def tree_to_numpy(tree):
 
 
 def oracle_grads_at_device_kinks(net, cfg, var, audio, ids=None, l2=None,
-                                 kink_tol=2e-5, **kw):
+                                 kink_tol=2e-5, cache=None, **kw):
     """float64 oracle loss / gradients evaluated with the DEVICE's ReLU
     decisions (see oracle.loss_and_grads: relu_masks).  First checks that the
     device's masks differ from the oracle's own only where the oracle's
     pre-activation is within `kink_tol` of zero (forward rounding), i.e. that
     passing them changes which subgradient is taken at a kink and nothing
-    else.  Returns (loss, grads, cache, n_flipped)."""
+    else.  `cache`: the float64 forward cache of O.loss(keep=True) on the same
+    inputs when the caller already holds it.  Returns (loss, grads, cache,
+    n_flipped)."""
     B = cfg['batch_size']
-    _, c = O.loss(cfg, var, audio, ids, l2, np.float64, keep=True)
+    c = cache
+    if c is None:
+        _, c = O.loss(cfg, var, audio, ids, l2, np.float64, keep=True)
     T = c['logits'].shape[1]
     ws = [w for w in net._ws.values() if w.T == T and w.training][0]
     S = cfg['skip_channels']

@@ -84,6 +84,14 @@ def get_arguments(argv=None):
     p.add_argument('--histograms', type=_str_to_bool, default=False)
     p.add_argument('--gc_channels', type=int, default=None,
                    help='Number of global condition channels.')
+    p.add_argument('--dp_overlap_allreduce', type=_str_to_bool, default=False,
+                   help='Data-parallel runs: all-reduce the skip / '
+                        'post-processing gradients on a communication stream '
+                        'beside the backward stack (two calls per step) '
+                        'instead of one all-reduce at the update.  Off by '
+                        'default: `bench.py --gpus N` times both schedules on '
+                        'the node at hand -- switch it on where that run '
+                        'reports allreduce_calls == 2 and overlap_failed false.')
     p.add_argument('--synthetic', action='store_true',
                    help='Train on synthetic sine clips (no --data_dir needed).')
     p.add_argument('--gc_cardinality', type=int, default=None,
@@ -277,8 +285,9 @@ def main(argv=None):
         raise
     parallel.broadcast_parameters(net)
     # every loss() below is followed by optimizer.minimize(): the skip /
-    # post-processing gradients' all-reduce may start inside the backward pass
-    net.dp_overlap_allreduce = world > 1
+    # post-processing gradients' all-reduce MAY start inside the backward pass
+    # (opt-in: the schedule has not been measured on an N-GPU RCCL node yet)
+    net.dp_overlap_allreduce = bool(args.dp_overlap_allreduce) and world > 1
 
     threads = reader.start_threads()
     events = None

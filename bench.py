@@ -393,9 +393,16 @@ def overlap_trial(net, parallel, timed, instrumented, over_ranks, args, isteps,
             net.dp_overlap_allreduce = True
             for _ in range(2):
                 net_step_loss = timed(1)[1]
+            # (tests: WN_BENCH_INJECT_OVERLAP_FAILURE=raise|hang|nan exercises
+            # the three guards on a box where the schedule itself works)
+            inject = os.environ.get('WN_BENCH_INJECT_OVERLAP_FAILURE')
+            if inject == 'raise':
+                raise RuntimeError('injected failure')
+            if inject == 'hang':
+                time.sleep(1e6)
             dt, loss = timed(args.steps)
             _, ar_us = instrumented(isteps)
-            lossf = float(loss)
+            lossf = float('nan') if inject == 'nan' else float(loss)
             if not math.isfinite(lossf) or not math.isfinite(float(net_step_loss)):
                 why = 'non-finite loss under the two-call schedule'
             try:

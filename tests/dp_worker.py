@@ -50,6 +50,35 @@ def main():
                   open(spec['out'], 'w'))
         dist.destroy_process_group()
         return
+    if spec['mode'] == 'nccl1_overlap':
+        # the DEFAULT stack (persistent stack launches) at world size 1 over
+        # RCCL with the collectives really issued (rehearse_world_one)
+        import torch.distributed as dist
+        from util import DEFAULT
+        from wavenet import WaveNetModel
+        from util import model_kwargs, synth_audio
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group(backend='nccl', rank=0, world_size=1)
+        parallel.rehearse_world_one = True
+        assert parallel.is_distributed()
+        net = WaveNetModel(seed=0, **model_kwargs(cfg_with(DEFAULT, batch_size=B)))
+        net.dp_overlap_allreduce = bool(spec['overlap'])
+        opt = optimizer_factory['adam'](learning_rate=1e-3, momentum=0.9)
+        a = synth_audio(B, T)
+        losses = []
+        for s in range(steps):
+            loss = net.loss(a)
+            assert (net._tail_work is not None) == bool(spec['overlap'])
+            opt.minimize(loss)
+            assert net._tail_work is None
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        net.check_device_errors()
+        np.savez(spec['out'], params=net.params.cpu().numpy(), losses=np.asarray(losses),
+                 comm_stream_used=bool(parallel._comm_streams))
+        dist.destroy_process_group()
+        return
     if rank == 1:                       # broadcast must repair this
         with torch.no_grad():
             net.params.add_(1.0)

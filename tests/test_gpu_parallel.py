@@ -153,6 +153,15 @@ def test_bench_many_ranks_rehearsal(hip_lib, gc):
     assert r['allreduce_bytes'] == 4 * (1630432 if gc else 1515968)
     assert r['collective']['rccl_version'] and 'NCCL_ALGO' in r['collective']
     assert r['allreduce_us_per_step'] > 0
+    # both gradient-exchange schedules were timed in the same process, the
+    # line carries both and says which one `value` is from
+    sch = r['allreduce_schedules']
+    assert set(sch) == {'one_call', 'two_call'} and r['overlap_failed'] is False
+    assert r['allreduce_calls'] in (1, 2)
+    best = min(sch.values(), key=lambda e: e['ms_per_step'])
+    assert r['ms_per_step'] == best['ms_per_step']
+    assert r['allreduce_calls'] == (2 if best is sch['two_call'] else 1)
+    assert all(e['ms_per_step'] > 0 and np.isfinite(e['final_loss']) for e in sch.values())
     for k in range(n):
         assert '[bench] rank %d/%d' % (k, n) in err and 'PCI' in err
     if gc:
@@ -167,6 +176,53 @@ def test_bench_many_ranks_rehearsal(hip_lib, gc):
     assert abs(one['config']['global_loss'] - r['config']['global_loss']) <= 5e-6
     if gc:
         assert one['config']['gc_ids'] == r['config']['gc_ids']
+
+
+@pytest.mark.parametrize('how', ['raise', 'hang', 'nan'])
+def test_bench_overlap_trial_failure_falls_back_in_process(hip_lib, how):
+    """First-contact guard of `bench.py --gpus N`: when the two-call schedule
+    raises, hangs (watchdog) or produces a non-finite loss, the SAME processes
+    still print ONE line -- the one-call figures, "overlap_failed": true, the
+    reason -- and exit 0."""
+    env = dict(os.environ, WN_SHARE_GPU='1', WN_DIST_BACKEND='gloo',
+               WN_BENCH_INJECT_OVERLAP_FAILURE=how, WN_OVERLAP_TRIAL_TIMEOUT='20')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2',
+                        '--batch', '1', '--steps', '2', '--warmup', '1', '--samples',
+                        '4000', '--no-secondary', '--no-cpu-baseline'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r['overlap_failed'] is True and r['allreduce_calls'] == 1
+    assert set(r['allreduce_schedules']) == {'one_call'}
+    assert r['ms_per_step'] == r['allreduce_schedules']['one_call']['ms_per_step']
+    assert r['value'] > 0 and r['ranks_seen'] == 2
+    want = {'raise': 'injected failure', 'hang': 'did not return within', 'nan': 'non-finite'}
+    assert want[how] in r['overlap_failure']
+
+
+@pytest.mark.parametrize('B,T', [(1, 4000), (8, 16000)], ids=['side_stream_gemms', 'one_stream'])
+def test_rccl_world_one_two_call_schedule_beside_the_backward_stack(hip_lib, tmp_path, B, T):
+    """The two-call schedule through RCCL itself (backend "nccl", world size
+    1, parallel.rehearse_world_one): the tail's all-reduce KERNEL runs on the
+    communication stream beside the persistent backward-stack launch of the
+    default stack (B = 8: issued before the stack launch; B = 1: after the
+    side-stream GEMMs' join), the head's at the update; three Adam steps
+    through eager, recorded and replayed launch plans.  A sum over one rank is
+    the identity, so losses and parameters equal the one-call run BITWISE, no
+    dependency wait expires and no tail is left dangling."""
+    res = {}
+    for ov in (False, True):
+        out = str(tmp_path / ('w1_%d.npz' % ov))
+        _run_ranks(dict(mode='nccl1_overlap', B=B, T=T, steps=3, overlap=ov, out=out), 1)
+        res[ov] = np.load(out)
+    assert res[True]['comm_stream_used'] and not res[False]['comm_stream_used']
+    assert np.array_equal(res[True]['losses'], res[False]['losses'])
+    assert np.array_equal(res[True]['params'], res[False]['params'])
+    assert np.isfinite(res[True]['losses']).all()
 
 
 def test_rccl_world_one_allreduces_the_gradient_bucket(hip_lib, tmp_path):

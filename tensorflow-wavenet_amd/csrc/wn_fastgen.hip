@@ -1084,6 +1084,71 @@ __device__ __forceinline__ double wave_scan_f64(double x) {
   return x;
 }
 
+// ---- a 32-input mat-vec without an LDS round trip (round 6).  The input
+// vector sits REPLICATED in every 16-lane row of two registers (lo: inputs
+// 0..15, hi: 16..31 -- one v_permlane16_swap of a register that holds input
+// (lane & 31) in every lane gives both); lane j then adds input k times ITS
+// weight with the input read through the DPP row broadcast of lane k of the
+// lane's own row: one v_fmac_f32_dpp per product, no ds_write / ds_read /
+// s_waitcnt on the dependent path (the LDS version: ~130 cycles of round trip
+// per broadcast, two per layer).  Four accumulator chains, input 4c + e into
+// chain e in ascending c: the order of fg_chain_kernel / fastgen_kernel, so
+// the results are bitwise theirs.  (Inline asm: the compiler leaves
+// update_dpp + fma as v_mov_b32_dpp + v_fmac, twice the instructions.  s_nop 1:
+// a VALU write of the DPP operand needs two wait states before the read.)
+#define FG_DPPF(A, W, K) "v_fmac_f32_dpp " A ", %[x], " W " row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"
+#define FG_DPPM(A, W, K) "v_mul_f32_dpp " A ", %[x], " W " row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"
+#define FG_MV16_TAIL \
+      FG_DPPF("%[a0]", "%[w10]", 4) FG_DPPF("%[a1]", "%[w11]", 5) FG_DPPF("%[a2]", "%[w12]", 6) FG_DPPF("%[a3]", "%[w13]", 7) \
+      FG_DPPF("%[a0]", "%[w20]", 8) FG_DPPF("%[a1]", "%[w21]", 9) FG_DPPF("%[a2]", "%[w22]", 10) FG_DPPF("%[a3]", "%[w23]", 11) \
+      FG_DPPF("%[a0]", "%[w30]", 12) FG_DPPF("%[a1]", "%[w31]", 13) FG_DPPF("%[a2]", "%[w32]", 14) FG_DPPF("%[a3]", "%[w33]", 15)
+#define FG_MV16_WOPS \
+        [x] "v"(x), [w00] "v"(w0[0]), [w01] "v"(w0[1]), [w02] "v"(w0[2]), [w03] "v"(w0[3]), \
+        [w10] "v"(w1[0]), [w11] "v"(w1[1]), [w12] "v"(w1[2]), [w13] "v"(w1[3]), \
+        [w20] "v"(w2[0]), [w21] "v"(w2[1]), [w22] "v"(w2[2]), [w23] "v"(w2[3]), \
+        [w30] "v"(w3[0]), [w31] "v"(w3[1]), [w32] "v"(w3[2]), [w33] "v"(w3[3])
+// a_e += sum_c in(4c + e) * w_c[e]: sixteen FMAs.  NOP: the DPP operand was
+// written by the VALU instruction just before (the row-halves swap).
+template <bool NOP>
+__device__ __forceinline__ void fg_mv16_dpp(float& a0, float& a1, float& a2, float& a3, float x,
+                                            const f32x4& w0, const f32x4& w1, const f32x4& w2,
+                                            const f32x4& w3) {
+  if (NOP)
+    asm volatile("s_nop 1\n\t"
+        FG_DPPF("%[a0]", "%[w00]", 0) FG_DPPF("%[a1]", "%[w01]", 1) FG_DPPF("%[a2]", "%[w02]", 2) FG_DPPF("%[a3]", "%[w03]", 3)
+        FG_MV16_TAIL
+        : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3) : FG_MV16_WOPS);
+  else
+    asm volatile(
+        FG_DPPF("%[a0]", "%[w00]", 0) FG_DPPF("%[a1]", "%[w01]", 1) FG_DPPF("%[a2]", "%[w02]", 2) FG_DPPF("%[a3]", "%[w03]", 3)
+        FG_MV16_TAIL
+        : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3) : FG_MV16_WOPS);
+}
+// the same with chains 1..3 (A0: chain 0 too) STARTING here: their first
+// product is a v_mul (= fmaf(in, w, +0) up to the sign of a zero, which no
+// later value depends on) instead of an FMA into a register zeroed by a v_mov
+template <bool A0>
+__device__ __forceinline__ void fg_mv16_dpp_first(float& a0, float& a1, float& a2, float& a3, float x,
+                                                  const f32x4& w0, const f32x4& w1, const f32x4& w2,
+                                                  const f32x4& w3) {
+  if (A0)
+    asm volatile("s_nop 1\n\t"
+        FG_DPPM("%[a0]", "%[w00]", 0) FG_DPPM("%[a1]", "%[w01]", 1) FG_DPPM("%[a2]", "%[w02]", 2) FG_DPPM("%[a3]", "%[w03]", 3)
+        FG_MV16_TAIL
+        : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3) : FG_MV16_WOPS);
+  else
+    asm volatile("s_nop 1\n\t"
+        FG_DPPF("%[a0]", "%[w00]", 0) FG_DPPM("%[a1]", "%[w01]", 1) FG_DPPM("%[a2]", "%[w02]", 2) FG_DPPM("%[a3]", "%[w03]", 3)
+        FG_MV16_TAIL
+        : [a0] "+v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3) : FG_MV16_WOPS);
+}
+// (lo, hi) row-replicated halves of a register holding value (lane & 31) in every lane
+__device__ __forceinline__ void fg_row_halves(float v, float& lo, float& hi) {
+  const auto pr = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  lo = __uint_as_float(pr[0]);
+  hi = __uint_as_float(pr[1]);
+}
+
 // What the draw reads from ctl[]: constant over a launch, read once.
 struct FgDrawCtl {
   int base, n_given, proba_every;
@@ -1286,6 +1351,96 @@ __device__ __forceinline__ void fgp_post_role(const float* W, const float* bias,
   }
 }
 
+// ---- the serial chain of one segment of fg_persist_kernel, one step (round 6).
+// A lone wave issues one instruction every ~5 cycles whatever its kind
+// (tools/ubench/dpp_matvec.hip), so a layer costs its instruction COUNT: the
+// chain wave's layer is written for that -- no LDS round trip and no exec-mask
+// region on the dependent path, every operand of a layer in ONE per-layer LDS
+// block read with immediate offsets, the queue stores after the hand-over.
+//   LDS block of layer ll (FGP_BLK floats): 12 KB of weights in lane order
+//   (float4 [c][lane]: c < 8 filter | gate column chunks, 8 + cc: dense column
+//   n's K half lane >> 5) | float4 [lane] {past-tap pre-activation, ring row
+//   (float offset, int bits), dense bias, -}.
+// x: channel lane & 31 in EVERY lane.  NL > 0: the segment's layer count at
+// compile time (loop unrolled, a layer's queue entry kept in registers and
+// stored after the hand-over); NL == 0: any count, entries stored at once.
+#define FGP_BLK (FGC_CW + 256)
+struct FgpLW { f32x4 qw[8], pw[4], ms; };
+__device__ __forceinline__ void fgp_lw_load(FgpLW& w, const float* wres, int ll, int lane) {
+  const f32x4* b = reinterpret_cast<const f32x4*>(wres) + ll * (FGP_BLK / 4) + lane;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) w.qw[c] = b[c * 64];
+#pragma unroll
+  for (int cc = 0; cc < 4; ++cc) w.pw[cc] = b[512 + cc * 64];
+  w.ms = b[768];
+}
+template <int NL>
+__device__ __forceinline__ float fgp_chain_layers(float x, const float* wres, FgpLW& wa, int nl,
+                                                  int l0, int L, float* state, fgp_ll_t* zrow,
+                                                  fgp_ll_t* xout, unsigned step, int lane) {
+  constexpr bool UNR = NL > 0;
+  const int n = UNR ? NL : nl;
+  const int nn = lane & 31;
+  const bool gsel = lane >= 32;
+  const float kexp = gsel ? -1.4426950408889634f : -2.8853900817779268f;
+  const float kmul = gsel ? 1.f : 2.f, kadd = gsel ? 0.f : -1.f;
+  float xq[UNR ? NL : 1];
+  int rq[UNR ? NL : 1];
+  FgpLW wb;
+  auto layer = [&](int ll, const FgpLW& w, FgpLW& wn) {
+    float a0 = w.ms[0], a1, a2, a3;
+    float xlo, xhi;
+    fg_row_halves(x, xlo, xhi);
+    fg_mv16_dpp_first<false>(a0, a1, a2, a3, xlo, w.qw[0], w.qw[1], w.qw[2], w.qw[3]);
+    fg_mv16_dpp<false>(a0, a1, a2, a3, xhi, w.qw[4], w.qw[5], w.qw[6], w.qw[7]);
+    if (UNR) {
+      xq[UNR ? ll : 0] = x;                              // enqueue x_l[t]: after the hand-over
+      rq[UNR ? ll : 0] = __float_as_int(w.ms[1]);
+    } else {
+      fgp_st(state + __float_as_int(w.ms[1]) + nn, x);
+    }
+    // the next layer's operands: they land under the gate and the dense part
+    fgp_lw_load(wn, wres, ll + 1 < n ? ll + 1 : ll, lane);
+    const float av = (a0 + a1) + (a2 + a3);
+    // gate lanes: sigmoid(av); filter lanes: tanh(av) = 2 sigmoid(2 av) - 1.  The
+    // lane's constants instead of selects: exp2(av * (-log2 e) * {1, 2}) is the
+    // bits of wn_sigmoid(gsel ? av : 2 av) (a scaling by two is exact), and
+    // fma(sg, 1, 0) = sg.
+    const float sg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(av * kexp));
+    const float act = fmaf(sg, kmul, kadd);
+    const auto pr = __builtin_amdgcn_permlane32_swap(__float_as_uint(act), __float_as_uint(act),
+                                                     false, false);
+    const float z = __uint_as_float(pr[0]) * __uint_as_float(pr[1]);   // channel nn, every lane
+    fgp_put(zrow + ll * 32, z, step);                    // (lanes n and n + 32: the same word)
+    if (ll + 1 < n || l0 + n < L) {                      // (every layer but the network's last)
+      // z[16 (lane >> 5) + j] to the lanes of the lane's half: rows {lo, lo, hi, hi}
+      const auto p16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(z), __float_as_uint(z),
+                                                        false, false);
+      const auto p32 = __builtin_amdgcn_permlane32_swap(p16[0], p16[1], false, false);
+      float d0, d1, d2, d3;
+      fg_mv16_dpp_first<true>(d0, d1, d2, d3, __uint_as_float(p32[0]), w.pw[0], w.pw[1], w.pw[2], w.pw[3]);
+      const float dh = (d0 + d1) + (d2 + d3);
+      const auto pd = __builtin_amdgcn_permlane32_swap(__float_as_uint(dh), __float_as_uint(dh),
+                                                       false, false);
+      x += w.ms[2] + (__uint_as_float(pd[0]) + __uint_as_float(pd[1]));
+    }
+  };
+  constexpr int UF = UNR ? (NL + 1) / 2 : 1;
+#pragma unroll UF
+  for (int ll = 0; ll < n; ll += 2) {
+    layer(ll, wa, wb);
+    if (ll + 1 < n) layer(ll + 1, wb, wa);
+  }
+  // x to the next segment at once; the queue entries are for this segment's
+  // own helper waves
+  if (xout) fgp_put(xout + nn, x, step);
+  if (UNR) {
+#pragma unroll
+    for (int ll = 0; ll < (UNR ? NL : 0); ++ll) fgp_st(state + rq[ll] + nn, xq[ll]);
+  }
+  return x;
+}
+
 __global__ __launch_bounds__(FGP_THREADS) void fg_persist_kernel(FgPersist a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const FgStep& g = a.g;
@@ -1315,142 +1470,72 @@ __global__ __launch_bounds__(FGP_THREADS) void fg_persist_kernel(FgPersist a) {
     const int l0 = __builtin_amdgcn_readfirstlane((int)((long)seg * L / nseg));
     const int l1 = (int)((long)(seg + 1) * L / nseg);
     const int nl = __builtin_amdgcn_readfirstlane(l1 - l0);
-    float* wres = lds;                                 // [nl][FGC_CW]
-    float* pre_s = wres + (size_t)nl * FGC_CW;         // [nl][64] this step's past-tap pre-activations
-    float* bd_s = pre_s + nl * 64;                     // [nl][32] dense biases
-    float* inv = bd_s + nl * 32;                       // [32] x broadcast
-    float* zv = inv + 32;                              // [32]
-    int* meta = reinterpret_cast<int*>(zv + 32);       // [nl] ring offset (rows), [nl] dilation
+    float* wres = lds;                                 // [nl][FGP_BLK]: weights | {pre, row, bd, -}
+    int* meta = reinterpret_cast<int*>(wres + (size_t)nl * FGP_BLK);   // [nl] ring offset (rows), [nl] dilation
     int* flags = meta + 2 * FGP_SEGL;                  // [0] pre ready for step, [1] chain done with step
-    int* rowoff = flags + 8;                           // [2][FGP_SEGL] float offset of the ring row of
-                                                       // the step (parity): no modulo on the chain
     // resident weights in LANE order: chunk c of the chain lane's row at float4
     // [c][lane] (filter | gate rows: c < 8; dense rows: [8 + cc][lane], lane =
-    // 32 (c >> 2) + n), so a layer's twelve reads are one lane address plus
+    // 32 (c >> 2) + n), so a layer's reads are one lane address plus
     // immediates and conflict-free (the ring-slot image is [matrix][n][chunk ^ (n & 7)])
     for (int i = tid; i < nl * FGC_CW / 4; i += FGP_THREADS) {
       const int ll = i / (FGC_CW / 4), q = i % (FGC_CW / 4);
       const int m = q >> 8, n = (q >> 3) & 31, c = (q & 7) ^ (n & 7);
       const int dst = m < 2 ? c * 64 + m * 32 + n : 512 + (c & 3) * 64 + (c >> 2) * 32 + n;
-      reinterpret_cast<f32x4*>(wres)[ll * (FGC_CW / 4) + dst] =
+      reinterpret_cast<f32x4*>(wres)[ll * (FGP_BLK / 4) + dst] =
           reinterpret_cast<const f32x4*>(g.cw_img + (size_t)l0 * FGC_CW)[i];
     }
-    for (int i = tid; i < nl * 64; i += FGP_THREADS) pre_s[i] = g.pre[(size_t)l0 * 64 + i];
-    for (int i = tid; i < nl * 32; i += FGP_THREADS)
-      bd_s[i] = g.use_dense_bias
-                    ? g.layer0[(size_t)(l0 + (i >> 5)) * g.layer_stride + LAYER_OFF_BD + (i & 31)]
-                    : 0.f;
     if (tid < nl) {
       int ro = 0;
       for (int q = 0; q < l0 + tid; ++q) ro += g.dil[q];
       meta[tid] = ro;
       meta[FGP_SEGL + tid] = g.dil[l0 + tid];
-      rowoff[tid] = (ro + base % g.dil[l0 + tid]) * 32;
+    }
+    __syncthreads();
+    for (int i = tid; i < nl * 64; i += FGP_THREADS) {
+      const int ll = i >> 6, ln = i & 63;
+      f32x4 ms;
+      ms[0] = g.pre[(size_t)l0 * 64 + i];
+      ms[1] = __int_as_float((meta[ll] + base % meta[FGP_SEGL + ll]) * 32);
+      ms[2] = g.use_dense_bias
+                  ? g.layer0[(size_t)(l0 + ll) * g.layer_stride + LAYER_OFF_BD + (ln & 31)] : 0.f;
+      ms[3] = 0.f;
+      reinterpret_cast<f32x4*>(wres)[ll * (FGP_BLK / 4) + 768 + ln] = ms;
     }
     if (tid == 0) { flags[0] = 1; flags[1] = 0; flags[2] = 0; flags[3] = 0; }
     __syncthreads();
-    const int nn = lane & 31, gsel = lane >> 5;
+    const int nn = lane & 31;
     if (wave == 0) {
-      // ---- the serial chain of this segment (body of fg_chain_kernel, no
-      // workgroup barrier, weights resident)
+      // ---- the serial chain of this segment (no workgroup barrier, weights
+      // resident): fgp_chain_layers
       int prev_code = g.cursors[1];
+      fgp_ll_t* zrow = zll + l0 * 32 + nn;
+      fgp_ll_t* xo = seg + 1 < nseg ? xll + seg * 32 : nullptr;
       for (int i = 0; i < n_steps; ++i) {
         const unsigned step = (unsigned)(i + 1);
+        // this step's past-tap pre-activations are in LDS (helper waves): the
+        // first layer's operands are requested before x is waited for
+        while (!dead && __hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < i + 1)
+          __builtin_amdgcn_s_sleep(1);
+        FgpLW wa;
+        fgp_lw_load(wa, wres, 0, lane);
         float x = 0.f;
         if (seg == 0) {
           int code = g.samples[0];
           if (i > 0) code = __float_as_int(fgp_get(codell, (unsigned)i, sync, dead));
           PSTAMP(i * 16 + 0);
-          if (lane < 32) {
+          {   // (x lives in EVERY lane: channel lane & 31)
             float v = 0.f;
-            if (prev_code >= 0 && prev_code < Q) v = g.causal[(long)prev_code * 32 + lane];
-            if (code >= 0 && code < Q) v += g.causal[((long)Q + code) * 32 + lane];
+            if (prev_code >= 0 && prev_code < Q) v = g.causal[(long)prev_code * 32 + nn];
+            if (code >= 0 && code < Q) v += g.causal[((long)Q + code) * 32 + nn];
             x = v;
           }
           prev_code = code;
         } else {
-          x = fgp_get(xll + (seg - 1) * 32 + (lane & 31), step, sync, dead);
+          x = fgp_get(xll + (seg - 1) * 32 + nn, step, sync, dead);
         }
-        // this step's past-tap pre-activations are in LDS (helper waves)
-        while (!dead && __hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < i + 1)
-          __builtin_amdgcn_s_sleep(1);
         PSTAMP(i * 16 + 1 + seg);
-        // A layer's weights, past-tap pre-activation and dense bias do not
-        // depend on the chain: layer ll + 1's are requested while layer ll
-        // computes (round 5: twelve LDS reads per layer off the chain wave's
-        // dependent path), two register sets used alternately.
-        struct LW { f32x4 qw[8], pw[4]; float a0, bdl; int row; };
-        auto lw_load = [&](LW& w, int ll) {
-          const f32x4* wl = reinterpret_cast<const f32x4*>(wres) + ll * (FGC_CW / 4) + lane;
-#pragma unroll
-          for (int c = 0; c < 8; ++c) w.qw[c] = wl[c * 64];
-#pragma unroll
-          for (int cc = 0; cc < 4; ++cc) w.pw[cc] = wl[512 + cc * 64];
-          w.a0 = pre_s[ll * 64 + lane];
-          w.bdl = bd_s[ll * 32 + (lane & 31)];
-          w.row = rowoff[(i & 1) * FGP_SEGL + ll];
-        };
-        auto layer = [&](int ll, const LW& w, LW& wn) {
-          float a0 = w.a0, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-          // x to every lane through LDS FIRST: the queue store (its ring row was
-          // requested a layer ahead) is not on the dependent path
-          if (lane < 32) inv[lane] = x;
-          __builtin_amdgcn_wave_barrier();
-          f32x4 xv[8];
-#pragma unroll
-          for (int c = 0; c < 8; ++c) xv[c] = *reinterpret_cast<const f32x4*>(inv + 4 * c);
-          __builtin_amdgcn_sched_barrier(0);
-          if (lane < 32) fgp_st(g.state + w.row + lane, x);   // enqueue x_l[t]
-#pragma unroll
-          for (int c = 0; c < 8; ++c) {
-            const f32x4 q = w.qw[c];
-            a0 = fmaf(xv[c][0], q[0], a0); a1 = fmaf(xv[c][1], q[1], a1);
-            a2 = fmaf(xv[c][2], q[2], a2); a3 = fmaf(xv[c][3], q[3], a3);
-          }
-          // (the next layer's operands behind this layer's FMAs -- in front of
-          // them the FMAs' counted waits would include these reads: the LDS
-          // counter has 4 bits -- they land under the gate and the dense part)
-          __builtin_amdgcn_sched_barrier(0);
-          lw_load(wn, ll + 1 < nl ? ll + 1 : ll);
-          __builtin_amdgcn_sched_barrier(0);
-          const float av = (a0 + a1) + (a2 + a3);
-          const float sg = wn_sigmoid(gsel ? av : 2.f * av);
-          const float act = gsel ? sg : fmaf(2.f, sg, -1.f);
-          const auto pr = __builtin_amdgcn_permlane32_swap(
-              __float_as_uint(act), __float_as_uint(act), false, false);
-          const float z = __uint_as_float(pr[0]) * __uint_as_float(pr[1]);
-          if (lane < 32) {
-            zv[lane] = z;
-            fgp_put(zll + (l0 + ll) * 32 + lane, z, step);
-          }
-          if (l0 + ll + 1 < L) {
-            __builtin_amdgcn_wave_barrier();
-            float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-              const int c = gsel * 4 + cc;
-              const f32x4 zz = *reinterpret_cast<const f32x4*>(zv + 4 * c);
-              const f32x4 pq = w.pw[cc];
-              d0 = fmaf(zz[0], pq[0], d0); d1 = fmaf(zz[1], pq[1], d1);
-              d2 = fmaf(zz[2], pq[2], d2); d3 = fmaf(zz[3], pq[3], d3);
-            }
-            const float dh = (d0 + d1) + (d2 + d3);
-            const auto pd2 = __builtin_amdgcn_permlane32_swap(
-                __float_as_uint(dh), __float_as_uint(dh), false, false);
-            if (lane < 32)
-              x += w.bdl + (__uint_as_float(pd2[0]) + __uint_as_float(pd2[1]));
-          }
-          __builtin_amdgcn_wave_barrier();
-        };
-        LW wa, wb;
-        lw_load(wa, 0);
-        for (int ll = 0; ll < nl; ll += 2) {
-          layer(ll, wa, wb);
-          if (ll + 1 < nl) layer(ll + 1, wb, wa);
-        }
-        // x to the next segment at once; the queue entries this segment wrote
-        // are for its own helper waves: drained behind the hand-over
-        if (seg + 1 < nseg && lane < 32) fgp_put(xll + seg * 32 + lane, x, step);
+        if (nl == 10) x = fgp_chain_layers<10>(x, wres, wa, nl, l0, L, g.state, zrow, xo, step, lane);
+        else x = fgp_chain_layers<0>(x, wres, wa, nl, l0, L, g.state, zrow, xo, step, lane);
         PSTAMP(i * 16 + 6 + seg);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0)
@@ -1485,11 +1570,13 @@ __global__ __launch_bounds__(FGP_THREADS) void fg_persist_kernel(FgPersist a) {
           }
           acc[(ll - hw) >> 2] = (g.bias_fg ? g.bias_fg[l * 64 + lane] : 0.f) + ((p0 + p1) + (p2 + p3));
         }
-        // (the chain wave is past this segment's layers of step i: pre_s is free)
-        for (int ll = hw; ll < nl; ll += 4) pre_s[ll * 64 + lane] = acc[(ll - hw) >> 2];
-        if (hw == 0 && lane < nl)
-          rowoff[((i + 1) & 1) * FGP_SEGL + lane] =
-              (meta[lane] + tpos % meta[FGP_SEGL + lane]) * 32;
+        // (the chain wave is past this segment's layers of step i: the
+        // {pre, row} words of the layers' blocks are free)
+        for (int ll = hw; ll < nl; ll += 4) {
+          float* ms = wres + (size_t)ll * FGP_BLK + 3072 + lane * 4;
+          ms[0] = acc[(ll - hw) >> 2];
+          ms[1] = __int_as_float((meta[ll] + tpos % meta[FGP_SEGL + ll]) * 32);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // four helper waves: the last one to finish raises the step
         if (lane == 0) {
@@ -2366,7 +2453,7 @@ int wn_fastgen_persist(const float* params_causal, const float* layer0,
 #endif
   const int wgs = wn_fastgen_persist_workgroups(L, S, Q);
   // dynamic LDS: the largest role
-  size_t chain = (size_t)per * FGC_CW + per * 64 + per * 32 + 64 + 2 * FGP_SEGL + 8 + 2 * FGP_SEGL;
+  size_t chain = (size_t)per * FGP_BLK + 2 * FGP_SEGL + 8;
   size_t skip = (size_t)((L * 32 + 3) & ~3) + (size_t)L * 32 * 16 + 256;
   size_t post = (size_t)((S + 3) & ~3) + (size_t)S * 16 + 256;
   size_t draw = (size_t)((Q + 3) & ~3) + 40;

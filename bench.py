@@ -195,6 +195,37 @@ def pmc_traffic(kernel):
     return (None, None, None) if e is None else (e['hbm_bytes_per_launch'], src, stale)
 
 
+def rocprof_avg_us(kernel_prefix):
+    """(average launch duration in us of the kernel whose name starts with
+    `kernel_prefix`, source file, stale) from the newest committed
+    `rocprofv3 --kernel-trace --stats` summary profiles/*_bench_kernel_stats.csv
+    (tools/collect_profiles.sh: the same bench.py command).  stale as in
+    _newest_profile, from the PMC summary of the same tag."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_bench_kernel_stats.csv')))
+    for path in reversed(files):
+        try:
+            with open(path) as f:
+                rows = [r for r in csv.DictReader(f) if r['Name'].startswith(kernel_prefix)]
+        except (OSError, KeyError):
+            continue
+        if not rows:
+            continue
+        calls = sum(int(r['Calls']) for r in rows)
+        total = sum(float(r['TotalDurationNs']) for r in rows)
+        stale = True
+        try:
+            with open(path.replace('_bench_kernel_stats.csv', '_pmc_traffic.json')) as f:
+                sha = (json.load(f).get('_meta') or {}).get('csrc_sha16')
+            cur = _csrc_sha16()
+            stale = sha is None or cur is None or sha != cur
+        except (OSError, ValueError):
+            pass
+        return total / calls / 1e3, os.path.relpath(path, ROOT), stale
+    return None, None, None
+
+
 def pmc_issue(kernel):
     """(issue-slot summary of `kernel`, source file, stale) from the newest
     profiles/*_issue.json (tools/pmc_issue.py), or (None, None, None)."""
@@ -425,7 +456,8 @@ def overlap_trial(net, parallel, timed, instrumented, over_ranks, args, isteps,
         entry = {'ms_per_step': dt_max / args.steps * 1e3,
                  'step_ms_min': dt_min / args.steps * 1e3,
                  'step_ms_max': dt_max / args.steps * 1e3,
-                 'allreduce_us_per_step': ar, 'final_loss': float(res['loss'])}
+                 'allreduce_us_per_step': ar, 'final_loss': float(res['loss']),
+                 'global_loss': gl}
         return {'entry': entry, 'dt_max': dt_max, 'dt_min': dt_min, 'ar_us': ar,
                 'final_loss': float(res['loss']), 'global_loss': gl}
 
@@ -649,7 +681,8 @@ def main():
         'ms_per_step': dt / args.steps * 1e3,
         'step_ms_min': dt_min / args.steps * 1e3,
         'step_ms_max': dt_max / args.steps * 1e3,
-        'allreduce_us_per_step': ar_us, 'final_loss': float(loss)}
+        'allreduce_us_per_step': ar_us, 'final_loss': float(loss),
+        'global_loss': global_loss}
 
     def result_line(cur):
         """The JSON line from the figures of the schedule in `cur` (the
@@ -694,6 +727,8 @@ def main():
         # shape / variant rules pick), each tagged stale when the kernel sources
         # changed since it was collected.  The TB/s figure is information, not a
         # fraction of a bound.
+        rp_us, rp_src, rp_stale = rocprof_avg_us(dom) if (B, T) == (8, 16000) \
+            else (None, None, None)
         stacks = {}
         lib_ = net  # (kernel names follow wn_stack_tile_rows / the variant word)
         tws = [w for w in net._ws.values() if w.training]
@@ -722,7 +757,6 @@ def main():
                 'mfma_busy_frac_live_at_2p4ghz': tile_layers * mfma_cyc[ev_name] / 1024.0 / (us * 2400.0),
                 'issue': None if iss is None else {
                     k: iss.get(k) for k in ('mfma_busy_frac', 'valu_issue_frac', 'issue_frac',
-                                            'mfma_valu_coexec_frac', 'vmem_inst_cycles_frac',
                                             'clock_ghz', 'avg_us')},
                 'issue_source': isrc, 'issue_stale': istale,
                 'traffic': by, 'traffic_source': src, 'traffic_stale': stale,
@@ -776,6 +810,13 @@ def main():
                          else traffic / algo_bytes,
                          'launches_per_step': nlaunch // isteps,
                          'avg_launch_us': ktime / max(nlaunch, 1) * 1e6,
+                         # the same fraction from the committed rocprofv3 --stats
+                         # summary (its average launch duration; the profiler's
+                         # own overhead makes it a few per cent lower than live)
+                         'frac_rocprof': None if not (rp_us and nlaunch) else
+                         flops / nlaunch / (rp_us * 1e-6) / 1e12 / peak,
+                         'rocprof_avg_launch_us': rp_us, 'rocprof_source': rp_src,
+                         'rocprof_stale': rp_stale,
                          'flops_per_step': flops / isteps,
                          'measured_over': '%d instrumented steps after the timed '
                                           'region' % isteps,

@@ -173,7 +173,10 @@ def test_bench_many_ranks_rehearsal(hip_lib, gc):
     # (the weight-gradient slabs of N x 1 clip and 1 x N clips group the tiles
     # differently: after three optimizer steps the float32 losses, ~5.3, may
     # differ by a few units in the last place, 4.8e-7 each)
-    assert abs(one['config']['global_loss'] - r['config']['global_loss']) <= 5e-6
+    # (N > 1 goes on to time the two-call schedule: the comparison is with the
+    # one-call schedule's loss, taken after the same number of steps)
+    assert abs(one['config']['global_loss'] -
+               r['allreduce_schedules']['one_call']['global_loss']) <= 5e-6
     if gc:
         assert one['config']['gc_ids'] == r['config']['gc_ids']
 

@@ -79,26 +79,15 @@ int wn_causal_wgrad(const int32_t* q, const float* dx0, float* slabs,
  * wblock = Wf[2][32][32] Wg[2][32][32] Wd[32][32] bf[32] bg[32] bd[32].
  * bias_fg: [B or 1][64] per-clip (bias + global-conditioning) or NULL. */
 /* save_ts: 0 = nothing kept for backward (inference); 1 = tanh and sigmoid
- * planes (th, sg; wn_layer_bwd / wn_layer_bwdw / the *_k kernels); 2 = the
+ * planes (th, sg; the generic-tap *_k / channel-block *_blk kernels); 2 = the
  * sigmoid plane only (sg; th may be NULL) for wn_layer_bwd2, which recovers
  * tanh = z / sigmoid. */
 int wn_layer_fwd(const float* x, float* x_out, float* z, float* th, float* sg,
                  const float* wblock, const float* bias_fg,
                  int bias_clip_stride, int B, int T, int dilation,
                  int has_dense, int save_ts, void* stream);
-/* backward-data of the same block (TF autodiff of model.py:236-330):
- * phase B of layer l (dx from da[t], da[t+d]) and/or phase A of layer l-1
- * (da from dZ, dx, tanh, sigmoid). */
-int wn_layer_bwd(const float* daf_cur, const float* dag_cur, const float* dxin,
-                 float* dx_out, const float* wblock_b, const float* dZ,
-                 const float* th, const float* sg, const float* wblock_a,
-                 float* daf_next, float* dag_next, int B, int T, int dilation,
-                 int do_b, int do_a, void* stream);
-/* backward-weights of the block into per-workgroup slabs (layout = wblock) */
+/* floats of a per-workgroup weight-gradient slab (layout = wblock) */
 int wn_layer_wgrad_slab_floats(void);
-int wn_layer_wgrad(const float* x, const float* daf, const float* dag,
-                   const float* z, const float* dxin, float* slabs,
-                   int num_slabs, int B, int T, int dilation, void* stream);
 
 /* generic filter width K >= 2 (off-default; the K = 2 kernels above are the
  * tuned path): block = Wf[K][32][32] Wg[K][32][32] Wd[32][32] bf bg bd,
@@ -181,25 +170,15 @@ int wn_layer_bwd_blk(const float* daf, const float* dag, long da_plane_stride,
                      int B, int T, int dilation, int K, int k0, int Ktot,
                      int dx_blocks, long dx_plane_stride, void* stream);
 
-/* fused backward of one block: phase B + all weight gradients of layer l and
- * phase A of layer l-1 in one pass (reads da_l / dx_{l+1} once).
- * tile_colsum (optional): [B * ceil(T/32)][64] per-tile column sums of
- * da_f | da_g, reduced per clip for the global-conditioning gradients. */
-int wn_layer_bwdw_slabs(int B, int T);
-int wn_layer_bwdw(const float* x, const float* z, const float* daf_cur,
-                  const float* dag_cur, const float* dxin, float* dx_out,
-                  const float* wblock_b, const float* dZ, const float* th,
-                  const float* sg, const float* wblock_a, float* daf_next,
-                  float* dag_next, float* slabs, float* tile_colsum, int B,
-                  int T, int dilation, int do_a, void* stream);
-
 /* default backward of one block (TF autodiff of model.py:236-330), no
  * pre-activation-gradient planes in HBM: every tile recomputes da for its
  * rows t and t+d from dZ_l, dx_{l+1}, z_l and the sigmoid plane, so the only
  * plane written is dx_l (768 B of HBM traffic per sample and layer instead of
  * 1408 B).  dxin == NULL for the last layer (its dense output is unused,
  * model.py:294-300).  slabs: [wn_layer_bwd2_slabs(B, T)][wblock layout] weight
- * gradients of layer l; tile_colsum as in wn_layer_bwdw. */
+ * gradients of layer l; tile_colsum (optional): [B * ceil(T/32)][64] per-tile
+ * column sums of da_f | da_g, reduced per clip for the global-conditioning
+ * gradients. */
 int wn_layer_bwd2_slabs(int B, int T);
 /* wimg: this layer's image out of wn_layer_bwd2_pack (the five matrices
  * transposed with row stride 33, wn_layer_bwd2_wimg_floats() floats per layer,

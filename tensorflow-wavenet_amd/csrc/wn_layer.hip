@@ -172,132 +172,6 @@ __global__ __launch_bounds__(LAYER_WG) void layer_fwd_kernel(
 #undef FWSTAMP
 }
 
-// Backward-data.  Phase B of layer l then phase A of layer l-1 on the same
-// rows (a kernel boundary is only needed before phase B because of the
-// anti-causal tap t+d):
-//   B(l):   dx_l[t]  = dxin[t] + da_l[t]*W1^T + da_l[t+d]*W0^T
-//   A(l-1): dz       = dZ_{l-1}[t] + dx_l[t]*Wd_{l-1}^T
-//           da_f     = dz * sig * (1 - tanh^2);  da_g = dz * tanh * sig*(1-sig)
-// da is stored as two planes: daf[rows][32], dag[rows][32].
-// 512-thread workgroups (8 waves, 85 KB LDS) so that layer_wgrad_kernel
-// (64 KB LDS) fits on the same CU and overlaps from a second stream.
-#define BWD_WG 512
-#define BWD_WAVES (BWD_WG / 64)
-
-template <bool DO_B, bool DO_A, bool HAS_DXIN>
-__global__ __launch_bounds__(BWD_WG) void layer_bwd_kernel(
-    const float* __restrict__ daf_cur, const float* __restrict__ dag_cur,
-    const float* __restrict__ dxin, float* __restrict__ dx_out,
-    const float* __restrict__ wblock_b,   // layer l block (phase B)
-    const float* __restrict__ dZ, const float* __restrict__ th,
-    const float* __restrict__ sg, const float* __restrict__ wblock_a,  // l-1
-    float* __restrict__ daf_next, float* __restrict__ dag_next, int B, int T,
-    int d) {
-  // LDS: transposed weights, rows padded to 33 floats so that both the
-  // transposing stores and the MFMA A-operand reads are bank-conflict free.
-  // [0..4) conv: Wf0^T, Wf1^T, Wg0^T, Wg1^T with row = dilation channel
-  // (contraction), col = residual channel; [4] Wd^T with row = residual
-  // channel (contraction), col = dilation channel.
-  constexpr int LDT = 33, MT = 32 * LDT;
-  __shared__ float wl[5 * MT];
-  __shared__ __attribute__((aligned(16))) float tiles[BWD_WAVES * 2 * 1024];
-  const int tid = threadIdx.x;
-  if (DO_B) {
-    for (int i = tid; i < 4096; i += BWD_WG) {
-      const int m = i >> 10, rr = (i >> 5) & 31, cc = i & 31;  // W[m][rr][cc]
-      wl[m * MT + cc * LDT + rr] = wblock_b[i];
-    }
-  }
-  if (DO_A) {
-    for (int i = tid; i < 1024; i += BWD_WG) {
-      const int rr = i >> 5, cc = i & 31;  // Wd[dch rr][res cc]
-      wl[4 * MT + cc * LDT + rr] = wblock_a[4096 + i];
-    }
-  }
-  __syncthreads();
-  const int lane = tid & 63, wave = tid >> 6;
-  const int j = lane & 31, h = lane >> 5;
-  float* ta = tiles + wave * 2048;
-  float* tb = ta + 1024;
-  const int tiles_per_clip = (T + 31) >> 5;
-  const int ntiles = tiles_per_clip * B;
-  for (int tile = blockIdx.x * BWD_WAVES + wave; tile < ntiles;
-       tile += gridDim.x * BWD_WAVES) {
-    int woff = j + 4 * h * LDT;  // opaque: no hoisting of the weight reads
-    asm volatile("" : "+v"(woff));
-    const float* wlane = wl + woff;
-    const int b = tile / tiles_per_clip;
-    const int t0 = (tile - b * tiles_per_clip) * 32;
-    const int hi = min(32, T - t0);
-    const int hi_f = min(hi, T - d - t0);   // rows whose t+d tap exists (may be <= 0)
-    const size_t off0 = ((size_t)b * T + t0) * WN_CH;
-    f32x16 dx;
-    if (HAS_DXIN) {
-      rows_to_lds(ta, lane, rows_load(dxin + off0, lane, 0, hi));
-      __builtin_amdgcn_wave_barrier();
-      dx = frag_from_lds(ta, j, h);
-      __builtin_amdgcn_wave_barrier();
-    } else {
-      dx = frag_zero();
-    }
-    if (DO_B) {
-      const RowRegs rf0 = rows_load(daf_cur + off0, lane, 0, hi);
-      const RowRegs rg0 = rows_load(dag_cur + off0, lane, 0, hi);
-      const RowRegs rf1 = rows_load(daf_cur + off0 + (size_t)d * WN_CH, lane, 0, hi_f);
-      const RowRegs rg1 = rows_load(dag_cur + off0 + (size_t)d * WN_CH, lane, 0, hi_f);
-      rows_to_lds(ta, lane, rf0);
-      rows_to_lds(tb, lane, rg0);
-      __builtin_amdgcn_wave_barrier();
-      f32x16 f0 = frag_from_lds(ta, j, h);
-      f32x16 g0 = frag_from_lds(tb, j, h);
-      mma32<LDT>(dx, f0, wlane + 1 * MT);  // da_f[t]   * Wf[1]^T
-      mma32<LDT>(dx, g0, wlane + 3 * MT);  // da_g[t]   * Wg[1]^T
-      __builtin_amdgcn_wave_barrier();
-      rows_to_lds(ta, lane, rf1);
-      rows_to_lds(tb, lane, rg1);
-      __builtin_amdgcn_wave_barrier();
-      f32x16 f1 = frag_from_lds(ta, j, h);
-      f32x16 g1 = frag_from_lds(tb, j, h);
-      mma32<LDT>(dx, f1, wlane + 0 * MT);  // da_f[t+d] * Wf[0]^T
-      mma32<LDT>(dx, g1, wlane + 2 * MT);  // da_g[t+d] * Wg[0]^T
-      __builtin_amdgcn_wave_barrier();
-      frag_to_lds(ta, j, h, dx);
-      __builtin_amdgcn_wave_barrier();
-      rows_store(dx_out + off0, lane, hi, rows_from_lds(ta, lane));
-      __builtin_amdgcn_wave_barrier();
-    }
-    if (DO_A) {
-      const RowRegs rz = rows_load(dZ + off0, lane, 0, hi);
-      const RowRegs rt = rows_load(th + off0, lane, 0, hi);
-      const RowRegs rs = rows_load(sg + off0, lane, 0, hi);
-      rows_to_lds(ta, lane, rz);
-      rows_to_lds(tb, lane, rt);
-      __builtin_amdgcn_wave_barrier();
-      f32x16 dz = frag_from_lds(ta, j, h);
-      f32x16 tt = frag_from_lds(tb, j, h);
-      __builtin_amdgcn_wave_barrier();
-      rows_to_lds(ta, lane, rs);
-      __builtin_amdgcn_wave_barrier();
-      f32x16 ss = frag_from_lds(ta, j, h);
-      if (DO_B || HAS_DXIN) mma32<LDT>(dz, dx, wlane + 4 * MT);
-      f32x16 df, dg;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float zs = dz[r] * ss[r];
-        df[r] = zs * (1.f - tt[r] * tt[r]);
-        dg[r] = zs * tt[r] * (1.f - ss[r]);
-      }
-      __builtin_amdgcn_wave_barrier();
-      frag_to_lds(ta, j, h, df);
-      frag_to_lds(tb, j, h, dg);
-      __builtin_amdgcn_wave_barrier();
-      rows_store(daf_next + off0, lane, hi, rows_from_lds(ta, lane));
-      rows_store(dag_next + off0, lane, hi, rows_from_lds(tb, lane));
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
-}
-
 // Backward-weights of one layer.  Every wave walks 32-row tiles and keeps 5
 // accumulator tiles with channels on BOTH MFMA axes (the row pair of a step
 // is the contraction):
@@ -633,250 +507,6 @@ __global__ __launch_bounds__(512) void layer_wgrad_cbn_kernel(
   }
 }
 
-// ---------------------------------------------------------------------------
-// Fused backward of one residual block: data gradient (phase B of layer l),
-// ALL weight gradients of layer l, and phase A of layer l-1, in one pass over
-// the rows.  Versus layer_bwd_kernel + layer_wgrad_kernel it reads da_l and
-// dx_{l+1} once instead of twice (-49 MB per layer at B*T = 128000) and saves
-// a launch.  One 512-thread workgroup per CU; every wave owns four 4 KB LDS
-// tiles that serve BOTH views of a tile: fragments (time on lanes, operands
-// of the data products) and transposed element reads (channel on lanes,
-// operands of the weight-gradient products).
-// ---------------------------------------------------------------------------
-#define BW_WG 512
-#define BW_WAVES (BW_WG / 64)
-
-template <bool DO_A, bool HAS_DXIN>
-__global__ __launch_bounds__(BW_WG) void layer_bwdw_kernel(
-    const float* __restrict__ x, const float* __restrict__ z,
-    const float* __restrict__ daf_cur, const float* __restrict__ dag_cur,
-    const float* __restrict__ dxin, float* __restrict__ dx_out,
-    const float* __restrict__ wblock_b, const float* __restrict__ dZ,
-    const float* __restrict__ th, const float* __restrict__ sg,
-    const float* __restrict__ wblock_a, float* __restrict__ daf_next,
-    float* __restrict__ dag_next, float* __restrict__ slabs,
-    float* __restrict__ tile_colsum, int B, int T, int d) {
-  constexpr int LDT = 33, MT = 32 * LDT;
-  __shared__ float wl[5 * MT];
-  __shared__ __attribute__((aligned(16))) float tiles[BW_WAVES * 4 * 1024];
-  const int tid = threadIdx.x;
-  for (int i = tid; i < 4096; i += BW_WG) {
-    const int m = i >> 10, rr = (i >> 5) & 31, cc = i & 31;  // W[m][rr][cc]
-    wl[m * MT + cc * LDT + rr] = wblock_b[i];
-  }
-  if (DO_A) {
-    for (int i = tid; i < 1024; i += BW_WG) {
-      const int rr = i >> 5, cc = i & 31;  // Wd[dch rr][res cc]
-      wl[4 * MT + cc * LDT + rr] = wblock_a[4096 + i];
-    }
-  }
-  __syncthreads();
-  const int lane = tid & 63, wave = tid >> 6;
-  const int j = lane & 31, h = lane >> 5;
-  float* t0 = tiles + wave * 4096;
-  float* t1 = t0 + 1024;
-  float* t2 = t1 + 1024;
-  float* t3 = t2 + 1024;
-  const int tiles_per_clip = (T + 31) >> 5;
-  const int ntiles = tiles_per_clip * B;
-  f32x16 cf0 = frag_zero(), cf1 = frag_zero(), cg0 = frag_zero(),
-         cg1 = frag_zero(), cd = frag_zero();
-  float sf = 0.f, sgs = 0.f, sd = 0.f;
-  for (int tile = blockIdx.x * BW_WAVES + wave; tile < ntiles;
-       tile += gridDim.x * BW_WAVES) {
-    int woff = j + 4 * h * LDT;  // opaque: no hoisting of the weight reads
-    asm volatile("" : "+v"(woff));
-    const float* wlane = wl + woff;
-    const int b = tile / tiles_per_clip;
-    const int tt0 = (tile - b * tiles_per_clip) * 32;
-    const int hi = min(32, T - tt0);
-    const int hi_f = min(hi, T - d - tt0);  // rows whose t+d tap exists
-    const int lo_p = max(0, d - tt0);       // rows whose t-d tap exists
-    const size_t off0 = ((size_t)b * T + tt0) * WN_CH;
-    // ---- data gradient, current tap; weight gradients.  Global loads are
-    // issued at most ~3 tiles ahead of their LDS write to bound VGPR use.
-    f32x16 dx;
-    {
-      RowRegs rdx;
-      if (HAS_DXIN) rdx = rows_load(dxin + off0, lane, 0, hi);
-      const RowRegs rf0 = rows_load(daf_cur + off0, lane, 0, hi);
-      const RowRegs rg0 = rows_load(dag_cur + off0, lane, 0, hi);
-      const RowRegs rxc = rows_load(x + off0, lane, 0, hi);
-      if (HAS_DXIN) rows_to_lds(t0, lane, rdx);   // t0 keeps dx_{l+1}
-      rows_to_lds(t1, lane, rf0);
-      rows_to_lds(t2, lane, rg0);
-      rows_to_lds(t3, lane, rxc);
-    }
-    const RowRegs rxp = rows_load(x + off0 - (size_t)d * WN_CH, lane, lo_p, hi);
-    __builtin_amdgcn_wave_barrier();
-    if (HAS_DXIN) dx = frag_from_lds(t0, j, h); else dx = frag_zero();
-    {
-      const f32x16 f0 = frag_from_lds(t1, j, h);
-      const f32x16 g0 = frag_from_lds(t2, j, h);
-      mma32<LDT>(dx, f0, wlane + 1 * MT);  // da_f[t]   * Wf[1]^T
-      mma32<LDT>(dx, g0, wlane + 3 * MT);  // da_g[t]   * Wg[1]^T
-    }
-    float tsf = 0.f, tsg = 0.f;          // this tile's column sums of da
-#pragma unroll 4
-    for (int s = 0; s < 16; ++s) {       // dW[1] += x[t]^T da[t]
-      const int row = 2 * s + h;
-      const float axc = tile_elem(t3, row, j);
-      const float bf = tile_elem(t1, row, j), bg = tile_elem(t2, row, j);
-      cf1 = __builtin_amdgcn_mfma_f32_32x32x2f32(axc, bf, cf1, 0, 0, 0);
-      cg1 = __builtin_amdgcn_mfma_f32_32x32x2f32(axc, bg, cg1, 0, 0, 0);
-      tsf += bf;
-      tsg += bg;
-    }
-    sf += tsf;
-    sgs += tsg;
-    if (tile_colsum) {
-      // per-tile column sums (a tile lies inside one clip): the per-clip sums
-      // the global-conditioning gradients need (model.py:272-284 under
-      // autodiff) without a separate pass over da
-      const float a = tsf + __shfl_xor(tsf, 32), b2 = tsg + __shfl_xor(tsg, 32);
-      if (h == 0) {
-        tile_colsum[(size_t)tile * 64 + j] = a;
-        tile_colsum[(size_t)tile * 64 + 32 + j] = b2;
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    rows_to_lds(t3, lane, rxp);
-    __builtin_amdgcn_wave_barrier();
-    RowRegs rzz;
-    if (HAS_DXIN) rzz = rows_load(z + off0, lane, 0, hi);
-    const RowRegs rf1 = rows_load(daf_cur + off0 + (size_t)d * WN_CH, lane, 0, hi_f);
-#pragma unroll 4
-    for (int s = 0; s < 16; ++s) {       // dW[0] += x[t-d]^T da[t]
-      const int row = 2 * s + h;
-      const float axp = tile_elem(t3, row, j);
-      const float bf = tile_elem(t1, row, j), bg = tile_elem(t2, row, j);
-      cf0 = __builtin_amdgcn_mfma_f32_32x32x2f32(axp, bf, cf0, 0, 0, 0);
-      cg0 = __builtin_amdgcn_mfma_f32_32x32x2f32(axp, bg, cg0, 0, 0, 0);
-    }
-    const RowRegs rg1 = rows_load(dag_cur + off0 + (size_t)d * WN_CH, lane, 0, hi_f);
-    if (HAS_DXIN) {                      // dWd += z^T dx_{l+1}
-      __builtin_amdgcn_wave_barrier();
-      rows_to_lds(t3, lane, rzz);
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll 4
-      for (int s = 0; s < 16; ++s) {
-        const int row = 2 * s + h;
-        const float az = tile_elem(t3, row, j), bd = tile_elem(t0, row, j);
-        cd = __builtin_amdgcn_mfma_f32_32x32x2f32(az, bd, cd, 0, 0, 0);
-        sd += bd;
-      }
-    }
-    // ---- data gradient, anti-causal tap
-    __builtin_amdgcn_wave_barrier();
-    rows_to_lds(t1, lane, rf1);
-    rows_to_lds(t2, lane, rg1);
-    __builtin_amdgcn_wave_barrier();
-    RowRegs rdz, rth;
-    if (DO_A) {
-      rdz = rows_load(dZ + off0, lane, 0, hi);
-      rth = rows_load(th + off0, lane, 0, hi);
-    }
-    {
-      const f32x16 f1 = frag_from_lds(t1, j, h);
-      const f32x16 g1 = frag_from_lds(t2, j, h);
-      mma32<LDT>(dx, f1, wlane + 0 * MT);  // da_f[t+d] * Wf[0]^T
-      mma32<LDT>(dx, g1, wlane + 2 * MT);  // da_g[t+d] * Wg[0]^T
-    }
-    __builtin_amdgcn_wave_barrier();
-    frag_to_lds(t3, j, h, dx);
-    __builtin_amdgcn_wave_barrier();
-    rows_store(dx_out + off0, lane, hi, rows_from_lds(t3, lane));
-    // ---- phase A of layer l-1
-    if (DO_A) {
-      const RowRegs rsg = rows_load(sg + off0, lane, 0, hi);
-      __builtin_amdgcn_wave_barrier();
-      rows_to_lds(t0, lane, rdz);
-      rows_to_lds(t1, lane, rth);
-      rows_to_lds(t2, lane, rsg);
-      __builtin_amdgcn_wave_barrier();
-      f32x16 dz = frag_from_lds(t0, j, h);
-      const f32x16 tt = frag_from_lds(t1, j, h);
-      const f32x16 ss = frag_from_lds(t2, j, h);
-      mma32<LDT>(dz, dx, wlane + 4 * MT);
-      f32x16 df, dg;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float zs = dz[r] * ss[r];
-        df[r] = zs * (1.f - tt[r] * tt[r]);
-        dg[r] = zs * tt[r] * (1.f - ss[r]);
-      }
-      __builtin_amdgcn_wave_barrier();
-      frag_to_lds(t0, j, h, df);
-      frag_to_lds(t1, j, h, dg);
-      __builtin_amdgcn_wave_barrier();
-      rows_store(daf_next + off0, lane, hi, rows_from_lds(t0, lane));
-      rows_store(dag_next + off0, lane, hi, rows_from_lds(t1, lane));
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-  // ---- weight-gradient slab of this workgroup (fixed-order wave reduction)
-  sf += __shfl_xor(sf, 32);
-  sgs += __shfl_xor(sgs, 32);
-  sd += __shfl_xor(sd, 32);
-  __syncthreads();
-  float* red = tiles;
-  for (int w = 0; w < BW_WAVES; ++w) {
-    if (wave == w) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = 8 * (r >> 2) + 4 * h + (r & 3);
-        const int e = m * 32 + j;
-        if (w == 0) {
-          red[0 * 1024 + e] = cf0[r];
-          red[1 * 1024 + e] = cf1[r];
-          red[2 * 1024 + e] = cg0[r];
-          red[3 * 1024 + e] = cg1[r];
-          red[4 * 1024 + e] = cd[r];
-        } else {
-          red[0 * 1024 + e] += cf0[r];
-          red[1 * 1024 + e] += cf1[r];
-          red[2 * 1024 + e] += cg0[r];
-          red[3 * 1024 + e] += cg1[r];
-          red[4 * 1024 + e] += cd[r];
-        }
-      }
-      if (h == 0) {
-        if (w == 0) {
-          red[LAYER_W_FLOATS + j] = sf;
-          red[LAYER_W_FLOATS + 32 + j] = sgs;
-          red[LAYER_W_FLOATS + 64 + j] = sd;
-        } else {
-          red[LAYER_W_FLOATS + j] += sf;
-          red[LAYER_W_FLOATS + 32 + j] += sgs;
-          red[LAYER_W_FLOATS + 64 + j] += sd;
-        }
-      }
-    }
-    __syncthreads();
-  }
-  float* out = slabs + (size_t)blockIdx.x * LAYER_BLOCK_FLOATS;
-  for (int e = tid; e < LAYER_BLOCK_FLOATS; e += BW_WG) out[e] = red[e];
-}
-
-// ---------------------------------------------------------------------------
-// Backward of one residual block WITHOUT pre-activation-gradient planes
-// (the default).  layer_bwdw_kernel above passes da_f / da_g of layer l from
-// one launch to the next through HBM (2 planes written, 4 tile reads) because
-// the data gradient needs the anti-causal tap da[t+d].  Here every tile
-// computes da for its own rows t AND for the rows t+d from what the forward
-// pass and the dZ GEMM left behind:
-//     dz[s]   = dZ_l[s] + dx_{l+1}[s] * Wd^T            s in {t, t+d}
-//     tanh    = z / sigmoid                             (z = tanh * sigmoid)
-//     da_f[s] = dz * sigmoid * (1 - tanh^2);  da_g[s] = dz * z * (1 - sigmoid)
-//     dx_l[t] = dx_{l+1}[t] + da[t] * W[1]^T + da[t+d] * W[0]^T
-//     dW[1] += x[t]^T da[t];  dW[0] += x[t-d]^T da[t];  dWd += z[t]^T dx_{l+1}[t]
-// so a launch depends on the previous one only through the dx plane, nothing
-// but dx is written, and the tanh plane is never stored.  Per sample and
-// layer: 5 planes read (dx_{l+1}, dZ, z, sigmoid, x; the shifted second reads
-// of a plane come from L2 / the Infinity Cache) + 1 written = 768 B of HBM
-// traffic instead of 1408 B, for 16 more MFMAs per tile (176 vs 160).
-// Rows outside the clip load as zeros; sigmoid == 0 there, which the guard
-// turns into da == 0.
 // ---------------------------------------------------------------------------
 #define B2_WAVES 8
 // (B2_WIMG and gate_grad live in wn_common.h: wn_stack.hip shares them)
@@ -1823,34 +1453,6 @@ int wn_layer_fwd(const float* x, float* x_out, float* z, float* th, float* sg,
   return wn_check_launch();
 }
 
-int wn_layer_bwd(const float* daf_cur, const float* dag_cur, const float* dxin,
-                 float* dx_out, const float* wblock_b, const float* dZ,
-                 const float* th, const float* sg, const float* wblock_a,
-                 float* daf_next, float* dag_next, int B, int T, int dilation,
-                 int do_b, int do_a, void* stream) {
-  if (B <= 0 || T <= 0 || dilation <= 0) return WN_ERR_BAD_SHAPE;
-  if (!do_a && !do_b) return WN_ERR_BAD_SHAPE;
-  if (do_b && (!daf_cur || !dag_cur || !dx_out || !wblock_b)) return WN_ERR_NULL;
-  if (do_a && (!dZ || !th || !sg || !wblock_a || !daf_next || !dag_next))
-    return WN_ERR_NULL;
-  const void* ptrs[] = {daf_cur, dag_cur, dxin, dx_out, dZ, th,
-                        sg,      daf_next, dag_next};
-  for (const void* p : ptrs)
-    if (p && !wn_aligned16(p)) return WN_ERR_MISALIGNED;
-  dim3 grid(layer_grid(B, T, BWD_WAVES)), block(BWD_WG);
-  hipStream_t s = (hipStream_t)stream;
-  const bool hx = dxin != nullptr;
-#define LAUNCH(DB, DA, HX)                                                   \
-  hipLaunchKernelGGL((layer_bwd_kernel<DB, DA, HX>), grid, block, 0, s,      \
-                     daf_cur, dag_cur, dxin, dx_out, wblock_b, dZ, th, sg,   \
-                     wblock_a, daf_next, dag_next, B, T, dilation)
-  if (do_b && do_a) { if (hx) LAUNCH(true, true, true); else LAUNCH(true, true, false); }
-  else if (do_b) { if (hx) LAUNCH(true, false, true); else LAUNCH(true, false, false); }
-  else { if (hx) LAUNCH(false, true, true); else LAUNCH(false, true, false); }
-#undef LAUNCH
-  return wn_check_launch();
-}
-
 int wn_layer_wgrad_slab_floats(void) { return LAYER_BLOCK_FLOATS; }
 
 // ---- generic filter width (K taps); block = (2K+1)*1024 + 96 floats
@@ -2108,37 +1710,6 @@ int wn_dense_planes_gate(const float* in, long in_plane_stride, const float* W,
   return wn_check_launch();
 }
 
-int wn_layer_bwdw_slabs(int B, int T) { return layer_grid(B, T, BW_WAVES); }
-
-int wn_layer_bwdw(const float* x, const float* z, const float* daf_cur,
-                  const float* dag_cur, const float* dxin, float* dx_out,
-                  const float* wblock_b, const float* dZ, const float* th,
-                  const float* sg, const float* wblock_a, float* daf_next,
-                  float* dag_next, float* slabs, float* tile_colsum, int B,
-                  int T, int dilation, int do_a, void* stream) {
-  if (B <= 0 || T <= 0 || dilation <= 0) return WN_ERR_BAD_SHAPE;
-  if (!x || !daf_cur || !dag_cur || !dx_out || !wblock_b || !slabs)
-    return WN_ERR_NULL;
-  if ((dxin != nullptr) != (z != nullptr)) return WN_ERR_NULL;
-  if (do_a && (!dZ || !th || !sg || !wblock_a || !daf_next || !dag_next))
-    return WN_ERR_NULL;
-  const void* ptrs[] = {x, z, daf_cur, dag_cur, dxin, dx_out, dZ, th, sg,
-                        daf_next, dag_next};
-  for (const void* p : ptrs)
-    if (p && !wn_aligned16(p)) return WN_ERR_MISALIGNED;
-  dim3 grid(layer_grid(B, T, BW_WAVES)), block(BW_WG);
-  hipStream_t s = (hipStream_t)stream;
-#define LAUNCH(DA, HX)                                                        \
-  hipLaunchKernelGGL((layer_bwdw_kernel<DA, HX>), grid, block, 0, s, x, z,    \
-                     daf_cur, dag_cur, dxin, dx_out, wblock_b, dZ, th, sg,    \
-                     wblock_a, daf_next, dag_next, slabs, tile_colsum, B, T, \
-                     dilation)
-  if (do_a) { if (dxin) LAUNCH(true, true); else LAUNCH(true, false); }
-  else { if (dxin) LAUNCH(false, true); else LAUNCH(false, false); }
-#undef LAUNCH
-  return wn_check_launch();
-}
-
 // number of slabs (workgroups) wn_layer_bwd2 writes for this shape (an upper
 // bound over the kernel variants: slabs past the launched grid stay unused)
 int wn_layer_bwd2_slabs(int B, int T) {
@@ -2176,24 +1747,6 @@ int wn_layer_bwd2(const float* x, const float* z, const float* sg,
   if (dxin) LAUNCH((layer_bwd2d_kernel<true>), wimg);
   else LAUNCH((layer_bwd2d_kernel<false>), wimg);
 #undef LAUNCH
-  return wn_check_launch();
-}
-
-int wn_layer_wgrad(const float* x, const float* daf, const float* dag,
-                   const float* z, const float* dxin, float* slabs,
-                   int num_slabs, int B, int T, int dilation, void* stream) {
-  if (!x || !daf || !dag || !slabs) return WN_ERR_NULL;
-  if (B <= 0 || T <= 0 || dilation <= 0 || num_slabs <= 0)
-    return WN_ERR_BAD_SHAPE;
-  if ((dxin != nullptr) != (z != nullptr)) return WN_ERR_NULL;
-  hipStream_t s = (hipStream_t)stream;
-  dim3 grid(num_slabs), block(256);
-  if (dxin)
-    hipLaunchKernelGGL((layer_wgrad_kernel<true>), grid, block, 0, s, x, daf,
-                       dag, z, dxin, slabs, B, T, dilation, 1, 0L);
-  else
-    hipLaunchKernelGGL((layer_wgrad_kernel<false>), grid, block, 0, s, x, daf,
-                       dag, z, dxin, slabs, B, T, dilation, 1, 0L);
   return wn_check_launch();
 }
 

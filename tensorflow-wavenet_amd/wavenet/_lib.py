@@ -45,11 +45,7 @@ SIGNATURES = {
     'wn_stack_bwd_slabs': (c_int, [c_int, c_int, c_int]),
     'wn_stack_bwd': (c_int, [P, P, P, P, P, c_long, P, P, P, c_long, P, P, P,
                              P, P, c_int, c_int, c_int, c_int, P]),
-    'wn_layer_bwd': (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int,
-                             c_int, c_int, c_int, P]),
     'wn_layer_wgrad_slab_floats': (c_int, []),
-    'wn_layer_wgrad': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int,
-                               P]),
     'wn_dense_planes': (c_int, [P, c_long, P, P, P, c_long, P, c_long, c_long, c_int,
                                 P]),
     'wn_dense_planes_gate': (c_int, [P, c_long, P, P, c_long, P, P, c_long, P, P,
@@ -67,9 +63,6 @@ SIGNATURES = {
     'wn_layer_bwd_blk': (c_int, [P, P, c_long, c_int, P, P, P, P, c_int,
                                  c_long, c_int, c_int, c_int, c_int, c_int,
                                  c_int, c_int, c_long, P]),
-    'wn_layer_bwdw_slabs': (c_int, [c_int, c_int]),
-    'wn_layer_bwdw': (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
-                              c_int, c_int, c_int, c_int, P]),
     'wn_layer_bwd2_slabs': (c_int, [c_int, c_int]),
     'wn_layer_bwd2_wimg_floats': (c_int, []),
     'wn_layer_bwd2_pack': (c_int, [P, c_long, P, c_int, P]),

@@ -119,9 +119,9 @@ class _Workspace(object):
             alloc('pre', (2 * CB, N, CH))
         if not training:
             return
-        # legacy backward kernels (un-fused pair, wn_layer_bwdw, generic
-        # filter widths) also need the tanh plane and two ping-pong pairs of
-        # pre-activation-gradient planes; the default wn_layer_bwd2 does not
+        # the generic-tap / channel-block backward kernels also need the tanh
+        # plane and two ping-pong pairs of pre-activation-gradient planes; the
+        # default wn_stack_bwd / wn_layer_bwd2 do not
         self.legacy = net._legacy_bwd()
         self.TH = alloc('TH', (LP, N, CH)) if self.legacy else None
         alloc('SG', (LP, N, CH))
@@ -138,8 +138,7 @@ class _Workspace(object):
         # / Infinity Cache; DX[0] ends up as dL/dx_0).  The per-layer checks of
         # tests/test_gpu_stack.py (`net.stack_bwd_keep_dx`) keep dL/dx_l of
         # EVERY layer.  Plus the q planes, flags and control block (allocated
-        # whenever the option could apply, so that switching `layer_bwd` /
-        # `fused_bwd` back and forth keeps one behaviour)
+        # whenever the option could apply)
         self.stack_bwd = (net.stack_bwd and not net.blocked and not net.generic_layers
                           and L <= 256 and N * CH * 4 < 2 ** 31)
         if self.stack_bwd:
@@ -176,7 +175,6 @@ class _Workspace(object):
             # row splits beyond 8 GB instead of an opaque allocation failure
             per = CB * CB * ((2 * min(net.KW, 8) + 1) * 1024 + 96) * 4
             self.nslab = max(1, min(self.nslab, (8 << 30) // per))
-        self.nslab_f = lib.wn_layer_bwdw_slabs(B, T)      # fused kernel
         self.nslab_2 = lib.wn_layer_bwd2_slabs(B, T)
         self.nslab_s = lib.wn_stack_bwd_slabs(B, T, self.stack_variant) \
             if self.stack_bwd else 0
@@ -189,7 +187,7 @@ class _Workspace(object):
                              (2 * min(net.KW, 8) + 1) * 1024 + 96))
             alloc('lslabs', (1, 1, 4))
         else:
-            alloc('lslabs', (L, max(self.nslab, self.nslab_f, self.nslab_2,
+            alloc('lslabs', (L, max(self.nslab, self.nslab_2,
                                     self.nslab_s), net.LAYER_BLOCK))
         need = 0
         self.splits = {}
@@ -224,12 +222,6 @@ class _Workspace(object):
         self.dsum_part = alloc(
             'dsum_part', (B * lib.wn_colsum_clip_chunks(T) * 64,)) \
             if net.G else None
-        # cross-stream events: weight-gradient kernels run on a side stream
-        if parent is not None and getattr(parent, 'ev_ready', None):
-            self.ev_ready, self.ev_done = parent.ev_ready, parent.ev_done
-        else:
-            self.ev_ready = [torch.cuda.Event() for _ in range(L)]
-            self.ev_done = [torch.cuda.Event() for _ in range(L)]
         alloc('l2_parts', (lib.wn_l2_partials_count(),))
         alloc('l2', (1,), fill=0.0)
 
@@ -285,11 +277,6 @@ class WaveNetModel(object):
         # model.py:28 passes the bias *name* as `trainable`, so the reference's
         # L2 filter "'bias' in v.name" (model.py:676) does not exclude biases.
         self.tf_bias_name_quirk = True
-        # Optional: run the layer weight-gradient kernels on a second HIP stream
-        # next to the data-gradient chain.  Measured SLOWER on MI355X (13.55 vs
-        # 12.80 ms/step: 100 cross-stream event edges per step cost more than
-        # the overlap recovers), so it is off by default.
-        self.overlap_wgrad = False
         # Run the three weight-gradient (TN) GEMMs of the skip / post-processing
         # convs on a second, lower-priority HIP stream next to the dZ GEMM and
         # the residual-stack backward (one fork after the dtotal GEMM, one join
@@ -308,13 +295,6 @@ class WaveNetModel(object):
         # column sums (bias gradients) of the weight-gradient GEMMs spread over
         # all tile rows of a split (False: one owner tile row, A/B)
         self.tn_spread_colsum = True
-        # backward of a residual block: 'bwd2' (default: one kernel per layer,
-        # pre-activation gradients recomputed per tile, only dx goes through
-        # HBM, tanh recovered as z / sigmoid); 'bwdw' (round-1 fused kernel:
-        # da planes through HBM, tanh + sigmoid planes); fused_bwd=False: the
-        # un-fused data / weight kernel pair.  Kept for A/B and tests.
-        self.layer_bwd = 'bwd2'
-        self.fused_bwd = True
         # forward of the residual stack as ONE persistent launch
         # (wn_stack_fwd: tiles stay in registers from layer to layer, the
         # dilated taps are handed over through per-tile flags) instead of one
@@ -634,8 +614,6 @@ class WaveNetModel(object):
 
     # ------------------------------------------------------------------ helpers
     def _overlap_tn_on(self, ws):
-        if self.overlap_wgrad:
-            return False
         if self.overlap_tn is not None:
             return bool(self.overlap_tn)
         return ws.B * ((ws.T + 31) // 32) <= 1024 and not self.blocked
@@ -658,8 +636,11 @@ class WaveNetModel(object):
         return self._side
 
     def _legacy_bwd(self):
-        return (self.layer_bwd != 'bwd2' or not self.fused_bwd
-                or self.generic_layers or self.overlap_wgrad or self.blocked)
+        """The generic-tap (filter_width > 2) and channel-block (> 32 channels)
+        models: their backward keeps the tanh plane and ping-pong
+        pre-activation-gradient planes; the default-width two-tap model runs
+        wn_stack_bwd / wn_layer_bwd2, which do not."""
+        return self.generic_layers or self.blocked
 
     def check_device_errors(self):
         """Raise if a persistent stack launch recorded an expired dependency
@@ -829,7 +810,7 @@ class WaveNetModel(object):
     # ------------------------------------------------------------ launch plans
     def _plan_key(self, tag, ws, ids, extra):
         return (tag, extra, ids is not None, self.generic_layers,
-                self.fused_bwd, self.layer_bwd, self.overlap_tn,
+                self.overlap_tn,
                 self.overlap_tn_split_frac, self.wide_fuse_gate, self.tn_spread_colsum, self.stack_fwd, self.stack_fwd_skip, self.stack_bwd, ws.stack_variant, self._early_on(), self.gemm_mode, self.causal_wgrad_segsum, self.tf_xent_zero_label_quirk,
                 _lib.stream(), self.params.data_ptr(), self.grads.data_ptr())
 
@@ -861,9 +842,9 @@ class WaveNetModel(object):
 
     def _backward(self, ws, ids):
         ids = self._stage_ids(ws, ids)
-        if not self.use_launch_plans or self.overlap_wgrad or self.blocked:
-            # (side stream with torch events / the channel-block path, whose
-            # gradient-block copies are torch ops a launch plan cannot replay)
+        if not self.use_launch_plans or self.blocked:
+            # (the channel-block path, whose gradient-block copies are torch ops
+            # a launch plan cannot replay)
             return self._backward_eager(ws, ids)
         key = self._plan_key('bwd', ws, ids, None)
         plan = ws.plans.get(key, 0)
@@ -1163,23 +1144,18 @@ class WaveNetModel(object):
             self._backward_tail(ws, ids, dxin, ws.nslab_2, True)
             return
 
+        # generic filter width (wn_layer_*_k; also a K = 2 model with
+        # `generic_layers` forced, tests): phase A of layer l - 1 and phase B
+        # of layer l per launch, pre-activation gradients through two ping-pong
+        # plane pairs, weight gradients per layer into slabs
         def da(p):
             return ws.da[p][0], ws.da[p][1]
-        gen = self.generic_layers
 
         def layer_bwd(*a):           # (..., B, T, d, do_b, do_a, stream)
-            if gen:
-                _lib.call('wn_layer_bwd_k', *a[:14], self.KW, *a[14:16], 1, 0,
-                          a[16])
-            else:
-                _lib.call('wn_layer_bwd', *a)
+            _lib.call('wn_layer_bwd_k', *a[:14], self.KW, *a[14:16], 1, 0, a[16])
 
         def layer_wgrad(*a):         # (..., nslab, B, T, d, stream)
-            if gen:
-                _lib.call('wn_layer_wgrad_k', *a[:10], self.KW, 0, self.KW,
-                          1, 0, a[10])
-            else:
-                _lib.call('wn_layer_wgrad', *a)
+            _lib.call('wn_layer_wgrad_k', *a[:10], self.KW, 0, self.KW, 1, 0, a[10])
         cur = 0
         f, g = da(cur)
         # phase A of the last layer (no gradient flows into its x' output)
@@ -1190,54 +1166,18 @@ class WaveNetModel(object):
                   _lib.ptr(g), B, T, 1, 0, 1, st)
         dxin = None           # dL/dx' of layer l (None for the last layer)
         xp = 0
-        # The weight-gradient kernel of layer l only READS da_l / dx_{l+1}; it
-        # runs on a side stream concurrently with the data-gradient kernel of
-        # the same layer (their LDS footprints are sized to share a CU).  The
-        # data kernel of layer l-1 overwrites those buffers, so it waits for it.
-        main = torch.cuda.current_stream()
-        side = self._side_stream() if self.overlap_wgrad else main
-        fused = self.fused_bwd and side is main and not gen
-        nslab = ws.nslab_f if fused else ws.nslab
+        nslab = ws.nslab
         for l in range(L - 1, -1, -1):
             d = int(self.dilations[l])
             f, g = da(cur)
             dxo = ws.dx[xp]
-            if fused:
-                # one pass: dx_l, every weight gradient of layer l, da_{l-1}
-                fn, gn = da(1 - cur) if l > 0 else (None, None)
-                _lib.call('wn_layer_bwdw', _lib.ptr(ws.X[l]),
-                          None if dxin is None else _lib.ptr(ws.Z[l]),
-                          _lib.ptr(f), _lib.ptr(g),
-                          None if dxin is None else _lib.ptr(dxin),
-                          _lib.ptr(dxo), _lib.ptr(self._layer_block(P, l)),
-                          _lib.ptr(ws.dZ[l - 1]) if l > 0 else None,
-                          _lib.ptr(ws.TH[l - 1]) if l > 0 else None,
-                          _lib.ptr(ws.SG[l - 1]) if l > 0 else None,
-                          _lib.ptr(self._layer_block(P, l - 1)) if l > 0
-                          else None,
-                          _lib.ptr(fn), _lib.ptr(gn), _lib.ptr(ws.lslabs[l]),
-                          None if ws.dsum is None else _lib.ptr(ws.tilesum[l]),
-                          B, T, d, 1 if l > 0 else 0, st)
-                if l > 0:
-                    cur = 1 - cur
-                dxin = dxo
-                xp = 1 - xp
-                continue
-            if side is not main:
-                ws.ev_ready[l].record(main)
-                side.wait_event(ws.ev_ready[l])
-            sst = side.cuda_stream
             layer_wgrad(_lib.ptr(ws.X[l]), _lib.ptr(f), _lib.ptr(g),
                         None if dxin is None else _lib.ptr(ws.Z[l]),
                         None if dxin is None else _lib.ptr(dxin),
-                        _lib.ptr(ws.lslabs[l]), ws.nslab, B, T, d, sst)
+                        _lib.ptr(ws.lslabs[l]), ws.nslab, B, T, d, st)
             if ws.dsum is not None:
                 _lib.call('wn_colsum_clip', _lib.ptr(f), _lib.ptr(g), B, T,
-                          _lib.ptr(ws.dsum_part), _lib.ptr(ws.dsum[l]), sst)
-            if side is not main:
-                ws.ev_done[l].record(side)
-                if l < L - 1:
-                    main.wait_event(ws.ev_done[l + 1])
+                          _lib.ptr(ws.dsum_part), _lib.ptr(ws.dsum[l]), st)
             if l > 0:
                 fn, gn = da(1 - cur)
                 layer_bwd(_lib.ptr(f), _lib.ptr(g),
@@ -1256,9 +1196,7 @@ class WaveNetModel(object):
                           st)
             dxin = dxo
             xp = 1 - xp
-        if side is not main:
-            main.wait_event(ws.ev_done[0])
-        self._backward_tail(ws, ids, dxin, nslab, fused)
+        self._backward_tail(ws, ids, dxin, nslab, False)
 
     def _backward_tail(self, ws, ids, dxin, nslab, fused, tile_rows=32):
         """After the residual stack: slab reductions of the layer-block

@@ -51,8 +51,8 @@ def test_argument_validation_without_gpu(hip_lib):
     assert hip_lib.wn_gemm_nn(a + 4, 8, 0, 0, a, 8, None, None, 0, None, 0, a,
                               8, 0, 0, None, 4, 8, 8, 0, None) == -3  # align
     assert hip_lib.wn_xent(a, 6, a, a, a, 1, 1, 6, 1, None) == -2
-    assert hip_lib.wn_layer_bwd(None, None, None, None, None, None, None, None,
-                                None, None, None, 1, 8, 1, 0, 0, None) == -1
+    assert hip_lib.wn_layer_bwd2(None, None, None, None, None, None, None, None,
+                                 None, None, 0, 8, 1, None) == -1
     assert hip_lib.wn_mu_law_thresholds_host(1, a) == -1
     assert hip_lib.wn_fastgen_run(a, a, 0, a, None, a, None, a, None, None, a,
                                   2, 1024, 16, a, a, a, 1, 1, 1.0, 0, None, 1,

@@ -423,11 +423,15 @@ def test_global_conditioning_training_and_generation(hip_lib):
 
 
 @pytest.mark.parametrize('B,T', [(5, 16000), (8, 16000), (3, 22016)])
-def test_fused_vs_unfused_backward_many_tiles(hip_lib, B, T):
-    """Fused backward kernel (one or two tiles per wave, per-tile column sums
-    for GC) against the un-fused kernel pair at tile counts above the number
-    of resident waves, dilations below, at and above the 32-row tile, incl. a
-    clip length with an odd number of tiles."""
+def test_three_backward_formulations_many_tiles(hip_lib, B, T):
+    """The persistent stack launches (default), the one-launch-per-layer
+    kernels (wn_layer_fwd / wn_layer_bwd2: da recomputed per tile, tanh = z /
+    sigmoid) and the generic-tap kernel pairs forced on this two-tap model
+    (wn_layer_*_k: da planes through memory, tanh plane, separate data and
+    weight-gradient launches -- an independent formulation) at tile counts
+    above the number of resident waves, dilations below, at and above the
+    32-row tile, incl. a clip length with an odd number of tiles, with global
+    conditioning (per-tile column sums)."""
     from wavenet import WaveNetModel
     cfg = cfg_with(DEFAULT, batch_size=B, dilations=[1, 32, 64, 512, 2, 256, 16],
                    skip_channels=64, global_condition_channels=4,
@@ -436,18 +440,20 @@ def test_fused_vs_unfused_backward_many_tiles(hip_lib, B, T):
     audio = synth_audio(B, T)
     ids = np.arange(B) % 5
     res = []
-    for kind, fused in (('bwd2', True), ('bwdw', True), ('bwdw', False)):
-        # default (da recomputed per tile, tanh = z / sigmoid), round-1 fused
-        # kernel (da planes, tanh plane), un-fused kernel pair
-        net.layer_bwd, net.fused_bwd = kind, fused
+    for stack, generic in ((True, False), (False, False), (False, True)):
+        net.stack_fwd = net.stack_bwd = stack
+        net.generic_layers = generic
         res.append((float(net.loss(audio, ids)), net.grads.clone()))
     (l0, g0), (l1, g1), (l2, g2) = res
-    assert l0 == l1 == l2
+    assert l0 == l1                       # (bitwise the same arithmetic, test_gpu_stack.py)
+    assert abs(l2 - l0) <= 1e-6 * abs(l0)
     scale = g2.abs().max().item()
     assert (g1 - g2).abs().max().item() <= 2e-5 * max(scale, 1.0)
     assert (g0 - g2).abs().max().item() <= 2e-5 * max(scale, 1.0)
     # the TN GEMMs on a second stream: same kernels, same slab order -> same bits
-    net.layer_bwd, net.fused_bwd = 'bwd2', True
+    net.stack_fwd = net.stack_bwd = True
+    net.generic_layers = False
+    net._ws = {}                           # (a workspace with the stack launches' buffers again)
     for ovl in (True, False, True):
         net.overlap_tn = ovl
         for _ in range(3):                 # eager, recorded, replayed plan

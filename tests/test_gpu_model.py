@@ -306,7 +306,7 @@ def test_launch_plan_replay_tracks_new_inputs(hip_lib):
     ws = list(net._ws.values())[0]
     assert any(isinstance(p, list) and len(p) > 10 for p in ws.plans.values())
     # switching a flag that changes the launch sequence takes a new plan
-    net.fused_bwd = False
+    net.stack_fwd = net.stack_bwd = False          # one launch per layer
     loss = net.loss(audio, ids)
     assert abs(float(loss) - ref_loss) < TOL
     check_grads(net, ref_g)

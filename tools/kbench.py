@@ -169,19 +169,10 @@ def layer():
         t = timeit(lambda: _lib.call('wn_layer_fwd', x.data_ptr(), xo.data_ptr(), z.data_ptr(), th.data_ptr(),
                                      sg.data_ptr(), w.data_ptr(), None, 0, B, T, d, 1, 1, st()), n=20)
         print('layer_fwd d=%3d: %6.1f us' % (d, t * 1e6), flush=True)
-    nsl = lib.wn_layer_bwdw_slabs(B, T)
-    slabs2 = torch.empty(max(nsl, 1) * 5216, device=dev)
-    for d in (1, 64, 512):
-        t = timeit(lambda: _lib.call('wn_layer_bwdw', x.data_ptr(), z.data_ptr(), f.data_ptr(), g.data_ptr(),
-                                     dx.data_ptr(), dxo.data_ptr(), w.data_ptr(), dz.data_ptr(), th.data_ptr(),
-                                     sg.data_ptr(), w.data_ptr(), f2.data_ptr(), g2.data_ptr(), slabs2.data_ptr(),
-                                     None, B, T, d, 1, st()), n=20)
-        print('layer_bwdw d=%3d: %6.1f us' % (d, t * 1e6), flush=True)
 
 
 def bwd2():
-    """wn_layer_bwd2 next to wn_layer_bwdw, several batch sizes: per-tile
-    latency vs throughput"""
+    """wn_layer_bwd2 at several batch sizes: per-tile latency vs throughput"""
     T = 16000
     for B in (1, 2, 4, 8, 16):
         N = B * T
@@ -198,13 +189,6 @@ def bwd2():
                                          dxin.data_ptr(), dxo.data_ptr(), w.data_ptr(), wimg.data_ptr(), slabs.data_ptr(), None,
                                          B, T, d, st()), n=20, warm=3)
             line += '  bwd2 %6.1f us' % (t * 1e6)
-            nsl = lib.wn_layer_bwdw_slabs(B, T)
-            slabs = torch.empty(nsl * 5216, device=dev)
-            t = timeit(lambda: _lib.call('wn_layer_bwdw', x.data_ptr(), z.data_ptr(), f.data_ptr(), g.data_ptr(),
-                                         dxin.data_ptr(), dxo.data_ptr(), w.data_ptr(), dZ.data_ptr(), th.data_ptr(),
-                                         sg.data_ptr(), w.data_ptr(), fn.data_ptr(), gn.data_ptr(), slabs.data_ptr(),
-                                         None, B, T, d, 1, st()), n=20, warm=3)
-            line += '  bwdw %6.1f us' % (t * 1e6)
             print(line, flush=True)
 
 
@@ -237,8 +221,6 @@ def layerpad():
     N = B * T
     w = torch.randn(5216, device=dev) * 0.1
     wimg = torch.randn(5376, device=dev) * 0.1
-    nsl = lib.wn_layer_bwdw_slabs(B, T)
-    slabs2 = torch.empty(max(nsl, 1) * 5216, device=dev)
     for pad in (0, 64, 1088, 8256, 65600, 524352):
         big = torch.randn(12 * (N * 32 + pad) + 64, device=dev)
         pl = [big[i * (N * 32 + pad): i * (N * 32 + pad) + N * 32] for i in range(12)]
@@ -246,11 +228,7 @@ def layerpad():
         d = 64
         tf = timeit(lambda: _lib.call('wn_layer_fwd', x.data_ptr(), xo.data_ptr(), z.data_ptr(), th.data_ptr(),
                                       sg.data_ptr(), w.data_ptr(), None, 0, B, T, d, 1, 1, st()), n=30)
-        tb = timeit(lambda: _lib.call('wn_layer_bwdw', x.data_ptr(), z.data_ptr(), f.data_ptr(), g.data_ptr(),
-                                      dx.data_ptr(), dxo.data_ptr(), w.data_ptr(), dz.data_ptr(), th.data_ptr(),
-                                      sg.data_ptr(), w.data_ptr(), f2.data_ptr(), g2.data_ptr(), slabs2.data_ptr(),
-                                      None, B, T, d, 1, st()), n=30)
-        print('pad %7d floats: fwd %5.1f us  bwdw %5.1f us' % (pad, tf * 1e6, tb * 1e6), flush=True)
+        print('pad %7d floats: fwd %5.1f us' % (pad, tf * 1e6), flush=True)
 
 
 def nnsmall():

@@ -7,7 +7,8 @@ Algorithmic FLOPs per launch at the bench shape (B*T = 128000, default stack):
   gemm_nn3: 620.757 GFLOP per step over 6 launches (skip, post1, post2 and
             their data gradients); gemm_tn3<5,1>: dWs; <4,2>: dW1 and dW2;
   layer_fwd: 80 MFMA / 32-row tile = 10 240 FLOP per audio sample;
-  layer_bwdw: 160 MFMA / tile = 20 480 FLOP per audio sample;
+  (layer_bwdw: the round-1 fused backward, 160 MFMA / tile, removed in round 6;
+   its rows in the round-1 tables stay readable through the entry below)
   layer_bwd2d: 176 MFMA / tile = 22 528 FLOP per audio sample;
   stack_fwd / stack_bwd: the same per layer, all 50 layers in one launch.
 With profiles/<tag>_mfma_util.json (tools/pmc_mfma.py) the table also carries

@@ -1457,7 +1457,26 @@ __global__ __launch_bounds__(FGP_THREADS) void fg_persist_kernel(FgPersist a) {
   fgp_ll_t* xll = lgll + Q;
   fgp_ll_t* codell = xll + FGP_MAXSEG * 32;
   bool dead = false;
+  // Role of this workgroup.  Workgroups go to the eight XCDs round-robin
+  // (blockIdx % 8) and a hand-over word between two workgroups of ONE XCD costs
+  // 0.59 - 0.64 us, between two XCDs 0.76 (tools/ubench/ll_hop.hip): the serial
+  // chain's hand-overs -- draw -> segment 0 -> ... -> last segment -- stay on
+  // one XCD: those nseg + 1 roles take the blocks 0, 8, 16, ..., the mat-vec
+  // roles (skip | post1 | logits) the rest in order.  Roles are numbered
+  // chain segments, skip, post1, logits, draw.
   int role = blockIdx.x;
+  {
+    const int nsp = nseg + 1, total = (int)gridDim.x;
+    if (total > 8 * (nsp - 1)) {
+      const int b = blockIdx.x;
+      if ((b & 7) == 0 && (b >> 3) < nsp) {
+        role = (b >> 3) < nseg ? (b >> 3) : total - 1;
+      } else {
+        const int before = min(nsp, (b + 7) >> 3);     // chain / draw blocks below b
+        role = nseg + (b - before);
+      }
+    }
+  }
 #ifdef FGP_STAMPS
 #define PSTAMP(slot) if (a.dbg && (tid & 63) == 0) a.dbg[(size_t)(slot)] = __builtin_amdgcn_s_memrealtime()
 #else

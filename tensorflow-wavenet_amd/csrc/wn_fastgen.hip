@@ -2195,6 +2195,24 @@ static unsigned long long* g_fgp_dbg = nullptr;   // [n_steps][16] (diagnostic b
 extern "C" int wn_diag_fgp_dbg(unsigned long long* p) { g_fgp_dbg = p; return WN_OK; }
 #endif
 
+// A launch whose workgroups wait for each other (hand-over words) must have
+// them all resident at once.  hipLaunchCooperativeKernel makes that the
+// RUNTIME's promise: it refuses (an error, nothing has run, the caller takes
+// its single-workgroup / step-kernel path at once) where a plain launch would
+// start a partial grid that spins until its 2 s bounded waits expire.
+template <typename Arg>
+static int fg_launch_cooperative(const void* kernel, int wgs, int threads, size_t lds, hipStream_t s,
+                                 Arg& a) {
+  void* args[] = {(void*)&a};
+  const hipError_t e = hipLaunchCooperativeKernel(kernel, dim3(wgs), dim3(threads), args,
+                                                  (unsigned)lds, s);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return e == hipErrorCooperativeLaunchTooLarge ? WN_ERR_UNSUPPORTED : WN_ERR_LAUNCH;
+  }
+  return wn_check_launch();
+}
+
 extern "C" {
 
 long wn_fastgen_state_floats(const int32_t* dilations_host, int L) {
@@ -2341,11 +2359,11 @@ int wn_fastgen_run_wide(const float* params_causal, const float* layer0,
       a.ll = reinterpret_cast<fgp_ll_t*>(a.sync + FGP_WORDS);
       if (hipMemsetAsync(coop, 0, (size_t)wn_fastgen_wide_coop_bytes(L, C, S, Q), s) != hipSuccess)
         return WN_ERR_LAUNCH;
-      if (f64)
-        hipLaunchKernelGGL((fastgen_wide_kernel<true, true>), dim3(wgs), dim3(512), cl, s, a);
-      else
-        hipLaunchKernelGGL((fastgen_wide_kernel<false, true>), dim3(wgs), dim3(FGW_THREADS), cl, s, a);
-      return wn_check_launch();
+      const int rc = f64
+          ? fg_launch_cooperative((const void*)fastgen_wide_kernel<true, true>, wgs, 512, cl, s, a)
+          : fg_launch_cooperative((const void*)fastgen_wide_kernel<false, true>, wgs, FGW_THREADS, cl, s, a);
+      if (rc == WN_OK) return rc;
+      // (refused by the runtime -- CUs held elsewhere: the single workgroup below)
     }
   }
   if (f64)
@@ -2498,8 +2516,7 @@ int wn_fastgen_persist(const float* params_causal, const float* layer0,
   if (hipMemsetAsync(sync, 0, FGP_WORDS * sizeof(unsigned), s) != hipSuccess ||
       hipMemsetAsync(ll, 0, (size_t)wn_fastgen_persist_ll_words(L, S, Q) * 8, s) != hipSuccess)
     return WN_ERR_LAUNCH;
-  hipLaunchKernelGGL(fg_persist_kernel, dim3(wgs), dim3(FGP_THREADS), bytes, s, a);
-  return wn_check_launch();
+  return fg_launch_cooperative((const void*)fg_persist_kernel, wgs, FGP_THREADS, bytes, s, a);
 }
 
 // Past-tap pre-activations pre[L][64] of the step the queues are at

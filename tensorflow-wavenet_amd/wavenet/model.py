@@ -335,6 +335,10 @@ class WaveNetModel(object):
         # in-launch hand-overs instead of four kernel boundaries per sample);
         # False: the step kernels replayed from a hipGraph
         self.fastgen_persistent = True
+        # persistent / cooperative generation launches that expired once on this
+        # device (CUs held elsewhere): not tried again by any generator of this
+        # model; `reset_generator_launch_failures()` clears it
+        self._gen_launch_failed = {}
         # 64-channel models: wn_fastgen_run_wide's cooperative launch
         self.fastgen_wide_coop = True
         # 'fp32' (default): fp32 MFMA GEMMs.  'bf16x6' / 'bf16x9' / 'bf16x3':
@@ -656,6 +660,10 @@ class WaveNetModel(object):
                         'stack launch expired (2 s); the results of that step '
                         'are invalid.  net.stack_fwd / net.stack_bwd = False '
                         'select the one-launch-per-layer kernels.' % name)
+
+    def reset_generator_launch_failures(self):
+        """Try the persistent / cooperative generation launches again."""
+        self._gen_launch_failed = {}
 
     def reset_device_errors(self):
         """Clear the expired-wait record (control word 3 and the NaN poison
@@ -1513,7 +1521,7 @@ class WaveNetModel(object):
             # back to the single workgroup by itself when the workgroups would
             # not all be resident
             coop = None
-            if self.fastgen_wide_coop and not g.get('coop_failed'):
+            if self.fastgen_wide_coop and not self._gen_launch_failed.get('coop'):
                 if 'coop' not in g:
                     nb = _lib.load().wn_fastgen_wide_coop_bytes(
                         self.L, self.CHn, self.S, self.Q)
@@ -1549,7 +1557,9 @@ class WaveNetModel(object):
                     g['state'].copy_(snap[0])
                     g['cursors'].copy_(snap[1])
                     samples_io.copy_(snap[2])
-                    g['coop_failed'] = True
+                    # (remembered on the MODEL: a new generator on the same busy
+                    # device must not pay another expired wait)
+                    self._gen_launch_failed['coop'] = True
                     run(None)
                 del snap
             if push:
@@ -1596,7 +1606,7 @@ class WaveNetModel(object):
                 _lib.ptr(g['h1']), _lib.ptr(g['h2']), _lib.ptr(g['logits']))
 
         lib = _lib.load()
-        if self.fastgen_persistent and not g.get('persist_failed'):
+        if self.fastgen_persistent and not self._gen_launch_failed.get('persist'):
             # ONE persistent launch for the run.  Every workgroup has to be
             # resident at once; the library checks that against the launch
             # configuration's occupancy (WN_ERR_UNSUPPORTED: the step kernels
@@ -1628,7 +1638,7 @@ class WaveNetModel(object):
                 g['cursors'].copy_(snap[1])
                 g['pre'].copy_(snap[2])
                 io[:n_io].copy_(samples_io[:n_io])
-                g['persist_failed'] = True
+                self._gen_launch_failed['persist'] = True
             elif code != -2:             # WN_ERR_UNSUPPORTED: not resident / shape
                 _lib.check(code, 'wn_fastgen_persist')
             del snap

@@ -168,7 +168,7 @@ def test_persistent_launch_failure_restores_state_and_falls_back(hip_lib, monkey
     with pytest.warns(UserWarning, match='state restored'):
         out_a = a.generate(150, seed_samples=seed, seed=9).cpu().numpy()
     out_b = b.generate(150, seed_samples=seed, seed=9).cpu().numpy()
-    assert calls == [0] and a._gen['persist_failed']
+    assert calls == [0] and a._gen_launch_failed['persist']
     assert np.array_equal(out_a, out_b)
     assert a._gen['steps'] == b._gen['steps']
     more_a = a.continue_generation(90, int(out_a[-1]), seed=4).cpu().numpy()

@@ -748,7 +748,7 @@ def test_wide_cooperative_launch_failure_restores_state_and_falls_back(hip_lib, 
     with pytest.warns(UserWarning, match='state restored'):
         out_a = a.generate(120, seed_samples=[128, 3, 77], seed=9).cpu().numpy()
     out_b = b.generate(120, seed_samples=[128, 3, 77], seed=9).cpu().numpy()
-    assert coop_calls == [0] and a._gen['coop_failed']
+    assert coop_calls == [0] and a._gen_launch_failed['coop']
     assert np.array_equal(out_a, out_b)
     assert a._gen['steps'] == b._gen['steps']
     more_a = a.continue_generation(60, int(out_a[-1]), seed=4).cpu().numpy()

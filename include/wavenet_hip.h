@@ -274,7 +274,8 @@ int wn_stack_fwd(float* X, float* Z, float* SG, const float* wimg,
  * the same launch -- a partner wave per tile takes the tile's z of every layer
  * through LDS while the chain wave goes on; the launch's matrix pipe is three
  * quarters idle otherwise.  skip_img: wn_stack_skip_img_floats(L) floats written
- * by wn_stack_skip_pack from skip_w [L * 32][512] (once per weight update);
+ * by wn_stack_skip_pack from skip_w [L * 32][512] (a function of the weights
+ * only; the Python host repacks it on every forward call);
  * skip_bsum: [512] or NULL.  Same sums as the GEMM up to the order of additions. */
 int wn_stack_fwd_skip_ok(int B, int T, int S, int variant);
 long wn_stack_skip_img_floats(int L);
@@ -460,9 +461,10 @@ int wn_fastgen_run(const float* params_causal, const float* layer0,
  * Q <= 512): a COOPERATIVE launch,
  * workgroup 0 runs the layers and the draw, 2 S / 16 + Q / 16 more workgroups the
  * skip sum and the post-processing mat-vecs (hand-over words in `coop`; the
- * same samples up to the rounding of the skip sum's order).  It is taken only
- * when the runtime reports every workgroup resident; otherwise, or with
- * coop = NULL, the single workgroup runs.
+ * same samples up to the rounding of the skip sum's order).  It is launched
+ * with hipLaunchCooperativeKernel (residency is the runtime's promise) behind
+ * the library's own occupancy check; refused, or with coop = NULL, the single
+ * workgroup runs.
  * coop: NULL, or wn_fastgen_wide_coop_bytes(L, C, S, Q) bytes (16-byte aligned,
  * zeroed by the call).  After a cooperative run ((unsigned*)coop)[12] != 0
  * means a hand-over wait expired (2 s): that run's samples are not valid. */
@@ -515,12 +517,15 @@ int wn_fastgen_finish(int Q, int32_t* cursors, int32_t* samples_io,
  * entry.  sync: 16 uint32 (zeroed by the call; sync[12] != 0 afterwards = a
  * bounded wait expired, results invalid); ll: wn_fastgen_persist_ll_words(L, S,
  * Q) 8-byte hand-over words (payload + step in one store; zeroed by the call).
- * Needs all wn_fastgen_persist_workgroups(L, S, Q) workgroups resident at once
- * (checked against hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs for the
- * launch configuration), else WN_ERR_UNSUPPORTED, returned before anything is
- * written: use wn_fastgen_step.  CUs held by another process or stream are
- * invisible to that check: they surface as sync[12] -- the caller restores its
- * own snapshot of state / cursors / pre and takes the step kernels. */
+ * Needs all wn_fastgen_persist_workgroups(L, S, Q) workgroups resident at once:
+ * checked against hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs for the
+ * launch configuration, then launched with hipLaunchCooperativeKernel, which
+ * makes residency the runtime's promise -- else WN_ERR_UNSUPPORTED, returned
+ * before any generator state is written: use wn_fastgen_step.  Should a
+ * hand-over wait expire all the same (2 s), it surfaces as sync[12] -- the
+ * caller restores its own snapshot of state / cursors / pre and takes the step
+ * kernels.  The chain's workgroups (draw, segments) take the blocks 0, 8, 16,
+ * ... (one XCD: a hand-over word is 0.15 us faster inside an XCD). */
 int wn_fastgen_persist_workgroups(int L, int S, int Q);
 long wn_fastgen_persist_ll_words(int L, int S, int Q);
 int wn_fastgen_persist(const float* params_causal, const float* layer0,

@@ -1176,7 +1176,8 @@ __device__ __forceinline__ FgDrawCtl fg_draw_ctl(const FgStep& g) {
 // part: 16 doubles of LDS; nxt: 2 ints of LDS (the code drawn at step parity).
 template <int PER>   // values per computing thread: 1 (Q <= 256) or 2
 __device__ __forceinline__ void fg_draw_wg256(const FgStep& g, const FgDrawCtl& dc, const float* lgs,
-                                              double* part, int* nxt, fgp_ll_t* codell,
+                                              double* part, int* nxt, fgp_ll_t* x0ll,
+                                              const float* ctab, int cur_code,
                                               unsigned step, bool publish, int tid,
                                               int steps_done) {
   const int Q = g.Q, lane = tid & 63, wave = tid >> 6;
@@ -1184,6 +1185,20 @@ __device__ __forceinline__ void fg_draw_wg256(const FgStep& g, const FgDrawCtl& 
   const int npl = (Q + 63) >> 6;                       // logits per lane in the max pass (<= 8)
   constexpr int per = PER;
   const int q0 = min(Q, tid * per), q1 = min(Q, q0 + per);
+  // What segment 0 needs of the drawn code is the causal layer's output for the
+  // NEXT step, x0[n] = W[0][cur][n] + W[1][next][n] (model.py:341-346; a code
+  // outside [0, Q) contributes nothing), not the code: the wave that holds the
+  // drawing thread reads the two rows from the draw workgroup's LDS copy of the
+  // table and publishes the 32 values -- segment 0's two dependent global
+  // loads per step (0.28 us behind the code word) are gone.  `code`: the same
+  // value in every lane of the wave.
+  auto publish_x0 = [&](int code) {
+    if (!publish || lane >= 32) return;
+    float v = 0.f;
+    if (cur_code >= 0 && cur_code < Q) v = ctab[cur_code * 32 + lane];
+    if (code >= 0 && code < Q) v += ctab[(Q + code) * 32 + lane];
+    fgp_put(x0ll + lane, v, step);
+  };
   // (the step's random number does not wait for the logits)
   const uint64_t r = splitmix64(dc.seed ^ splitmix64((uint64_t)steps_done));
   // the maximum: every wave for itself over all Q logits
@@ -1218,10 +1233,10 @@ __device__ __forceinline__ void fg_draw_wg256(const FgStep& g, const FgDrawCtl& 
       pq[j] = (double)p32;
     }
   if (local + 1 < dc.n_given) {                        // still inside the given samples
-    if (tid == 0) {
-      const int next = g.samples[local + 1];
-      nxt[step & 1] = next;
-      if (publish) fgp_put(codell, __int_as_float(next), step);
+    if (wave == 0) {
+      const int next = g.samples[local + 1];           // (one address: a broadcast load)
+      if (tid == 0) nxt[step & 1] = next;
+      publish_x0(next);
     }
     return;
   }
@@ -1262,7 +1277,12 @@ __device__ __forceinline__ void fg_draw_wg256(const FgStep& g, const FgDrawCtl& 
   if (next >= 0) {
     g.samples[local + 1] = next;
     nxt[step & 1] = next;
-    if (publish) fgp_put(codell, __int_as_float(next), step);
+  }
+  // the wave of the drawing thread (exactly one thread has next >= 0)
+  const unsigned long long hit = __builtin_amdgcn_ballot_w64(next >= 0);
+  if (hit != 0) {
+    const int src = __builtin_ctzll(hit);
+    publish_x0(__builtin_amdgcn_readlane(next, src));
   }
 }
 
@@ -1449,13 +1469,13 @@ __global__ __launch_bounds__(FGP_THREADS) void fg_persist_kernel(FgPersist a) {
   const int nsk = (S + 15) / 16, nlg = (Q + 15) / 16;
   const int base = g.ctl[FGCTL_BASE];
   unsigned* sync = a.sync;
-  // hand-over words: z [L][32] | h1 [S] | h2 [S] | logits [Q] | x [nseg][32] | code
+  // hand-over words: z [L][32] | h1 [S] | h2 [S] | logits [Q] | x [nseg][32] | x0 [32]
   fgp_ll_t* zll = a.ll;
   fgp_ll_t* h1ll = zll + L * 32;
   fgp_ll_t* h2ll = h1ll + S;
   fgp_ll_t* lgll = h2ll + S;
   fgp_ll_t* xll = lgll + Q;
-  fgp_ll_t* codell = xll + FGP_MAXSEG * 32;
+  fgp_ll_t* x0ll = xll + FGP_MAXSEG * 32;            // [32] the causal layer's output for the next step
   bool dead = false;
   // Role of this workgroup.  Workgroups go to the eight XCDs round-robin
   // (blockIdx % 8) and a hand-over word between two workgroups of ONE XCD costs
@@ -1526,7 +1546,7 @@ __global__ __launch_bounds__(FGP_THREADS) void fg_persist_kernel(FgPersist a) {
     if (wave == 0) {
       // ---- the serial chain of this segment (no workgroup barrier, weights
       // resident): fgp_chain_layers
-      int prev_code = g.cursors[1];
+      const int prev_code = g.cursors[1];
       fgp_ll_t* zrow = zll + l0 * 32 + nn;
       fgp_ll_t* xo = seg + 1 < nseg ? xll + seg * 32 : nullptr;
       for (int i = 0; i < n_steps; ++i) {
@@ -1539,16 +1559,18 @@ __global__ __launch_bounds__(FGP_THREADS) void fg_persist_kernel(FgPersist a) {
         fgp_lw_load(wa, wres, 0, lane);
         float x = 0.f;
         if (seg == 0) {
-          int code = g.samples[0];
-          if (i > 0) code = __float_as_int(fgp_get(codell, (unsigned)i, sync, dead));
-          PSTAMP(i * 16 + 0);
-          {   // (x lives in EVERY lane: channel lane & 31)
+          // (x lives in EVERY lane: channel lane & 31)
+          if (i > 0) {
+            // the draw workgroup's x0 of this step (fg_draw_wg256)
+            x = fgp_get(x0ll + nn, (unsigned)i, sync, dead);
+          } else {
+            const int code = g.samples[0];
             float v = 0.f;
             if (prev_code >= 0 && prev_code < Q) v = g.causal[(long)prev_code * 32 + nn];
             if (code >= 0 && code < Q) v += g.causal[((long)Q + code) * 32 + nn];
             x = v;
           }
-          prev_code = code;
+          PSTAMP(i * 16 + 0);
         } else {
           x = fgp_get(xll + (seg - 1) * 32 + nn, step, sync, dead);
         }
@@ -1663,17 +1685,23 @@ __global__ __launch_bounds__(FGP_THREADS) void fg_persist_kernel(FgPersist a) {
   float* lgs = lds;                                             // [Q] the step's logits
   double* dpart = reinterpret_cast<double*>(lds + ((Q + 3) & ~3));  // 16 doubles: per-wave partials
   int* nxt = reinterpret_cast<int*>(dpart + 16);                 // [2] the code drawn at step parity
+  float* ctab = reinterpret_cast<float*>(nxt + 8);               // [2][Q][32] the causal layer's filter
+  for (int i = tid; i < 2 * Q * 32; i += 256) ctab[i] = g.causal[i];
   const FgDrawCtl dc = fg_draw_ctl(g);
+  __syncthreads();
   for (int i = 0; i < n_steps; ++i) {
     const unsigned step = (unsigned)(i + 1);
     fgp_get2(lgs, lgll, tid, Q, step, sync, dead);
     PSTAMP(i * 16 + 14);
     __syncthreads();
+    // the code this step consumes (drawn / given one step ago: written behind
+    // the previous step's last barrier, read behind this one)
+    const int cur_code = i == 0 ? g.samples[0] : nxt[i & 1];
     // (dpart[] is rewritten a step later only after this barrier, which every
     // wave reaches after its last read of the step before)
     // the drawing thread publishes the code of step i + 1 for segment 0
-    if (Q <= 256) fg_draw_wg256<1>(g, dc, lgs, dpart, nxt, codell, step, i + 1 < n_steps, tid, base + i);
-    else fg_draw_wg256<2>(g, dc, lgs, dpart, nxt, codell, step, i + 1 < n_steps, tid, base + i);
+    if (Q <= 256) fg_draw_wg256<1>(g, dc, lgs, dpart, nxt, x0ll, ctab, cur_code, step, i + 1 < n_steps, tid, base + i);
+    else fg_draw_wg256<2>(g, dc, lgs, dpart, nxt, x0ll, ctab, cur_code, step, i + 1 < n_steps, tid, base + i);
     PSTAMP(i * 16 + 15);
   }
   __syncthreads();
@@ -2442,7 +2470,7 @@ int wn_fastgen_finish(int Q, int32_t* cursors, int32_t* samples_io,
 // 8-byte hand-over words of wn_fastgen_persist (z, h1, h2, logits, x, code)
 long wn_fastgen_persist_ll_words(int L, int S, int Q) {
   if (L <= 0 || S <= 0 || Q <= 0) return 0;
-  return (long)L * 32 + 2L * S + Q + FGP_MAXSEG * 32 + 8;
+  return (long)L * 32 + 2L * S + Q + FGP_MAXSEG * 32 + 32;
 }
 
 int wn_fastgen_persist_workgroups(int L, int S, int Q) {
@@ -2493,7 +2521,7 @@ int wn_fastgen_persist(const float* params_causal, const float* layer0,
   size_t chain = (size_t)per * FGP_BLK + 2 * FGP_SEGL + 8;
   size_t skip = (size_t)((L * 32 + 3) & ~3) + (size_t)L * 32 * 16 + 256;
   size_t post = (size_t)((S + 3) & ~3) + (size_t)S * 16 + 256;
-  size_t draw = (size_t)((Q + 3) & ~3) + 40;
+  size_t draw = (size_t)((Q + 3) & ~3) + 48 + (size_t)2 * Q * 32;   // + the causal table
   size_t fl = chain;
   if (skip > fl) fl = skip;
   if (post > fl) fl = post;

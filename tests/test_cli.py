@@ -85,3 +85,47 @@ def test_synthetic_reader():
     g = r.dequeue_gc(3)
     assert tuple(a.shape) == (3, 1000, 1) and float(a.abs().max()) <= 1
     assert tuple(g.shape) == (3,) and int(g.max()) < 7
+
+
+def _run_snippet(code, timeout=120):
+    import subprocess
+    p = subprocess.run([sys.executable, '-c', code], cwd=ROOT, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=timeout)
+    return p.returncode, p.stdout.decode(), p.stderr.decode()
+
+
+def test_bench_emitter_watchdog_prints_the_prepared_line_and_exits_zero():
+    """bench.py's first-contact guard (N > 1: the two-call all-reduce trial):
+    a guarded region that does not return within its bound makes rank 0 print
+    the line prepared from the schedule already measured -- with the reason in
+    place of the marker -- exactly once, and the process leaves with status 0."""
+    code = (
+        "import time, bench\n"
+        "e = bench._Emitter()\n"
+        "e.fallback = '{\"value\": 1.0, \"overlap_failed\": true, \"overlap_failure\": \"@WHY@\"}'\n"
+        "e.guarded(lambda: time.sleep(60), 'the two-call all-reduce trial', bound=0.5)\n"
+        "print('not reached')\n")
+    rc, out, err = _run_snippet(code)
+    assert rc == 0, err[-2000:]
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1 and 'not reached' not in out
+    import json
+    r = json.loads(lines[0])
+    assert r['overlap_failed'] is True
+    assert 'did not return within' in r['overlap_failure'] and 'two-call' in r['overlap_failure']
+
+
+def test_bench_emitter_prints_once_and_cancels_its_watchdog():
+    """The normal path: the guarded region returns, its watchdog is cancelled,
+    and only the first `line` call prints."""
+    code = (
+        "import time, bench\n"
+        "e = bench._Emitter()\n"
+        "e.fallback = 'FALLBACK @WHY@'\n"
+        "assert e.guarded(lambda: 7, 'x', bound=0.3) == 7\n"
+        "time.sleep(0.8)\n"
+        "e.line('first')\n"
+        "e.line('second')\n")
+    rc, out, err = _run_snippet(code)
+    assert rc == 0, err[-2000:]
+    assert out.split() == ['first']

@@ -297,6 +297,78 @@ def main(argv=None):
 
     step = None
     last_saved_step = saved_global_step
+    pending = None            # (step, mean loss tensor, start time) not yet printed
+    last_report = [None]
+
+    def report(k, mean_loss, started):
+        """Fetch step k's loss (waits for that step), check it, print / log the
+        reference's line (train.py:310-311).  sec/step: from the previous line
+        (the pipeline's cadence), or from the step's start for the first."""
+        # (float(tensor) would wait for EVERYTHING queued on the stream, the
+        # next step included: the loss went to a pinned scalar behind an event)
+        host_scalar, done = mean_loss
+        done.synchronize()
+        loss_value = float(host_scalar)
+        if not np.isfinite(loss_value):
+            # every rank sees the same NaN mean: decide TOGETHER whether a
+            # kernel reported an error, so that no rank is left waiting in
+            # the next step's collectives
+            dev_err = None
+            try:
+                net.check_device_errors()
+            except Exception as e:
+                dev_err = e
+            if parallel.any_rank(dev_err is not None, net.device):
+                raise dev_err or RuntimeError(
+                    'rank %d: another rank reported an expired dependency '
+                    'wait in a persistent stack launch at step %d'
+                    % (rank, k))
+        now = time.time()
+        duration = now - (last_report[0] if last_report[0] is not None and
+                          last_report[0] > started else started)
+        last_report[0] = now
+        if rank == 0:
+            print('step {:d} - loss = {:.3f}, ({:.3f} sec/step)'
+                  .format(k, loss_value, duration))
+            events.write(json.dumps({'step': k, 'loss': loss_value,
+                                     'sec_per_step': duration}) + '\n')
+            events.flush()
+
+    fetch_slots = {}
+
+    def fetch_later(t, k):
+        """(pinned host scalar, event): the scalar holds t once the event has
+        completed; two slots used alternately (a slot is read before the step
+        after next overwrites it)."""
+        if not t.is_cuda:
+            class _Done(object):
+                def synchronize(self):
+                    pass
+            return t.detach().reshape(()).clone(), _Done()
+        if (k & 1) not in fetch_slots:
+            fetch_slots[k & 1] = (torch.empty((), dtype=torch.float32).pin_memory(),
+                                  torch.cuda.Event())
+        host_scalar, ev = fetch_slots[k & 1]
+        host_scalar.copy_(t.detach().reshape(()).float(), non_blocking=True)
+        ev.record()
+        return host_scalar, ev
+
+    copy_stream = [None]
+
+    def stage_in(host, k):
+        """host [B, n] float tensor -> device tensor, copied on a stream of its
+        own: the (pageable, hence host-blocking) copy then does not queue
+        behind the previous step's kernels, and the training stream only
+        waits for the copy.  (Pinned staging buffers measured 33 instead of
+        9.6 ms per step on this platform, tools/h2d_probe.py.)"""
+        if copy_stream[0] is None:
+            copy_stream[0] = torch.cuda.Stream(device=net.device)
+        with torch.cuda.stream(copy_stream[0]):
+            dev = host.contiguous().to(net.device)
+        torch.cuda.current_stream().wait_stream(copy_stream[0])
+        dev.record_stream(torch.cuda.current_stream())
+        return dev
+
     try:
         for step in range(saved_global_step + 1, args.num_steps):
             start_time = time.time()
@@ -317,7 +389,14 @@ def main(argv=None):
             if n_t < 2:
                 continue
             audio = audio[:, :n_t]
-            trace = args.store_metadata and step % 50 == 0 and rank == 0
+            if audio.device.type == 'cpu' and net.device.type == 'cuda':
+                # pinned staging + asynchronous copy: a pageable host tensor
+                # handed to net.loss is copied synchronously BEHIND the previous
+                # step's kernels, i.e. the host would wait for the device every
+                # step and prepare the next batch while it idles
+                audio = stage_in(audio.reshape(audio.shape[0], -1), step)
+            trace_step = args.store_metadata and step % 50 == 0
+            trace = trace_step and rank == 0
             if trace:
                 print('Storing metadata')
                 prof = torch.profiler.profile(
@@ -327,44 +406,44 @@ def main(argv=None):
             loss = net.loss(input_batch=audio, global_condition_batch=gc,
                             l2_regularization_strength=l2)
             optimizer.minimize(loss)
-            loss_value = float(parallel.allreduce_mean_scalar(loss))
-            if not np.isfinite(loss_value):
-                # every rank sees the same NaN mean: decide TOGETHER whether a
-                # kernel reported an error, so that no rank is left waiting in
-                # the next step's collectives
-                dev_err = None
-                try:
-                    net.check_device_errors()
-                except Exception as e:
-                    dev_err = e
-                if parallel.any_rank(dev_err is not None, net.device):
-                    raise dev_err or RuntimeError(
-                        'rank %d: another rank reported an expired dependency '
-                        'wait in a persistent stack launch at step %d'
-                        % (rank, step))
+            # The reference fetches the loss inside sess.run and so waits for
+            # every step (train.py:300-311).  Here the step is queued on the
+            # device and its loss is read ONE step later, while the next step
+            # runs (the same lines, one step late; 12.0 -> 9.5 ms per step at
+            # 8 x 16000: bench.py's step time) -- except where the step's own state is needed at
+            # once: a checkpoint step, a traced step, the last step.
+            mean_loss = fetch_later(parallel.allreduce_mean_scalar(loss), step)
+            if pending is not None:
+                report(*pending)
+            pending = (step, mean_loss, start_time)
+            if trace_step:
+                report(*pending)
+                pending = None
             if trace:
                 prof.__exit__(None, None, None)
                 prof.export_chrome_trace(os.path.join(logdir,
                                                       'timeline.trace'))
-            duration = time.time() - start_time
-            if rank == 0:
-                print('step {:d} - loss = {:.3f}, ({:.3f} sec/step)'
-                      .format(step, loss_value, duration))
-                events.write(json.dumps({'step': step, 'loss': loss_value,
-                                         'sec_per_step': duration}) + '\n')
-                events.flush()
-                if step % args.checkpoint_every == 0:
-                    save(net, logdir, step)
-                    last_saved_step = step
-                    if args.histograms:
-                        # the reference's histogram summaries (model.py:314-325)
-                        # as an .npz next to the checkpoint
-                        hs = net.histogram_summaries()
-                        np.savez(os.path.join(
-                            logdir, 'histograms-%d.npz' % step),
-                            **{k + '/counts': v[0] for k, v in hs.items()},
-                            **{k + '/range': np.asarray(v[1:])
-                               for k, v in hs.items()})
+            if step % args.checkpoint_every == 0:
+                # (every rank resolves the step here, so that the ranks'
+                # collective sequences stay equal on the error path of report)
+                if pending is not None:
+                    report(*pending)
+                    pending = None
+            if rank == 0 and step % args.checkpoint_every == 0:
+                save(net, logdir, step)
+                last_saved_step = step
+                if args.histograms:
+                    # the reference's histogram summaries (model.py:314-325)
+                    # as an .npz next to the checkpoint
+                    hs = net.histogram_summaries()
+                    np.savez(os.path.join(
+                        logdir, 'histograms-%d.npz' % step),
+                        **{k + '/counts': v[0] for k, v in hs.items()},
+                        **{k + '/range': np.asarray(v[1:])
+                           for k, v in hs.items()})
+        if pending is not None:
+            report(*pending)
+            pending = None
     except KeyboardInterrupt:
         print()
     finally:

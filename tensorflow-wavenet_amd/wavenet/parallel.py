@@ -46,12 +46,22 @@ import torch.distributed as dist
 rehearse_world_one = False
 
 
+_ctl_group = [None]      # gloo group for the control plane when the backend is RCCL
+
+
+def _ctl(device):
+    """(group, device) for a control-plane collective"""
+    if _ctl_group[0] is not None:
+        return _ctl_group[0], 'cpu'
+    return None, device
+
+
 def is_distributed():
     return dist.is_available() and dist.is_initialized() and \
         (dist.get_world_size() > 1 or rehearse_world_one)
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, host_control_plane=False):
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (the
     launcher's env).  Returns (rank, world, local_rank).  No-op when
     WORLD_SIZE is absent or 1."""
@@ -75,6 +85,18 @@ def init_from_env(backend=None):
             seconds=float(os.environ.get('WN_DIST_TIMEOUT', '300')))
         dist.init_process_group(backend=backend, rank=rank, world_size=world,
                                 timeout=tmo)
+        if backend == 'nccl' and host_control_plane:
+            # control-plane collectives (agree_step, any_rank: a few integers
+            # per step) over a gloo group on the host: on the RCCL group they
+            # need a device tensor and a .cpu() behind it, which waits for
+            # everything queued on the stream -- the training loop would stop
+            # overlapping its host work with the device every step.  Asked for
+            # by train.py only: bench.py has no per-step control collective and
+            # keeps its first contact with an N-GPU node to ONE process group.
+            try:
+                _ctl_group[0] = dist.new_group(backend='gloo', timeout=tmo)
+            except Exception:           # noqa: BLE001 (no gloo transport: the RCCL group serves)
+                _ctl_group[0] = None
     return rank, world, local
 
 
@@ -227,9 +249,10 @@ def agree_step(n_samples, ok=True, device='cpu'):
     1/N average of the module docstring is exact."""
     if not is_distributed():
         return int(n_samples), bool(ok)
+    group, device = _ctl(device)
     t = torch.tensor([int(n_samples), 1 if ok else 0], dtype=torch.int64,
                      device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
     t = t.cpu()
     return int(t[0]), bool(int(t[1]))
 
@@ -240,6 +263,7 @@ def any_rank(flag, device='cpu'):
     on a device error one rank saw)."""
     if not is_distributed():
         return bool(flag)
+    group, device = _ctl(device)
     t = torch.tensor([1 if flag else 0], dtype=torch.int64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return bool(int(t.cpu()[0]))

@@ -227,7 +227,7 @@ def main(argv=None):
 
     from wavenet import WaveNetModel, AudioReader, optimizer_factory, parallel
     from wavenet.audio_reader import Coordinator
-    rank, world, local = parallel.init_from_env()
+    rank, world, local = parallel.init_from_env(host_control_plane=True)
     if torch.cuda.is_available():
         torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
 

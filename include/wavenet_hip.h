@@ -527,6 +527,10 @@ int wn_fastgen_finish(int Q, int32_t* cursors, int32_t* samples_io,
  * kernels.  The chain's workgroups (draw, segments) take the blocks 0, 8, 16,
  * ... (one XCD: a hand-over word is 0.15 us faster inside an XCD). */
 int wn_fastgen_persist_workgroups(int L, int S, int Q);
+/* role (0 .. total - 1: chain segments, skip, post1, logits, draw) of workgroup
+ * `block` of the launch: the chain's roles on the blocks 0, 8, 16, ... (host-side
+ * mirror of the kernel's mapping, for tests) */
+int wn_fastgen_persist_role(int block, int total, int nseg);
 long wn_fastgen_persist_ll_words(int L, int S, int Q);
 int wn_fastgen_persist(const float* params_causal, const float* layer0,
                        long layer_stride, const float* skip_w,

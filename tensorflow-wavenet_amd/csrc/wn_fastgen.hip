@@ -930,6 +930,21 @@ __global__ __launch_bounds__(64) void fg_draw_kernel(FgStep g) {
 #define FGP_ERR 12
 #define FGP_WORDS 16
 
+// Role of workgroup `b` of a `total`-workgroup persistent launch with `nseg`
+// chain segments (roles are numbered: chain segments, skip, post1, logits,
+// draw = total - 1).  Workgroups go to the eight XCDs round-robin (b % 8): the
+// nseg + 1 roles of the serial chain (segments, draw) take the blocks 0, 8,
+// 16, ... -- one XCD --, the mat-vec roles the other blocks in order; a grid too
+// small for that keeps the identity.  A permutation of [0, total)
+// (wn_fastgen_persist_role exports it for the host-side test).
+__host__ __device__ inline int fgp_role_of_block(int b, int total, int nseg) {
+  const int nsp = nseg + 1;
+  if (total <= 8 * (nsp - 1)) return b;
+  if ((b & 7) == 0 && (b >> 3) < nsp) return (b >> 3) < nseg ? (b >> 3) : total - 1;
+  const int before = ((b + 7) >> 3) < nsp ? ((b + 7) >> 3) : nsp;   // chain / draw blocks below b
+  return nseg + (b - before);
+}
+
 struct FgPersist {
   FgStep g;
   unsigned* sync;        // FGP_WORDS words, zero before the launch ([12]: error)
@@ -1484,19 +1499,7 @@ __global__ __launch_bounds__(FGP_THREADS) void fg_persist_kernel(FgPersist a) {
   // one XCD: those nseg + 1 roles take the blocks 0, 8, 16, ..., the mat-vec
   // roles (skip | post1 | logits) the rest in order.  Roles are numbered
   // chain segments, skip, post1, logits, draw.
-  int role = blockIdx.x;
-  {
-    const int nsp = nseg + 1, total = (int)gridDim.x;
-    if (total > 8 * (nsp - 1)) {
-      const int b = blockIdx.x;
-      if ((b & 7) == 0 && (b >> 3) < nsp) {
-        role = (b >> 3) < nseg ? (b >> 3) : total - 1;
-      } else {
-        const int before = min(nsp, (b + 7) >> 3);     // chain / draw blocks below b
-        role = nseg + (b - before);
-      }
-    }
-  }
+  int role = fgp_role_of_block((int)blockIdx.x, (int)gridDim.x, nseg);
 #ifdef FGP_STAMPS
 #define PSTAMP(slot) if (a.dbg && (tid & 63) == 0) a.dbg[(size_t)(slot)] = __builtin_amdgcn_s_memrealtime()
 #else
@@ -2468,6 +2471,11 @@ int wn_fastgen_finish(int Q, int32_t* cursors, int32_t* samples_io,
 // ceil(Q / 16) + 1 workgroups against the occupancy the runtime reports for the
 // launch configuration x CUs, else WN_ERR_UNSUPPORTED (use wn_fastgen_step).
 // 8-byte hand-over words of wn_fastgen_persist (z, h1, h2, logits, x, code)
+int wn_fastgen_persist_role(int block, int total, int nseg) {
+  if (block < 0 || total <= 0 || block >= total || nseg < 1 || nseg + 1 > total) return WN_ERR_BAD_SHAPE;
+  return fgp_role_of_block(block, total, nseg);
+}
+
 long wn_fastgen_persist_ll_words(int L, int S, int Q) {
   if (L <= 0 || S <= 0 || Q <= 0) return 0;
   return (long)L * 32 + 2L * S + Q + FGP_MAXSEG * 32 + 32;

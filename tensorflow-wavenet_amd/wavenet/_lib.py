@@ -128,6 +128,7 @@ SIGNATURES = {
                                 c_int, c_int, P, P, P, P, P, c_int, P, P, P,
                                 P, P, P, P]),
     'wn_fastgen_persist_workgroups': (c_int, [c_int, c_int, c_int]),
+    'wn_fastgen_persist_role': (c_int, [c_int, c_int, c_int]),
     'wn_fastgen_persist_ll_words': (c_long, [c_int, c_int, c_int]),
     'wn_fastgen_persist': (c_int, [P, P, c_long, P, P, P, P, P, P, P, P, c_int,
                                    c_int, c_int, P, P, P, P, P, c_int, P, P, P,

@@ -156,3 +156,26 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libwavenet_hip.so')
     with pytest.raises(_lib.WaveNetHipError):
         _lib.load()
+
+
+def test_persistent_generator_role_mapping_is_a_permutation(hip_lib):
+    """fg_persist_kernel's workgroup -> role mapping (host-side mirror
+    wn_fastgen_persist_role of the kernel's own function): a permutation of the
+    roles for every grid, the chain's roles -- segments 0 .. nseg - 1 and the
+    draw (= total - 1) -- on the blocks 0, 8, 16, ... (one XCD) when the grid is
+    large enough, the identity otherwise."""
+    for total, nseg in ((86, 5), (41, 5), (42, 5), (40, 5), (27, 2), (5, 1), (9, 1),
+                        (10, 1), (100, 8), (65, 8), (66, 8), (2, 1)):
+        roles = [hip_lib.wn_fastgen_persist_role(b, total, nseg) for b in range(total)]
+        assert sorted(roles) == list(range(total)), (total, nseg)
+        if total > 8 * nseg:
+            for k in range(nseg):
+                assert roles[8 * k] == k
+            assert roles[8 * nseg] == total - 1
+            # the other roles keep their order
+            rest = [r for b, r in enumerate(roles) if not (b % 8 == 0 and b // 8 <= nseg)]
+            assert rest == sorted(rest)
+        else:
+            assert roles == list(range(total))
+    assert hip_lib.wn_fastgen_persist_role(5, 5, 1) == -1       # block out of range
+    assert hip_lib.wn_fastgen_persist_role(0, 1, 1) == -1       # no room for chain + draw
